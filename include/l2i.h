@@ -1,0 +1,131 @@
+/* libl2i_hip.so -- C ABI of the MI355X (gfx950) layout-to-image hot path.
+ *
+ * The reference (wtliao/layout2img) is pure Python; its intended native boundary is the op-level
+ * extension `model.roi_layers._C` that setup.py:19-23,48 would have built (roi_align_forward /
+ * roi_align_backward taking tensors + scalars). This header generalises that boundary to every
+ * device computation on the path named by BASELINE.json: plain pointers and
+ * sizes, no torch types, caller-owned buffers, one HIP stream argument, int return code.
+ *
+ * Conventions
+ *   - All activations are NHWC ("channels last"). "stream" tensors are f32, "operand" tensors
+ *     (inputs of MFMA kernels) are of type T selected by `dtype`: 0 = f32, 1 = bf16.
+ *   - Channel counts seen by the kernels are padded to multiples of 8 by the caller.
+ *   - Kernels never allocate, free or synchronise; outputs (and atomically accumulated outputs,
+ *     marked "+=") are pre-allocated / pre-zeroed by the caller.
+ *   - Return 0 on success, L2I_ERR_ARG (-1) for a rejected argument, L2I_ERR_LAUNCH (-2) when
+ *     the HIP runtime reported a launch error. No exceptions cross the ABI.
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream).
+ */
+#ifndef L2I_H
+#define L2I_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2I_OK 0
+#define L2I_ERR_ARG (-1)
+#define L2I_ERR_LAUNCH (-2)
+#define L2I_F32 0
+#define L2I_BF16 1
+
+int l2i_version(void);
+
+/* Implicit-GEMM convolution / linear layer, forward and data-gradient (MFMA).
+ * Replaces nn.Conv2d 3x3 / 1x1 and nn.Linear as used at model/resnet_generator_app_v2.py:633-639,
+ * 657-670 (nearest x2 upsample fused: up2), model/rcnn_discriminator_app.py:297-344 (avg_pool2d(2)
+ * fused: pool2, alpha = 0.25) and their input gradients (same kernel on the dgrad weight pack).
+ *   out = alpha * pool?(conv(up?(x), w)) + bias ; zeroed where relu_mask <= 0 ; + res
+ * x [B,Hi,Wi,Ci] T; w packed [Npad][Kpad] T (l2i_weights_prepare); (Ho,Wo) = conv-output grid
+ * (= 2*(Hi,Wi) if up2); out/res/relu_mask/out_op* are [B,Ho>>pool2,Wo>>pool2,Co]. KH in {1,3}. */
+int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float* res, const void* relu_mask,
+                   float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
+                   int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, void* stream);
+
+/* Weight gradient of the same convolution: dw[Co][ldw] += alpha * dYfull^T . im2col(x)
+ * (autograd of the layers above). dy [B,Ho>>pool2,Wo>>pool2,Co] T; k order (ky,kx,ci). */
+int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
+                     int Co, int KH, int up2, int pool2, int ldw, float alpha, void* stream);
+
+/* Weight arena: spectral-norm power iteration (one step, train mode), sigma, and the forward /
+ * dgrad packs of every GEMM-shaped weight of a network in three multi-tensor launches.
+ * Replaces torch.nn.utils.spectral_norm's pre-forward hook as installed by conv2d()
+ * (model/resnet_generator_app_v2.py:681-686, model/rcnn_discriminator_app.py:10-15) and by
+ * nn.utils.spectral_norm(nn.Linear/nn.Embedding) (model/norm_module.py:158-159,
+ * model/mask_regression.py:64-81, model/rcnn_discriminator_app.py:95,104-109).
+ * layers: 16 x int64 per layer, tables built by layout2img_amd/arena.py. */
+int l2i_weights_prepare(const long long* layers, int n_layers, const int* tab_wtu, int n_wtu, const int* tab_wv, int n_wv,
+                        const int* tab_pack, int n_pack, const float* params, float* sn_state, float* pass_uv,
+                        long long uv_len, float* norms, void* packed, int dtype, int training, void* stream);
+
+/* Backward of the above: grads[w] += (G - <G,Wbar> u v^T) / sigma for every layer (G = dwbar). */
+int l2i_weights_backward(const long long* layers, int n_layers, const int* tab_dot, int n_dot, const int* tab_apply,
+                         int n_apply, const float* params, const float* dwbar, const float* pass_uv, float* norms,
+                         float* grads, void* stream);
+
+/* Per-channel sum / sum of squares over rows of x [rows][C] (grouped): sums/sqsums [G][C] +=.
+ * Batch statistics of SynchronizedBatchNorm2d (model/sync_batchnorm/batchnorm.py:51-68), of
+ * nn.InstanceNorm2d (rows_per_group = H*W) and bias gradients. */
+int l2i_channel_stats(const float* x, long long rows, int C, long long rows_per_group, float* sums, float* sqsums,
+                      void* stream);
+
+/* Normalise + modulate + ReLU in one pass. mode 0: ISLA (SpatialAdaptiveSynBatchNorm2d.forward,
+ * model/norm_module.py:163-186); mode 1: per-channel affine; mode 2: none.
+ * x [B][HW][C] f32; statistics [G][C] with G = 1 (stat_stride 0) or B (stat_stride C); mask
+ * [B][O][HW] at x's resolution; wproj/bproj [B][O][C] addressed b*pstride_b + o*pstride_o + c. */
+int l2i_norm_mod_fwd(const float* x, int B, int HW, int C, const float* sums, const float* sqsums, float count, float eps,
+                     int stat_stride, const float* mask, int O, const float* wproj, const float* bproj,
+                     long long pstride_b, long long pstride_o, int mode, int relu, void* out_op, float* out_f32, int dtype,
+                     void* stream);
+
+/* Backward, first pass: dxhat = dy*[y>0]*gamma (may alias dy); s1 += sum dxhat, s2 += sum dxhat*xhat;
+ * dwproj/dbproj += ; dmask += (all pre-zeroed by the caller). */
+int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW, int C, const float* sums, const float* sqsums,
+                       float count, float eps, int stat_stride, const float* mask, int O, const float* wproj,
+                       const float* bproj, long long pstride_b, long long pstride_o, int mode, int relu, float* dxhat,
+                       float* s1, float* s2, float* dwproj, float* dbproj, float* dmask, void* stream);
+
+/* Backward, second pass: dx (+)= invstd * (dxhat - s1/count - xhat*s2/count). */
+int l2i_norm_bwd_b(const float* x, const float* dxhat, const float* sums, const float* sqsums, const float* s1,
+                   const float* s2, float* dx, long long rows, int C, long long rows_per_group, float count, float eps,
+                   int accumulate, void* stream);
+
+/* ROIAlign (torchvision.ops.RoIAlign semantics, aligned=False) with the two-scale routing of
+ * model/rcnn_discriminator_app.py:98-99,131-145; rows with valid == 0 give zeros. */
+int l2i_roi_align_fwd(const float* feat_s, const float* feat_l, const float* rois, const int* valid, float* out, int R,
+                      int C, int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l, float thr, int sampling,
+                      void* stream);
+int l2i_roi_align_bwd(const float* rois, const int* valid, const float* dout, float* dfeat_s, float* dfeat_l, int R, int C,
+                      int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l, float thr, int sampling,
+                      void* stream);
+
+/* box_attention core (model/resnet_generator_app_v2.py:79-120; geo == NULL gives the VG variant,
+ * model/resnet_generator_vg.py:77-122). q,k,v,out [B][O][D]; geo, prob [B][O][O]; keyvalid [B][O]. */
+int l2i_box_attention_fwd(const float* q, const float* k, const float* v, const float* geo, const int* keyvalid, float* out,
+                          float* prob, int B, int O, int D, float scale, void* stream);
+int l2i_box_attention_bwd(const float* q, const float* k, const float* v, const float* geo, const float* prob,
+                          const float* dout, float* dq, float* dk, float* dv, float* dgeo, int B, int O, int D, float scale,
+                          void* stream);
+
+/* Hinge losses with fused backward (train_context_app_v2.py:159-172,180-187).
+ * mode 0: mean relu(1-x); 1: mean relu(1+x); 2: -mean x. loss_out += weight*loss; grad = weight*dloss/dx.
+ * count_ptr (device, optional): divisor override = global row count under data parallelism. */
+int l2i_hinge_fwd_bwd(const float* x, const int* valid, int n, int mode, float weight, const float* count_ptr,
+                      float* loss_out, float* grad, void* stream);
+
+/* L1 pixel loss with fused backward (train_context_app_v2.py:143,184). */
+int l2i_l1_fwd_bwd(const float* a, const float* b, long long n, float weight, float* loss_out, float* grad, void* stream);
+
+/* torch.optim.Adam step over one flat buffer (train_context_app_v2.py:121,127,174,189). */
+int l2i_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                  int step, float grad_scale, void* stream);
+
+/* f32 stream -> T operand copies (raw and/or ReLU'd). */
+int l2i_cast_op(const float* x, void* raw, void* act, long long n, int dtype, void* stream);
+
+/* ReLU backward on f32 streams: out = g*[mask>0] (+ add). */
+int l2i_relu_bwd(const float* g, const float* mask, const float* add, float* out, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,10 @@
+"""layout2img_amd -- MI355X (gfx950) native hot path of wtliao/layout2img.
+
+Public surface mirrors the reference's module boundary:
+  ResnetGenerator128_context, CombineDiscriminator128_app  (+ GanTrainer for the training iteration).
+The compute path is the C-ABI library libl2i_hip.so (include/l2i.h); it must be built first
+(`python -m layout2img_amd.build`) and there is no CPU / PyTorch fallback.
+"""
+from .discriminator import CombineDiscriminator128_app, ResnetDiscriminator128_app  # noqa: F401
+from .generator import ResnetGenerator128_context  # noqa: F401
+from .trainer import FlatAdam, GanTrainer  # noqa: F401

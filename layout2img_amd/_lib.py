@@ -1,0 +1,60 @@
+"""ctypes binding of libl2i_hip.so (the C ABI declared in include/l2i.h).
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libl2i_hip.so")
+
+F32, BF16 = 0, 1
+
+_p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+SIGNATURES = {
+    "l2i_version": [],
+    "l2i_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "l2i_conv2d_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "l2i_weights_prepare": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _ll, _p, _p, _i, _i, _p],
+    "l2i_weights_backward": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p],
+    "l2i_channel_stats": [_p, _ll, _i, _ll, _p, _p, _p],
+    "l2i_norm_mod_fwd": [_p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _i, _p],
+    "l2i_norm_mod_bwd_a": [_p, _p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "l2i_norm_bwd_b": [_p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _f, _f, _i, _p],
+    "l2i_roi_align_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f, _i, _p],
+    "l2i_roi_align_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f, _i, _p],
+    "l2i_box_attention_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "l2i_box_attention_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "l2i_hinge_fwd_bwd": [_p, _p, _i, _i, _f, _p, _p, _p, _p],
+    "l2i_l1_fwd_bwd": [_p, _p, _ll, _f, _p, _p, _p],
+    "l2i_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p],
+    "l2i_cast_op": [_p, _p, _p, _ll, _i, _p],
+    "l2i_relu_bwd": [_p, _p, _p, _p, _ll, _p],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once). Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -m layout2img_amd.build` (or __graft_entry__.build()). "
+            "There is no CPU or PyTorch fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _i
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc} ({'bad argument' if rc == -1 else 'HIP launch error'})")

@@ -1,0 +1,258 @@
+"""Flat parameter storage and the weight arena (spectral norm + MFMA weight packs).
+
+Design (MI355X-first, 288 GB HBM): all parameters of a network live in ONE flat f32 buffer and all
+gradients in another, so Adam is one elementwise launch and the data-parallel gradient exchange is
+an all-reduce over contiguous slices with no bucketing copies. Every forward pass packs all
+GEMM-shaped weights (after spectral normalisation) into a per-pass arena in the layouts the MFMA
+kernels read; per-pass arenas keep W/sigma, u, v alive for that pass's backward, which is what the
+reference's autograd does implicitly when netD is called twice before backward
+(train_context_app_v2.py:158,167,173).
+"""
+import struct
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+ALIGN = 4  # elements (16 bytes)
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class FlatParams:
+    """Re-homes every parameter (and its .grad) of `module` into two flat f32 buffers on `device`."""
+
+    def __init__(self, module: nn.Module, device):
+        module.to(device)
+        params = [(n, p) for n, p in module.named_parameters()]
+        offs, total = {}, 0
+        for n, p in params:
+            offs[n] = total
+            total += _round_up(p.numel(), ALIGN)
+        total = _round_up(max(total, ALIGN), ALIGN)
+        self.data = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.offsets = offs
+        self.numel = total
+        with torch.no_grad():
+            for n, p in params:
+                o, k = offs[n], p.numel()
+                self.data[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.data[o:o + k].view(p.shape)
+                p.grad = self.grad[o:o + k].view(p.shape)
+        self._params = params
+        self._by_id = {id(p): offs[n] for n, p in params}
+
+    def offset_of(self, param):
+        return self._by_id[id(param)]
+
+    def zero_grad(self):
+        self.grad.zero_()
+        base = self.grad.data_ptr()
+        for _, p in self._params:  # re-attach a view if someone set .grad to None
+            o = self._by_id[id(p)]
+            if p.grad is None or p.grad.data_ptr() != base + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class FlatBuffers:
+    """Same idea for the spectral-norm u / v buffers (registered module buffers named weight_u/_v)."""
+
+    def __init__(self, tensors, device):
+        offs, total = [], 0
+        for t in tensors:
+            offs.append(total)
+            total += _round_up(t.numel(), ALIGN)
+        self.data = torch.zeros(max(total, ALIGN), dtype=torch.float32, device=device)
+        self.offsets = offs
+        with torch.no_grad():
+            for t, o in zip(tensors, offs):
+                self.data[o:o + t.numel()].copy_(t.reshape(-1))
+                t.data = self.data[o:o + t.numel()].view(t.shape)
+
+
+class GemmWeight(nn.Module):
+    """Holder of one GEMM-shaped weight in the reference's state_dict layout.
+
+    With spectral norm the keys are `weight_orig`, `weight_u`, `weight_v` (+ `bias`), exactly what
+    torch.nn.utils.spectral_norm leaves on nn.Conv2d / nn.Linear / nn.Embedding; without it
+    `weight` (+ `bias`). kind: 'conv' (Co,Ci,KH,KH), 'linear' (Co,Ci), 'embedding' (rows, dim).
+    """
+
+    def __init__(self, kind, co, ci, kh=1, bias=True, sn=True, eps=1e-12):
+        super().__init__()
+        self.kind, self.co, self.ci, self.kh, self.sn, self.eps = kind, co, ci, kh, sn, eps
+        shape = (co, ci, kh, kh) if kind == "conv" else (co, ci)
+        w = torch.empty(shape)
+        if kind == "embedding":
+            nn.init.normal_(w)
+        else:
+            nn.init.kaiming_uniform_(w, a=5 ** 0.5)
+        if sn:
+            self.weight_orig = nn.Parameter(w)
+            # torch draws u, v ~ N(0,1) normalised at wrap time
+            u = torch.nn.functional.normalize(torch.randn(co), dim=0, eps=eps)
+            v = torch.nn.functional.normalize(torch.randn(ci * kh * kh), dim=0, eps=eps)
+            self.register_buffer("weight_u", u)
+            self.register_buffer("weight_v", v)
+        else:
+            self.weight = nn.Parameter(w)
+        if bias:
+            fan_in = ci * kh * kh
+            bound = 1.0 / fan_in ** 0.5
+            self.bias = nn.Parameter(torch.empty(co).uniform_(-bound, bound))
+        else:
+            self.bias = None
+        self.layer_id = -1  # set by WeightArena
+
+    @property
+    def w(self):
+        return self.weight_orig if self.sn else self.weight
+
+    @property
+    def co_p(self):
+        return _round_up(self.co, 8)
+
+    @property
+    def ci_p(self):
+        return _round_up(self.ci, 8)
+
+
+def _f32_bits(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+class WeightArena:
+    def __init__(self, net: nn.Module, flat: FlatParams, device, op_dtype):
+        self.flat = flat
+        self.device = device
+        self.op_dtype = op_dtype
+        self.dtype_code = _lib.BF16 if op_dtype == torch.bfloat16 else _lib.F32
+        bk = 64 if op_dtype == torch.bfloat16 else 32
+        holders = [m for m in net.modules() if isinstance(m, GemmWeight)]
+        self.holders = holders
+        sn_tensors = []
+        for h in holders:
+            if h.sn:
+                sn_tensors += [h.weight_u, h.weight_v]
+        for t in sn_tensors:
+            t.data = t.data.to(device)
+        self.sn_flat = FlatBuffers(sn_tensors, device)
+        L = len(holders)
+        tab = np.zeros((L, 16), dtype=np.int64)
+        packed_len = dw_len = 0
+        k = 0
+        t_wtu, t_wv, t_pack, t_dot, t_apply = [], [], [], [], []
+        for i, h in enumerate(holders):
+            h.layer_id = i
+            taps = h.kh * h.kh
+            kt = h.ci * taps
+            kp = taps * h.ci_p
+            kpad, npad = _round_up(kp, bk), _round_up(h.co_p, 128)
+            kp_d = taps * h.co_p
+            kpad_d, npad_d = _round_up(kp_d, bk), _round_up(h.ci_p, 128)
+            row = tab[i]
+            row[0] = flat.offset_of(h.w)
+            if h.sn:
+                row[1], row[2] = self.sn_flat.offsets[k], self.sn_flat.offsets[k + 1]
+                k += 2
+            else:
+                row[1] = row[2] = -1
+            row[3], row[4], row[5], row[6], row[7] = h.co, h.ci, h.kh, h.co_p, h.ci_p
+            row[8], row[9], row[10] = kpad, npad, packed_len
+            packed_len += npad * kpad
+            row[11], row[12], row[13] = kpad_d, npad_d, packed_len
+            packed_len += npad_d * kpad_d
+            row[14] = dw_len
+            dw_len += _round_up(h.co_p * kp, ALIGN)
+            row[15] = _f32_bits(h.eps)
+            h.kpad, h.npad, h.fwd_off = kpad, npad, int(row[10])
+            h.kpad_d, h.npad_d, h.dg_off = kpad_d, npad_d, int(row[13])
+            h.dw_off, h.kp = int(row[14]), kp
+            if h.sn:
+                for cc in range((kt + 255) // 256):
+                    for rc in range((h.co + 255) // 256):
+                        t_wtu.append((i, cc, rc))
+                for rc in range((h.co + 15) // 16):
+                    t_wv.append((i, rc))
+                for c in range((h.co * kt + 4095) // 4096):
+                    t_dot.append((i, c))
+            for c in range((npad * kpad + 2047) // 2048):
+                t_pack.append((i, 0, c))
+            for c in range((npad_d * kpad_d + 2047) // 2048):
+                t_pack.append((i, 1, c))
+            for c in range((h.co * kt + 4095) // 4096):
+                t_apply.append((i, c))
+        self.n_layers = L
+        self.packed_len, self.dw_len = packed_len, max(dw_len, ALIGN)
+        self.uv_len = self.sn_flat.data.numel()
+        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.array(a, dtype=dt).reshape(-1))).to(device)
+        self.layers = torch.from_numpy(tab.reshape(-1)).to(device)
+        self.t_wtu, self.n_wtu = dev(t_wtu or [(0, 0, 0)], np.int32), len(t_wtu)
+        self.t_wv, self.n_wv = dev(t_wv or [(0, 0)], np.int32), len(t_wv)
+        self.t_pack, self.n_pack = dev(t_pack, np.int32), len(t_pack)
+        self.t_dot, self.n_dot = dev(t_dot or [(0, 0)], np.int32), len(t_dot)
+        self.t_apply, self.n_apply = dev(t_apply, np.int32), len(t_apply)
+        self.pending = []
+
+    def prepare(self, training=True, need_wgrad=True):
+        """Run the power iteration (train mode) and pack all weights; returns the pass context."""
+        p = PassCtx(self, training, need_wgrad)
+        _lib.call("l2i_weights_prepare", self.layers.data_ptr(), self.n_layers, self.t_wtu.data_ptr(), self.n_wtu,
+                  self.t_wv.data_ptr(), self.n_wv, self.t_pack.data_ptr(), self.n_pack, self.flat.data.data_ptr(),
+                  self.sn_flat.data.data_ptr(), p.pass_uv.data_ptr(), self.uv_len, p.norms.data_ptr(),
+                  p.packed.data_ptr(), self.dtype_code, 1 if training else 0, torch.cuda.current_stream().cuda_stream)
+        if need_wgrad and torch.is_grad_enabled():
+            self.pending.append(p)
+            if len(self.pending) > 8:  # forwards that were never followed by an optimiser step
+                self.pending.pop(0)
+        return p
+
+    def flush_grads(self):
+        """Apply the spectral-norm backward of every pending pass into the flat gradient buffer."""
+        for p in self.pending:
+            if p.dwbar is None:
+                continue
+            _lib.call("l2i_weights_backward", self.layers.data_ptr(), self.n_layers, self.t_dot.data_ptr(), self.n_dot,
+                      self.t_apply.data_ptr(), self.n_apply, self.flat.data.data_ptr(), p.dwbar.data_ptr(),
+                      p.pass_uv.data_ptr(), p.norms.data_ptr(), self.flat.grad.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+        self.pending = []
+
+    def drop_pending(self):
+        self.pending = []
+
+
+class PassCtx:
+    """Packed weights, u/v snapshot, sigma and the dWbar accumulator of ONE forward pass."""
+
+    def __init__(self, arena: WeightArena, training, need_wgrad):
+        self.arena = arena
+        self.training = training
+        self.need_wgrad = need_wgrad
+        dev = arena.device
+        self.packed = torch.empty(arena.packed_len, dtype=arena.op_dtype, device=dev)
+        self.pass_uv = torch.empty(arena.uv_len, dtype=torch.float32, device=dev)
+        self.norms = torch.empty(4 * arena.n_layers, dtype=torch.float32, device=dev)
+        self.dwbar = None
+
+    def dw(self):
+        if self.dwbar is None:
+            self.dwbar = torch.zeros(self.arena.dw_len, dtype=torch.float32, device=self.arena.device)
+        return self.dwbar
+
+    def fwd_pack(self, h: GemmWeight):
+        return self.packed[h.fwd_off:h.fwd_off + h.npad * h.kpad]
+
+    def dgrad_pack(self, h: GemmWeight):
+        return self.packed[h.dg_off:h.dg_off + h.npad_d * h.kpad_d]
+
+    def dw_slice(self, h: GemmWeight):
+        return self.dw()[h.dw_off:h.dw_off + h.co_p * h.kp]
+
+    def sigma(self, h: GemmWeight):
+        return self.norms[4 * h.layer_id + 2]

@@ -1,0 +1,228 @@
+// Weight gradient of the implicit-GEMM convolution (gfx950 MFMA), NHWC operands.
+//
+//   dW[co, k] += alpha * sum_m dYfull[m, co] * A[m, k]
+//   m = (b, y, x) over the conv-output grid (Ho, Wo), k = (ky, kx, ci)
+//   dYfull[m]  = dY[b, y >> pool2, x >> pool2]      (alpha carries the 1/4 of avg_pool2d)
+//   A[m, k]    = X[b, (y+ky-pad) >> up2, (x+kx-pad) >> up2, ci]
+//
+// This is the autograd of nn.Conv2d / nn.Linear weights on the reference path
+// (model/resnet_generator_app_v2.py:633-639, model/rcnn_discriminator_app.py:297-326)
+// and is a "TN" GEMM: both operands are stored with the reduction index (pixels)
+// strided and the channel contiguous, while MFMA fragments want the reduction
+// index contiguous per lane. Each thread therefore loads an EPG-pixel x
+// EPG-channel block (EPG 16-byte loads), transposes it in registers and writes
+// EPG 16-byte rows [channel][pixel0..] into LDS; after that the LDS image and
+// the MFMA loop are the same as the forward kernel's. The pixel reduction is
+// split over `splits` workgroups per output tile, combined by f32 atomics.
+#include "igemm.h"
+
+struct WgradArgs {
+    const void* x;   // T [B, Hi, Wi, Ci]
+    const void* dy;  // T [B, Hd, Wd, Co]
+    float* dw;       // f32 [Co, ldw], accumulated atomically
+    int B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2;
+    int K, ldw, M, Mper, tiles_co, tiles_k, splits;
+    float alpha;
+};
+
+template <typename T> struct Tr;
+template <> struct Tr<bf16_t> {
+    // r[j] = 8 channels of pixel j  ->  o[c] = 8 pixels of channel c
+    __device__ static __forceinline__ void run(const uint4 (&r)[8], uint4 (&o)[8]) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = d == 0 ? r[j].x : d == 1 ? r[j].y : d == 2 ? r[j].z : r[j].w;
+            uint4 lo, hi;
+            lo.x = (v[0] & 0xffffu) | (v[1] << 16); hi.x = (v[0] >> 16) | (v[1] & 0xffff0000u);
+            lo.y = (v[2] & 0xffffu) | (v[3] << 16); hi.y = (v[2] >> 16) | (v[3] & 0xffff0000u);
+            lo.z = (v[4] & 0xffffu) | (v[5] << 16); hi.z = (v[4] >> 16) | (v[5] & 0xffff0000u);
+            lo.w = (v[6] & 0xffffu) | (v[7] << 16); hi.w = (v[6] >> 16) | (v[7] & 0xffff0000u);
+            o[2 * d] = lo;
+            o[2 * d + 1] = hi;
+        }
+    }
+};
+template <> struct Tr<float> {
+    __device__ static __forceinline__ void run(const uint4 (&r)[4], uint4 (&o)[4]) {
+        o[0] = make_uint4(r[0].x, r[1].x, r[2].x, r[3].x);
+        o[1] = make_uint4(r[0].y, r[1].y, r[2].y, r[3].y);
+        o[2] = make_uint4(r[0].z, r[1].z, r[2].z, r[3].z);
+        o[3] = make_uint4(r[0].w, r[1].w, r[2].w, r[3].w);
+    }
+};
+
+template <typename T, int BMO>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+    constexpr int BNK = 128;  // k-columns per tile
+    constexpr int BK = Mma<T>::BK;
+    constexpr int EPG = OpT<T>::EPG;
+    constexpr int TM = BMO / 64, TN = 2;
+    constexpr int N1 = 8 * (BMO / EPG);  // staging tasks for the dY operand
+    constexpr int N2 = 8 * (BNK / EPG);  // staging tasks for the im2col operand
+    constexpr int NIT = (N1 + N2 + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                  // [BMO][pixels]
+    char* Bs = smem + BMO * IG_ROWB;  // [BNK][pixels]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int split = bid % p.splits; bid /= p.splits;
+    const int tile_k = bid % p.tiles_k, tile_co = bid / p.tiles_k;
+    const int co0 = tile_co * BMO, kc0 = tile_k * BNK;
+    const int pad = p.KH >> 1;
+    const int Hd = p.Ho >> p.pool2, Wd = p.Wo >> p.pool2;
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+
+    const int m_begin = split * p.Mper;
+    const int m_end = min(p.M, m_begin + p.Mper);
+
+    // per-task constants
+    int t_pg[NIT], t_row[NIT], t_chan[NIT], t_ky[NIT], t_kx[NIT];
+    bool t_is1[NIT], t_on[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int task = tid + it * 256;
+        t_is1[it] = task < N1;
+        const int u = t_is1[it] ? task : task - N1;
+        t_pg[it] = u & 7;
+        const int cg = u >> 3;
+        t_row[it] = cg * EPG;
+        t_on[it] = task < N1 + N2;
+        t_ky[it] = 0; t_kx[it] = 0;
+        if (t_is1[it]) {
+            t_chan[it] = co0 + cg * EPG;
+            t_on[it] = t_on[it] && t_chan[it] < p.Co;
+        } else {
+            const int kc = kc0 + cg * EPG;
+            const int tap = kc / p.Ci;
+            t_chan[it] = kc - tap * p.Ci;
+            t_ky[it] = tap / p.KH;
+            t_kx[it] = tap - t_ky[it] * p.KH;
+            t_on[it] = t_on[it] && kc < p.K;
+        }
+    }
+
+    uint4 stage[NIT][EPG];
+    auto load_step = [&](int mstep) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int m = mstep + t_pg[it] * EPG;
+            int b = m / (p.Ho * p.Wo);
+            int rem = m - b * p.Ho * p.Wo;
+            int y = rem / p.Wo, x = rem - y * p.Wo;
+#pragma unroll
+            for (int j = 0; j < EPG; ++j) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (t_on[it] && m + j < m_end) {
+                    if (t_is1[it]) {
+                        const size_t off = ((size_t)(b * Hd + (y >> p.pool2)) * Wd + (x >> p.pool2)) * p.Co + t_chan[it];
+                        v = *reinterpret_cast<const uint4*>(DY + off);
+                    } else {
+                        const int yy = y + t_ky[it] - pad, xx = x + t_kx[it] - pad;
+                        if (yy >= 0 && yy < p.Ho && xx >= 0 && xx < p.Wo) {
+                            const size_t off = ((size_t)(b * p.Hi + (yy >> p.up2)) * p.Wi + (xx >> p.up2)) * p.Ci + t_chan[it];
+                            v = *reinterpret_cast<const uint4*>(X + off);
+                        }
+                    }
+                }
+                stage[it][j] = v;
+                if (++x == p.Wo) { x = 0; if (++y == p.Ho) { y = 0; ++b; } }
+            }
+        }
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (tid + it * 256 >= N1 + N2) continue;
+            uint4 o[EPG];
+            Tr<T>::run(stage[it], o);
+            char* tile = t_is1[it] ? As : Bs;
+#pragma unroll
+            for (int c = 0; c < EPG; ++c)
+                *reinterpret_cast<uint4*>(tile + (t_row[it] + c) * IG_ROWB + t_pg[it] * 16) = o[c];
+        }
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int wrow = (wave >> 1) * (BMO / 2), wcol = (wave & 1) * 64;
+    if (m_begin < m_end) {
+        load_step(m_begin);
+        for (int ms = m_begin; ms < m_end; ms += BK) {
+            store_step();
+            __syncthreads();
+            if (ms + BK < m_end) load_step(ms + BK);
+            Mma<T>::template step<TM, TN>(As, Bs, wrow, wcol, lane, acc);
+            __syncthreads();
+        }
+    }
+
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = kc0 + wcol + j * 32 + c;
+            if (col >= p.K) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = co0 + wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < p.Co) atomicAdd(p.dw + (size_t)row * p.ldw + col, p.alpha * acc[i][j][e]);
+            }
+        }
+}
+
+template <typename T>
+static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
+    constexpr int BK = Mma<T>::BK;
+    constexpr int EPG = OpT<T>::EPG;
+    if (a.KH != 1 && a.KH != 3) return L2I_ERR_ARG;
+    if (a.Ci % EPG || a.Co % EPG) return L2I_ERR_ARG;
+    if (a.up2 && (a.Ho != 2 * a.Hi || a.Wo != 2 * a.Wi)) return L2I_ERR_ARG;
+    if (!a.up2 && (a.Ho != a.Hi || a.Wo != a.Wi)) return L2I_ERR_ARG;
+    if (a.pool2 && ((a.Ho & 1) || (a.Wo & 1))) return L2I_ERR_ARG;
+    a.K = a.KH * a.KH * a.Ci;
+    if (a.ldw < a.K) return L2I_ERR_ARG;
+    a.M = a.B * a.Ho * a.Wo;
+    const int BMO = a.Co <= 64 ? 64 : 128;
+    a.tiles_co = (a.Co + BMO - 1) / BMO;
+    a.tiles_k = (a.K + 127) / 128;
+    const int tiles = a.tiles_co * a.tiles_k;
+    const int steps = (a.M + BK - 1) / BK;
+    int splits = 1024 / tiles;
+    if (splits > steps / 4) splits = steps / 4;
+    if (splits < 1) splits = 1;
+    int per = (steps + splits - 1) / splits;
+    a.Mper = per * BK;
+    a.splits = (a.M + a.Mper - 1) / a.Mper;
+    const size_t lds = (size_t)(BMO + 128) * IG_ROWB;
+    const int nblk = tiles * a.splits;
+    if (BMO == 64)
+        hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), dim3(nblk), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), dim3(nblk), dim3(256), lds, stream, a);
+    return l2i_check_launch();
+}
+
+extern "C" int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
+                                int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
+                                void* stream) {
+    if (!x || !dy || !dw) return L2I_ERR_ARG;
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.dw = dw;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
+    a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.ldw = ldw; a.alpha = alpha;
+    if (dtype == 0) return launch_wgrad<float>(a, (hipStream_t)stream);
+    if (dtype == 1) return launch_wgrad<bf16_t>(a, (hipStream_t)stream);
+    return L2I_ERR_ARG;
+}

@@ -1,0 +1,75 @@
+// Implicit-GEMM building blocks shared by the conv forward/dgrad kernel and the
+// wgrad kernel: LDS tile geometry, MFMA fragment reads and the K-step compute.
+//
+// LDS image of both operands is [rows][BK] with the reduction index contiguous,
+// rows padded to 144 bytes (128 B of data + 16 B) so that ds_read_b128 fragment
+// reads of 32 consecutive rows spread over all 16-byte slots of the bank row.
+#pragma once
+#include "common.h"
+
+#define IG_ROWB 144  // bytes per LDS tile row (128 data + 16 pad)
+
+template <typename T> struct Mma;
+
+// bf16: v_mfma_f32_32x32x16_bf16, BK = 64 per K-step (4 MFMA k-slices)
+template <> struct Mma<bf16_t> {
+    static constexpr int BK = 64;
+    template <int TM, int TN>
+    __device__ static __forceinline__ void step(const char* As, const char* Bs, int wrow, int wcol, int lane,
+                                                f32x16_t (&acc)[TM][TN]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const bf16x8_t*>(As + (wrow + i * 32 + r) * IG_ROWB + kk * 32 + h * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wcol + j * 32 + r) * IG_ROWB + kk * 32 + h * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[i]),
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+// f32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain), BK = 32 per K-step.
+// Lane half h owns k in [16h, 16h+16): MFMA slice t contracts k = t and k = 16+t.
+template <> struct Mma<float> {
+    static constexpr int BK = 32;
+    template <int TM, int TN>
+    __device__ static __forceinline__ void step(const char* As, const char* Bs, int wrow, int wcol, int lane,
+                                                f32x16_t (&acc)[TM][TN]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const f32x4_t*>(As + (wrow + i * 32 + r) * IG_ROWB + h * 64 + q * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const f32x4_t*>(Bs + (wcol + j * 32 + r) * IG_ROWB + h * 64 + q * 16);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+// XCD-aware bijective block remap: the dispatcher places block b on XCD b % 8;
+// give each XCD a contiguous run of tiles so neighbouring tiles share its L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}

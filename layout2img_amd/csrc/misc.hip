@@ -1,0 +1,173 @@
+// Loss, optimiser and operand-cast kernels.
+//
+//  * hinge losses with fused backward (reference train_context_app_v2.py:159-172, 180-187):
+//      mode 0: mean(relu(1 - x))   (D, real)      mode 1: mean(relu(1 + x))  (D, fake)
+//      mode 2: -mean(x)            (G)
+//    mean over rows with valid != 0 (the reference drops label-0 rows before the loss, model/
+//    rcnn_discriminator_app.py:415-417). loss_out += weight * loss ; grad = weight * dloss/dx.
+//    count_ptr (optional, device) overrides the divisor with the global row count under data parallelism.
+//  * L1 pixel loss with fused backward (train_context_app_v2.py:143,184).
+//  * Adam (train_context_app_v2.py:121,127: betas (0, 0.999), eps 1e-8) over one flat buffer.
+//  * f32 stream -> T operand casts (raw and/or ReLU'd copy) feeding the MFMA kernels.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void hinge_kernel(const float* __restrict__ x, const int* __restrict__ valid, int n, int mode,
+                                                    float weight, const float* __restrict__ count_ptr,
+                                                    float* __restrict__ loss_out, float* __restrict__ grad) {
+    __shared__ float red[16];
+    float cnt = 0.f, acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const bool ok = !valid || valid[i] != 0;
+        if (!ok) continue;
+        cnt += 1.f;
+        const float v = x[i];
+        acc += mode == 0 ? fmaxf(1.f - v, 0.f) : mode == 1 ? fmaxf(1.f + v, 0.f) : -v;
+    }
+    cnt = block_sum(cnt, red);
+    acc = block_sum(acc, red);
+    if (count_ptr) cnt = *count_ptr;  // data-parallel: mean over the GLOBAL number of rows
+    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const bool ok = !valid || valid[i] != 0;
+        const float v = x[i];
+        float g = 0.f;
+        if (ok) g = mode == 0 ? (1.f - v > 0.f ? -1.f : 0.f) : mode == 1 ? (1.f + v > 0.f ? 1.f : 0.f) : -1.f;
+        grad[i] = g * inv * weight;
+    }
+    if (threadIdx.x == 0) atomicAdd(loss_out, weight * acc * inv);
+}
+
+extern "C" int l2i_hinge_fwd_bwd(const float* x, const int* valid, int n, int mode, float weight, const float* count_ptr,
+                                 float* loss_out, float* grad, void* stream) {
+    if (!x || !loss_out || !grad || n < 0 || mode < 0 || mode > 2) return L2I_ERR_ARG;
+    hipLaunchKernelGGL(hinge_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, valid, n, mode, weight, count_ptr,
+                       loss_out, grad);
+    return l2i_check_launch();
+}
+
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                 float weight, float* __restrict__ loss_out, float* __restrict__ grad) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    const float gs = weight / (float)n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        acc += fabsf(d);
+        grad[i] = d > 0.f ? gs : d < 0.f ? -gs : 0.f;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss_out, acc * gs);
+}
+
+extern "C" int l2i_l1_fwd_bwd(const float* a, const float* b, long long n, float weight, float* loss_out, float* grad,
+                              void* stream) {
+    if (!a || !b || !loss_out || !grad || n <= 0) return L2I_ERR_ARG;
+    long long nblk = (n + 255) / 256;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(l1_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a, b, n, weight, loss_out, grad);
+    return l2i_check_launch();
+}
+
+// torch.optim.Adam (no amsgrad, no weight decay): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n4, float b1, float b2, float eps,
+                                                   float step_size, float inv_sqrt_bc2, float grad_scale) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+#define L2I_ADAM(f)                                                        \
+        {                                                                  \
+            const float gr = gg.f * grad_scale;                            \
+            mm.f = b1 * mm.f + (1.f - b1) * gr;                            \
+            vv.f = b2 * vv.f + (1.f - b2) * gr * gr;                       \
+            pp.f -= step_size * mm.f / (sqrtf(vv.f) * inv_sqrt_bc2 + eps); \
+        }
+        L2I_ADAM(x) L2I_ADAM(y) L2I_ADAM(z) L2I_ADAM(w)
+#undef L2I_ADAM
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+
+extern "C" int l2i_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                             float eps, int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || n % 4 || step < 1) return L2I_ERR_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    long long nblk = (n / 4 + 255) / 256;
+    if (nblk > 2048) nblk = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, beta1, beta2,
+                       eps, step_size, inv_sqrt_bc2, grad_scale);
+    return l2i_check_launch();
+}
+
+// f32 -> T copies (raw and/or relu). n multiple of 4.
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, T* __restrict__ raw, T* __restrict__ act,
+                                                   long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        if constexpr (sizeof(T) == 2) {
+            if (raw) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                reinterpret_cast<uint2*>(raw)[i] = pk;
+            }
+            if (act) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(fmaxf(v.x, 0.f)) | ((uint32_t)f2bf(fmaxf(v.y, 0.f)) << 16);
+                pk.y = (uint32_t)f2bf(fmaxf(v.z, 0.f)) | ((uint32_t)f2bf(fmaxf(v.w, 0.f)) << 16);
+                reinterpret_cast<uint2*>(act)[i] = pk;
+            }
+        } else {
+            if (raw) reinterpret_cast<float4*>(raw)[i] = v;
+            if (act)
+                reinterpret_cast<float4*>(act)[i] = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        }
+    }
+}
+
+extern "C" int l2i_cast_op(const float* x, void* raw, void* act, long long n, int dtype, void* stream) {
+    if (!x || (!raw && !act) || n <= 0 || n % 4) return L2I_ERR_ARG;
+    long long nblk = (n / 4 + 255) / 256;
+    if (nblk > 4096) nblk = 4096;
+    if (dtype == 0)
+        hipLaunchKernelGGL(cast_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, (float*)raw,
+                           (float*)act, n / 4);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)raw,
+                           (bf16_t*)act, n / 4);
+    else
+        return L2I_ERR_ARG;
+    return l2i_check_launch();
+}
+
+// dx = g * [mask > 0] (+ add)   -- ReLU backward on f32 streams (mask: f32 pre- or post-activation values)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ mask,
+                                                       const float* __restrict__ add, float* __restrict__ out, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(g)[i];
+        const float4 m = reinterpret_cast<const float4*>(mask)[i];
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        if (add) {
+            const float4 a = reinterpret_cast<const float4*>(add)[i];
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+extern "C" int l2i_relu_bwd(const float* g, const float* mask, const float* add, float* out, long long n, void* stream) {
+    if (!g || !mask || !out || n <= 0 || n % 4) return L2I_ERR_ARG;
+    long long nblk = (n / 4 + 255) / 256;
+    if (nblk > 4096) nblk = 4096;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, g, mask, add, out, n / 4);
+    return l2i_check_launch();
+}
+
+extern "C" int l2i_version(void) { return 1; }

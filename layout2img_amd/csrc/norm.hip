@@ -1,0 +1,401 @@
+// Normalisation kernels (HBM-bound), NHWC f32 streams -> T operands.
+//
+// Replaces on the hot path:
+//  * SpatialAdaptiveSynBatchNorm2d.forward (reference model/norm_module.py:163-186): affine-free
+//    batch norm followed by the ISLA modulation
+//        gamma(p,c) = 1 + sum_o m_o(p) W[b,o,c] / (sum_o m_o(p) + 1e-6),  beta likewise,
+//    fused with the ReLU that always follows it (model/resnet_generator_app_v2.py:655-661).
+//    The reference materialises two (b,o,C,h,w) products; here gamma/beta are formed per pixel
+//    tile from an LDS copy of W,B and never touch HBM.
+//  * SynchronizedBatchNorm2d / nn.BatchNorm2d / nn.InstanceNorm2d + ReLU
+//    (model/sync_batchnorm/batchnorm.py:48-78, model/resnet_generator_app_v2.py:416-417,648-650,
+//    735-746, model/mask_regression.py:66-80): same kernels, mode 1 (per-channel affine) / 2 (none),
+//    statistics grouped per image for the instance norm.
+//  * their backward passes (autograd of the above in the reference).
+#include "common.h"
+
+#define NM_PT 64    // pixels per block
+#define NM_CC 128   // channels per block
+#define NM_MAXO 32
+
+// ---------------------------------------------------------------- channel statistics
+// x [rows][C] f32, rows grouped in consecutive runs of rows_per_group. sums/sqsums [G][C] += .
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, long long rows, int C,
+                                                            long long rows_per_group, int slabs_per_group,
+                                                            float* __restrict__ sums, float* __restrict__ sqsums) {
+    __shared__ float4 red[2][256];
+    const int cols4 = C >> 2;
+    const int group = blockIdx.x / slabs_per_group, slab = blockIdx.x % slabs_per_group;
+    const long long slab_rows = (rows_per_group + slabs_per_group - 1) / slabs_per_group;
+    const long long r0 = group * rows_per_group + slab * slab_rows;
+    const long long r1 = min(group * rows_per_group + rows_per_group, r0 + slab_rows);
+    for (int cbase = 0; cbase < cols4; cbase += 256) {
+        const int ncol = min(256, cols4 - cbase);
+        const int TY = 256 / ncol;
+        const int tx = threadIdx.x % ncol, ty = threadIdx.x / ncol;
+        float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+        if (ty < TY) {
+            for (long long r = r0 + ty; r < r1; r += TY) {
+                const float4 v = *reinterpret_cast<const float4*>(x + r * C + 4 * (cbase + tx));
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+            }
+        }
+        __syncthreads();
+        red[0][threadIdx.x] = s;
+        red[1][threadIdx.x] = q;
+        __syncthreads();
+        if (threadIdx.x < ncol) {
+            for (int j = 1; j < TY; ++j) {
+                const float4 a = red[0][j * ncol + tx], b = red[1][j * ncol + tx];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+                q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+            }
+            float* so = sums + (size_t)group * C + 4 * (cbase + tx);
+            atomicAdd(so + 0, s.x); atomicAdd(so + 1, s.y); atomicAdd(so + 2, s.z); atomicAdd(so + 3, s.w);
+            if (sqsums) {
+                float* qo = sqsums + (size_t)group * C + 4 * (cbase + tx);
+                atomicAdd(qo + 0, q.x); atomicAdd(qo + 1, q.y); atomicAdd(qo + 2, q.z); atomicAdd(qo + 3, q.w);
+            }
+        }
+    }
+}
+
+extern "C" int l2i_channel_stats(const float* x, long long rows, int C, long long rows_per_group, float* sums,
+                                 float* sqsums, void* stream) {
+    if (!x || !sums || C % 4 || rows_per_group <= 0 || rows % rows_per_group) return L2I_ERR_ARG;
+    const long long G = rows / rows_per_group;
+    long long slabs = (2048 + G - 1) / G;
+    const long long max_slabs = (rows_per_group + 31) / 32;
+    if (slabs > max_slabs) slabs = max_slabs;
+    if (slabs < 1) slabs = 1;
+    hipLaunchKernelGGL(channel_stats_kernel, dim3((unsigned)(G * slabs)), dim3(256), 0, (hipStream_t)stream, x, rows, C,
+                       rows_per_group, (int)slabs, sums, sqsums);
+    return l2i_check_launch();
+}
+
+// ---------------------------------------------------------------- modulated norm, forward
+struct NormArgs {
+    const float* x;        // [B][HW][C]
+    const float* dy;       // bwd: gradient wrt the (post-ReLU) output
+    const float* sums;     // [G][C]
+    const float* sqsums;   // [G][C]
+    const float* mask;     // [B][O][HW] or null
+    const float* wproj;    // mode 0: [B][O][C] via strides; mode 1: [C]
+    const float* bproj;
+    void* out_op;          // T [B][HW][C] or null
+    float* out_f32;        // fwd: optional f32 copy; bwd: dxhat
+    float* s1; float* s2;  // bwd: [G][C]
+    float* dwproj; float* dbproj; float* dmask;
+    long long pstride_b, pstride_o;
+    int B, HW, C, O, mode, relu, stat_stride;
+    float count, eps;
+};
+
+__device__ __forceinline__ float4 f4mad(float a, float4 b, float4 c) {
+    return make_float4(fmaf(a, b.x, c.x), fmaf(a, b.y, c.y), fmaf(a, b.z, c.z), fmaf(a, b.w, c.w));
+}
+
+// LDS carve: Wl[O][CC] Bl[O][CC] mn[O][PT] sinv[PT]
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void norm_mod_kernel(NormArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int O = p.mode == 0 ? p.O : 0;
+    float* Wl = reinterpret_cast<float*>(smem);
+    float* Bl = Wl + O * NM_CC;
+    float* mn = Bl + O * NM_CC;
+    float* sinv = mn + O * NM_PT;
+
+    const int tiles_p = (p.HW + NM_PT - 1) / NM_PT;
+    const int tiles_c = (p.C + NM_CC - 1) / NM_CC;
+    int bid = blockIdx.x;
+    const int tc = bid % tiles_c; bid /= tiles_c;
+    const int tp = bid % tiles_p;
+    const int b = bid / tiles_p;
+    const int c0 = tc * NM_CC, p0 = tp * NM_PT;
+    const int cc = min(NM_CC, p.C - c0);
+    const int tid = threadIdx.x;
+
+    if (O > 0) {
+        for (int i = tid; i < O * NM_CC; i += 256) {
+            const int o = i / NM_CC, c = i - o * NM_CC;
+            float w = 0.f, bb = 0.f;
+            if (c < cc) {
+                const size_t off = (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + c0 + c;
+                w = p.wproj[off];
+                bb = p.bproj[off];
+            }
+            Wl[i] = w;
+            Bl[i] = bb;
+        }
+        if (tid < NM_PT) {
+            const int px = p0 + tid;
+            float S = 1e-6f;
+            if (px < p.HW)
+                for (int o = 0; o < O; ++o) S += p.mask[((size_t)b * O + o) * p.HW + px];
+            const float inv = 1.f / S;
+            sinv[tid] = inv;
+            for (int o = 0; o < O; ++o)
+                mn[o * NM_PT + tid] = px < p.HW ? p.mask[((size_t)b * O + o) * p.HW + px] * inv : 0.f;
+        }
+        __syncthreads();
+    }
+
+    const int cv = tid & 31, prow = tid >> 5;  // 32 float4 columns x 8 pixel rows
+    const int c = c0 + 4 * cv;
+    const bool con = 4 * cv < cc;
+    float4 mean = make_float4(0, 0, 0, 0), istd = make_float4(1, 1, 1, 1);
+    float4 aw = make_float4(1, 1, 1, 1), ab = make_float4(0, 0, 0, 0);
+    if (con) {
+        const size_t so = (size_t)b * p.stat_stride + c;
+        const float4 s = *reinterpret_cast<const float4*>(p.sums + so);
+        const float4 q = *reinterpret_cast<const float4*>(p.sqsums + so);
+        const float ic = 1.f / p.count;
+        mean = make_float4(s.x * ic, s.y * ic, s.z * ic, s.w * ic);
+        istd.x = rsqrtf(fmaxf(q.x * ic - mean.x * mean.x, 0.f) + p.eps);
+        istd.y = rsqrtf(fmaxf(q.y * ic - mean.y * mean.y, 0.f) + p.eps);
+        istd.z = rsqrtf(fmaxf(q.z * ic - mean.z * mean.z, 0.f) + p.eps);
+        istd.w = rsqrtf(fmaxf(q.w * ic - mean.w * mean.w, 0.f) + p.eps);
+        if (p.mode == 1) {
+            aw = *reinterpret_cast<const float4*>(p.wproj + c);
+            ab = *reinterpret_cast<const float4*>(p.bproj + c);
+        }
+    }
+    float4 acc_s1 = make_float4(0, 0, 0, 0), acc_s2 = make_float4(0, 0, 0, 0);
+    float4 acc_dw = make_float4(0, 0, 0, 0), acc_db = make_float4(0, 0, 0, 0);  // mode 1 (affine) grads
+    T* OutOp = reinterpret_cast<T*>(p.out_op);
+
+    float4 gk[NM_PT / 8], gxk[NM_PT / 8];  // bwd: g and g*xhat kept for the per-object pass
+#pragma unroll
+    for (int it = 0; it < NM_PT / 8; ++it) {
+        const int pl = prow + 8 * it, px = p0 + pl;
+        const bool on = con && px < p.HW;
+        const size_t off = ((size_t)b * p.HW + px) * p.C + c;
+        float4 xh = make_float4(0, 0, 0, 0), ga = aw, be = ab, y = make_float4(0, 0, 0, 0);
+        if (on) {
+            const float4 xv = *reinterpret_cast<const float4*>(p.x + off);
+            xh = make_float4((xv.x - mean.x) * istd.x, (xv.y - mean.y) * istd.y, (xv.z - mean.z) * istd.z,
+                             (xv.w - mean.w) * istd.w);
+            if (p.mode == 0) {
+                ga = make_float4(1, 1, 1, 1);
+                be = make_float4(0, 0, 0, 0);
+                for (int o = 0; o < O; ++o) {
+                    const float m = mn[o * NM_PT + pl];
+                    ga = f4mad(m, *reinterpret_cast<const float4*>(Wl + o * NM_CC + 4 * cv), ga);
+                    be = f4mad(m, *reinterpret_cast<const float4*>(Bl + o * NM_CC + 4 * cv), be);
+                }
+            }
+            y = make_float4(fmaf(ga.x, xh.x, be.x), fmaf(ga.y, xh.y, be.y), fmaf(ga.z, xh.z, be.z),
+                            fmaf(ga.w, xh.w, be.w));
+        }
+        float4 g = make_float4(0, 0, 0, 0), gx = g;
+        if (!BWD) {
+            if (on) {
+                if (p.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + off) = y;
+                if (OutOp) {
+                    if constexpr (sizeof(T) == 2) {
+                        uint2 pk;
+                        pk.x = (uint32_t)f2bf(y.x) | ((uint32_t)f2bf(y.y) << 16);
+                        pk.y = (uint32_t)f2bf(y.z) | ((uint32_t)f2bf(y.w) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(OutOp) + off) = pk;
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(OutOp) + off) = y;
+                    }
+                }
+            }
+        } else {
+            if (on) {
+                const float4 d = *reinterpret_cast<const float4*>(p.dy + off);
+                g.x = (!p.relu || y.x > 0.f) ? d.x : 0.f;
+                g.y = (!p.relu || y.y > 0.f) ? d.y : 0.f;
+                g.z = (!p.relu || y.z > 0.f) ? d.z : 0.f;
+                g.w = (!p.relu || y.w > 0.f) ? d.w : 0.f;
+                gx = make_float4(g.x * xh.x, g.y * xh.y, g.z * xh.z, g.w * xh.w);
+                const float4 dxh = make_float4(g.x * ga.x, g.y * ga.y, g.z * ga.z, g.w * ga.w);
+                *reinterpret_cast<float4*>(p.out_f32 + off) = dxh;
+                acc_s1.x += dxh.x; acc_s1.y += dxh.y; acc_s1.z += dxh.z; acc_s1.w += dxh.w;
+                acc_s2.x += dxh.x * xh.x; acc_s2.y += dxh.y * xh.y; acc_s2.z += dxh.z * xh.z; acc_s2.w += dxh.w * xh.w;
+                if (p.mode == 1) {
+                    acc_dw.x += gx.x; acc_dw.y += gx.y; acc_dw.z += gx.z; acc_dw.w += gx.w;
+                    acc_db.x += g.x; acc_db.y += g.y; acc_db.z += g.z; acc_db.w += g.w;
+                }
+            }
+            if (p.mode == 0 && p.dmask) {
+                // o-independent part of dmask: -sum_c g (xh (gamma-1) + beta) / S ; zero for inactive lanes.
+                // The shuffle is executed by every lane (block-uniform condition) so no lane reads a parked one.
+                float t0 = gx.x * (ga.x - 1.f) + g.x * be.x + gx.y * (ga.y - 1.f) + g.y * be.y +
+                           gx.z * (ga.z - 1.f) + g.z * be.z + gx.w * (ga.w - 1.f) + g.w * be.w;
+#pragma unroll
+                for (int s = 16; s > 0; s >>= 1) t0 += __shfl_xor(t0, s, 64);
+                if (cv == 0 && px < p.HW) {
+                    const float si = sinv[pl];
+                    for (int o = 0; o < O; ++o) atomicAdd(p.dmask + ((size_t)b * O + o) * p.HW + px, -t0 * si);
+                }
+            }
+        }
+        gk[it] = g;
+        gxk[it] = gx;
+    }
+    if (!BWD) return;
+
+    // per-object gradients: dW[b,o,c] += sum_p gx * mn_o(p);  dB += sum_p g * mn_o(p);
+    // dmask_o(p) += sum_c (gx W_oc + g B_oc) / S(p)
+    if (p.mode == 0) {
+        for (int o = 0; o < O; ++o) {
+            const float4 wv = *reinterpret_cast<const float4*>(Wl + o * NM_CC + 4 * cv);
+            const float4 bv = *reinterpret_cast<const float4*>(Bl + o * NM_CC + 4 * cv);
+            float4 dw = make_float4(0, 0, 0, 0), db = dw;
+#pragma unroll
+            for (int it = 0; it < NM_PT / 8; ++it) {
+                const int pl = prow + 8 * it, px = p0 + pl;
+                const float m = mn[o * NM_PT + pl];
+                dw = f4mad(m, gxk[it], dw);
+                db = f4mad(m, gk[it], db);
+                if (p.dmask) {
+                    float a = gxk[it].x * wv.x + gxk[it].y * wv.y + gxk[it].z * wv.z + gxk[it].w * wv.w +
+                              gk[it].x * bv.x + gk[it].y * bv.y + gk[it].z * bv.z + gk[it].w * bv.w;
+#pragma unroll
+                    for (int s = 16; s > 0; s >>= 1) a += __shfl_xor(a, s, 64);
+                    if (cv == 0 && px < p.HW) atomicAdd(p.dmask + ((size_t)b * O + o) * p.HW + px, a * sinv[pl]);
+                }
+            }
+            // reduce dw/db over the 8 pixel rows: lanes tid and tid^32 share cv within a wave; then across 4 waves
+            dw.x += __shfl_xor(dw.x, 32, 64); dw.y += __shfl_xor(dw.y, 32, 64);
+            dw.z += __shfl_xor(dw.z, 32, 64); dw.w += __shfl_xor(dw.w, 32, 64);
+            db.x += __shfl_xor(db.x, 32, 64); db.y += __shfl_xor(db.y, 32, 64);
+            db.z += __shfl_xor(db.z, 32, 64); db.w += __shfl_xor(db.w, 32, 64);
+            if ((tid & 32) == 0 && con) {
+                const size_t off = (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + c;
+                atomicAdd(p.dwproj + off + 0, dw.x); atomicAdd(p.dwproj + off + 1, dw.y);
+                atomicAdd(p.dwproj + off + 2, dw.z); atomicAdd(p.dwproj + off + 3, dw.w);
+                atomicAdd(p.dbproj + off + 0, db.x); atomicAdd(p.dbproj + off + 1, db.y);
+                atomicAdd(p.dbproj + off + 2, db.z); atomicAdd(p.dbproj + off + 3, db.w);
+            }
+        }
+    }
+    // s1/s2 (+ affine grads)
+    acc_s1.x += __shfl_xor(acc_s1.x, 32, 64); acc_s1.y += __shfl_xor(acc_s1.y, 32, 64);
+    acc_s1.z += __shfl_xor(acc_s1.z, 32, 64); acc_s1.w += __shfl_xor(acc_s1.w, 32, 64);
+    acc_s2.x += __shfl_xor(acc_s2.x, 32, 64); acc_s2.y += __shfl_xor(acc_s2.y, 32, 64);
+    acc_s2.z += __shfl_xor(acc_s2.z, 32, 64); acc_s2.w += __shfl_xor(acc_s2.w, 32, 64);
+    if (p.mode == 1) {
+        acc_dw.x += __shfl_xor(acc_dw.x, 32, 64); acc_dw.y += __shfl_xor(acc_dw.y, 32, 64);
+        acc_dw.z += __shfl_xor(acc_dw.z, 32, 64); acc_dw.w += __shfl_xor(acc_dw.w, 32, 64);
+        acc_db.x += __shfl_xor(acc_db.x, 32, 64); acc_db.y += __shfl_xor(acc_db.y, 32, 64);
+        acc_db.z += __shfl_xor(acc_db.z, 32, 64); acc_db.w += __shfl_xor(acc_db.w, 32, 64);
+    }
+    if ((tid & 32) == 0 && con) {
+        const size_t so = (size_t)b * p.stat_stride + c;
+        atomicAdd(p.s1 + so + 0, acc_s1.x); atomicAdd(p.s1 + so + 1, acc_s1.y);
+        atomicAdd(p.s1 + so + 2, acc_s1.z); atomicAdd(p.s1 + so + 3, acc_s1.w);
+        atomicAdd(p.s2 + so + 0, acc_s2.x); atomicAdd(p.s2 + so + 1, acc_s2.y);
+        atomicAdd(p.s2 + so + 2, acc_s2.z); atomicAdd(p.s2 + so + 3, acc_s2.w);
+        if (p.mode == 1) {
+            atomicAdd(p.dwproj + c + 0, acc_dw.x); atomicAdd(p.dwproj + c + 1, acc_dw.y);
+            atomicAdd(p.dwproj + c + 2, acc_dw.z); atomicAdd(p.dwproj + c + 3, acc_dw.w);
+            atomicAdd(p.dbproj + c + 0, acc_db.x); atomicAdd(p.dbproj + c + 1, acc_db.y);
+            atomicAdd(p.dbproj + c + 2, acc_db.z); atomicAdd(p.dbproj + c + 3, acc_db.w);
+        }
+    }
+}
+
+static size_t norm_lds(const NormArgs& a) {
+    const int O = a.mode == 0 ? a.O : 0;
+    return sizeof(float) * ((size_t)2 * O * NM_CC + (size_t)O * NM_PT + NM_PT) + 16;
+}
+
+static int norm_check(const NormArgs& a) {
+    if (!a.x || !a.sums || !a.sqsums || a.C % 4 || a.B <= 0 || a.HW <= 0) return L2I_ERR_ARG;
+    if (a.mode < 0 || a.mode > 2) return L2I_ERR_ARG;
+    if (a.mode == 0 && (!a.mask || !a.wproj || !a.bproj || a.O < 1 || a.O > NM_MAXO)) return L2I_ERR_ARG;
+    if (a.mode == 1 && (!a.wproj || !a.bproj)) return L2I_ERR_ARG;
+    return L2I_OK;
+}
+
+extern "C" int l2i_norm_mod_fwd(const float* x, int B, int HW, int C, const float* sums, const float* sqsums, float count,
+                                float eps, int stat_stride, const float* mask, int O, const float* wproj,
+                                const float* bproj, long long pstride_b, long long pstride_o, int mode, int relu,
+                                void* out_op, float* out_f32, int dtype, void* stream) {
+    NormArgs a = {};
+    a.x = x; a.B = B; a.HW = HW; a.C = C; a.sums = sums; a.sqsums = sqsums; a.count = count; a.eps = eps;
+    a.stat_stride = stat_stride; a.mask = mask; a.O = O; a.wproj = wproj; a.bproj = bproj;
+    a.pstride_b = pstride_b; a.pstride_o = pstride_o; a.mode = mode; a.relu = relu; a.out_op = out_op; a.out_f32 = out_f32;
+    if (norm_check(a) != L2I_OK || (!out_op && !out_f32)) return L2I_ERR_ARG;
+    const int nblk = B * ((HW + NM_PT - 1) / NM_PT) * ((C + NM_CC - 1) / NM_CC);
+    if (dtype == 0)
+        hipLaunchKernelGGL((norm_mod_kernel<float, false>), dim3(nblk), dim3(256), norm_lds(a), (hipStream_t)stream, a);
+    else if (dtype == 1)
+        hipLaunchKernelGGL((norm_mod_kernel<bf16_t, false>), dim3(nblk), dim3(256), norm_lds(a), (hipStream_t)stream, a);
+    else
+        return L2I_ERR_ARG;
+    return l2i_check_launch();
+}
+
+extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW, int C, const float* sums,
+                                  const float* sqsums, float count, float eps, int stat_stride, const float* mask, int O,
+                                  const float* wproj, const float* bproj, long long pstride_b, long long pstride_o,
+                                  int mode, int relu, float* dxhat, float* s1, float* s2, float* dwproj, float* dbproj,
+                                  float* dmask, void* stream) {
+    NormArgs a = {};
+    a.x = x; a.dy = dy; a.B = B; a.HW = HW; a.C = C; a.sums = sums; a.sqsums = sqsums; a.count = count; a.eps = eps;
+    a.stat_stride = stat_stride; a.mask = mask; a.O = O; a.wproj = wproj; a.bproj = bproj;
+    a.pstride_b = pstride_b; a.pstride_o = pstride_o; a.mode = mode; a.relu = relu; a.out_f32 = dxhat;
+    a.s1 = s1; a.s2 = s2; a.dwproj = dwproj; a.dbproj = dbproj; a.dmask = dmask;
+    if (norm_check(a) != L2I_OK || !dy || !dxhat || !s1 || !s2) return L2I_ERR_ARG;
+    if (mode != 2 && (!dwproj || !dbproj)) return L2I_ERR_ARG;
+    const int nblk = B * ((HW + NM_PT - 1) / NM_PT) * ((C + NM_CC - 1) / NM_CC);
+    hipLaunchKernelGGL((norm_mod_kernel<float, true>), dim3(nblk), dim3(256), norm_lds(a), (hipStream_t)stream, a);
+    return l2i_check_launch();
+}
+
+// ---------------------------------------------------------------- batch-norm backward, second pass
+//   dx = invstd * (dxhat - s1/count - xhat * s2/count)      (+= into dx_out when accumulate)
+__global__ __launch_bounds__(256) void norm_bwd_b_kernel(const float* __restrict__ x, const float* __restrict__ dxhat,
+                                                         const float* __restrict__ sums, const float* __restrict__ sqsums,
+                                                         const float* __restrict__ s1, const float* __restrict__ s2,
+                                                         float* __restrict__ dx, long long rows, int C, long long rows_per_group,
+                                                         float count, float eps, int accumulate) {
+    const int cols4 = C >> 2;
+    const long long total = rows * cols4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cols4;
+        const int c = 4 * (int)(i - r * cols4);
+        const size_t so = (size_t)(r / rows_per_group) * C + c;
+        const float ic = 1.f / count;
+        const float4 s = *reinterpret_cast<const float4*>(sums + so);
+        const float4 q = *reinterpret_cast<const float4*>(sqsums + so);
+        const float4 a1 = *reinterpret_cast<const float4*>(s1 + so);
+        const float4 a2 = *reinterpret_cast<const float4*>(s2 + so);
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+        const float4 d = *reinterpret_cast<const float4*>(dxhat + r * C + c);
+        float4 o;
+#define L2I_BWDB(f)                                                            \
+        {                                                                      \
+            const float m = s.f * ic;                                          \
+            const float is = rsqrtf(fmaxf(q.f * ic - m * m, 0.f) + eps);       \
+            const float xh = (xv.f - m) * is;                                  \
+            o.f = is * (d.f - a1.f * ic - xh * a2.f * ic);                     \
+        }
+        L2I_BWDB(x) L2I_BWDB(y) L2I_BWDB(z) L2I_BWDB(w)
+#undef L2I_BWDB
+        float4* dst = reinterpret_cast<float4*>(dx + r * C + c);
+        if (accumulate) {
+            const float4 prev = *dst;
+            o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
+        }
+        *dst = o;
+    }
+}
+
+extern "C" int l2i_norm_bwd_b(const float* x, const float* dxhat, const float* sums, const float* sqsums, const float* s1,
+                              const float* s2, float* dx, long long rows, int C, long long rows_per_group, float count,
+                              float eps, int accumulate, void* stream) {
+    if (!x || !dxhat || !sums || !sqsums || !s1 || !s2 || !dx || C % 4 || rows_per_group <= 0) return L2I_ERR_ARG;
+    const long long total = rows * (C / 4);
+    long long nblk = (total + 255) / 256;
+    if (nblk > 4096) nblk = 4096;
+    hipLaunchKernelGGL(norm_bwd_b_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, dxhat, sums, sqsums, s1,
+                       s2, dx, rows, C, rows_per_group, count, eps, accumulate);
+    return l2i_check_launch();
+}

@@ -1,0 +1,132 @@
+// ROIAlign forward/backward, NHWC, two-scale selection in one launch.
+//
+// Replaces torchvision.ops.RoIAlign((8,8), 1/4, 0) / ((8,8), 1/8, 0) as constructed at reference
+// model/rcnn_discriminator_app.py:98-99 and called at :139,143, including the small/large routing of
+// :131-134 (an ROI whose width AND height are < thr pixels pools from the fine map, otherwise from
+// the coarse map). Algorithm restated from torchvision's published roi_align (aligned=False):
+//   roi = box * scale; roi_w = max(x2-x1, 1), roi_h likewise; bin = roi/pooled;
+//   grid = sampling_ratio > 0 ? sampling_ratio : ceil(roi / pooled);
+//   sample (iy, ix) of bin (ph, pw): y = y1 + ph*bin_h + (iy+.5)*bin_h/grid_h, x likewise;
+//   y < -1 or y > H (same for x): 0; else clamp to >= 0, low = (int)y, if low >= H-1: low = high = H-1,
+//   y = low; bilinear of the 4 neighbours; bin value = mean over samples.
+// Rows with valid[r] == 0 (padding slots, label 0) produce zeros and receive no gradient, which lets
+// the caller keep a fixed R = b*o instead of the reference's host-synchronising nonzero() (:415).
+#include "common.h"
+
+struct RoiArgs {
+    const float* feat_s; const float* feat_l;  // [B][Hs][Ws][C], [B][Hl][Wl][C] (feat_l may be null)
+    float* dfeat_s; float* dfeat_l;            // backward targets (atomic accumulate)
+    const float* rois;                         // [R][5] = batch, x1, y1, x2, y2 (image pixels)
+    const int* valid;                          // [R] or null
+    float* out;                                // fwd: [R][P][P][C]; bwd: incoming gradient
+    int R, C, P, Hs, Ws, Hl, Wl, sampling;
+    float scale_s, scale_l, thr;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(128) void roi_align_kernel(RoiArgs p) {
+    const int bin = blockIdx.x % (p.P * p.P), r = blockIdx.x / (p.P * p.P);
+    const int ph = bin / p.P, pw = bin % p.P;
+    const int cols4 = p.C >> 2;
+    float* o = p.out + ((size_t)r * p.P * p.P + bin) * p.C;
+    const bool ok = !p.valid || p.valid[r] != 0;
+    if (!ok) {
+        if (!BWD)
+            for (int c4 = threadIdx.x; c4 < cols4; c4 += 128) reinterpret_cast<float4*>(o)[c4] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const float* roi = p.rois + 5 * r;
+    const int b = (int)roi[0];
+    const bool small = !p.feat_l || ((roi[3] - roi[1]) < p.thr && (roi[4] - roi[2]) < p.thr);
+    const float scale = small ? p.scale_s : p.scale_l;
+    const int H = small ? p.Hs : p.Hl, W = small ? p.Ws : p.Wl;
+    const float* feat = (small ? p.feat_s : p.feat_l) + (size_t)b * H * W * p.C;
+    float* dfeat = BWD ? (small ? p.dfeat_s : p.dfeat_l) + (size_t)b * H * W * p.C : nullptr;
+    const float x1 = roi[1] * scale, y1 = roi[2] * scale, x2 = roi[3] * scale, y2 = roi[4] * scale;
+    const float roi_w = fmaxf(x2 - x1, 1.f), roi_h = fmaxf(y2 - y1, 1.f);
+    const float bin_h = roi_h / p.P, bin_w = roi_w / p.P;
+    const int gh = p.sampling > 0 ? p.sampling : (int)ceilf(roi_h / p.P);
+    const int gw = p.sampling > 0 ? p.sampling : (int)ceilf(roi_w / p.P);
+    const float inv_count = 1.f / fmaxf((float)(gh * gw), 1.f);
+
+    for (int c4 = threadIdx.x; c4 < cols4; c4 += 128) {
+        float4 acc = make_float4(0, 0, 0, 0);
+        float4 g = make_float4(0, 0, 0, 0);
+        if (BWD) {
+            g = reinterpret_cast<const float4*>(o)[c4];
+            g.x *= inv_count; g.y *= inv_count; g.z *= inv_count; g.w *= inv_count;
+        }
+        for (int iy = 0; iy < gh; ++iy) {
+            float y = y1 + ph * bin_h + (iy + 0.5f) * bin_h / gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                float x = x1 + pw * bin_w + (ix + 0.5f) * bin_w / gw;
+                if (y < -1.f || y > (float)H || x < -1.f || x > (float)W) continue;
+                float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+                int yl = (int)yy, xl = (int)xx, yh, xh;
+                if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+                if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
+                const float ly = yy - yl, lx = xx - xl, hy = 1.f - ly, hx = 1.f - lx;
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                const size_t o1 = ((size_t)yl * W + xl) * p.C + 4 * c4, o2 = ((size_t)yl * W + xh) * p.C + 4 * c4;
+                const size_t o3 = ((size_t)yh * W + xl) * p.C + 4 * c4, o4 = ((size_t)yh * W + xh) * p.C + 4 * c4;
+                if (!BWD) {
+                    const float4 v1 = *reinterpret_cast<const float4*>(feat + o1);
+                    const float4 v2 = *reinterpret_cast<const float4*>(feat + o2);
+                    const float4 v3 = *reinterpret_cast<const float4*>(feat + o3);
+                    const float4 v4 = *reinterpret_cast<const float4*>(feat + o4);
+                    acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+                    acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+                    acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+                    acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+                } else {
+                    const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        atomicAdd(dfeat + o1 + e, w1 * gv[e]);
+                        atomicAdd(dfeat + o2 + e, w2 * gv[e]);
+                        atomicAdd(dfeat + o3 + e, w3 * gv[e]);
+                        atomicAdd(dfeat + o4 + e, w4 * gv[e]);
+                    }
+                }
+            }
+        }
+        if (!BWD) {
+            acc.x *= inv_count; acc.y *= inv_count; acc.z *= inv_count; acc.w *= inv_count;
+            reinterpret_cast<float4*>(o)[c4] = acc;
+        }
+    }
+}
+
+static int roi_fill(RoiArgs& a, const float* feat_s, const float* feat_l, const float* rois, const int* valid, int R, int C,
+                    int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l, float thr, int sampling) {
+    if (!feat_s || !rois || R < 0 || C % 4 || P <= 0) return L2I_ERR_ARG;
+    a.feat_s = feat_s; a.feat_l = feat_l; a.rois = rois; a.valid = valid; a.R = R; a.C = C; a.P = P;
+    a.Hs = Hs; a.Ws = Ws; a.scale_s = scale_s; a.Hl = Hl; a.Wl = Wl; a.scale_l = scale_l; a.thr = thr;
+    a.sampling = sampling;
+    return L2I_OK;
+}
+
+extern "C" int l2i_roi_align_fwd(const float* feat_s, const float* feat_l, const float* rois, const int* valid, float* out,
+                                 int R, int C, int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l,
+                                 float thr, int sampling, void* stream) {
+    RoiArgs a = {};
+    if (roi_fill(a, feat_s, feat_l, rois, valid, R, C, P, Hs, Ws, scale_s, Hl, Wl, scale_l, thr, sampling) || !out)
+        return L2I_ERR_ARG;
+    a.out = out;
+    if (R == 0) return L2I_OK;
+    hipLaunchKernelGGL(roi_align_kernel<false>, dim3(R * P * P), dim3(128), 0, (hipStream_t)stream, a);
+    return l2i_check_launch();
+}
+
+extern "C" int l2i_roi_align_bwd(const float* rois, const int* valid, const float* dout, float* dfeat_s, float* dfeat_l,
+                                 int R, int C, int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l,
+                                 float thr, int sampling, void* stream) {
+    RoiArgs a = {};
+    // the gradient maps stand in for the feature maps (only "is there a coarse map" is read from them)
+    if (roi_fill(a, dfeat_s, dfeat_l, rois, valid, R, C, P, Hs, Ws, scale_s, Hl, Wl, scale_l, thr, sampling) || !dout)
+        return L2I_ERR_ARG;
+    a.dfeat_s = dfeat_s; a.dfeat_l = dfeat_l; a.out = const_cast<float*>(dout);
+    if (R == 0) return L2I_OK;
+    hipLaunchKernelGGL(roi_align_kernel<true>, dim3(R * P * P), dim3(128), 0, (hipStream_t)stream, a);
+    return l2i_check_launch();
+}

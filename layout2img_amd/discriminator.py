@@ -1,0 +1,151 @@
+"""RCNN-style discriminator with appearance head on the HIP path.
+
+Mirrors `CombineDiscriminator128_app` / `ResnetDiscriminator128_app`
+(reference model/rcnn_discriminator_app.py:84-168, 294-344, 396-421; rcnn_discriminator_vg.py is
+byte-identical): same class names, constructor arguments, call signature, outputs and state_dict
+keys. All 3x3/1x1 convolutions run on the MFMA implicit-GEMM kernel (ReLU prologue, avg-pool
+epilogue), ROIAlign is one HIP launch over a FIXED R = b*o rows with a validity mask (no
+host-synchronising nonzero()), the small heads use device-side torch ops on arena weights.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .arena import FlatParams, GemmWeight, WeightArena
+from .ops import RELU, arena_weight, fused_conv
+
+
+def _conv(ci, co, k):
+    return GemmWeight("conv", co, ci, k, sn=True, eps=1e-4)
+
+
+class OptimizedBlock(nn.Module):
+    """reference :294-314 -- the shortcut pools BEFORE its 1x1 conv."""
+
+    def __init__(self, in_ch, out_ch, downsample=False):
+        super().__init__()
+        self.conv1, self.conv2, self.c_sc = _conv(in_ch, out_ch, 3), _conv(out_ch, out_ch, 3), _conv(in_ch, out_ch, 1)
+        self.downsample = downsample
+
+    def forward(self, x, pc):
+        h = fused_conv(x, self.conv1, pc)
+        xs = x
+        if self.downsample:
+            xs = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
+        sc = fused_conv(xs, self.c_sc, pc)
+        return fused_conv(h, self.conv2, pc, prologue=RELU, res=sc, pool2=self.downsample)
+
+
+class ResBlock(nn.Module):
+    """reference :317-344 -- pre-activation block; the shortcut pools AFTER its 1x1 conv."""
+
+    def __init__(self, in_ch, out_ch, downsample=False):
+        super().__init__()
+        self.conv1, self.conv2 = _conv(in_ch, out_ch, 3), _conv(out_ch, out_ch, 3)
+        self.downsample = downsample
+        self.learnable_sc = (in_ch != out_ch) or downsample
+        if self.learnable_sc:
+            self.c_sc = _conv(in_ch, out_ch, 1)
+
+    def forward(self, x, pc):
+        h = fused_conv(x, self.conv1, pc, prologue=RELU)
+        sc = fused_conv(x, self.c_sc, pc, pool2=self.downsample) if self.learnable_sc else x
+        return fused_conv(h, self.conv2, pc, prologue=RELU, res=sc, pool2=self.downsample)
+
+
+class ResnetDiscriminator128_app(nn.Module):
+    def __init__(self, num_classes=0, input_dim=3, ch=64):
+        super().__init__()
+        self.num_classes, self.ch = num_classes, ch
+        self.block1 = OptimizedBlock(input_dim, ch, downsample=True)
+        self.block2 = ResBlock(ch, ch * 2, downsample=True)
+        self.block3 = ResBlock(ch * 2, ch * 4, downsample=True)
+        self.block4 = ResBlock(ch * 4, ch * 8, downsample=True)
+        self.block5 = ResBlock(ch * 8, ch * 16, downsample=True)
+        self.block6 = ResBlock(ch * 16, ch * 16, downsample=False)
+        self.l7 = GemmWeight("linear", 1, ch * 16, sn=True)
+        self.block_obj3 = ResBlock(ch * 2, ch * 4, downsample=False)
+        self.block_obj4 = ResBlock(ch * 4, ch * 8, downsample=False)
+        self.block_obj5 = ResBlock(ch * 8, ch * 16, downsample=True)
+        self.l_obj = GemmWeight("linear", 1, ch * 16, sn=True)
+        self.l_y = GemmWeight("embedding", num_classes, ch * 16, bias=False, sn=True)
+        self.app_conv = ResBlock(ch * 8, ch * 8, downsample=False)
+        self.l_y_app = GemmWeight("embedding", num_classes, ch * 8, bias=False, sn=True)
+        self.app = GemmWeight("linear", 1, ch * 16, sn=True)
+
+    def forward(self, x, y, rois, valid, pc):
+        """x (b,H,W,8) f32 NHWC (3 real channels); y (R,) labels; rois (R,5); valid (R,) int32."""
+        x = self.block1(x, pc)
+        x1 = self.block2(x, pc)
+        x2 = self.block3(x1, pc)
+        x = self.block4(x2, pc)
+        x = self.block5(x, pc)
+        x = self.block6(x, pc)
+        feat = F.relu(x).sum(dim=(1, 2))
+        out_im = F.linear(feat, arena_weight(self.l7, pc), self.l7.bias)
+
+        feat_s = self.block_obj4(self.block_obj3(x1, pc), pc)
+        feat_l = self.block_obj4(x2, pc)
+        obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0)  # (R,8,8,C)
+
+        # appearance head (reference :148-157): Gram of the ROI features + class embedding
+        a = F.relu(self.app_conv(obj, pc))
+        R, s2 = a.shape[0], a.shape[3]
+        A = a.view(R, -1, s2)
+        gram = torch.bmm(A.transpose(1, 2), A) / s2                       # (R, C, C)
+        wa = arena_weight(self.app, pc)                                   # (1, 2C)
+        emb_app = arena_weight(self.l_y_app, pc)[y]                       # (R, C)
+        out_app = (gram @ wa[0, :s2]).mean(dim=1, keepdim=True) + emb_app @ wa[0, s2:].unsqueeze(1) + self.app.bias
+
+        # projection head (reference :160-166)
+        f = F.relu(self.block_obj5(obj, pc)).sum(dim=(1, 2))              # (R, 16ch)
+        out_obj = F.linear(f, arena_weight(self.l_obj, pc), self.l_obj.bias)
+        out_obj = out_obj + torch.sum(arena_weight(self.l_y, pc)[y] * f, dim=1, keepdim=True)
+        return out_im, out_obj, out_app
+
+
+class CombineDiscriminator128_app(nn.Module):
+    """netD(images (b,3,H,W), bbox (b,o,4) xywh in [0,1], label (b,o,1)|(b,o)) ->
+    (d_img (b,1), d_obj (R,1), d_app (R,1)) with R = number of label != 0 rows, ordered large ROIs
+    first then small, original order within each (reference :145-146, 401-421). `bbox` is never
+    modified. `forward_padded` is the sync-free form used by the training loop."""
+
+    def __init__(self, num_classes=81):
+        super().__init__()
+        self.obD = ResnetDiscriminator128_app(num_classes=num_classes, input_dim=3)
+
+    def finalize(self, device, op_dtype=torch.bfloat16):
+        self.op_dtype = op_dtype
+        self.flat = FlatParams(self, device)
+        self.arena = WeightArena(self, self.flat, device, op_dtype)
+        return self
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()  # pending pass contexts stay: they are consumed by FlatAdam.step()
+
+    def forward_padded(self, images, bbox, label, need_wgrad=True):
+        if not images.is_cuda:
+            raise RuntimeError("layout2img_amd discriminators run on the GPU HIP path only")
+        b, o = bbox.size(0), bbox.size(1)
+        size = images.size(2)
+        bb = bbox.to(images.device).float()
+        xyxy = torch.stack((bb[..., 0], bb[..., 1], bb[..., 0] + bb[..., 2], bb[..., 1] + bb[..., 3]), dim=-1) * size
+        idx = torch.arange(b, device=images.device, dtype=torch.float32).view(b, 1, 1).expand(b, o, 1)
+        rois = torch.cat((idx, xyxy), dim=2).view(-1, 5).contiguous()
+        y = label.reshape(-1)
+        valid = (y != 0).to(torch.int32).contiguous()
+        x = F.pad(images.permute(0, 2, 3, 1), (0, 8 - images.size(1))).contiguous()
+        pc = self.obD_arena().prepare(training=self.training, need_wgrad=need_wgrad)
+        d_img, d_obj, d_app = self.obD(x, y, rois, valid, pc)
+        return d_img, d_obj, d_app, valid, rois
+
+    def obD_arena(self):
+        return self.arena
+
+    def forward(self, images, bbox, label, mask=None):
+        d_img, d_obj, d_app, valid, rois = self.forward_padded(images, bbox, label)
+        small = ((rois[:, 3] - rois[:, 1]) < 64) & ((rois[:, 4] - rois[:, 2]) < 64)
+        v = valid.bool()
+        order = torch.cat((torch.nonzero(v & ~small).view(-1), torch.nonzero(v & small).view(-1)))
+        return d_img, d_obj[order], d_app[order]

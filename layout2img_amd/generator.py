@@ -1,0 +1,381 @@
+"""Context-aware layout-to-image generators on the HIP path.
+
+Module boundary mirrors the reference (same class names, constructor arguments, forward signature,
+state_dict keys): `ResnetGenerator128_context` (model/resnet_generator_app_v2.py:400-506) and the
+VG `context_aware_generator` (model/resnet_generator_vg.py:639-727). Internally activations are
+NHWC f32 streams, every conv / linear runs through the MFMA implicit-GEMM kernel with a fused
+prologue (cast | ISLA norm+ReLU | BN+ReLU | IN+ReLU), and all weights come from the per-pass
+WeightArena. Small layout-sized tensors (masks, embeddings, box geometry) are handled with
+device-side torch ops.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .arena import FlatParams, GemmWeight, WeightArena
+from .ops import NormSpec, fused_conv
+
+
+def _pad_last(t, n):
+    return t if t.shape[-1] == n else F.pad(t, (0, n - t.shape[-1]))
+
+
+class BNState(nn.Module):
+    """Buffers (and optional affine parameters) of a batch-norm layer under the reference's key names."""
+
+    def __init__(self, c, affine=True, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.c, self.eps, self.momentum, self.affine = c, eps, momentum, affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones(c))
+            self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def spec(self, training, sync, cp=None):
+        """NormSpec + (weight, bias) padded to cp channels."""
+        cp = cp or self.c
+        rm, rv = self.running_mean, self.running_var
+        if cp != self.c:  # padded channels: keep private padded running stats
+            if not hasattr(self, "_rm_p") or self._rm_p.device != rm.device:
+                self._rm_p, self._rv_p = _pad_last(rm.detach().clone(), cp), F.pad(rv.detach().clone(), (0, cp - self.c), value=1.0)
+            else:
+                self._rm_p[:self.c].copy_(rm), self._rv_p[:self.c].copy_(rv)
+            running = (self._rm_p, self._rv_p)
+        else:
+            running = (rm, rv)
+        s = NormSpec(1 if self.affine else 2, eps=self.eps, relu=True, sync=sync, running=running, momentum=self.momentum,
+                     training=training)
+        w = b = None
+        if self.affine:
+            w, b = _pad_last(self.weight, cp), _pad_last(self.bias, cp)
+        return s, w, b
+
+    def commit(self, cp=None):
+        """Copy padded running stats back after a train-mode forward."""
+        if cp and cp != self.c and hasattr(self, "_rm_p"):
+            self.running_mean.copy_(self._rm_p[:self.c]), self.running_var.copy_(self._rv_p[:self.c])
+        if self.training:
+            self.num_batches_tracked += 1
+
+
+class ISLANorm(nn.Module):
+    """SpatialAdaptiveSynBatchNorm2d (reference model/norm_module.py:152-186): parameters only; the
+    computation is the fused norm prologue of the following convolution."""
+
+    def __init__(self, c, num_w):
+        super().__init__()
+        self.c = c
+        self.weight_proj = GemmWeight("linear", c, num_w, sn=True, eps=1e-12)
+        self.bias_proj = GemmWeight("linear", c, num_w, sn=True, eps=1e-12)
+        self.batch_norm2d = BNState(c, affine=False)
+
+    def project(self, w, pc, B, O):
+        gw = fused_conv(w, self.weight_proj, pc).view(B, O, -1)
+        gb = fused_conv(w, self.bias_proj, pc).view(B, O, -1)
+        return gw, gb
+
+    def spec(self, training, sync):
+        bn = self.batch_norm2d
+        return NormSpec(0, eps=bn.eps, relu=True, sync=sync, running=(bn.running_mean, bn.running_var),
+                        momentum=bn.momentum, training=training)
+
+
+def _resize_mask(mask, H, W):
+    return mask if mask.shape[-2:] == (H, W) else F.interpolate(mask, size=(H, W), mode="bilinear")
+
+
+class PSPModule(nn.Module):
+    """reference model/resnet_generator_app_v2.py:724-752. Pyramid stages are tiny (1..6 px) and stay in
+    torch ops; the 528->100 3x3 bottleneck (15 % of generator FLOPs) runs on the MFMA kernel."""
+
+    def __init__(self, features, out_features=100, sizes=(1, 2, 3, 6)):
+        super().__init__()
+        self.stages = nn.ModuleList([nn.Sequential(nn.AdaptiveAvgPool2d((s, s)), nn.Conv2d(features, out_features, 1, bias=False),
+                                                   nn.BatchNorm2d(out_features), nn.ReLU()) for s in sizes])
+        self.bottleneck = nn.ModuleList([GemmWeight("conv", out_features, features + len(sizes) * out_features, 3, bias=False, sn=False),
+                                         BNState(out_features)])
+        self.dropout_p = 0.1
+
+    def forward(self, feats, pc, sync):
+        # feats: (B,H,W,C) f32
+        B, H, W, C = feats.shape
+        f_nchw = feats.permute(0, 3, 1, 2)
+        priors = [F.interpolate(st(f_nchw), size=(H, W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1) for st in self.stages]
+        cat = torch.cat(priors + [feats], dim=3).contiguous()
+        conv, bn = self.bottleneck
+        h = fused_conv(cat, conv, pc)
+        spec, w, b = bn.spec(self.training, sync, conv.co_p)
+        y = ops.norm_act(h, spec, w, b)
+        bn.commit(conv.co_p)
+        if self.training and self.dropout_p > 0:  # nn.Dropout2d: whole channels per sample
+            keep = (torch.rand(B, 1, 1, y.shape[3], device=y.device) >= self.dropout_p).float() / (1 - self.dropout_p)
+            y = y * keep
+        return y
+
+
+class ConvMaskHead(nn.ModuleList):
+    """conv_mask of the generator ResBlock (reference :643-651). Keys 0,1,3 (plain) or 0,1 (PSP)."""
+
+    def __init__(self, c, psp):
+        if psp:
+            super().__init__([PSPModule(c, 100), GemmWeight("conv", 184, 100, 1, sn=False)])
+        else:
+            super().__init__([GemmWeight("conv", 100, c, 3, sn=False), BNState(100), nn.Identity(),
+                              GemmWeight("conv", 184, 100, 1, sn=False)])
+        self.psp = psp
+
+    def forward(self, x, pc, sync):
+        if self.psp:
+            y = self[0](x, pc, sync)
+            return fused_conv(y, self[1], pc)
+        conv, bn, _, out = self
+        h = fused_conv(x, conv, pc)
+        spec, w, b = bn.spec(self.training, sync, conv.co_p)
+        m = fused_conv(h, out, pc, prologue=spec, wproj=w, bproj=b)
+        bn.commit(conv.co_p)
+        return m
+
+
+class ResBlock(nn.Module):
+    """Generator up-block (reference model/resnet_generator_app_v2.py:628-678)."""
+
+    def __init__(self, in_ch, out_ch, upsample=True, num_w=308, predict_mask=True, psp_module=False):
+        super().__init__()
+        self.upsample = upsample
+        self.conv1 = GemmWeight("conv", out_ch, in_ch, 3, sn=True, eps=1e-4)
+        self.conv2 = GemmWeight("conv", out_ch, out_ch, 3, sn=True, eps=1e-4)
+        self.b1 = ISLANorm(in_ch, num_w)
+        self.b2 = ISLANorm(out_ch, num_w)
+        self.learnable_sc = in_ch != out_ch or upsample
+        if self.learnable_sc:
+            self.c_sc = GemmWeight("conv", out_ch, in_ch, 1, sn=True, eps=1e-4)
+        self.predict_mask = predict_mask
+        if predict_mask:
+            self.conv_mask = ConvMaskHead(out_ch, psp_module)
+
+    def forward(self, x, w, mask, pc, sync):
+        B, H, W, C = x.shape
+        O = mask.shape[1]
+        up = self.upsample
+        gw1, gb1 = self.b1.project(w, pc, B, O)
+        h = fused_conv(x, self.conv1, pc, prologue=self.b1.spec(self.training, sync), mask=_resize_mask(mask, H, W).contiguous(),
+                       wproj=gw1, bproj=gb1, up2=up)
+        H2, W2 = h.shape[1], h.shape[2]
+        sc = fused_conv(x, self.c_sc, pc, up2=up) if self.learnable_sc else x
+        gw2, gb2 = self.b2.project(w, pc, B, O)
+        out = fused_conv(h, self.conv2, pc, prologue=self.b2.spec(self.training, sync),
+                         mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc)
+        if self.training:
+            self.b1.batch_norm2d.num_batches_tracked += 1
+            self.b2.batch_norm2d.num_batches_tracked += 1
+        m = self.conv_mask(out, pc, sync) if self.predict_mask else None
+        return out, m
+
+
+def box_relational_embedding(f_g, dim_g=64, wave_len=1000.0):
+    """reference model/resnet_generator_app_v2.py:17-76 (xywh boxes read as corner boxes, as there)."""
+    B = f_g.size(0)
+    x_min, y_min, x_max, y_max = torch.chunk(f_g, 4, dim=-1)
+    cx, cy = (x_min + x_max) * 0.5, (y_min + y_max) * 0.5
+    w, h = (x_max - x_min) + 1.0, (y_max - y_min) + 1.0
+    dx = torch.log(torch.clamp(torch.abs((cx - cx.view(B, 1, -1)) / w), min=1e-3))
+    dy = torch.log(torch.clamp(torch.abs((cy - cy.view(B, 1, -1)) / h), min=1e-3))
+    dw = torch.log(w / w.view(B, 1, -1))
+    dh = torch.log(h / h.view(B, 1, -1))
+    pos = torch.stack((dx, dy, dw, dh), dim=-1)  # (B,O,O,4)
+    feat_range = torch.arange(dim_g / 8, device=f_g.device)
+    dim_mat = 1.0 / torch.pow(torch.tensor(wave_len, device=f_g.device), feat_range / (dim_g / 8))
+    mul = (100.0 * pos).unsqueeze(-1) * dim_mat.view(1, 1, 1, 1, -1)
+    mul = mul.reshape(B, pos.size(1), pos.size(2), -1)
+    return torch.cat((torch.sin(mul), torch.cos(mul)), -1)
+
+
+class BoxMultiHeadedAttention(nn.Module):
+    """reference model/resnet_generator_app_v2.py:123-214 (h = 1, dropout 0). `geometry=False` gives the
+    VG variant whose logits ignore the box geometry (model/resnet_generator_vg.py:115)."""
+
+    def __init__(self, h, d_model, geometry=True):
+        super().__init__()
+        assert h == 1
+        self.d = d_model
+        self.geometry = geometry
+        self.linears = nn.ModuleList([GemmWeight("linear", d_model, d_model, sn=False) for _ in range(4)])
+        self.WGs = nn.ModuleList([nn.Linear(64, 1, bias=True)])
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.layer_norm0 = nn.LayerNorm(d_model)
+
+    def forward(self, w0, bbox, y, pc):
+        B, O, D = w0.shape
+        dp = self.linears[0].ci_p
+        wp = _pad_last(w0, dp).reshape(B * O, 1, 1, dp)
+        q, k, v = [fused_conv(wp, l, pc).view(B, O, -1)[..., :D].contiguous() for l in self.linears[:3]]
+        geo = None
+        if self.geometry:
+            emb = box_relational_embedding(bbox)
+            geo = F.relu(self.WGs[0](emb.view(-1, 64))).view(B, O, O)
+        keyvalid = (y != 0).to(torch.int32).contiguous()
+        x = ops.box_attention(q, k, v, geo, keyvalid, 1.0 / math.sqrt(D))
+        # reference :197-198: with h = 1 this "concat heads" view shuffles each image's (o,d) matrix; kept as is
+        x = x.transpose(1, 2).contiguous().view(B, -1, D)
+        out0 = self.layer_norm0(x + w0)
+        o2 = fused_conv(_pad_last(out0, dp).reshape(B * O, 1, 1, dp), self.linears[3], pc).view(B, O, -1)[..., :D]
+        return self.layer_norm(o2 + out0)
+
+
+def masks_to_layout(boxes, masks, H):
+    """reference utils/bilinear.py:137-192: box-relative grid_sample of (b,o,M,M) masks onto HxH."""
+    b, o, _ = boxes.shape
+    M = masks.size(2)
+    bx = boxes.reshape(b * o, 4, 1, 1)
+    x0, y0, ww, hh = bx[:, 0], bx[:, 1], bx[:, 2], bx[:, 3]
+    X = torch.linspace(0, 1, steps=H, device=boxes.device).view(1, 1, H)
+    Y = torch.linspace(0, 1, steps=H, device=boxes.device).view(1, H, 1)
+    X = ((X - x0) / ww).expand(b * o, H, H)
+    Y = ((Y - y0) / hh).expand(b * o, H, H)
+    grid = torch.stack([X, Y], dim=3).mul(2).sub(1)
+    return F.grid_sample(masks.reshape(b * o, 1, M, M), grid, mode="bilinear", align_corners=False).view(b, o, H, H)
+
+
+def bbox_mask(bbox, H, W):
+    """reference model/resnet_generator_app_v2.py:697-721: hard rectangle indicator."""
+    b, o, _ = bbox.shape
+    N = b * o
+    bb = bbox.float().reshape(N, 4)
+    x0, y0, ww, hh = bb[:, 0:1], bb[:, 1:2], bb[:, 2:3], bb[:, 3:4]
+    X = (torch.linspace(0, 1, steps=W, device=bbox.device).view(1, W) - x0) / ww
+    Y = (torch.linspace(0, 1, steps=H, device=bbox.device).view(1, H) - y0) / hh
+    xo = ((X < 0) | (X > 1)).view(N, 1, W).expand(N, H, W)
+    yo = ((Y < 0) | (Y > 1)).view(N, H, 1).expand(N, H, W)
+    return (1.0 - (xo | yo).float()).view(b, o, H, W)
+
+
+class MaskRegressNetv2(nn.Module):
+    """reference model/mask_regression.py:58-102 (256 ch, InstanceNorm). v1 (:11-55): 128 ch, SyncBN."""
+
+    def __init__(self, obj_feat=308, mask_size=16, map_size=64, ch=256, instance=True):
+        super().__init__()
+        self.mask_size, self.map_size, self.ch, self.instance = mask_size, map_size, ch, instance
+        self.fc = GemmWeight("linear", ch * 16, obj_feat, sn=True, eps=1e-12)
+
+        def block(extra):
+            mods = [GemmWeight("conv", ch, ch, 3, sn=True, eps=1e-12), nn.Identity() if instance else BNState(ch), nn.Identity()]
+            return nn.ModuleList(mods + extra)
+        self.conv1, self.conv2 = block([]), block([])
+        self.conv3 = block([GemmWeight("conv", 1, ch, 1, sn=True, eps=1e-12), nn.Identity()])
+
+    def _spec(self, blk, sync):
+        if self.instance:
+            return NormSpec(2, eps=1e-5, relu=True, instance=True), None, None
+        return blk[1].spec(self.training, sync)
+
+    def forward(self, w, bbox, pc, sync):
+        b, o, _ = bbox.shape
+        N = b * o
+        x = fused_conv(w, self.fc, pc).view(N, self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
+        h = fused_conv(x, self.conv1[0], pc)
+        for blk_prev, blk, size in ((self.conv1, self.conv2, 8), (self.conv2, self.conv3, 16)):
+            spec, wa, ba = self._spec(blk_prev, sync)
+            a = ops.norm_act(h, spec, wa, ba)
+            if not self.instance:
+                blk_prev[1].commit()
+            a = F.interpolate(a.permute(0, 3, 1, 2), size=size, mode="bilinear").permute(0, 2, 3, 1).contiguous()
+            h = fused_conv(a, blk[0], pc)
+        spec, wa, ba = self._spec(self.conv3, sync)
+        m = fused_conv(h, self.conv3[3], pc, prologue=spec, wproj=wa, bproj=ba)[..., 0]
+        if not self.instance:
+            self.conv3[1].commit()
+        m = torch.sigmoid(m).view(b, o, self.mask_size, self.mask_size)
+        return masks_to_layout(bbox, m, self.map_size)
+
+
+class _GeneratorBase(nn.Module):
+    """Shared plumbing: flat parameters, weight arena, SyncBN hook, state_dict layout."""
+
+    def finalize(self, device, op_dtype=torch.bfloat16):
+        self.op_dtype = op_dtype
+        self.flat = FlatParams(self, device)
+        self.arena = WeightArena(self, self.flat, device, op_dtype)
+        self.sync = None  # set by parallel.attach_sync_bn for world_size > 1
+        return self
+
+    def init_parameter(self):
+        """reference :501-506: orthogonal_ on every parameter with dim > 1, zeros on '*bias'."""
+        for name, p in self.named_parameters():
+            if p.dim() > 1:
+                torch.nn.init.orthogonal_(p)
+            if name[-4:] == "bias":
+                torch.nn.init.constant_(p, 0)
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()  # pending pass contexts stay: they are consumed by FlatAdam.step()
+
+    def _latent(self, z, y):
+        b, o = z.size(0), z.size(1)
+        emb = self.label_embedding(y)
+        return torch.cat((z.reshape(b * o, -1), emb.reshape(b * o, -1)), dim=1).view(b, o, -1)
+
+
+class ResnetGenerator128_context(_GeneratorBase):
+    def __init__(self, ch=64, z_dim=128, num_classes=10, output_dim=3):
+        super().__init__()
+        self.num_classes, self.ch, self.output_dim = num_classes, ch, output_dim
+        self.label_embedding = nn.Embedding(num_classes, 180)
+        num_w = 128 + 180
+        self.context = BoxMultiHeadedAttention(1, num_w)
+        self.fc = GemmWeight("linear", 4 * 4 * 16 * ch, z_dim, sn=True, eps=1e-12)
+        self.res1 = ResBlock(ch * 16, ch * 16, num_w=num_w)
+        self.res2 = ResBlock(ch * 16, ch * 8, num_w=num_w)
+        self.res3 = ResBlock(ch * 8, ch * 4, num_w=num_w)
+        self.res4 = ResBlock(ch * 4, ch * 2, num_w=num_w, psp_module=True)
+        self.res5 = ResBlock(ch * 2, ch * 1, num_w=num_w, predict_mask=False)
+        self.final = nn.ModuleList([BNState(ch), nn.Identity(), GemmWeight("conv", output_dim, ch, 3, sn=True, eps=1e-4), nn.Identity()])
+        self.alpha1 = nn.Parameter(torch.zeros(1, 184, 1))
+        self.alpha2 = nn.Parameter(torch.zeros(1, 184, 1))
+        self.alpha3 = nn.Parameter(torch.zeros(1, 184, 1))
+        self.alpha4 = nn.Parameter(torch.zeros(1, 184, 1))
+        self.mask_regress = MaskRegressNetv2(num_w)
+        self.init_parameter()
+
+    def _stage_mask(self, stage_logits, bmask, bbox_mask_, alpha, y):
+        """reference :465-470: blend the regressed mask with the predicted semantic mask."""
+        B, H, W, _ = stage_logits.shape
+        b, o = y.shape
+        idx = y.view(b, 1, 1, o).expand(b, H, W, o)
+        seman = torch.sigmoid(torch.gather(stage_logits, 3, idx)).permute(0, 3, 1, 2)
+        seman = seman * F.interpolate(bbox_mask_, size=(H, W), mode="nearest")
+        a = torch.gather(torch.sigmoid(alpha).expand(b, -1, -1), dim=1, index=y.view(b, o, 1)).unsqueeze(-1)
+        return (F.interpolate(bmask, size=(H, W), mode="bilinear") * (1 - a) + seman * a).contiguous()
+
+    def forward(self, z, bbox, z_im=None, y=None, taps=None):
+        if not z.is_cuda:
+            raise RuntimeError("layout2img_amd generators run on the GPU HIP path only")
+        b, o = z.size(0), z.size(1)
+        bbox = bbox.to(z.device).float()
+        pc = self.arena.prepare(training=self.training)
+        w = self.context(self._latent(z, y), bbox, y, pc)
+        wp = _pad_last(w.reshape(b * o, -1), self.res1.b1.weight_proj.ci_p).reshape(b * o, 1, 1, -1).contiguous()
+        bmask = self.mask_regress(wp, bbox, pc, self.sync)
+        if z_im is None:
+            z_im = torch.randn((b, 128), device=z.device)
+        bbox_mask_ = bbox_mask(bbox, 64, 64)
+        x = fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc).view(b, 16 * self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
+        x, m = self.res1(x, wp, bmask, pc, self.sync)
+        stage = bmask
+        stages = []
+        for blk, alpha in ((self.res2, self.alpha1), (self.res3, self.alpha2), (self.res4, self.alpha3), (self.res5, self.alpha4)):
+            stage = self._stage_mask(m, bmask, bbox_mask_, alpha, y)
+            stages.append(stage)
+            x, m = blk(x, wp, stage, pc, self.sync)
+        bn, _, conv, _ = self.final
+        spec, wa, ba = bn.spec(self.training, self.sync)
+        pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
+        bn.commit()
+        img = torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()
+        if taps is not None:
+            taps.update(w=w, bmask=bmask, stages=stages, pre_tanh=pre[..., :self.output_dim])
+        return img

@@ -1,0 +1,425 @@
+"""Torch-facing wrappers of the C ABI (include/l2i.h) and the autograd Functions built on them.
+
+Internal tensor conventions: activations are plain contiguous NHWC tensors (B, H, W, C) -- linear
+layers are (rows, 1, 1, C); "streams" are f32, MFMA "operands" are `op_dtype` (bf16 | f32); masks
+are planar (B, O, H, W) f32. Everything here requires a GPU and the built library: there is no
+fallback of any kind.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .arena import GemmWeight, PassCtx
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _code(dtype):
+    return _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+
+
+def _chk(t, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError("layout2img_amd ops run on the GPU only (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError("layout2img_amd ops need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    return t
+
+
+# ----------------------------------------------------------------------------- raw kernels
+def cast_op(x, op_dtype, raw=True, act=False):
+    """f32 stream -> operand copies. Returns (raw_copy | None, relu_copy | None)."""
+    _chk(x, torch.float32)
+    r = torch.empty(x.shape, dtype=op_dtype, device=x.device) if raw else None
+    a = torch.empty(x.shape, dtype=op_dtype, device=x.device) if act else None
+    _lib.call("l2i_cast_op", x.data_ptr(), _p(r), _p(a), x.numel(), _code(op_dtype), _stream())
+    return r, a
+
+
+def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, up2=False, pool2=False, alpha=1.0,
+             want_f32=True, want_op=False, relu_op=False, want_raw=False):
+    """out = alpha*pool?(conv(up?(x))) + bias, masked, + res.  x_op (B,Hi,Wi,Ci) operand dtype."""
+    _chk(x_op)
+    B, Hi, Wi, Ci = x_op.shape
+    Ho, Wo = (2 * Hi, 2 * Wi) if up2 else (Hi, Wi)
+    Hq, Wq = (Ho // 2, Wo // 2) if pool2 else (Ho, Wo)
+    dev = x_op.device
+    out = torch.empty((B, Hq, Wq, co), dtype=torch.float32, device=dev) if want_f32 else None
+    out_op = torch.empty((B, Hq, Wq, co), dtype=x_op.dtype, device=dev) if want_op else None
+    out_raw = torch.empty((B, Hq, Wq, co), dtype=x_op.dtype, device=dev) if want_raw else None
+    if res is not None:
+        _chk(res, torch.float32)
+        assert res.shape == (B, Hq, Wq, co), (res.shape, (B, Hq, Wq, co))
+    if relu_mask is not None:
+        _chk(relu_mask, x_op.dtype)
+        assert relu_mask.shape == (B, Hq, Wq, co), (relu_mask.shape, (B, Hq, Wq, co))
+    _lib.call("l2i_conv2d_fwd", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
+              _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
+              float(alpha), _stream())
+    return out, out_op, out_raw
+
+
+def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0):
+    _chk(x_op)
+    _chk(dy_op, x_op.dtype)
+    B, Hi, Wi, Ci = x_op.shape
+    Ho, Wo = (2 * Hi, 2 * Wi) if up2 else (Hi, Wi)
+    _lib.call("l2i_conv2d_wgrad", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
+              Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _stream())
+
+
+def channel_stats(x2d, rows_per_group=None, want_sq=True):
+    """x2d: (rows, C) f32 view. Returns sums (G, C) and sqsums (G, C)|None."""
+    _chk(x2d, torch.float32)
+    rows, C = x2d.shape
+    rpg = rows if rows_per_group is None else rows_per_group
+    G = rows // rpg
+    sums = torch.zeros((G, C), dtype=torch.float32, device=x2d.device)
+    sq = torch.zeros((G, C), dtype=torch.float32, device=x2d.device) if want_sq else None
+    _lib.call("l2i_channel_stats", x2d.data_ptr(), rows, C, rpg, sums.data_ptr(), _p(sq), _stream())
+    return sums, sq
+
+
+# ----------------------------------------------------------------------------- prologues
+class Prologue:
+    """How a conv obtains its operand from an f32 stream: 'cast', 'relu', or a fused norm."""
+    kind = "cast"
+
+
+class NormSpec(Prologue):
+    """Normalise (+modulate) (+ReLU) prologue. mode 0 ISLA, 1 affine, 2 none; instance=True groups
+    statistics per image (InstanceNorm). `sync` is a callable all-reducing stat tensors in place."""
+    kind = "norm"
+
+    def __init__(self, mode, eps=1e-5, relu=True, instance=False, sync=None, running=None, momentum=0.1,
+                 training=True):
+        self.mode, self.eps, self.relu, self.instance = mode, eps, relu, instance
+        self.sync, self.running, self.momentum, self.training = sync, running, momentum, training
+
+
+def _norm_stats(x, spec: NormSpec):
+    """Returns (sums, sqsums, count, stat_stride). Updates running stats in train mode."""
+    B, H, W, C = x.shape
+    x2 = x.view(B * H * W, C)
+    if spec.instance:
+        sums, sq = channel_stats(x2, H * W)
+        return sums, sq, float(H * W), C
+    if not spec.training and spec.running is not None:
+        rm, rv = spec.running
+        return rm.view(1, C).clone(), (rv + rm * rm).view(1, C), 1.0, 0
+    sums, sq = channel_stats(x2)
+    count = float(B * H * W)
+    if spec.sync is not None:
+        count = spec.sync(sums, sq, count)
+    if spec.running is not None:
+        rm, rv = spec.running
+        with torch.no_grad():
+            mean = sums[0] / count
+            var = (sq[0] / count - mean * mean).clamp_min_(0)
+            rm.mul_(1 - spec.momentum).add_(mean, alpha=spec.momentum)
+            rv.mul_(1 - spec.momentum).add_(var * (count / max(count - 1.0, 1.0)), alpha=spec.momentum)
+    return sums, sq, count, 0
+
+
+def norm_fwd_raw(x, sums, sq, count, stat_stride, spec, mask, wproj, bproj, op_dtype, want_f32=False):
+    B, H, W, C = x.shape
+    O = mask.shape[1] if mask is not None else 0
+    if spec.mode == 0:
+        _chk(mask, torch.float32), _chk(wproj, torch.float32), _chk(bproj, torch.float32)
+        assert mask.shape == (B, O, H, W) and wproj.shape == (B, O, C) and bproj.shape == (B, O, C)
+        psb, pso = O * C, C
+    else:
+        psb = pso = 0
+    out_op = torch.empty((B, H, W, C), dtype=op_dtype, device=x.device)
+    out_f = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device) if want_f32 else None
+    _lib.call("l2i_norm_mod_fwd", x.data_ptr(), B, H * W, C, sums.data_ptr(), sq.data_ptr(), float(count), float(spec.eps),
+              stat_stride, _p(mask), O, _p(wproj), _p(bproj), psb, pso, spec.mode, int(spec.relu), out_op.data_ptr(),
+              _p(out_f), _code(op_dtype), _stream())
+    return out_op, out_f
+
+
+def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, add_to=None, need_mask_grad=True):
+    """Returns (dx, dwproj, dbproj, dmask). dy is overwritten with dxhat."""
+    B, H, W, C = x.shape
+    O = mask.shape[1] if mask is not None else 0
+    dev = x.device
+    G = sums.shape[0]
+    s1 = torch.zeros((G, C), dtype=torch.float32, device=dev)
+    s2 = torch.zeros((G, C), dtype=torch.float32, device=dev)
+    dw = db = dm = None
+    psb = pso = 0
+    if spec.mode == 0:
+        dw, db = torch.zeros_like(wproj), torch.zeros_like(bproj)
+        dm = torch.zeros_like(mask) if need_mask_grad else None
+        psb, pso = O * C, C
+    elif spec.mode == 1:
+        dw, db = torch.zeros_like(wproj), torch.zeros_like(bproj)
+    _lib.call("l2i_norm_mod_bwd_a", x.data_ptr(), dy.data_ptr(), B, H * W, C, sums.data_ptr(), sq.data_ptr(), float(count),
+              float(spec.eps), stat_stride, _p(mask), O, _p(wproj), _p(bproj), psb, pso, spec.mode, int(spec.relu),
+              dy.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(dw), _p(db), _p(dm), _stream())
+    frozen = (not spec.training) and spec.running is not None and not spec.instance
+    if frozen:
+        raise RuntimeError("backward through eval-mode batch norm is not part of the hot path")
+    if spec.sync is not None and not spec.instance:
+        spec.sync(s1, s2, None)
+    rpg = H * W if spec.instance else B * H * W
+    dx = add_to if add_to is not None else dy
+    _lib.call("l2i_norm_bwd_b", x.data_ptr(), dy.data_ptr(), sums.data_ptr(), sq.data_ptr(), s1.data_ptr(), s2.data_ptr(),
+              dx.data_ptr(), B * H * W, C, rpg, float(count), float(spec.eps), int(add_to is not None), _stream())
+    return dx, dw, db, dm
+
+
+# ----------------------------------------------------------------------------- fused conv Function
+class FusedConvFn(Function):
+    """[prologue] -> implicit-GEMM conv/linear (+bias, +res, up2 / pool2) with f32 streams on both
+    sides. The operand tensor produced by the prologue never becomes an autograd edge, so its
+    gradient stays f32.
+
+    forward(x, res, bias, mask, wproj, bproj, holder, passctx, prologue, up2, pool2)
+    """
+
+    @staticmethod
+    def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2):
+        _chk(x, torch.float32)
+        opd = pc.arena.op_dtype
+        B, H, W, C = x.shape
+        assert C == holder.ci_p, (C, holder.ci_p, holder.kind)
+        stats = None
+        if pro.kind == "norm":
+            sums, sq, count, sstride = _norm_stats(x, pro)
+            x_op, _ = norm_fwd_raw(x, sums, sq, count, sstride, pro, mask, wproj, bproj, opd)
+            stats = (sums, sq, count, sstride)
+        elif pro.kind == "relu":
+            _, x_op = cast_op(x, opd, raw=False, act=True)
+        else:
+            x_op, _ = cast_op(x, opd, raw=True, act=False)
+        bias_p = None
+        if bias is not None:
+            bias_p = bias if bias.numel() == holder.co_p else torch.nn.functional.pad(bias, (0, holder.co_p - bias.numel()))
+        out, _, _ = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p, res=res, up2=up2,
+                             pool2=pool2, alpha=0.25 if pool2 else 1.0)
+        ctx.holder, ctx.pc, ctx.pro, ctx.up2, ctx.pool2, ctx.stats = holder, pc, pro, up2, pool2, stats
+        ctx.has_bias, ctx.has_res = bias is not None, res is not None
+        keep_x = x if pro.kind == "norm" else None
+        ctx.save_for_backward(keep_x, x_op, mask, wproj, bproj)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, pc, pro = ctx.holder, ctx.pc, ctx.pro
+        x, x_op, mask, wproj, bproj = ctx.saved_tensors
+        dy = dy.contiguous()
+        opd = pc.arena.op_dtype
+        need_x = ctx.needs_input_grad[0]
+        need_mod = pro.kind == "norm" and pro.mode in (0, 1)
+        dy_op, _ = cast_op(dy, opd, raw=True, act=False)
+        alpha = 0.25 if ctx.pool2 else 1.0
+        d_bias = None
+        if pc.need_wgrad:
+            wgrad_raw(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha)
+            if ctx.has_bias:
+                d_bias = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False)[0][0][:h.co]
+        dx = d_mask = d_w = d_b = None
+        if need_x or need_mod:
+            # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
+            relu_mask = x_op if pro.kind == "relu" else None
+            dxo, _, _ = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
+                                 pool2=ctx.up2, alpha=alpha)
+            if pro.kind == "norm":
+                sums, sq, count, sstride = ctx.stats
+                dx, d_w, d_b, d_mask = norm_bwd_raw(x, dxo, sums, sq, count, sstride, pro, mask, wproj, bproj,
+                                                    need_mask_grad=mask is not None and ctx.needs_input_grad[3])
+            else:
+                dx = dxo
+        d_res = dy if ctx.has_res else None
+        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None
+
+
+def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False):
+    pro = prologue if prologue is not None else _CAST
+    return FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2)
+
+
+class _Simple(Prologue):
+    def __init__(self, kind):
+        self.kind = kind
+
+
+_CAST, RELU = _Simple("cast"), _Simple("relu")
+
+
+class NormActFn(Function):
+    """Stand-alone normalise (+modulate) (+ReLU) with an f32 result, for the places where something
+    other than a convolution follows (bilinear upsampling in the mask regressor, Dropout2d in PSP)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, wproj, bproj, spec):
+        _chk(x, torch.float32)
+        sums, sq, count, sstride = _norm_stats(x, spec)
+        out, _ = norm_fwd_raw(x, sums, sq, count, sstride, spec, mask, wproj, bproj, torch.float32)
+        ctx.spec, ctx.stats = spec, (sums, sq, count, sstride)
+        ctx.save_for_backward(x, mask, wproj, bproj)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mask, wproj, bproj = ctx.saved_tensors
+        sums, sq, count, sstride = ctx.stats
+        dy = dy.contiguous().clone()
+        dx, d_w, d_b, d_mask = norm_bwd_raw(x, dy, sums, sq, count, sstride, ctx.spec, mask, wproj, bproj,
+                                            need_mask_grad=mask is not None and ctx.needs_input_grad[1])
+        return dx, d_mask, d_w, d_b, None
+
+
+def norm_act(x, spec, wproj=None, bproj=None, mask=None):
+    return NormActFn.apply(x, mask, wproj, bproj, spec)
+
+
+class ArenaWeightFn(Function):
+    """Expose the normalised weight Wbar[:Co,:Ci] of a linear/embedding holder to glue code; the
+    gradient flowing back is added to the pass's dWbar accumulator (spectral-norm backward happens
+    in WeightArena.flush_grads)."""
+
+    @staticmethod
+    def forward(ctx, w_param, holder: GemmWeight, pc: PassCtx):
+        ctx.holder, ctx.pc = holder, pc
+        assert holder.kh == 1
+        return pc.fwd_pack(holder).view(holder.npad, holder.kpad)[:holder.co, :holder.ci].float()
+
+    @staticmethod
+    def backward(ctx, g):
+        h, pc = ctx.holder, ctx.pc
+        if pc.need_wgrad:
+            pc.dw_slice(h).view(h.co_p, h.kp)[:h.co, :h.ci].add_(g)
+        return None, None, None
+
+
+def arena_weight(holder, pc):
+    return ArenaWeightFn.apply(holder.w, holder, pc)
+
+
+# ----------------------------------------------------------------------------- ROIAlign
+class RoiAlignFn(Function):
+    @staticmethod
+    def forward(ctx, feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling):
+        _chk(feat_s, torch.float32)
+        B, Hs, Ws, C = feat_s.shape
+        Hl = Wl = 0
+        if feat_l is not None:
+            _chk(feat_l, torch.float32)
+            _, Hl, Wl, _ = feat_l.shape
+        rois = _chk(rois.contiguous(), torch.float32)
+        R = rois.shape[0]
+        out = torch.empty((R, P, P, C), dtype=torch.float32, device=feat_s.device)
+        _lib.call("l2i_roi_align_fwd", feat_s.data_ptr(), _p(feat_l), rois.data_ptr(), _p(valid), out.data_ptr(), R, C, P,
+                  Hs, Ws, float(scale_s), Hl, Wl, float(scale_l), float(thr), sampling, _stream())
+        ctx.save_for_backward(rois, valid)
+        ctx.cfg = (P, scale_s, scale_l, thr, sampling, feat_s.shape, None if feat_l is None else feat_l.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rois, valid = ctx.saved_tensors
+        P, scale_s, scale_l, thr, sampling, shp_s, shp_l = ctx.cfg
+        g = g.contiguous()
+        ds = torch.zeros(shp_s, dtype=torch.float32, device=g.device)
+        dl = torch.zeros(shp_l, dtype=torch.float32, device=g.device) if shp_l is not None else None
+        Hl, Wl = (shp_l[1], shp_l[2]) if shp_l is not None else (0, 0)
+        _lib.call("l2i_roi_align_bwd", rois.data_ptr(), _p(valid), g.data_ptr(), ds.data_ptr(), _p(dl), rois.shape[0],
+                  shp_s[3], P, shp_s[1], shp_s[2], float(scale_s), Hl, Wl, float(scale_l), float(thr), sampling, _stream())
+        return ds, dl, None, None, None, None, None, None, None
+
+
+def roi_align(feat_s, feat_l, rois, valid, P=8, scale_s=0.25, scale_l=0.125, thr=64.0, sampling=0):
+    return RoiAlignFn.apply(feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling)
+
+
+# ----------------------------------------------------------------------------- attention core
+class BoxAttentionFn(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, geo, keyvalid, scale):
+        q, k, v = _chk(q.contiguous(), torch.float32), _chk(k.contiguous(), torch.float32), _chk(v.contiguous(), torch.float32)
+        B, O, D = q.shape
+        geo_c = None if geo is None else _chk(geo.contiguous(), torch.float32)
+        out = torch.empty_like(q)
+        prob = torch.empty((B, O, O), dtype=torch.float32, device=q.device)
+        _lib.call("l2i_box_attention_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(geo_c), _p(keyvalid), out.data_ptr(),
+                  prob.data_ptr(), B, O, D, float(scale), _stream())
+        ctx.save_for_backward(q, k, v, geo_c, prob)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, geo, prob = ctx.saved_tensors
+        B, O, D = q.shape
+        g = g.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dgeo = torch.empty_like(geo) if geo is not None else None
+        _lib.call("l2i_box_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(geo), prob.data_ptr(), g.data_ptr(),
+                  dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(dgeo), B, O, D, float(ctx.scale), _stream())
+        return dq, dk, dv, dgeo, None, None
+
+
+def box_attention(q, k, v, geo, keyvalid, scale):
+    return BoxAttentionFn.apply(q, k, v, geo, keyvalid, scale)
+
+
+# ----------------------------------------------------------------------------- losses
+class HingeFn(Function):
+    """mode 0: mean relu(1-x) | 1: mean relu(1+x) | 2: -mean x, over rows with valid != 0."""
+
+    @staticmethod
+    def forward(ctx, x, valid, mode, weight, count):
+        xc = _chk(x.contiguous().view(-1), torch.float32)
+        loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(xc)
+        _lib.call("l2i_hinge_fwd_bwd", xc.data_ptr(), _p(valid), xc.numel(), mode, float(weight), _p(count),
+                  loss.data_ptr(), grad.data_ptr(), _stream())
+        ctx.save_for_backward(grad)
+        ctx.shape = x.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g).view(ctx.shape), None, None, None, None
+
+
+def hinge(x, valid, mode, weight=1.0, count=None):
+    """count: optional 1-element f32 device tensor = global number of rows (data parallel)."""
+    return HingeFn.apply(x, valid, mode, weight, count)
+
+
+class L1Fn(Function):
+    @staticmethod
+    def forward(ctx, a, b, weight):
+        ac, bc = _chk(a.contiguous(), torch.float32), _chk(b.contiguous(), torch.float32)
+        loss = torch.zeros((), dtype=torch.float32, device=a.device)
+        grad = torch.empty_like(ac)
+        _lib.call("l2i_l1_fwd_bwd", ac.data_ptr(), bc.data_ptr(), ac.numel(), float(weight), loss.data_ptr(), grad.data_ptr(),
+                  _stream())
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def l1_loss(a, b, weight=1.0):
+    return L1Fn.apply(a, b, weight)
+
+
+def adam_step(flat, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _lib.call("l2i_adam_step", flat.data.data_ptr(), flat.grad.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel, float(lr),
+              float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())

@@ -1,0 +1,77 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Replaces the reference's single-process nn.DataParallel + thread-based SyncBN
+(train_context_app_v2.py:108-110, model/sync_batchnorm/batchnorm.py:59-125, comm.py):
+  * gradients: the flat gradient buffer is all-reduced (SUM) in a few large contiguous chunks --
+    no per-step parameter broadcast, no bucket copies (xGMI rings are per-link bound, so chunks
+    are large: default 64 MiB);
+  * SyncBN: each BN layer all-reduces its [sum, sqsum] (forward) and [s1, s2] (backward) vectors;
+  * losses divide by GLOBAL counts, so SUM-reduced gradients equal the single-process gradients
+    of the global batch (DataParallel semantics).
+Everything here works on any backend (the CPU tests run it over gloo).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the process group from torchrun's environment. Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_flat_(flat_grad, chunk_bytes=64 << 20, async_op=False):
+    """SUM all-reduce of a flat buffer in large contiguous chunks (in place). Returns work handles."""
+    if world_size() == 1:
+        return []
+    n = flat_grad.numel()
+    step = max(1, chunk_bytes // flat_grad.element_size())
+    works = []
+    for s in range(0, n, step):
+        w = dist.all_reduce(flat_grad[s:min(n, s + step)], op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
+
+
+def sync_bn_stats(a, b, count):
+    """SyncBN exchange: all-reduce two stat tensors (one message) and scale the element count.
+
+    Forward: (sum, sqsum, count) -> returns global count. Backward: (s1, s2, None) -> returns None.
+    """
+    ws = world_size()
+    if ws == 1:
+        return count
+    buf = torch.cat((a.reshape(-1), b.reshape(-1)))
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    a.copy_(buf[:a.numel()].view_as(a))
+    b.copy_(buf[a.numel():].view_as(b))
+    return None if count is None else count * ws
+
+
+def global_count(local_count_tensor):
+    """All-reduce a 1-element f32 device tensor holding a row count (stays on the device)."""
+    if world_size() > 1:
+        dist.all_reduce(local_count_tensor, op=dist.ReduceOp.SUM)
+    return local_count_tensor
+
+
+def broadcast_flat_(flat, src=0):
+    if world_size() > 1:
+        dist.broadcast(flat, src=src)

@@ -1,0 +1,88 @@
+"""The GAN training iteration of reference train_context_app_v2.py:148-189 on the HIP path.
+
+D step: hinge(real) + hinge(fake) over (image x0.1, object x1, appearance x1), Adam.
+G step: -D(fake) terms + L1(fake, real), Adam. (The VGG perceptual term needs downloaded
+weights and is excluded, as stated in BASELINE.md / DESIGN.md.) Adam betas (0, 0.999), lr 1e-4.
+
+Differences from the reference that do not change the mathematics:
+  * the third D forward (G step) skips D's weight gradients -- the reference computes and then
+    discards them at the next netD.zero_grad() (:156,178-188);
+  * ROI rows are a fixed b*o with a validity mask, losses average over valid rows;
+  * under data parallelism losses divide by global counts and gradients are SUM all-reduced.
+"""
+import torch
+
+from . import ops, parallel
+
+
+class FlatAdam:
+    """torch.optim.Adam(betas=(0, 0.999)) semantics over a network's flat parameter buffer
+    (train_context_app_v2.py:112-127). step(): spectral-norm backward flush -> gradient all-reduce
+    -> one fused Adam launch."""
+
+    def __init__(self, net, lr=1e-4, betas=(0.0, 0.999), eps=1e-8):
+        self.net, self.lr, self.betas, self.eps = net, lr, betas, eps
+        self.m = torch.zeros_like(net.flat.data)
+        self.v = torch.zeros_like(net.flat.data)
+        self.t = 0
+
+    def step(self):
+        self.net.arena.flush_grads()
+        parallel.allreduce_flat_(self.net.flat.grad)
+        self.t += 1
+        ops.adam_step(self.net.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t)
+
+
+class GanTrainer:
+    def __init__(self, netG, netD, g_lr=1e-4, d_lr=1e-4, lamb_obj=1.0, lamb_app=1.0, lamb_img=0.1, z_dim=128):
+        self.netG, self.netD = netG, netD
+        self.g_opt, self.d_opt = FlatAdam(netG, g_lr), FlatAdam(netD, d_lr)
+        self.l_obj, self.l_app, self.l_img, self.z_dim = lamb_obj, lamb_app, lamb_img, z_dim
+        self.world = parallel.world_size()
+        if self.world > 1:
+            netG.sync = parallel.sync_bn_stats
+            parallel.broadcast_flat_(netG.flat.data)
+            parallel.broadcast_flat_(netD.flat.data)
+            parallel.broadcast_flat_(netG.arena.sn_flat.data)
+            parallel.broadcast_flat_(netD.arena.sn_flat.data)
+
+    def _counts(self, valid, b):
+        if self.world == 1:
+            return None, None
+        n_roi = parallel.global_count(valid.sum().float().view(1))
+        n_img = torch.full((1,), float(b * self.world), device=valid.device)
+        return n_roi, n_img
+
+    def _d_terms(self, outs, valid, mode, n_roi, n_img):
+        d_img, d_obj, d_app = outs
+        return (ops.hinge(d_obj, valid, mode, self.l_obj, n_roi) + ops.hinge(d_img, None, mode, self.l_img, n_img) +
+                ops.hinge(d_app, valid, mode, self.l_app, n_roi))
+
+    def step(self, real, label, bbox, z=None, z_im=None):
+        """One iteration. real (b,3,H,W) in [-1,1]; label (b,o) int64; bbox (b,o,4). Returns loss tensors
+        (device scalars, no host sync)."""
+        netG, netD = self.netG, self.netD
+        b, o = label.shape[0], label.shape[1]
+        y = label.view(b, o)
+        if z is None:
+            z = torch.randn(b, o, self.z_dim, device=real.device)
+        # ---- D step (reference :156-174)
+        netD.zero_grad()
+        *outs_r, valid, _ = netD.forward_padded(real, bbox, y)
+        n_roi, n_img = self._counts(valid, b)
+        d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
+        fake = netG(z, bbox, z_im=z_im, y=y)
+        *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y)
+        d_loss_fake = self._d_terms(outs_f, valid, 1, n_roi, n_img)
+        d_loss = d_loss_real + d_loss_fake
+        d_loss.backward()
+        self.d_opt.step()
+        # ---- G step (reference :178-189)
+        netG.zero_grad()
+        *outs_g, _, _ = netD.forward_padded(fake, bbox, y, need_wgrad=False)
+        g_adv = self._d_terms(outs_g, valid, 2, n_roi, n_img)
+        pixel = ops.l1_loss(fake, real, 1.0 / self.world)
+        g_loss = g_adv + pixel
+        g_loss.backward()
+        self.g_opt.step()
+        return {"d_loss": d_loss.detach(), "g_loss": g_loss.detach(), "pixel": pixel.detach(), "fake": fake.detach()}

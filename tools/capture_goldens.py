@@ -1,0 +1,223 @@
+"""Generate tests/golden/*.npz by importing the REAL reference (build container only).
+
+Patches applied to make the reference importable/runnable on CPU:
+ (1) stub `torchvision` (`ops.RoIAlign` = the oracle's restated roi_align, `ops.RoIPool`, `models`);
+ (2) `torch.Tensor.cuda` -> identity; (3) always pass z_im; (4) clone bbox per D call;
+ (5) Adam betas as floats; (6) Dropout2d p = 0.
+Parameters come from tests/golden/recipe.py (loaded into the reference with load_state_dict), so the
+fixtures hold only key names/shapes, inputs and the reference's outputs. Nothing of the reference's
+source travels. Run:  python tools/capture_goldens.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import model as O  # noqa: E402
+from tests.golden import recipe  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def patch_env():
+    class RoIAlign(nn.Module):
+        def __init__(self, output_size, spatial_scale, sampling_ratio):
+            super().__init__()
+            self.o, self.s, self.r = output_size, spatial_scale, sampling_ratio
+
+        def forward(self, x, rois):
+            return O.roi_align(x, rois, self.o[0], self.s, self.r)
+
+    tv = types.ModuleType("torchvision")
+    tv.ops = types.ModuleType("torchvision.ops")
+    tv.ops.RoIAlign = RoIAlign
+    tv.ops.RoIPool = RoIAlign
+    tv.models = types.ModuleType("torchvision.models")
+    sys.modules.update({"torchvision": tv, "torchvision.ops": tv.ops, "torchvision.models": tv.models})
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+
+
+def shapes_of(m):
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def load(m, seed):
+    sd = recipe.make_state_dict(shapes_of(m), seed)
+    m.load_state_dict(sd)
+    for mod in m.modules():
+        if isinstance(mod, nn.Dropout2d):
+            mod.p = 0.0
+    return m
+
+
+def keys_blob(shapes):
+    ks = sorted(shapes)
+    return np.array(ks), np.array([",".join(map(str, shapes[k])) for k in ks])
+
+
+def grad_norms(m):
+    names = sorted(n for n, p in m.named_parameters())
+    d = dict(m.named_parameters())
+    return np.array(names), np.array([0.0 if d[n].grad is None else float(d[n].grad.norm()) for n in names], dtype=np.float64)
+
+
+def capture_generator(kind):
+    if kind == "coco":
+        from model.resnet_generator_app_v2 import ResnetGenerator128_context as G
+        o, ncls, seed = 8, 184, 11
+    else:
+        from model.resnet_generator_vg import context_aware_generator as G
+        o, ncls, seed = 31, 179, 12
+    torch.manual_seed(0)
+    g = load(G(num_classes=ncls, output_dim=3), seed)
+    inp = recipe.make_inputs(2, o, ncls, seed + 100)
+    ks, shp = keys_blob(shapes_of(g))
+    rec = dict(keys=ks, shapes=shp, **{k: v.numpy() for k, v in inp.items()})
+    g.train()
+    taps = {}
+    hooks = []
+    if kind == "coco":
+        def tap(name):
+            def hook(m, i, out):
+                taps[name] = out.detach().numpy().copy()
+            return hook
+
+        def tap_res(k):
+            def hook(m, i, out):
+                taps[f"res{k}"] = out[0].detach().numpy().copy()
+                taps[f"stage_in{k}"] = i[2].detach().numpy().copy()
+            return hook
+        hooks.append(g.mask_regress.register_forward_hook(tap("bmask")))
+        hooks.append(g.context.register_forward_hook(tap("w")))
+        hooks.append(g.final[2].register_forward_hook(tap("pre_tanh")))
+        for k in (1, 2, 3, 4, 5):
+            hooks.append(getattr(g, f"res{k}").register_forward_hook(tap_res(k)))
+    out1 = g(inp["z"], inp["bbox"], inp["z_im"], inp["y"])
+    # scalar loss for the backward golden: fixed random projection of the image
+    proj = torch.randn(out1.shape, generator=torch.Generator().manual_seed(5))
+    g.zero_grad()
+    (out1 * proj).sum().backward()
+    gn_names, gn = grad_norms(g)
+    rec.update(out_train1=out1.detach().numpy(), grad_names=gn_names, grad_norms=gn,
+               grad_alpha1=g.alpha1.grad.numpy().copy() if kind == "coco" else np.zeros(1),
+               grad_fc_bias=g.fc.bias.grad.numpy().copy(),
+               grad_emb=g.label_embedding.weight.grad.numpy().copy())
+    if kind == "coco":
+        rec.update(tap_w=taps["w"], tap_bmask=taps["bmask"], tap_pre_tanh=taps["pre_tanh"],
+                   tap_res1=taps["res1"], tap_res3_mean=taps["res3"].mean(axis=(0, 2, 3)),
+                   tap_stage_in2=taps["stage_in2"], tap_stage_in5=taps["stage_in5"][:, :, ::4, ::4])
+    for h in hooks:
+        h.remove()
+    out2 = g(inp["z"], inp["bbox"], inp["z_im"], inp["y"])
+    g.eval()
+    out_eval = g(inp["z"], inp["bbox"], inp["z_im"], inp["y"])
+    rec.update(out_train2_sub=out2.detach().numpy()[:, :, ::2, ::2], out_eval=out_eval.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, f"g_{kind}.npz"), **rec)
+    print(kind, "G captured; |out|max", float(out1.abs().max()), "eval", float(out_eval.abs().max()))
+
+
+def capture_discriminator():
+    from model.rcnn_discriminator_app import CombineDiscriminator128_app as D
+    torch.manual_seed(0)
+    d = load(D(num_classes=184), 21)
+    inp = recipe.make_inputs(2, 8, 184, 121)
+    ks, shp = keys_blob(shapes_of(d))
+    rec = dict(keys=ks, shapes=shp, **{k: v.numpy() for k, v in inp.items()})
+    d.train()
+    label = inp["y"].unsqueeze(-1)
+    real = inp["real"].clone().requires_grad_(True)
+    o1 = d(real, inp["bbox"].clone(), label)
+    d.zero_grad()
+    g = torch.Generator().manual_seed(6)
+    loss = sum((t * torch.randn(t.shape, generator=g)).sum() for t in o1)
+    loss.backward()
+    gn_names, gn = grad_norms(d)
+    rec.update(train1_img=o1[0].detach().numpy(), train1_obj=o1[1].detach().numpy(), train1_app=o1[2].detach().numpy(),
+               grad_names=gn_names, grad_norms=gn, grad_input_sub=real.grad.numpy()[:, :, ::4, ::4].copy(),
+               grad_l7_w=d.obD.l7.weight_orig.grad.numpy().copy())
+    o2 = d(inp["real"], inp["bbox"].clone(), label)
+    d.eval()
+    oe = d(inp["real"], inp["bbox"].clone(), label)
+    rec.update(train2_img=o2[0].detach().numpy(), train2_obj=o2[1].detach().numpy(), train2_app=o2[2].detach().numpy(),
+               eval_img=oe[0].detach().numpy(), eval_obj=oe[1].detach().numpy(), eval_app=oe[2].detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "d_coco.npz"), **rec)
+    print("D captured", [tuple(t.shape) for t in o1])
+
+
+def capture_train_loop():
+    """Two iterations of train_context_app_v2.py:148-189 (VGG term omitted) on reference modules."""
+    from model.rcnn_discriminator_app import CombineDiscriminator128_app as D
+    from model.resnet_generator_app_v2 import ResnetGenerator128_context as G
+    torch.manual_seed(0)
+    netG, netD = load(G(num_classes=184, output_dim=3), 31), load(D(num_classes=184), 32)
+    netG.train(), netD.train()
+    g_opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in netG.parameters()], betas=(0.0, 0.999))
+    d_opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in netD.parameters()], betas=(0.0, 0.999))
+    relu = torch.nn.ReLU()
+    rec = {}
+    for it in range(2):
+        inp = recipe.make_inputs(2, 8, 184, 200 + it)
+        real, label, bbox = inp["real"], inp["y"].unsqueeze(-1), inp["bbox"]
+        netD.zero_grad()
+        r_im, r_obj, r_app = netD(real, bbox.clone(), label)
+        fake = netG(inp["z"], bbox, inp["z_im"], label.squeeze(-1))
+        f_im, f_obj, f_app = netD(fake.detach(), bbox.clone(), label)
+        d_loss = (1.0 * (relu(1 - r_obj).mean() + relu(1 + f_obj).mean()) + 0.1 * (relu(1 - r_im).mean() + relu(1 + f_im).mean()) +
+                  1.0 * (relu(1 - r_app).mean() + relu(1 + f_app).mean()))
+        d_loss.backward()
+        d_opt.step()
+        netG.zero_grad()
+        g_im, g_obj, g_app = netD(fake, bbox.clone(), label)
+        pixel = torch.nn.L1Loss()(fake, real).mean()
+        g_loss = -g_obj.mean() * 1.0 - g_im.mean() * 0.1 + pixel - 1.0 * g_app.mean()
+        g_loss.backward()
+        g_opt.step()
+        rec[f"d_loss{it}"], rec[f"g_loss{it}"], rec[f"pixel{it}"] = float(d_loss), float(g_loss), float(pixel)
+        rec[f"fake_sub{it}"] = fake.detach().numpy()[:, :, ::4, ::4]
+    names = sorted(n for n, _ in netG.named_parameters())
+    dg, dd = dict(netG.named_parameters()), dict(netD.named_parameters())
+    rec["g_param_names"] = np.array(names)
+    rec["g_param_sums"] = np.array([float(dg[n].detach().double().sum()) for n in names])
+    dn = sorted(n for n, _ in netD.named_parameters())
+    rec["d_param_names"] = np.array(dn)
+    rec["d_param_sums"] = np.array([float(dd[n].detach().double().sum()) for n in dn])
+    np.savez_compressed(os.path.join(OUT, "train_loop.npz"), **rec)
+    print("loop captured", {k: v for k, v in rec.items() if isinstance(v, float)})
+
+
+def capture_small_ops():
+    """Known answers the survey lists for masks_to_layout / bbox_mask."""
+    from model.resnet_generator_app_v2 import bbox_mask
+    from utils.bilinear import masks_to_layout
+    boxes = torch.tensor([[[0.0, 0.0, 1.0, 1.0], [0.25, 0.25, 0.5, 0.5], [-0.6, -0.6, 0.5, 0.5]]])
+    m = masks_to_layout(boxes, torch.ones(1, 3, 16, 16), 64)
+    g = torch.Generator().manual_seed(3)
+    rm = torch.rand(1, 3, 16, 16, generator=g)
+    bm = bbox_mask(torch.zeros(1), boxes, 64, 64)
+    np.savez_compressed(os.path.join(OUT, "small_ops.npz"), boxes=boxes.numpy(), ones_layout=m.numpy(), rand_masks=rm.numpy(),
+                        rand_layout=masks_to_layout(boxes, rm, 64).numpy(), bbox_mask=bm.numpy())
+    print("small ops: sums", m.sum(dim=(2, 3)), bm.sum(dim=(2, 3)))
+
+
+if __name__ == "__main__":
+    patch_env()
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["small", "g_coco", "g_vg", "d", "loop"]
+    with torch.random.fork_rng():
+        if "small" in which:
+            capture_small_ops()
+        if "g_coco" in which:
+            capture_generator("coco")
+        if "g_vg" in which:
+            capture_generator("vg")
+        if "d" in which:
+            capture_discriminator()
+        if "loop" in which:
+            capture_train_loop()
