@@ -52,10 +52,12 @@ int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B,
  * (model/resnet_generator_app_v2.py:681-686, model/rcnn_discriminator_app.py:10-15) and by
  * nn.utils.spectral_norm(nn.Linear/nn.Embedding) (model/norm_module.py:158-159,
  * model/mask_regression.py:64-81, model/rcnn_discriminator_app.py:95,104-109).
- * layers: 16 x int64 per layer, tables built by layout2img_amd/arena.py. */
+ * layers: 20 x int64 per layer row, tables built by layout2img_amd/arena.py; one call per round (a weight the
+ * reference applies twice per forward is iterated twice, second round with clear = 0). */
 int l2i_weights_prepare(const long long* layers, int n_layers, const int* tab_wtu, int n_wtu, const int* tab_wv, int n_wv,
                         const int* tab_pack, int n_pack, const float* params, float* sn_state, float* pass_uv,
-                        long long uv_len, float* norms, void* packed, int dtype, int training, void* stream);
+                        long long uv_len, float* norms, void* packed, int dtype, int training, int clear,
+                        void* stream);
 
 /* Backward of the above: grads[w] += (G - <G,Wbar> u v^T) / sigma for every layer (G = dwbar). */
 int l2i_weights_backward(const long long* layers, int n_layers, const int* tab_dot, int n_dot, const int* tab_apply,

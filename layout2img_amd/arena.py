@@ -83,9 +83,14 @@ class GemmWeight(nn.Module):
     `weight` (+ `bias`). kind: 'conv' (Co,Ci,KH,KH), 'linear' (Co,Ci), 'embedding' (rows, dim).
     """
 
-    def __init__(self, kind, co, ci, kh=1, bias=True, sn=True, eps=1e-12):
+    def __init__(self, kind, co, ci, kh=1, bias=True, sn=True, eps=1e-12, uses=1):
         super().__init__()
         self.kind, self.co, self.ci, self.kh, self.sn, self.eps = kind, co, ci, kh, sn, eps
+        # `uses`: how many times the reference applies this module per forward. torch's spectral-norm
+        # pre-forward hook runs one power iteration PER APPLICATION, so a module applied twice
+        # (block_obj4, rcnn_discriminator_app.py:137,141) iterates twice and each application sees its
+        # own sigma. Each use gets its own row / packs in the arena.
+        self.uses = uses
         shape = (co, ci, kh, kh) if kind == "conv" else (co, ci)
         w = torch.empty(shape)
         if kind == "embedding":
@@ -108,6 +113,10 @@ class GemmWeight(nn.Module):
         else:
             self.bias = None
         self.layer_id = -1  # set by WeightArena
+        self.use_rows = []   # LayerUse per application, set by WeightArena
+
+    def use(self, k):
+        return self.use_rows[k] if k else self
 
     @property
     def w(self):
@@ -126,6 +135,27 @@ def _f32_bits(x):
     return struct.unpack("<I", struct.pack("<f", x))[0]
 
 
+class LayerUse:
+    """Arena row of the k-th application of a GemmWeight (k >= 1); quacks like the holder for ops.py."""
+
+    def __init__(self, h, **kw):
+        self.holder = h
+        self.kind, self.co, self.ci, self.kh, self.sn, self.eps = h.kind, h.co, h.ci, h.kh, h.sn, h.eps
+        self.co_p, self.ci_p = h.co_p, h.ci_p
+        self.__dict__.update(kw)
+
+    @property
+    def bias(self):
+        return self.holder.bias
+
+    @property
+    def w(self):
+        return self.holder.w
+
+
+LSTRIDE = 20
+
+
 class WeightArena:
     def __init__(self, net: nn.Module, flat: FlatParams, device, op_dtype):
         self.flat = flat
@@ -142,13 +172,22 @@ class WeightArena:
         for t in sn_tensors:
             t.data = t.data.to(device)
         self.sn_flat = FlatBuffers(sn_tensors, device)
-        L = len(holders)
-        tab = np.zeros((L, 16), dtype=np.int64)
-        packed_len = dw_len = 0
+        state_off = {}
         k = 0
-        t_wtu, t_wv, t_pack, t_dot, t_apply = [], [], [], [], []
-        for i, h in enumerate(holders):
-            h.layer_id = i
+        for h in holders:
+            if h.sn:
+                state_off[id(h)] = (self.sn_flat.offsets[k], self.sn_flat.offsets[k + 1])
+                k += 2
+        rows = [(h, u) for h in holders for u in range(h.uses)]
+        self.rounds = max(h.uses for h in holders)
+        L = len(rows)
+        tab = np.zeros((L, LSTRIDE), dtype=np.int64)
+        packed_len = dw_len = uv_len = 0
+        t_wtu = [[] for _ in range(self.rounds)]
+        t_wv = [[] for _ in range(self.rounds)]
+        t_pack = [[] for _ in range(self.rounds)]
+        t_dot, t_apply = [], []
+        for i, (h, use) in enumerate(rows):
             taps = h.kh * h.kh
             kt = h.ci * taps
             kp = taps * h.ci_p
@@ -158,8 +197,9 @@ class WeightArena:
             row = tab[i]
             row[0] = flat.offset_of(h.w)
             if h.sn:
-                row[1], row[2] = self.sn_flat.offsets[k], self.sn_flat.offsets[k + 1]
-                k += 2
+                row[1], row[2] = state_off[id(h)]
+                row[16], row[17] = uv_len, uv_len + _round_up(h.co, ALIGN)
+                uv_len += _round_up(h.co, ALIGN) + _round_up(kt, ALIGN)
             else:
                 row[1] = row[2] = -1
             row[3], row[4], row[5], row[6], row[7] = h.co, h.ci, h.kh, h.co_p, h.ci_p
@@ -170,42 +210,54 @@ class WeightArena:
             row[14] = dw_len
             dw_len += _round_up(h.co_p * kp, ALIGN)
             row[15] = _f32_bits(h.eps)
-            h.kpad, h.npad, h.fwd_off = kpad, npad, int(row[10])
-            h.kpad_d, h.npad_d, h.dg_off = kpad_d, npad_d, int(row[13])
-            h.dw_off, h.kp = int(row[14]), kp
+            attrs = dict(layer_id=i, kpad=kpad, npad=npad, fwd_off=int(row[10]), kpad_d=kpad_d, npad_d=npad_d,
+                         dg_off=int(row[13]), dw_off=int(row[14]), kp=kp)
+            if use == 0:
+                for a, v in attrs.items():
+                    setattr(h, a, v)
+                h.use_rows = [h]
+            else:
+                h.use_rows.append(LayerUse(h, **attrs))
             if h.sn:
                 for cc in range((kt + 255) // 256):
                     for rc in range((h.co + 255) // 256):
-                        t_wtu.append((i, cc, rc))
+                        t_wtu[use].append((i, cc, rc))
                 for rc in range((h.co + 15) // 16):
-                    t_wv.append((i, rc))
+                    t_wv[use].append((i, rc))
                 for c in range((h.co * kt + 4095) // 4096):
                     t_dot.append((i, c))
             for c in range((npad * kpad + 2047) // 2048):
-                t_pack.append((i, 0, c))
+                t_pack[use].append((i, 0, c))
             for c in range((npad_d * kpad_d + 2047) // 2048):
-                t_pack.append((i, 1, c))
+                t_pack[use].append((i, 1, c))
             for c in range((h.co * kt + 4095) // 4096):
                 t_apply.append((i, c))
         self.n_layers = L
         self.packed_len, self.dw_len = packed_len, max(dw_len, ALIGN)
-        self.uv_len = self.sn_flat.data.numel()
-        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.array(a, dtype=dt).reshape(-1))).to(device)
+        self.uv_len = max(uv_len, ALIGN)
+
+        def dev(a, width):
+            arr = np.array(a if a else [(0,) * width], dtype=np.int32).reshape(-1)
+            return torch.from_numpy(np.ascontiguousarray(arr)).to(device), len(a)
         self.layers = torch.from_numpy(tab.reshape(-1)).to(device)
-        self.t_wtu, self.n_wtu = dev(t_wtu or [(0, 0, 0)], np.int32), len(t_wtu)
-        self.t_wv, self.n_wv = dev(t_wv or [(0, 0)], np.int32), len(t_wv)
-        self.t_pack, self.n_pack = dev(t_pack, np.int32), len(t_pack)
-        self.t_dot, self.n_dot = dev(t_dot or [(0, 0)], np.int32), len(t_dot)
-        self.t_apply, self.n_apply = dev(t_apply, np.int32), len(t_apply)
+        self.t_wtu = [dev(t, 3) for t in t_wtu]
+        self.t_wv = [dev(t, 2) for t in t_wv]
+        self.t_pack = [dev(t, 3) for t in t_pack]
+        self.t_dot, self.n_dot = dev(t_dot, 2)
+        self.t_apply, self.n_apply = dev(t_apply, 2)
         self.pending = []
 
     def prepare(self, training=True, need_wgrad=True):
-        """Run the power iteration (train mode) and pack all weights; returns the pass context."""
+        """Run the power iteration(s) (train mode) and pack all weights; returns the pass context."""
         p = PassCtx(self, training, need_wgrad)
-        _lib.call("l2i_weights_prepare", self.layers.data_ptr(), self.n_layers, self.t_wtu.data_ptr(), self.n_wtu,
-                  self.t_wv.data_ptr(), self.n_wv, self.t_pack.data_ptr(), self.n_pack, self.flat.data.data_ptr(),
-                  self.sn_flat.data.data_ptr(), p.pass_uv.data_ptr(), self.uv_len, p.norms.data_ptr(),
-                  p.packed.data_ptr(), self.dtype_code, 1 if training else 0, torch.cuda.current_stream().cuda_stream)
+        for r in range(self.rounds):
+            (wtu, n_wtu), (wv, n_wv), (pk, n_pk) = self.t_wtu[r], self.t_wv[r], self.t_pack[r]
+            if n_pk == 0:
+                continue
+            _lib.call("l2i_weights_prepare", self.layers.data_ptr(), self.n_layers, wtu.data_ptr(), n_wtu, wv.data_ptr(), n_wv,
+                      pk.data_ptr(), n_pk, self.flat.data.data_ptr(), self.sn_flat.data.data_ptr(), p.pass_uv.data_ptr(),
+                      self.uv_len, p.norms.data_ptr(), p.packed.data_ptr(), self.dtype_code, 1 if training else 0,
+                      1 if r == 0 else 0, torch.cuda.current_stream().cuda_stream)
         if need_wgrad and torch.is_grad_enabled():
             self.pending.append(p)
             if len(self.pending) > 8:  # forwards that were never followed by an optimiser step
@@ -228,7 +280,7 @@ class WeightArena:
 
 
 class PassCtx:
-    """Packed weights, u/v snapshot, sigma and the dWbar accumulator of ONE forward pass."""
+    """Packed weights, u/v snapshots, sigma and the dWbar accumulator of ONE forward pass."""
 
     def __init__(self, arena: WeightArena, training, need_wgrad):
         self.arena = arena
@@ -245,14 +297,14 @@ class PassCtx:
             self.dwbar = torch.zeros(self.arena.dw_len, dtype=torch.float32, device=self.arena.device)
         return self.dwbar
 
-    def fwd_pack(self, h: GemmWeight):
+    def fwd_pack(self, h):
         return self.packed[h.fwd_off:h.fwd_off + h.npad * h.kpad]
 
-    def dgrad_pack(self, h: GemmWeight):
+    def dgrad_pack(self, h):
         return self.packed[h.dg_off:h.dg_off + h.npad_d * h.kpad_d]
 
-    def dw_slice(self, h: GemmWeight):
+    def dw_slice(self, h):
         return self.dw()[h.dw_off:h.dw_off + h.co_p * h.kp]
 
-    def sigma(self, h: GemmWeight):
+    def sigma(self, h):
         return self.norms[4 * h.layer_id + 2]

@@ -54,6 +54,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     __syncthreads();
     float r = 0.f;
     for (int i = 0; i < nw; ++i) r += red[i];
+    __syncthreads();  // red[] may be reused by the caller's next reduction
     return r;
 }
 

@@ -11,28 +11,26 @@
 //  * f32 stream -> T operand casts (raw and/or ReLU'd copy) feeding the MFMA kernels.
 #include "common.h"
 
-__global__ __launch_bounds__(256) void hinge_kernel(const float* __restrict__ x, const int* __restrict__ valid, int n, int mode,
-                                                    float weight, const float* __restrict__ count_ptr,
+// Branch-free form: value = max(c + s*x, lo) with (s, c, lo) = (-1, 1, 0) | (+1, 1, 0) | (-1, 0, -inf) for modes
+// 0 | 1 | 2. (A three-way `mode` select inside the loop was mis-compiled by hipcc 7.2 for mode 2.)
+__global__ __launch_bounds__(256) void hinge_kernel(const float* __restrict__ x, const int* __restrict__ valid, int n, float s,
+                                                    float c, float lo, float weight, const float* __restrict__ count_ptr,
                                                     float* __restrict__ loss_out, float* __restrict__ grad) {
     __shared__ float red[16];
     float cnt = 0.f, acc = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const bool ok = !valid || valid[i] != 0;
-        if (!ok) continue;
-        cnt += 1.f;
-        const float v = x[i];
-        acc += mode == 0 ? fmaxf(1.f - v, 0.f) : mode == 1 ? fmaxf(1.f + v, 0.f) : -v;
+        const float ok = (!valid || valid[i] != 0) ? 1.f : 0.f;
+        cnt += ok;
+        acc += ok * fmaxf(c + s * x[i], lo);
     }
     cnt = block_sum(cnt, red);
     acc = block_sum(acc, red);
     if (count_ptr) cnt = *count_ptr;  // data-parallel: mean over the GLOBAL number of rows
     const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const bool ok = !valid || valid[i] != 0;
-        const float v = x[i];
-        float g = 0.f;
-        if (ok) g = mode == 0 ? (1.f - v > 0.f ? -1.f : 0.f) : mode == 1 ? (1.f + v > 0.f ? 1.f : 0.f) : -1.f;
-        grad[i] = g * inv * weight;
+        const float ok = (!valid || valid[i] != 0) ? 1.f : 0.f;
+        const float on = (c + s * x[i] > lo) ? 1.f : 0.f;
+        grad[i] = ok * on * s * inv * weight;
     }
     if (threadIdx.x == 0) atomicAdd(loss_out, weight * acc * inv);
 }
@@ -40,7 +38,8 @@ __global__ __launch_bounds__(256) void hinge_kernel(const float* __restrict__ x,
 extern "C" int l2i_hinge_fwd_bwd(const float* x, const int* valid, int n, int mode, float weight, const float* count_ptr,
                                  float* loss_out, float* grad, void* stream) {
     if (!x || !loss_out || !grad || n < 0 || mode < 0 || mode > 2) return L2I_ERR_ARG;
-    hipLaunchKernelGGL(hinge_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, valid, n, mode, weight, count_ptr,
+    const float s = mode == 1 ? 1.f : -1.f, c = mode == 2 ? 0.f : 1.f, lo = mode == 2 ? -INFINITY : 0.f;
+    hipLaunchKernelGGL(hinge_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, valid, n, s, c, lo, weight, count_ptr,
                        loss_out, grad);
     return l2i_check_launch();
 }

@@ -10,13 +10,17 @@
 //   normalize(x, eps) = x / max(||x||_2, eps).   eval mode: sigma = u . (W v) with the stored u, v.
 //   backward: dW = (G - <G, Wbar> u v^T) / sigma,  G = dL/dWbar.
 //
-// Layer table: 16 int64 per layer (see layout2img_amd/arena.py):
+// Layer table: L2I_LSTRIDE (20) int64 per layer row (see layout2img_amd/arena.py); a weight that the reference
+// applies k times per forward (block_obj4, model/rcnn_discriminator_app.py:137,141 -- each application runs its own
+// power iteration) has k rows sharing w/u/v offsets and is processed in k sequential rounds:
 //   0 w_off  1 u_off(-1 = no SN)  2 v_off  3 Co  4 Ci  5 KH  6 Co_p  7 Ci_p
 //   8 Kpad  9 Npad  10 fwd_off  11 Kpad_d  12 Npad_d  13 dg_off  14 dw_off  15 eps(float bits)
+//   16 pass_u_off  17 pass_v_off (offsets into the per-pass u/v snapshot)  18,19 reserved
 // norms: f32 [L][4] = {||W^T u||^2, ||W v||^2 (eval: u.Wv), sigma, <G, W>}
 #include "common.h"
 
 #define LF(i) (L[(i)])
+#define L2I_LSTRIDE 20
 
 __device__ __forceinline__ float layer_eps(const long long* L) { return __uint_as_float((uint32_t)L[15]); }
 
@@ -25,7 +29,7 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const long long* __restrict
                                                      const float* __restrict__ params, const float* __restrict__ sn_state,
                                                      float* __restrict__ pass_uv) {
     const int* e = table + 3 * blockIdx.x;
-    const long long* L = layers + 16 * e[0];
+    const long long* L = layers + L2I_LSTRIDE * e[0];
     const int Co = (int)LF(3), Kt = (int)(LF(4) * LF(5) * LF(5));
     const int col = e[1] * 256 + threadIdx.x;
     const int r0 = e[2] * 256, r1 = min(Co, r0 + 256);
@@ -34,7 +38,7 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const long long* __restrict
     const float* u = sn_state + LF(1);
     float t = 0.f;
     for (int r = r0; r < r1; ++r) t += u[r] * W[(size_t)r * Kt + col];
-    atomicAdd(pass_uv + LF(2) + col, t);
+    atomicAdd(pass_uv + LF(17) + col, t);
 }
 
 // phase 2: s = W vhat (train: vhat = t / max(||t||, eps); eval: vhat = stored v). 16 rows per block.
@@ -45,10 +49,10 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const long long* __restrict_
     __shared__ float red[16];
     const int* e = table + 2 * blockIdx.x;
     const int layer = e[0];
-    const long long* L = layers + 16 * layer;
+    const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Kt = (int)(LF(4) * LF(5) * LF(5));
     const float* W = params + LF(0);
-    const float* vsrc = training ? pass_uv + LF(2) : sn_state + LF(2);
+    const float* vsrc = training ? pass_uv + LF(17) : sn_state + LF(2);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float blk = 0.f;
     float tn2_keep = 0.f;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const long long* __restrict_
             s = dot;
             if (lane == 0) blk += s * sn_state[LF(1) + r];  // sigma = u . (W v)
         }
-        if (lane == 0) pass_uv[LF(1) + r] = s;
+        if (lane == 0) pass_uv[LF(16) + r] = s;
     }
     // one atomic per block
     __syncthreads();
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restric
                                                       T* __restrict__ packed, int training) {
     const int* e = table + 3 * blockIdx.x;
     const int layer = e[0], kind = e[1], chunk = e[2];
-    const long long* L = layers + 16 * layer;
+    const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Co_p = (int)LF(6), Ci_p = (int)LF(7);
     const int Kt = Ci * KH * KH;
     const bool sn = LF(1) >= 0;
@@ -107,13 +111,13 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restric
             sigma = sn2 / fmaxf(snorm, eps);
             if (kind == 0) {
                 for (int i = chunk * 2048 + threadIdx.x; i < min(Co, (chunk + 1) * 2048); i += 256) {
-                    const float u = pass_uv[LF(1) + i] / fmaxf(snorm, eps);
-                    pass_uv[LF(1) + i] = u;
+                    const float u = pass_uv[LF(16) + i] / fmaxf(snorm, eps);
+                    pass_uv[LF(16) + i] = u;
                     sn_state[LF(1) + i] = u;
                 }
                 for (int i = chunk * 2048 + threadIdx.x; i < min(Kt, (chunk + 1) * 2048); i += 256) {
-                    const float v = pass_uv[LF(2) + i] / fmaxf(tnorm, eps);
-                    pass_uv[LF(2) + i] = v;
+                    const float v = pass_uv[LF(17) + i] / fmaxf(tnorm, eps);
+                    pass_uv[LF(17) + i] = v;
                     sn_state[LF(2) + i] = v;
                 }
             }
@@ -121,9 +125,9 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restric
             sigma = sn2;
             if (kind == 0) {
                 for (int i = chunk * 2048 + threadIdx.x; i < min(Co, (chunk + 1) * 2048); i += 256)
-                    pass_uv[LF(1) + i] = sn_state[LF(1) + i];
+                    pass_uv[LF(16) + i] = sn_state[LF(1) + i];
                 for (int i = chunk * 2048 + threadIdx.x; i < min(Kt, (chunk + 1) * 2048); i += 256)
-                    pass_uv[LF(2) + i] = sn_state[LF(2) + i];
+                    pass_uv[LF(17) + i] = sn_state[LF(2) + i];
             }
         }
         if (kind == 0 && chunk == 0 && threadIdx.x == 0) norms[4 * layer + 2] = sigma;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const long long* __restrict
     __shared__ float red[16];
     const int* e = table + 2 * blockIdx.x;
     const int layer = e[0];
-    const long long* L = layers + 16 * layer;
+    const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Ci_p = (int)LF(7);
     const int taps = KH * KH, Kt = Ci * taps, Kp = taps * Ci_p;
     const float* W = params + LF(0);
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
                                                        const float* __restrict__ norms, float* __restrict__ grads) {
     const int* e = table + 2 * blockIdx.x;
     const int layer = e[0];
-    const long long* L = layers + 16 * layer;
+    const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Ci_p = (int)LF(7);
     const int taps = KH * KH, Kt = Ci * taps, Kp = taps * Ci_p;
     const float* G = dwbar + LF(14);
@@ -201,19 +205,21 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
         const int co = (int)(i / Kt), kt = (int)(i - (long long)co * Kt);
         const int ci = kt / taps, tap = kt - ci * taps;
         float g = G[(size_t)co * Kp + tap * Ci_p + ci];
-        if (sn) g = (g - gw * pass_uv[LF(1) + co] * pass_uv[LF(2) + kt]) * inv;
-        dst[i] += g;
+        if (sn) g = (g - gw * pass_uv[LF(16) + co] * pass_uv[LF(17) + kt]) * inv;
+        atomicAdd(dst + i, g);  // rows of a multiply-applied weight update the same gradient concurrently
     }
 }
 
 extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const int* tab_wtu, int n_wtu,
                                    const int* tab_wv, int n_wv, const int* tab_pack, int n_pack, const float* params,
                                    float* sn_state, float* pass_uv, long long uv_len, float* norms, void* packed,
-                                   int dtype, int training, void* stream_) {
+                                   int dtype, int training, int clear, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!layers || !params || !packed || !norms) return L2I_ERR_ARG;
-    if (hipMemsetAsync(norms, 0, sizeof(float) * 4 * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
-    if (uv_len > 0 && hipMemsetAsync(pass_uv, 0, sizeof(float) * uv_len, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+    if (clear) {  // first round of a pass
+        if (hipMemsetAsync(norms, 0, sizeof(float) * 4 * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+        if (uv_len > 0 && hipMemsetAsync(pass_uv, 0, sizeof(float) * uv_len, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+    }
     if (training && n_wtu > 0)
         hipLaunchKernelGGL(sn_wtu_kernel, dim3(n_wtu), dim3(256), 0, stream, layers, tab_wtu, params, sn_state, pass_uv);
     if (n_wv > 0)

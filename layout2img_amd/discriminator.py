@@ -16,8 +16,8 @@ from .arena import FlatParams, GemmWeight, WeightArena
 from .ops import RELU, arena_weight, fused_conv
 
 
-def _conv(ci, co, k):
-    return GemmWeight("conv", co, ci, k, sn=True, eps=1e-4)
+def _conv(ci, co, k, uses=1):
+    return GemmWeight("conv", co, ci, k, sn=True, eps=1e-4, uses=uses)
 
 
 class OptimizedBlock(nn.Module):
@@ -40,18 +40,20 @@ class OptimizedBlock(nn.Module):
 class ResBlock(nn.Module):
     """reference :317-344 -- pre-activation block; the shortcut pools AFTER its 1x1 conv."""
 
-    def __init__(self, in_ch, out_ch, downsample=False):
+    def __init__(self, in_ch, out_ch, downsample=False, uses=1):
         super().__init__()
-        self.conv1, self.conv2 = _conv(in_ch, out_ch, 3), _conv(out_ch, out_ch, 3)
+        self.conv1, self.conv2 = _conv(in_ch, out_ch, 3, uses), _conv(out_ch, out_ch, 3, uses)
         self.downsample = downsample
         self.learnable_sc = (in_ch != out_ch) or downsample
         if self.learnable_sc:
-            self.c_sc = _conv(in_ch, out_ch, 1)
+            self.c_sc = _conv(in_ch, out_ch, 1, uses)
 
-    def forward(self, x, pc):
-        h = fused_conv(x, self.conv1, pc, prologue=RELU)
-        sc = fused_conv(x, self.c_sc, pc, pool2=self.downsample) if self.learnable_sc else x
-        return fused_conv(h, self.conv2, pc, prologue=RELU, res=sc, pool2=self.downsample)
+    def forward(self, x, pc, use=0):
+        """`use`: index of this application within the forward pass (each application of a spectral-normed
+        module runs its own power iteration in the reference)."""
+        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU)
+        sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample) if self.learnable_sc else x
+        return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample)
 
 
 class ResnetDiscriminator128_app(nn.Module):
@@ -66,7 +68,7 @@ class ResnetDiscriminator128_app(nn.Module):
         self.block6 = ResBlock(ch * 16, ch * 16, downsample=False)
         self.l7 = GemmWeight("linear", 1, ch * 16, sn=True)
         self.block_obj3 = ResBlock(ch * 2, ch * 4, downsample=False)
-        self.block_obj4 = ResBlock(ch * 4, ch * 8, downsample=False)
+        self.block_obj4 = ResBlock(ch * 4, ch * 8, downsample=False, uses=2)  # applied to x1-path and x2
         self.block_obj5 = ResBlock(ch * 8, ch * 16, downsample=True)
         self.l_obj = GemmWeight("linear", 1, ch * 16, sn=True)
         self.l_y = GemmWeight("embedding", num_classes, ch * 16, bias=False, sn=True)
@@ -85,8 +87,8 @@ class ResnetDiscriminator128_app(nn.Module):
         feat = F.relu(x).sum(dim=(1, 2))
         out_im = F.linear(feat, arena_weight(self.l7, pc), self.l7.bias)
 
-        feat_s = self.block_obj4(self.block_obj3(x1, pc), pc)
-        feat_l = self.block_obj4(x2, pc)
+        feat_s = self.block_obj4(self.block_obj3(x1, pc), pc, use=0)   # reference order :136-141
+        feat_l = self.block_obj4(x2, pc, use=1)
         obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0)  # (R,8,8,C)
 
         # appearance head (reference :148-157): Gram of the ROI features + class embedding

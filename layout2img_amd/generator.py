@@ -379,3 +379,42 @@ class ResnetGenerator128_context(_GeneratorBase):
         if taps is not None:
             taps.update(w=w, bmask=bmask, stages=stages, pre_tanh=pre[..., :self.output_dim])
         return img
+
+
+class context_aware_generator(_GeneratorBase):
+    """VG generator (reference model/resnet_generator_vg.py:639-727): context attention without the geometry
+    bias, MaskRegressNet (128 ch, SyncBN), the same regressed mask for every block, no mask heads."""
+
+    def __init__(self, ch=64, z_dim=128, num_classes=10, output_dim=3):
+        super().__init__()
+        self.num_classes, self.ch, self.output_dim = num_classes, ch, output_dim
+        self.label_embedding = nn.Embedding(num_classes, 180)
+        num_w = 128 + 180
+        self.context = BoxMultiHeadedAttention(1, num_w, geometry=False)
+        self.fc = GemmWeight("linear", 4 * 4 * 16 * ch, z_dim, sn=True, eps=1e-12)
+        chans = [(16, 16), (16, 8), (8, 4), (4, 2), (2, 1)]
+        for i, (a, b_) in enumerate(chans, 1):
+            setattr(self, f"res{i}", ResBlock(ch * a, ch * b_, num_w=num_w, predict_mask=False))
+        self.final = nn.ModuleList([BNState(ch), nn.Identity(), GemmWeight("conv", output_dim, ch, 3, sn=True, eps=1e-4), nn.Identity()])
+        self.mask_regress = MaskRegressNetv2(num_w, ch=128, instance=False)
+        self.init_parameter()
+
+    def forward(self, z, bbox, z_im=None, y=None):
+        if not z.is_cuda:
+            raise RuntimeError("layout2img_amd generators run on the GPU HIP path only")
+        b, o = z.size(0), z.size(1)
+        bbox = bbox.to(z.device).float()
+        pc = self.arena.prepare(training=self.training)
+        w = self.context(self._latent(z, y), bbox, y, pc)
+        wp = _pad_last(w.reshape(b * o, -1), self.res1.b1.weight_proj.ci_p).reshape(b * o, 1, 1, -1).contiguous()
+        mask = self.mask_regress(wp, bbox, pc, self.sync)
+        if z_im is None:
+            z_im = torch.randn((b, 128), device=z.device)
+        x = fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc).view(b, 16 * self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
+        for i in range(1, 6):
+            x, _ = getattr(self, f"res{i}")(x, wp, mask, pc, self.sync)
+        bn, _, conv, _ = self.final
+        spec, wa, ba = bn.spec(self.training, self.sync)
+        pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
+        bn.commit()
+        return torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()

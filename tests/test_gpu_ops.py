@@ -1,0 +1,456 @@
+"""GPU parity tests of every HIP kernel (through the C ABI) against the oracle / plain torch fp32 on CPU.
+
+Operands are pre-rounded to the operand dtype before the reference is evaluated, so the bf16 cases
+compare accumulation order only and can use tight tolerances; model-level bf16 tolerances live in
+tests/test_gpu_models.py.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from oracle import model as O
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rt(t, dt):
+    """round-trip through the operand dtype"""
+    return t.to(dt).float()
+
+
+def _pack(w, kpad_mult):
+    """(Co,Ci,KH,KH) -> [Npad][Kpad] with k = (ky,kx,ci)"""
+    co, ci, kh, _ = w.shape
+    k = kh * kh * ci
+    kpad, npad = (k + kpad_mult - 1) // kpad_mult * kpad_mult, (co + 127) // 128 * 128
+    p = torch.zeros(npad, kpad)
+    p[:co, :k] = w.permute(0, 2, 3, 1).reshape(co, k)
+    return p, kpad
+
+
+CONV_CASES = [
+    # B, H, W, Ci, Co, KH, up2, pool2
+    (2, 8, 8, 16, 24, 3, False, False),
+    (2, 4, 4, 64, 64, 3, True, False),
+    (1, 16, 16, 32, 136, 3, False, True),
+    (3, 32, 32, 8, 64, 3, False, False),
+    (2, 16, 16, 40, 104, 1, False, False),
+    (5, 1, 1, 312, 72, 1, False, False),
+    (130, 1, 1, 64, 8, 1, False, False),
+    (1, 64, 64, 16, 16, 3, True, False),
+    (2, 8, 8, 16, 16, 3, False, True),
+    (3, 8, 8, 16, 32, 1, False, True),
+    (2, 32, 32, 8, 8, 3, True, True),
+]
+
+
+def _ref_conv(x_nhwc, w, bias, up2, pool2):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    if up2:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    y = F.conv2d(x, w, bias, 1, w.shape[2] // 2)
+    if pool2:
+        y = F.avg_pool2d(y, 2)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(case, dt):
+    from layout2img_amd import ops
+    B, H, W, Ci, Co, KH, up2, pool2 = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    w = _rt(torch.randn(Co, Ci, KH, KH, generator=g) / math.sqrt(Ci * KH * KH), dt)
+    bias = torch.randn(Co, generator=g)
+    ref = _ref_conv(x, w, bias, up2, pool2)
+    res = torch.randn(ref.shape, generator=g)
+    pack, kpad = _pack(w, 64 if dt == torch.bfloat16 else 32)
+    out, out_op, out_raw = ops.conv_raw(x.to(_dev(), dt), pack.to(_dev(), dt), kpad, Co, KH, bias=bias.to(_dev()), res=res.to(_dev()),
+                                        up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, want_op=True, relu_op=True, want_raw=True)
+    # the kernel's pool2 sums a quad then scales by alpha; bias is added after -> same as avg_pool(conv)+bias
+    expect = ref + res
+    scale = float(expect.abs().max())
+    assert float((out.cpu() - expect).abs().max()) < 2e-5 * scale + 1e-5
+    assert float((out_raw.float().cpu() - _rt(out.cpu(), dt)).abs().max()) == 0.0
+    assert float((out_op.float().cpu() - _rt(out.cpu().clamp_min(0), dt)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_relu_mask(dt):
+    from layout2img_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = _rt(torch.randn(2, 8, 8, 16, generator=g), dt)
+    w = _rt(torch.randn(32, 16, 3, 3, generator=g) / 12, dt)
+    mask = _rt(torch.randn(2, 8, 8, 32, generator=g), dt)
+    res = torch.randn(2, 8, 8, 32, generator=g)
+    pack, kpad = _pack(w, 64 if dt == torch.bfloat16 else 32)
+    out, _, _ = ops.conv_raw(x.to(_dev(), dt), pack.to(_dev(), dt), kpad, 32, 3, res=res.to(_dev()), relu_mask=mask.to(_dev(), dt))
+    expect = _ref_conv(x, w, None, False, False) * (mask > 0).float() + res
+    assert float((out.cpu() - expect).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad(case, dt):
+    from layout2img_amd import ops
+    B, H, W, Ci, Co, KH, up2, pool2 = case
+    if Co % 8:
+        pytest.skip("operand channels are padded to 8 by the caller")
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 1)
+    x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    w = torch.zeros(Co, Ci, KH, KH, requires_grad=True)
+    y = _ref_conv(x, w, None, up2, pool2)
+    dy = _rt(torch.randn(y.shape, generator=g), dt)
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Co, -1)
+    K = KH * KH * Ci
+    dw = torch.zeros(Co, K, device=_dev())
+    ops.wgrad_raw(x.to(_dev(), dt), dy.to(_dev(), dt), dw, K, Co, KH, up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0)
+    scale = float(ref.abs().max())
+    assert float((dw.cpu() - ref).abs().max()) < 5e-5 * scale + 1e-5
+
+
+class _Net(nn.Module):
+    def __init__(self, holders):
+        super().__init__()
+        self.h = nn.ModuleList(holders)
+
+
+def _mk(holders, dt):
+    from layout2img_amd.arena import FlatParams, WeightArena
+    net = _Net(holders)
+    flat = FlatParams(net, _dev())
+    return net, flat, WeightArena(net, flat, _dev(), dt)
+
+
+def _sd_of(h, name="c."):
+    sd = {}
+    if h.sn:
+        sd[name + "weight_orig"] = h.weight_orig.detach().cpu().clone().requires_grad_(True)
+        sd[name + "weight_u"] = h.weight_u.detach().cpu().clone()
+        sd[name + "weight_v"] = h.weight_v.detach().cpu().clone()
+    else:
+        sd[name + "weight"] = h.weight.detach().cpu().clone().requires_grad_(True)
+    if h.bias is not None:
+        sd[name + "bias"] = h.bias.detach().cpu().clone().requires_grad_(True)
+    return sd
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_weight_arena_spectral_norm(training):
+    """power iteration, sigma, packs (f32) against torch's spectral-norm algebra; two passes."""
+    from layout2img_amd.arena import GemmWeight
+    torch.manual_seed(0)
+    hs = [GemmWeight("conv", 24, 16, 3, sn=True, eps=1e-4), GemmWeight("linear", 300, 308, sn=True, eps=1e-12),
+          GemmWeight("embedding", 184, 64, bias=False, sn=True), GemmWeight("conv", 100, 40, 1, sn=False),
+          GemmWeight("linear", 4096, 24, sn=True)]
+    sds = [_sd_of(h) for h in hs]
+    net, flat, arena = _mk(hs, torch.float32)
+    for _ in range(2):
+        pc = arena.prepare(training=training)
+        torch.cuda.synchronize()
+        for h, sd in zip(hs, sds):
+            wbar = O._w(sd, "c.", h.eps, training).detach()
+            co, ci, kh = h.co, h.ci, h.kh
+            fwd = pc.fwd_pack(h).view(h.npad, h.kpad).cpu()
+            expect = torch.zeros(h.npad, h.kpad)
+            w4 = wbar.reshape(co, ci, kh, kh)
+            blk = torch.zeros(co, kh * kh, h.ci_p)
+            blk[:, :, :ci] = w4.permute(0, 2, 3, 1).reshape(co, kh * kh, ci)
+            expect[:co, :kh * kh * h.ci_p] = blk.reshape(co, -1)
+            assert float((fwd - expect).abs().max()) < 2e-5 * float(expect.abs().max()), h.kind
+            dg = pc.dgrad_pack(h).view(h.npad_d, h.kpad_d).cpu()
+            expect = torch.zeros(h.npad_d, h.kpad_d)
+            blk = torch.zeros(ci, kh * kh, h.co_p)
+            blk[:, :, :co] = w4.flip(2, 3).permute(1, 2, 3, 0).reshape(ci, kh * kh, co)
+            expect[:ci, :kh * kh * h.co_p] = blk.reshape(ci, -1)
+            assert float((dg - expect).abs().max()) < 2e-5 * float(expect.abs().max()), h.kind
+            if h.sn:
+                assert float((h.weight_u.cpu() - sd["c.weight_u"]).abs().max()) < 1e-5
+                assert float((h.weight_v.cpu() - sd["c.weight_v"]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("pro", ["cast", "relu", "isla", "affine", "instance"])
+def test_fused_conv_fwd_bwd(pro, dt):
+    """FusedConvFn (prologue + conv + bias + res [+ up2]) forward and all gradients, incl. the spectral-norm
+    backward into the flat gradient buffer, against torch autograd on the oracle formulas."""
+    from layout2img_amd import ops
+    from layout2img_amd.arena import GemmWeight
+    torch.manual_seed(1)
+    B, H, W, Ci, Co, O_ = 3, 8, 8, 16, 24, 5
+    up2 = pro in ("isla", "cast")
+    h = GemmWeight("conv", Co, Ci, 3, sn=True, eps=1e-4)
+    sd = _sd_of(h)
+    net, flat, arena = _mk([h], dt)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, H, W, Ci, generator=g)
+    mask = torch.rand(B, O_, H, W, generator=g) * (torch.rand(B, O_, H, W, generator=g) > 0.3)
+    wproj, bproj = torch.randn(B, O_, Ci, generator=g) * 0.3, torch.randn(B, O_, Ci, generator=g) * 0.3
+    aw, ab = 1 + 0.2 * torch.randn(Ci, generator=g), 0.2 * torch.randn(Ci, generator=g)
+    Ho = 2 * H if up2 else H
+    res = torch.randn(B, Ho, Ho, Co, generator=g)
+    dy = torch.randn(B, Ho, Ho, Co, generator=g)
+
+    # ---- reference (CPU, f32, operand rounded to dt where the kernel rounds)
+    xr = x.clone().requires_grad_(True)
+    mr, wr, br = mask.clone().requires_grad_(True), wproj.clone().requires_grad_(True), bproj.clone().requires_grad_(True)
+    awr, abr = aw.clone().requires_grad_(True), ab.clone().requires_grad_(True)
+    resr = res.clone().requires_grad_(True)
+    xn = xr.permute(0, 3, 1, 2)
+    if pro == "cast":
+        a = xn
+    elif pro == "relu":
+        a = F.relu(xn)
+    elif pro == "isla":
+        xh = F.batch_norm(xn, None, None, None, None, True, 0.1, 1e-5)
+        den = mr.sum(1, keepdim=True) + 1e-6
+        a = F.relu((torch.einsum("bohw,boc->bchw", mr, wr) / den + 1) * xh + torch.einsum("bohw,boc->bchw", mr, br) / den)
+    elif pro == "affine":
+        a = F.relu(F.batch_norm(xn, None, None, awr, abr, True, 0.1, 1e-5))
+    else:
+        a = F.relu(F.instance_norm(xn, eps=1e-5))
+
+    class _STE(torch.autograd.Function):  # operand rounding with straight-through gradient
+        @staticmethod
+        def forward(ctx, t):
+            return _rt(t, dt)
+
+        @staticmethod
+        def backward(ctx, gg):
+            return gg
+    a = _STE.apply(a)
+    if up2:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    wbar = O._w(sd, "c.", 1e-4, True)
+    yref = F.conv2d(a, _STE.apply(wbar), sd["c.bias"], 1, 1).permute(0, 2, 3, 1) + resr
+    yref.backward(dy)
+
+    # ---- HIP
+    dev = _dev()
+    xg = x.to(dev).requires_grad_(True)
+    mg, wg, bg = mask.to(dev).requires_grad_(True), wproj.to(dev).requires_grad_(True), bproj.to(dev).requires_grad_(True)
+    awg, abg = aw.to(dev).requires_grad_(True), ab.to(dev).requires_grad_(True)
+    resg = res.to(dev).requires_grad_(True)
+    pc = arena.prepare(training=True)
+    kw = {}
+    if pro == "relu":
+        kw["prologue"] = ops.RELU
+    elif pro == "isla":
+        kw.update(prologue=ops.NormSpec(0), mask=mg, wproj=wg, bproj=bg)
+    elif pro == "affine":
+        kw.update(prologue=ops.NormSpec(1), wproj=awg, bproj=abg)
+    elif pro == "instance":
+        kw.update(prologue=ops.NormSpec(2, instance=True))
+    y = ops.fused_conv(xg, h, pc, res=resg, up2=up2, **kw)
+    y.backward(dy.to(dev))
+    arena.flush_grads()
+    torch.cuda.synchronize()
+
+    bf = dt == torch.bfloat16
+    tol = 2e-2 if bf else 2e-4   # bf16: dy and the dgrad weights are rounded as operands too
+    def close(a_, b_, name, t=tol):
+        s = float(b_.abs().max()) + 1e-6
+        d = float((a_.detach().cpu() - b_).abs().max())
+        assert d < t * s, (name, d, s)
+    close(y, yref, "y", 2e-3 if bf else 2e-5)
+    close(xg.grad, xr.grad, "dx")
+    close(resg.grad, resr.grad, "dres", 1e-6)
+    close(h.bias.grad, sd["c.bias"].grad, "dbias", 2e-3 if bf else 2e-5)
+    close(h.weight_orig.grad, sd["c.weight_orig"].grad, "dW")
+    if pro == "isla":
+        close(mg.grad, mr.grad, "dmask")
+        close(wg.grad, wr.grad, "dwproj")
+        close(bg.grad, br.grad, "dbproj")
+    if pro == "affine":
+        close(awg.grad, awr.grad, "daw")
+        close(abg.grad, abr.grad, "dab")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_fused_conv_pool_and_linear(dt):
+    """D-style block piece (relu prologue, avg-pool epilogue, 1x1 shortcut with pool) and a linear layer."""
+    from layout2img_amd import ops
+    from layout2img_amd.arena import GemmWeight
+    torch.manual_seed(2)
+    c1, csc, lin = GemmWeight("conv", 32, 16, 3, sn=True, eps=1e-4), GemmWeight("conv", 32, 16, 1, sn=True, eps=1e-4), \
+        GemmWeight("linear", 40, 308, sn=True)
+    sds = [_sd_of(c1, "a."), _sd_of(csc, "b."), _sd_of(lin, "l.")]
+    net, flat, arena = _mk([c1, csc, lin], dt)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 16, 16, 16, generator=g)
+    v = torch.randn(6, 312, generator=g)
+    v[:, 308:] = 0
+
+    class _STE(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return _rt(t, dt)
+
+        @staticmethod
+        def backward(ctx, gg):
+            return gg
+    xr, vr = x.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    xn = xr.permute(0, 3, 1, 2)
+    sc = F.avg_pool2d(F.conv2d(_STE.apply(xn), _STE.apply(O._w(sds[1], "b.", 1e-4, True)), sds[1]["b.bias"]), 2)
+    yr = F.avg_pool2d(F.conv2d(_STE.apply(F.relu(xn)), _STE.apply(O._w(sds[0], "a.", 1e-4, True)), sds[0]["a.bias"], 1, 1), 2) + sc
+    lr = F.linear(_STE.apply(vr[:, :308]), _STE.apply(O._w(sds[2], "l.", 1e-12, True)), sds[2]["l.bias"])
+    gy, gl = torch.randn(yr.shape, generator=g), torch.randn(lr.shape, generator=g)
+    (yr * gy).sum().backward()
+    (lr * gl).sum().backward()
+
+    dev = _dev()
+    xg, vg = x.to(dev).requires_grad_(True), v.to(dev).requires_grad_(True)
+    pc = arena.prepare(training=True)
+    scg = ops.fused_conv(xg, csc, pc, pool2=True)
+    yg = ops.fused_conv(xg, c1, pc, prologue=ops.RELU, res=scg, pool2=True)
+    lg = ops.fused_conv(vg.view(6, 1, 1, 312), lin, pc).view(6, -1)[:, :40]
+    (yg * gy.permute(0, 2, 3, 1).contiguous().to(dev)).sum().backward()
+    (lg * gl.to(dev)).sum().backward()
+    arena.flush_grads()
+    bf = dt == torch.bfloat16
+    tol = 2e-2 if bf else 2e-4
+
+    def close(a_, b_, name, t=tol):
+        s = float(b_.abs().max()) + 1e-6
+        d = float((a_.detach().cpu() - b_).abs().max())
+        assert d < t * s, (name, d, s)
+    close(yg, yr.permute(0, 2, 3, 1), "y", 2e-3 if bf else 2e-5)
+    close(lg, lr, "lin", 2e-3 if bf else 2e-5)
+    close(xg.grad, xr.grad, "dx")
+    close(vg.grad[:, :308], vr.grad[:, :308], "dv")
+    for hh, sd, p in ((c1, sds[0], "a."), (csc, sds[1], "b."), (lin, sds[2], "l.")):
+        close(hh.weight_orig.grad, sd[p + "weight_orig"].grad, p + "dW")
+        close(hh.bias.grad, sd[p + "bias"].grad, p + "db", 2e-3 if bf else 2e-5)
+
+
+def test_roi_align_fwd_bwd():
+    from layout2img_amd import ops
+    g = torch.Generator().manual_seed(4)
+    fs, fl = torch.randn(2, 32, 32, 16, generator=g), torch.randn(2, 16, 16, 16, generator=g)
+    rois = torch.tensor([[0, 10.0, 12.0, 100.0, 90.0], [1, 5.5, 3.25, 40.0, 60.0], [0, 0.0, 0.0, 128.0, 128.0],
+                         [1, 100.0, 100.0, 127.0, 120.0], [0, 60.0, 10.0, 70.0, 18.0], [1, -76.8, -76.8, -12.8, -12.8],
+                         [0, 20.0, 20.0, 83.0, 84.5]])
+    valid = torch.tensor([1, 1, 1, 1, 1, 0, 1], dtype=torch.int32)
+    fsr, flr = fs.clone().requires_grad_(True), fl.clone().requires_grad_(True)
+    small = ((rois[:, 3] - rois[:, 1]) < 64) & ((rois[:, 4] - rois[:, 2]) < 64)
+    ref = torch.zeros(7, 8, 8, 16)
+    for i in range(7):
+        if not valid[i]:
+            continue
+        f, sc = (fsr, 0.25) if small[i] else (flr, 0.125)
+        ref[i] = O.roi_align(f.permute(0, 3, 1, 2), rois[i:i + 1], 8, sc, 0)[0].permute(1, 2, 0)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    dev = _dev()
+    a, b = fs.to(dev).requires_grad_(True), fl.to(dev).requires_grad_(True)
+    out = ops.roi_align(a, b, rois.to(dev), valid.to(dev))
+    out.backward(gout.to(dev))
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-5
+    assert float((a.grad.cpu() - fsr.grad).abs().max()) < 1e-4
+    assert float((b.grad.cpu() - flr.grad).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("O_,geo", [(8, True), (31, False), (31, True)])
+def test_box_attention(O_, geo):
+    from layout2img_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, D = 3, 308
+    q, k, v = [torch.randn(B, O_, D, generator=g) for _ in range(3)]
+    ge = torch.rand(B, O_, O_, generator=g) * (torch.rand(B, O_, O_, generator=g) > 0.2) if geo else None
+    y = torch.randint(0, 3, (B, O_), generator=g)
+    y[:, 0] = 1
+    qr, kr, vr = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    gr = ge.clone().requires_grad_(True) if geo else None
+    s = torch.matmul(qr, kr.transpose(-2, -1)) / math.sqrt(D)
+    s = s.masked_fill(y.unsqueeze(1).expand(B, O_, O_) == 0, -1e9)
+    if geo:
+        s = torch.log(torch.clamp(gr, min=1e-6)) + s
+    ref = torch.matmul(torch.softmax(s, -1), vr)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    dev = _dev()
+    qg, kg, vg = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+    gg = ge.to(dev).requires_grad_(True) if geo else None
+    out = ops.box_attention(qg, kg, vg, gg, (y != 0).to(torch.int32).to(dev), 1 / math.sqrt(D))
+    out.backward(go.to(dev))
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 2e-5
+    for a_, b_ in ((qg, qr), (kg, kr), (vg, vr)):
+        assert float((a_.grad.cpu() - b_.grad).abs().max()) < 5e-5
+    if geo:
+        assert float((gg.grad.cpu() - gr.grad).abs().max()) < 1e-3 * float(gr.grad.abs().max())
+
+
+def test_hinge_l1_adam():
+    from layout2img_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(37, 1, generator=g) * 2
+    valid = (torch.rand(37, generator=g) > 0.3).to(torch.int32)
+    for mode in (0, 1, 2):
+        xr = x.clone().requires_grad_(True)
+        sel = xr[valid.bool()]
+        ref = (F.relu(1 - sel).mean() if mode == 0 else F.relu(1 + sel).mean() if mode == 1 else -sel.mean()) * 0.7
+        ref.backward()
+        xg = x.to(dev).requires_grad_(True)
+        out = ops.hinge(xg, valid.to(dev), mode, 0.7)
+        out.backward()
+        assert abs(float(out) - float(ref)) < 1e-5
+        assert float((xg.grad.cpu() - xr.grad).abs().max()) < 1e-6
+    a, b = torch.randn(2, 3, 16, 16, generator=g), torch.randn(2, 3, 16, 16, generator=g)
+    ar = a.clone().requires_grad_(True)
+    F.l1_loss(ar, b).backward()
+    ag = a.to(dev).requires_grad_(True)
+    l = ops.l1_loss(ag, b.to(dev))
+    l.backward()
+    assert abs(float(l) - float(F.l1_loss(a, b))) < 1e-5 and float((ag.grad.cpu() - ar.grad).abs().max()) < 1e-7
+    # Adam, betas (0, 0.999), three steps
+    p = torch.randn(1024, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-4, betas=(0.0, 0.999))
+
+    class _F:
+        pass
+    flat = _F()
+    flat.data, flat.grad, flat.numel = p.to(dev), torch.zeros(1024, device=dev), 1024
+    m, v = torch.zeros(1024, device=dev), torch.zeros(1024, device=dev)
+    for t in range(1, 4):
+        gr = torch.randn(1024, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        flat.grad.copy_(gr)
+        ops.adam_step(flat, m, v, 1e-4, 0.0, 0.999, 1e-8, t)
+    assert float((flat.data.cpu() - pr.detach()).abs().max()) < 1e-6
+
+
+def test_norm_act_standalone():
+    from layout2img_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 8, 8, 104, generator=g) * 2 + 0.5
+    aw, ab = 1 + 0.2 * torch.randn(104, generator=g), 0.2 * torch.randn(104, generator=g)
+    xr, awr, abr = x.clone().requires_grad_(True), aw.clone().requires_grad_(True), ab.clone().requires_grad_(True)
+    ref = F.relu(F.batch_norm(xr.permute(0, 3, 1, 2), None, None, awr, abr, True, 0.1, 1e-5)).permute(0, 2, 3, 1)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    dev = _dev()
+    xg, awg, abg = x.to(dev).requires_grad_(True), aw.to(dev).requires_grad_(True), ab.to(dev).requires_grad_(True)
+    rm, rv = torch.zeros(104, device=dev), torch.ones(104, device=dev)
+    out = ops.norm_act(xg, ops.NormSpec(1, running=(rm, rv)), awg, abg)
+    out.backward(go.to(dev))
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 2e-5
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) < 2e-4 * float(xr.grad.abs().max())
+    assert float((awg.grad.cpu() - awr.grad).abs().max()) < 2e-4 * float(awr.grad.abs().max())
+    assert float((abg.grad.cpu() - abr.grad).abs().max()) < 2e-4 * float(abr.grad.abs().max())
+    xm = x.reshape(-1, 104)
+    assert float((rm.cpu() - 0.1 * xm.mean(0)).abs().max()) < 1e-5
+    assert float((rv.cpu() - (0.9 + 0.1 * xm.var(0, unbiased=True))).abs().max()) < 1e-4
