@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of one full GAN training iteration (G+D fwd+bwd + both Adam steps) at
+128x128 COCO-layout, per-GPU batch 32, bf16 MFMA operands (BASELINE.json configs[2]; the reference loop
+train_context_app_v2.py:148-189 with the VGG term omitted -- its weights cannot be downloaded here).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     -- the implicit-GEMM conv kernel (forward + data-gradient launches): algorithmic FLOPs
+                  (2*M*N*K of the unpadded layer shapes) / launch time measured with HIP events on the
+                  launching stream inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline -- the oracle (pure-PyTorch restatement of the reference, oracle/model.py) timed on this
+                  host's cores on a bounded sample (batch 2) of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(netG, netD, size, seconds_budget=20.0):
+    """Oracle training iterations on the host CPU (all cores); returns images/sec."""
+    from oracle import model as O
+    from layout2img_amd.synthetic import make_batch
+    threads = min(os.cpu_count() or 1, 32)  # more threads than this slow the small-batch oracle down
+    torch.set_num_threads(threads)
+    sd_g = O.make_trainable({k: v.detach().float().cpu() for k, v in netG.state_dict().items()})
+    sd_d = O.make_trainable({k: v.detach().float().cpu() for k, v in netD.state_dict().items()})
+    tr = O.OracleTrainer(sd_g, sd_d)
+    b = 4
+    real, label, bbox, z, z_im = make_batch(b, size, "coco", seed=99, device="cpu")
+    tr.step(real, label, bbox, z, z_im)  # warm-up
+    t0, n = time.time(), 0
+    while n < 8 and (n == 0 or time.time() - t0 < seconds_budget):
+        tr.step(real, label, bbox, z, z_im)
+        n += 1
+    dt = time.time() - t0
+    return dict(value=b * n / dt, unit="images/sec", cores=threads, kind="port",
+                sample=f"{n} training iterations at batch {b}, {size}x{size}, fp32, oracle/model.py OracleTrainer (VGG term omitted)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import layout2img_amd as L
+    from layout2img_amd import ops, parallel
+    from layout2img_amd.synthetic import make_batch
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    op_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(1234)
+    netG = L.ResnetGenerator128_context(num_classes=184).finalize(dev, op_dtype)
+    netD = L.CombineDiscriminator128_app(num_classes=184).finalize(dev, op_dtype)
+    netG.train(), netD.train()
+    trainer = L.GanTrainer(netG, netD)
+    real, label, bbox, z, z_im = make_batch(args.batch, args.size, "coco", seed=1234 + rank, device=dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(real, label, bbox, z, None)
+    if rank == 0 and not args.no_kernel_timer:
+        ops.TIMER = ops.KernelTimer()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(real, label, bbox, z, None)
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+
+    if rank == 0:
+        roof = None
+        if ops.TIMER is not None:
+            s = ops.TIMER.summary()["conv_igemm"]
+            peak = 2500.0 if op_dtype == torch.bfloat16 else 157.3
+            ach = s["work"] / (s["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel="conv_igemm_kernel (fwd + dgrad launches)", achieved=round(ach, 2), peak=peak,
+                        unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None, launches_per_step=s["launches"] // args.steps,
+                        avg_launch_us=round(1e3 * s["ms"] / s["launches"], 2),
+                        gflop_per_launch=round(s["work"] / s["launches"] / 1e9, 3))
+            w = ops.TIMER.summary().get("conv_wgrad")
+            if w:
+                roof["wgrad_tflops"] = round(w["work"] / (w["ms"] * 1e-3) / 1e12, 2)
+            ops.TIMER = None
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(netG, netD, args.size)
+        out = {
+            "metric": "images/sec (G+D fwd+bwd) at 128x128 COCO-layout",
+            "value": round(args.batch * world * args.steps / elapsed, 2),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.size}x{args.size}, batch {args.batch}/GPU, COCO-stuff layouts (8 slots, 3-8 objects), "
+                                   "ResnetGenerator128_context + CombineDiscriminator128_app, full D-step + G-step with Adam, "
+                                   "VGG loss term omitted, random-init weights",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

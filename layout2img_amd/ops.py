@@ -44,8 +44,33 @@ def cast_op(x, op_dtype, raw=True, act=False):
     return r, a
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual launches (bench.py's roofline leg). Events are recorded on
+    the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = {}
+
+    def time(self, name, work):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(name, []).append((a, b, work))
+        a.record()
+        return b
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            out[name] = dict(launches=len(recs), ms=ms, work=float(sum(w for _, _, w in recs)))
+        return out
+
+
+TIMER = None  # set to a KernelTimer by bench.py
+
+
 def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, up2=False, pool2=False, alpha=1.0,
-             want_f32=True, want_op=False, relu_op=False, want_raw=False):
+             want_f32=True, want_op=False, relu_op=False, want_raw=False, flops=None):
     """out = alpha*pool?(conv(up?(x))) + bias, masked, + res.  x_op (B,Hi,Wi,Ci) operand dtype."""
     _chk(x_op)
     B, Hi, Wi, Ci = x_op.shape
@@ -61,19 +86,29 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
     if relu_mask is not None:
         _chk(relu_mask, x_op.dtype)
         assert relu_mask.shape == (B, Hq, Wq, co), (relu_mask.shape, (B, Hq, Wq, co))
+    end = None
+    if TIMER is not None:
+        end = TIMER.time("conv_igemm", flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci)
     _lib.call("l2i_conv2d_fwd", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
               _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
               float(alpha), _stream())
+    if end is not None:
+        end.record()
     return out, out_op, out_raw
 
 
-def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0):
+def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None):
     _chk(x_op)
     _chk(dy_op, x_op.dtype)
     B, Hi, Wi, Ci = x_op.shape
     Ho, Wo = (2 * Hi, 2 * Wi) if up2 else (Hi, Wi)
+    end = None
+    if TIMER is not None:
+        end = TIMER.time("conv_wgrad", flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci)
     _lib.call("l2i_conv2d_wgrad", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
               Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _stream())
+    if end is not None:
+        end.record()
 
 
 def channel_stats(x2d, rows_per_group=None, want_sq=True):
@@ -204,8 +239,11 @@ class FusedConvFn(Function):
         bias_p = None
         if bias is not None:
             bias_p = bias if bias.numel() == holder.co_p else torch.nn.functional.pad(bias, (0, holder.co_p - bias.numel()))
+        Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+        flops = 2.0 * B * Ho * Wo * holder.co * holder.ci * holder.kh * holder.kh  # algorithmic (unpadded) work
         out, _, _ = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p, res=res, up2=up2,
-                             pool2=pool2, alpha=0.25 if pool2 else 1.0)
+                             pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops)
+        ctx.flops = flops
         ctx.holder, ctx.pc, ctx.pro, ctx.up2, ctx.pool2, ctx.stats = holder, pc, pro, up2, pool2, stats
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
         keep_x = x if pro.kind == "norm" else None
@@ -224,7 +262,8 @@ class FusedConvFn(Function):
         alpha = 0.25 if ctx.pool2 else 1.0
         d_bias = None
         if pc.need_wgrad:
-            wgrad_raw(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha)
+            wgrad_raw(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
+                      flops=ctx.flops)
             if ctx.has_bias:
                 d_bias = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False)[0][0][:h.co]
         dx = d_mask = d_w = d_b = None
@@ -232,7 +271,7 @@ class FusedConvFn(Function):
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
             relu_mask = x_op if pro.kind == "relu" else None
             dxo, _, _ = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
-                                 pool2=ctx.up2, alpha=alpha)
+                                 pool2=ctx.up2, alpha=alpha, flops=ctx.flops)
             if pro.kind == "norm":
                 sums, sq, count, sstride = ctx.stats
                 dx, d_w, d_b, d_mask = norm_bwd_raw(x, dxo, sums, sq, count, sstride, pro, mask, wproj, bproj,

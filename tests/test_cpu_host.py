@@ -1,0 +1,91 @@
+"""CPU: host-side logic of the HIP package -- module/state_dict layout against the reference's keys,
+flat parameter storage, arena tables, synthetic layouts, and that the product path refuses to run
+without a GPU (no silent fallback)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import fixture_shapes, load_fixture
+
+
+def _models():
+    import layout2img_amd as L
+    from layout2img_amd import generator as G
+    return {"g_coco.npz": lambda: L.ResnetGenerator128_context(num_classes=184),
+            "g_vg.npz": lambda: G.context_aware_generator(num_classes=179),
+            "d_coco.npz": lambda: L.CombineDiscriminator128_app(num_classes=184)}
+
+
+@pytest.mark.parametrize("fixture", ["g_coco.npz", "g_vg.npz", "d_coco.npz"])
+def test_state_dict_layout_equals_reference(fixture):
+    torch.manual_seed(0)
+    m = _models()[fixture]()
+    ref = fixture_shapes(load_fixture(fixture))
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == ref
+
+
+def test_parameter_counts_match_survey():
+    torch.manual_seed(0)
+    ms = _models()
+    assert sum(p.numel() for p in ms["g_coco.npz"]().parameters()) == 40853873
+    assert sum(p.numel() for p in ms["d_coco.npz"]().parameters()) == 62696387
+
+
+def test_flat_params_and_arena_tables_on_cpu():
+    from layout2img_amd.arena import FlatParams, GemmWeight, WeightArena
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = GemmWeight("conv", 24, 3, 3, sn=True, eps=1e-4)
+            self.b = GemmWeight("linear", 10, 308, sn=True, uses=2)
+            self.c = GemmWeight("conv", 100, 16, 1, sn=False, bias=False)
+            self.s = torch.nn.Parameter(torch.ones(5))
+    net = Net()
+    w0 = net.a.weight_orig.detach().clone()
+    flat = FlatParams(net, "cpu")
+    assert torch.equal(net.a.weight_orig.detach(), w0)
+    assert net.a.weight_orig.data_ptr() == flat.data.data_ptr() + 4 * flat.offset_of(net.a.weight_orig)
+    (net.s * 2).sum().backward()
+    assert float(flat.grad.sum()) == 10.0          # autograd accumulated into the flat gradient view
+    flat.zero_grad()
+    assert float(flat.grad.abs().sum()) == 0.0 and net.s.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.offset_of(net.s)
+    arena = WeightArena(net, flat, "cpu", torch.bfloat16)
+    assert arena.n_layers == 4 and arena.rounds == 2          # b is applied twice -> two rows, two rounds
+    tab = arena.layers.view(-1, 20).numpy()
+    assert tab[0, 6] == 24 and tab[0, 7] == 8                  # Ci = 3 padded to 8
+    assert tab[1, 7] == 312 and tab[1, 8] == 320               # 308 -> 312, Kpad multiple of 64
+    assert tab[1, 0] == tab[2, 0] and tab[1, 1] == tab[2, 1] and tab[1, 16] != tab[2, 16] and tab[1, 10] != tab[2, 10]
+    assert tab[3, 1] == -1                                     # no spectral norm
+    assert net.b.use(1).fwd_off == tab[2, 10] and net.b.use(0) is net.b
+
+
+def test_no_silent_cpu_fallback():
+    import layout2img_amd as L
+    from layout2img_amd import ops
+    torch.manual_seed(0)
+    d = L.CombineDiscriminator128_app(num_classes=184)
+    with pytest.raises((RuntimeError, AttributeError)):
+        d(torch.zeros(1, 3, 128, 128), torch.zeros(1, 8, 4), torch.zeros(1, 8, 1, dtype=torch.long))
+    with pytest.raises(RuntimeError):
+        ops.cast_op(torch.zeros(8), torch.bfloat16)
+
+
+def test_synthetic_layout_statistics():
+    from layout2img_amd.synthetic import make_batch, make_layouts
+    label, bbox = make_layouts(64, "coco", seed=1)
+    n = (label != 0).sum(1)
+    assert label.shape == (64, 8) and int(n.min()) >= 3 and int(n.max()) <= 8 and int(label.max()) <= 183
+    real = bbox[label != 0]
+    assert float((real[:, 2] * real[:, 3]).min()) > 0.02 and float((real[:, 0] + real[:, 2]).max()) <= 1.0 + 1e-6
+    assert torch.allclose(bbox[label == 0], torch.tensor([-0.6, -0.6, 0.5, 0.5]))
+    label, bbox = make_layouts(16, "vg", seed=2)
+    assert label.shape == (16, 31)
+    for b in range(16):
+        k = int((label[b] != 0).sum())
+        assert torch.allclose(bbox[b, k], torch.tensor([0.0, 0.0, 1.0, 1.0])) and int(label[b, k]) == 0
+    real, label, bbox, z, z_im = make_batch(4, 128)
+    assert real.shape == (4, 3, 128, 128) and z.shape == (4, 8, 128) and z_im.shape == (4, 128)
+    assert float(real.min()) >= -1 and float(real.max()) <= 1
