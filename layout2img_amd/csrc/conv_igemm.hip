@@ -31,6 +31,7 @@ struct ConvArgs {
     int up2, pool2, relu_op;
     int Kpad, K;
     int PW, PH, hw_shift, lin, tiles_c, tiles_m, tiles_n;
+    int splits, ks_per;  // split-K: `out` pre-zeroed, partials combined with f32 atomics
     float alpha;
 };
 
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = p.tiles_m * p.tiles_n;
-    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int split = blockIdx.x / nblk;
+    const int bid = xcd_remap(blockIdx.x - split * nblk, nblk);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
     const int n0 = tile_n * BN;
@@ -113,9 +115,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (BN / 2);
-    const int nks = p.Kpad / BK;
-    load_tiles(0);
-    for (int ks = 0; ks < nks; ++ks) {
+    const int ks0 = split * p.ks_per;
+    const int nks = min(p.Kpad / BK, ks0 + p.ks_per);
+    load_tiles(ks0);
+    for (int ks = ks0; ks < nks; ++ks) {
         store_tiles();
         __syncthreads();
         if (ks + 1 < nks) load_tiles(ks + 1);  // in flight under the MFMAs
@@ -147,9 +150,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                     if (n >= p.Co) continue;
                     float v = acc[i][j][4 * g] + acc[i][j][4 * g + 1] + acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3];
                     v *= p.alpha;
-                    if (p.bias) v += p.bias[n];
+                    if (p.bias && split == 0) v += p.bias[n];
                     if (Mask && !(OpT<T>::to(Mask[rowoff + n]) > 0.f)) v = 0.f;
-                    if (p.res) v += p.res[rowoff + n];
+                    if (p.res && split == 0) v += p.res[rowoff + n];
+                    if (p.splits > 1) { atomicAdd(p.out + rowoff + n, v); continue; }
                     if (p.out) p.out[rowoff + n] = v;
                     if (OutOp) OutOp[rowoff + n] = OpT<T>::from(p.relu_op ? fmaxf(v, 0.f) : v);
                     if (OutRaw) OutRaw[rowoff + n] = OpT<T>::from(v);
@@ -168,9 +172,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                         const int n = n0 + wcol + j * 32 + c;
                         if (n >= p.Co) continue;
                         float v = acc[i][j][4 * g + e] * p.alpha;
-                        if (p.bias) v += p.bias[n];
+                        if (p.bias && split == 0) v += p.bias[n];
                         if (Mask && !(OpT<T>::to(Mask[rowoff + n]) > 0.f)) v = 0.f;
-                        if (p.res) v += p.res[rowoff + n];
+                        if (p.res && split == 0) v += p.res[rowoff + n];
+                        if (p.splits > 1) { atomicAdd(p.out + rowoff + n, v); continue; }
                         if (p.out) p.out[rowoff + n] = v;
                         if (OutOp) OutOp[rowoff + n] = OpT<T>::from(p.relu_op ? fmaxf(v, 0.f) : v);
                         if (OutRaw) OutRaw[rowoff + n] = OpT<T>::from(v);
@@ -216,11 +221,25 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     const int BN = a.Co <= 64 ? 64 : 128;
     a.tiles_n = (a.Co + BN - 1) / BN;
     const int nblk = a.tiles_m * a.tiles_n;
+    const int nks = a.Kpad / BK;
+    // split-K for small grids with a long reduction (D block5/6, G res1/res2, ROI heads): fill the 256 CUs
+    int splits = 1;
+    if (a.out && !a.out_op && !a.out_op_raw && nblk < 192 && nks >= 16) {
+        splits = (512 + nblk - 1) / nblk;
+        if (splits > nks / 4) splits = nks / 4;
+        if (splits < 1) splits = 1;
+    }
+    a.ks_per = (nks + splits - 1) / splits;
+    a.splits = (nks + a.ks_per - 1) / a.ks_per;
+    if (a.splits > 1) {
+        const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
+        if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+    }
     const size_t lds = (size_t)(128 + BN) * IG_ROWB;
     if (BN == 64)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3(nblk), dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3(nblk), dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
     return l2i_check_launch();
 }
 

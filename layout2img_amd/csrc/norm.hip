@@ -20,9 +20,15 @@
 
 // ---------------------------------------------------------------- channel statistics
 // x [rows][C] f32, rows grouped in consecutive runs of rows_per_group. sums/sqsums [G][C] += .
+// Optionally also writes the operand-dtype copy of x (the cast a following MFMA kernel needs), so the
+// bias-gradient reduction and the dY cast of a convolution's backward are one pass over dY.
+// ~512 blocks in total: each block's per-channel partials end in one atomic per channel, and many more
+// blocks than that serialise on the same few addresses in L2.
+template <typename T>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, long long rows, int C,
                                                             long long rows_per_group, int slabs_per_group,
-                                                            float* __restrict__ sums, float* __restrict__ sqsums) {
+                                                            float* __restrict__ sums, float* __restrict__ sqsums,
+                                                            T* __restrict__ raw) {
     __shared__ float4 red[2][256];
     const int cols4 = C >> 2;
     const int group = blockIdx.x / slabs_per_group, slab = blockIdx.x % slabs_per_group;
@@ -35,10 +41,22 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
         const int tx = threadIdx.x % ncol, ty = threadIdx.x / ncol;
         float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
         if (ty < TY) {
+#pragma unroll 4
             for (long long r = r0 + ty; r < r1; r += TY) {
-                const float4 v = *reinterpret_cast<const float4*>(x + r * C + 4 * (cbase + tx));
+                const size_t off = (size_t)r * C + 4 * (cbase + tx);
+                const float4 v = *reinterpret_cast<const float4*>(x + off);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+                if (raw) {
+                    if constexpr (sizeof(T) == 2) {
+                        uint2 pk;
+                        pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                        pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(raw) + off) = pk;
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(raw) + off) = v;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -62,15 +80,22 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 }
 
 extern "C" int l2i_channel_stats(const float* x, long long rows, int C, long long rows_per_group, float* sums,
-                                 float* sqsums, void* stream) {
+                                 float* sqsums, void* raw, int dtype, void* stream) {
     if (!x || !sums || C % 4 || rows_per_group <= 0 || rows % rows_per_group) return L2I_ERR_ARG;
     const long long G = rows / rows_per_group;
-    long long slabs = (2048 + G - 1) / G;
-    const long long max_slabs = (rows_per_group + 31) / 32;
+    long long slabs = (512 + G - 1) / G;
+    const long long max_slabs = (rows_per_group + 63) / 64;
     if (slabs > max_slabs) slabs = max_slabs;
     if (slabs < 1) slabs = 1;
-    hipLaunchKernelGGL(channel_stats_kernel, dim3((unsigned)(G * slabs)), dim3(256), 0, (hipStream_t)stream, x, rows, C,
-                       rows_per_group, (int)slabs, sums, sqsums);
+    const dim3 grid((unsigned)(G * slabs));
+    if (dtype == 1)
+        hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, C, rows_per_group,
+                           (int)slabs, sums, sqsums, (bf16_t*)raw);
+    else if (dtype == 0)
+        hipLaunchKernelGGL(channel_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, C, rows_per_group,
+                           (int)slabs, sums, sqsums, (float*)raw);
+    else
+        return L2I_ERR_ARG;
     return l2i_check_launch();
 }
 
@@ -78,6 +103,7 @@ extern "C" int l2i_channel_stats(const float* x, long long rows, int C, long lon
 struct NormArgs {
     const float* x;        // [B][HW][C]
     const float* dy;       // bwd: gradient wrt the (post-ReLU) output
+    float* dy_keep;        // bwd, O > 8 only: scratch copy of dy (dxhat may alias dy)
     const float* sums;     // [G][C]
     const float* sqsums;   // [G][C]
     const float* mask;     // [B][O][HW] or null
@@ -300,6 +326,228 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(NormArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- modulated norm, backward pass A
+// One block = (image b, 128-channel chunk, a run of 32-pixel sub-tiles). Per-channel sums (s1, s2, affine
+// grads) and the per-object projection grads dW[b,o,c], dB[b,o,c] are accumulated in REGISTERS across the
+// whole run and leave the block as one atomic per value; the per-pixel mask gradient needs a sum over the
+// channels held by the 32 lanes of a half-wave, done as a 32-value reduce-scatter (31 shuffles instead of
+// 5 per value). Objects are processed in chunks of 8 (o > 8 re-walks the run; only VG has o = 31).
+#define NB_PX 32
+#define NB_OC 8
+
+__global__ __launch_bounds__(256) void norm_bwd_a_kernel(NormArgs p, int nseg, int seg_pixels) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int O = p.mode == 0 ? p.O : 0;
+    float* Wl = reinterpret_cast<float*>(smem);
+    float* Bl = Wl + O * NM_CC;
+    float* mn = Bl + O * NM_CC;          // [O][NB_PX]
+    float* sinv = mn + O * NB_PX;        // [NB_PX]
+    float4* red = reinterpret_cast<float4*>(sinv + NB_PX);  // [4 waves][20 values][32 cv]
+
+    const int tiles_c = (p.C + NM_CC - 1) / NM_CC;
+    int bid = blockIdx.x;
+    const int tc = bid % tiles_c; bid /= tiles_c;
+    const int seg = bid % nseg;
+    const int b = bid / nseg;
+    const int c0 = tc * NM_CC;
+    const int cc = min(NM_CC, p.C - c0);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int px_begin = seg * seg_pixels, px_end = min(p.HW, px_begin + seg_pixels);
+
+    for (int i = tid; i < O * NM_CC; i += 256) {
+        const int o = i / NM_CC, c = i - o * NM_CC;
+        float w = 0.f, bb = 0.f;
+        if (c < cc) {
+            const size_t off = (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + c0 + c;
+            w = p.wproj[off];
+            bb = p.bproj[off];
+        }
+        Wl[i] = w;
+        Bl[i] = bb;
+    }
+
+    const int cv = tid & 31, prow = tid >> 5;
+    const int c = c0 + 4 * cv;
+    const bool con = 4 * cv < cc;
+    float4 mean = make_float4(0, 0, 0, 0), istd = make_float4(1, 1, 1, 1);
+    float4 aw = make_float4(1, 1, 1, 1), ab = make_float4(0, 0, 0, 0);
+    if (con) {
+        const size_t so = (size_t)b * p.stat_stride + c;
+        const float4 s = *reinterpret_cast<const float4*>(p.sums + so);
+        const float4 q = *reinterpret_cast<const float4*>(p.sqsums + so);
+        const float ic = 1.f / p.count;
+        mean = make_float4(s.x * ic, s.y * ic, s.z * ic, s.w * ic);
+        istd.x = rsqrtf(fmaxf(q.x * ic - mean.x * mean.x, 0.f) + p.eps);
+        istd.y = rsqrtf(fmaxf(q.y * ic - mean.y * mean.y, 0.f) + p.eps);
+        istd.z = rsqrtf(fmaxf(q.z * ic - mean.z * mean.z, 0.f) + p.eps);
+        istd.w = rsqrtf(fmaxf(q.w * ic - mean.w * mean.w, 0.f) + p.eps);
+        if (p.mode == 1) {
+            aw = *reinterpret_cast<const float4*>(p.wproj + c);
+            ab = *reinterpret_cast<const float4*>(p.bproj + c);
+        }
+    }
+    const float4 z4 = make_float4(0, 0, 0, 0);
+    float4 acc_s1 = z4, acc_s2 = z4, acc_aw = z4, acc_ab = z4;
+    const int nchunk = p.mode == 0 ? (O + NB_OC - 1) / NB_OC : 1;
+
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        float4 adw[NB_OC], adb[NB_OC];
+#pragma unroll
+        for (int k = 0; k < NB_OC; ++k) { adw[k] = z4; adb[k] = z4; }
+        for (int p0 = px_begin; p0 < px_end; p0 += NB_PX) {
+            __syncthreads();
+            if (O > 0 && tid < NB_PX) {
+                const int px = p0 + tid;
+                float S = 1e-6f;
+                if (px < px_end)
+                    for (int o = 0; o < O; ++o) S += p.mask[((size_t)b * O + o) * p.HW + px];
+                const float inv = 1.f / S;
+                sinv[tid] = inv;
+                for (int o = 0; o < O; ++o)
+                    mn[o * NB_PX + tid] = px < px_end ? p.mask[((size_t)b * O + o) * p.HW + px] * inv : 0.f;
+            }
+            __syncthreads();
+            float4 g[4], gx[4];
+            float t0[4];
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) {
+                const int pl = prow + 8 * pi, px = p0 + pl;
+                const bool on = con && px < px_end;
+                const size_t off = ((size_t)b * p.HW + px) * p.C + c;
+                g[pi] = z4; gx[pi] = z4; t0[pi] = 0.f;
+                if (on) {
+                    const float4 xv = *reinterpret_cast<const float4*>(p.x + off);
+                    const float4 xh = make_float4((xv.x - mean.x) * istd.x, (xv.y - mean.y) * istd.y,
+                                                  (xv.z - mean.z) * istd.z, (xv.w - mean.w) * istd.w);
+                    float4 ga = aw, be = ab;
+                    if (p.mode == 0) {
+                        ga = make_float4(1, 1, 1, 1);
+                        be = z4;
+                        for (int o = 0; o < O; ++o) {
+                            const float m = mn[o * NB_PX + pl];
+                            ga = f4mad(m, *reinterpret_cast<const float4*>(Wl + o * NM_CC + 4 * cv), ga);
+                            be = f4mad(m, *reinterpret_cast<const float4*>(Bl + o * NM_CC + 4 * cv), be);
+                        }
+                    }
+                    const float4 y = make_float4(fmaf(ga.x, xh.x, be.x), fmaf(ga.y, xh.y, be.y), fmaf(ga.z, xh.z, be.z),
+                                                 fmaf(ga.w, xh.w, be.w));
+                    // dy may alias the dxhat output: each element is read here before this thread overwrites it,
+                    // and later object chunks re-read x but take g from dy only in chunk 0 ... so for chunk > 0
+                    // the gate and gamma are recomputed and g is recovered as dxhat / gamma is NOT safe; instead
+                    // chunk > 0 reads the saved dy copy below.
+                    const float4 d = *reinterpret_cast<const float4*>((chunk == 0 ? p.dy : p.dy_keep) + off);
+                    float4 gg;
+                    gg.x = (!p.relu || y.x > 0.f) ? d.x : 0.f;
+                    gg.y = (!p.relu || y.y > 0.f) ? d.y : 0.f;
+                    gg.z = (!p.relu || y.z > 0.f) ? d.z : 0.f;
+                    gg.w = (!p.relu || y.w > 0.f) ? d.w : 0.f;
+                    g[pi] = gg;
+                    gx[pi] = make_float4(gg.x * xh.x, gg.y * xh.y, gg.z * xh.z, gg.w * xh.w);
+                    if (chunk == 0) {
+                        const float4 dxh = make_float4(gg.x * ga.x, gg.y * ga.y, gg.z * ga.z, gg.w * ga.w);
+                        if (p.dy_keep && nchunk > 1) *reinterpret_cast<float4*>(p.dy_keep + off) = d;
+                        *reinterpret_cast<float4*>(p.out_f32 + off) = dxh;
+                        acc_s1.x += dxh.x; acc_s1.y += dxh.y; acc_s1.z += dxh.z; acc_s1.w += dxh.w;
+                        acc_s2.x += dxh.x * xh.x; acc_s2.y += dxh.y * xh.y; acc_s2.z += dxh.z * xh.z; acc_s2.w += dxh.w * xh.w;
+                        if (p.mode == 1) {
+                            acc_aw.x += gx[pi].x; acc_aw.y += gx[pi].y; acc_aw.z += gx[pi].z; acc_aw.w += gx[pi].w;
+                            acc_ab.x += gg.x; acc_ab.y += gg.y; acc_ab.z += gg.z; acc_ab.w += gg.w;
+                        }
+                    }
+                    t0[pi] = gx[pi].x * (ga.x - 1.f) + gg.x * be.x + gx[pi].y * (ga.y - 1.f) + gg.y * be.y +
+                             gx[pi].z * (ga.z - 1.f) + gg.z * be.z + gx[pi].w * (ga.w - 1.f) + gg.w * be.w;
+                }
+            }
+            if (p.mode == 0) {
+                float v[NB_OC * 4];
+#pragma unroll
+                for (int ol = 0; ol < NB_OC; ++ol) {
+                    const int o = chunk * NB_OC + ol;
+                    float4 wv = z4, bv = z4;
+                    const bool oon = o < O;
+                    if (oon) {
+                        wv = *reinterpret_cast<const float4*>(Wl + o * NM_CC + 4 * cv);
+                        bv = *reinterpret_cast<const float4*>(Bl + o * NM_CC + 4 * cv);
+                    }
+#pragma unroll
+                    for (int pi = 0; pi < 4; ++pi) {
+                        const float m = oon ? mn[o * NB_PX + prow + 8 * pi] : 0.f;
+                        adw[ol] = f4mad(m, gx[pi], adw[ol]);
+                        adb[ol] = f4mad(m, g[pi], adb[ol]);
+                        v[ol * 4 + pi] = oon ? gx[pi].x * wv.x + gx[pi].y * wv.y + gx[pi].z * wv.z + gx[pi].w * wv.w +
+                                                   g[pi].x * bv.x + g[pi].y * bv.y + g[pi].z * bv.z + g[pi].w * bv.w - t0[pi]
+                                             : 0.f;
+                    }
+                }
+                if (p.dmask) {
+                    // reduce-scatter of v[32] over the 32 channel lanes of this pixel row: lane l ends with sum_j-th value j = l
+                    const int l = tid & 31;
+#define L2I_RS(N, S)                                                                 \
+                    _Pragma("unroll") for (int k = 0; k < N; ++k) {                  \
+                        const bool hi = (l & S) != 0;                                \
+                        const float send = hi ? v[k] : v[k + N];                     \
+                        const float keep = hi ? v[k + N] : v[k];                     \
+                        v[k] = keep + __shfl_xor(send, S, 64);                       \
+                    }
+                    L2I_RS(16, 16) L2I_RS(8, 8) L2I_RS(4, 4) L2I_RS(2, 2) L2I_RS(1, 1)
+#undef L2I_RS
+                    const int ol = l >> 2, pi = l & 3;
+                    const int o = chunk * NB_OC + ol, pl = prow + 8 * pi, px = p0 + pl;
+                    if (o < O && px < px_end) atomicAdd(p.dmask + ((size_t)b * O + o) * p.HW + px, v[0] * sinv[pl]);
+                }
+            }
+        }
+        // ---- block-level reduction of this chunk's per-object gradients (and, in chunk 0, the channel sums)
+        __syncthreads();
+        const int nval = (p.mode == 0 ? 2 * NB_OC : 0) + (chunk == 0 ? (p.mode == 1 ? 4 : 2) : 0);
+        {
+            int k = 0;
+            auto put = [&](float4 a) {
+                a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64);
+                a.z += __shfl_xor(a.z, 32, 64); a.w += __shfl_xor(a.w, 32, 64);
+                if ((tid & 32) == 0) red[(wave * 20 + k) * 32 + cv] = a;
+                ++k;
+            };
+            if (p.mode == 0) {
+#pragma unroll
+                for (int ol = 0; ol < NB_OC; ++ol) { put(adw[ol]); put(adb[ol]); }
+            }
+            if (chunk == 0) {
+                put(acc_s1); put(acc_s2);
+                if (p.mode == 1) { put(acc_aw); put(acc_ab); }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nval * 32; i += 256) {
+            const int k = i >> 5, lc = i & 31;
+            if (4 * lc >= cc) continue;
+            float4 a = red[(0 * 20 + k) * 32 + lc];
+            for (int w = 1; w < 4; ++w) {
+                const float4 t = red[(w * 20 + k) * 32 + lc];
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            float* dst;
+            const int cch = c0 + 4 * lc;
+            int kk = k;
+            if (p.mode == 0 && kk < 2 * NB_OC) {
+                const int o = chunk * NB_OC + (kk >> 1);
+                if (o >= O) continue;
+                dst = ((kk & 1) ? p.dbproj : p.dwproj) + (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + cch;
+            } else {
+                if (p.mode == 0) kk -= 2 * NB_OC;
+                const size_t so = (size_t)b * p.stat_stride + cch;
+                dst = kk == 0 ? p.s1 + so : kk == 1 ? p.s2 + so : kk == 2 ? p.dwproj + cch : p.dbproj + cch;
+            }
+            atomicAdd(dst + 0, a.x); atomicAdd(dst + 1, a.y); atomicAdd(dst + 2, a.z); atomicAdd(dst + 3, a.w);
+        }
+    }
+}
+
+static size_t norm_bwd_lds(const NormArgs& a) {
+    const int O = a.mode == 0 ? a.O : 0;
+    return sizeof(float) * ((size_t)2 * O * NM_CC + (size_t)O * NB_PX + NB_PX) + sizeof(float4) * 4 * 20 * 32 + 16;
+}
+
 static size_t norm_lds(const NormArgs& a) {
     const int O = a.mode == 0 ? a.O : 0;
     return sizeof(float) * ((size_t)2 * O * NM_CC + (size_t)O * NM_PT + NM_PT) + 16;
@@ -336,16 +584,24 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
                                   const float* sqsums, float count, float eps, int stat_stride, const float* mask, int O,
                                   const float* wproj, const float* bproj, long long pstride_b, long long pstride_o,
                                   int mode, int relu, float* dxhat, float* s1, float* s2, float* dwproj, float* dbproj,
-                                  float* dmask, void* stream) {
+                                  float* dmask, float* dy_keep, void* stream) {
     NormArgs a = {};
     a.x = x; a.dy = dy; a.B = B; a.HW = HW; a.C = C; a.sums = sums; a.sqsums = sqsums; a.count = count; a.eps = eps;
     a.stat_stride = stat_stride; a.mask = mask; a.O = O; a.wproj = wproj; a.bproj = bproj;
     a.pstride_b = pstride_b; a.pstride_o = pstride_o; a.mode = mode; a.relu = relu; a.out_f32 = dxhat;
-    a.s1 = s1; a.s2 = s2; a.dwproj = dwproj; a.dbproj = dbproj; a.dmask = dmask;
+    a.s1 = s1; a.s2 = s2; a.dwproj = dwproj; a.dbproj = dbproj; a.dmask = dmask; a.dy_keep = dy_keep;
     if (norm_check(a) != L2I_OK || !dy || !dxhat || !s1 || !s2) return L2I_ERR_ARG;
     if (mode != 2 && (!dwproj || !dbproj)) return L2I_ERR_ARG;
-    const int nblk = B * ((HW + NM_PT - 1) / NM_PT) * ((C + NM_CC - 1) / NM_CC);
-    hipLaunchKernelGGL((norm_mod_kernel<float, true>), dim3(nblk), dim3(256), norm_lds(a), (hipStream_t)stream, a);
+    if (mode == 0 && O > NB_OC && !dy_keep) return L2I_ERR_ARG;  // more than one object chunk needs the dy copy
+    const int tiles_c = (C + NM_CC - 1) / NM_CC;
+    const int subtiles = (HW + NB_PX - 1) / NB_PX;
+    int nseg = 2048 / (B * tiles_c);
+    if (nseg > subtiles) nseg = subtiles;
+    if (nseg < 1) nseg = 1;
+    const int seg_pixels = ((subtiles + nseg - 1) / nseg) * NB_PX;
+    nseg = (HW + seg_pixels - 1) / seg_pixels;
+    hipLaunchKernelGGL(norm_bwd_a_kernel, dim3(B * nseg * tiles_c), dim3(256), norm_bwd_lds(a), (hipStream_t)stream, a, nseg,
+                       seg_pixels);
     return l2i_check_launch();
 }
 

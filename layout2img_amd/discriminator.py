@@ -94,11 +94,13 @@ class ResnetDiscriminator128_app(nn.Module):
         # appearance head (reference :148-157): Gram of the ROI features + class embedding
         a = F.relu(self.app_conv(obj, pc))
         R, s2 = a.shape[0], a.shape[3]
-        A = a.view(R, -1, s2)
-        gram = torch.bmm(A.transpose(1, 2), A) / s2                       # (R, C, C)
+        A = a.view(R, -1, s2)                                             # (R, hw, C) = F^T of the reference's (C, hw)
         wa = arena_weight(self.app, pc)                                   # (1, 2C)
         emb_app = arena_weight(self.l_y_app, pc)[y]                       # (R, C)
-        out_app = (gram @ wa[0, :s2]).mean(dim=1, keepdim=True) + emb_app @ wa[0, s2:].unsqueeze(1) + self.app.bias
+        # sum_rows(Gram @ wa1)/C with Gram = F F^T / C, without materialising the (R,C,C) Gram matrices:
+        #   sum_i sum_j G_ij wa1_j = (1/C) sum_p (sum_i F_ip) (sum_j F_jp wa1_j)
+        gram_term = ((A.sum(dim=2) * (A @ wa[0, :s2])).sum(dim=1, keepdim=True)) / (s2 * s2)
+        out_app = gram_term + emb_app @ wa[0, s2:].unsqueeze(1) + self.app.bias
 
         # projection head (reference :160-166)
         f = F.relu(self.block_obj5(obj, pc)).sum(dim=(1, 2))              # (R, 16ch)

@@ -111,15 +111,19 @@ def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0
         end.record()
 
 
-def channel_stats(x2d, rows_per_group=None, want_sq=True):
-    """x2d: (rows, C) f32 view. Returns sums (G, C) and sqsums (G, C)|None."""
+def channel_stats(x2d, rows_per_group=None, want_sq=True, cast_to=None):
+    """x2d: (rows, C) f32 view. Returns sums (G, C), sqsums (G, C)|None [, operand-dtype copy if cast_to]."""
     _chk(x2d, torch.float32)
     rows, C = x2d.shape
     rpg = rows if rows_per_group is None else rows_per_group
     G = rows // rpg
-    sums = torch.zeros((G, C), dtype=torch.float32, device=x2d.device)
-    sq = torch.zeros((G, C), dtype=torch.float32, device=x2d.device) if want_sq else None
-    _lib.call("l2i_channel_stats", x2d.data_ptr(), rows, C, rpg, sums.data_ptr(), _p(sq), _stream())
+    buf = torch.zeros((2 if want_sq else 1, G, C), dtype=torch.float32, device=x2d.device)
+    sums, sq = buf[0], (buf[1] if want_sq else None)
+    raw = torch.empty(x2d.shape, dtype=cast_to, device=x2d.device) if cast_to is not None else None
+    _lib.call("l2i_channel_stats", x2d.data_ptr(), rows, C, rpg, sums.data_ptr(), _p(sq), _p(raw),
+              _code(cast_to) if cast_to is not None else _lib.F32, _stream())
+    if cast_to is not None:
+        return sums, sq, raw
     return sums, sq
 
 
@@ -197,9 +201,10 @@ def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, 
         psb, pso = O * C, C
     elif spec.mode == 1:
         dw, db = torch.zeros_like(wproj), torch.zeros_like(bproj)
+    keep = torch.empty_like(dy) if (spec.mode == 0 and O > 8) else None
     _lib.call("l2i_norm_mod_bwd_a", x.data_ptr(), dy.data_ptr(), B, H * W, C, sums.data_ptr(), sq.data_ptr(), float(count),
               float(spec.eps), stat_stride, _p(mask), O, _p(wproj), _p(bproj), psb, pso, spec.mode, int(spec.relu),
-              dy.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(dw), _p(db), _p(dm), _stream())
+              dy.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(dw), _p(db), _p(dm), _p(keep), _stream())
     frozen = (not spec.training) and spec.running is not None and not spec.instance
     if frozen:
         raise RuntimeError("backward through eval-mode batch norm is not part of the hot path")
@@ -258,14 +263,17 @@ class FusedConvFn(Function):
         opd = pc.arena.op_dtype
         need_x = ctx.needs_input_grad[0]
         need_mod = pro.kind == "norm" and pro.mode in (0, 1)
-        dy_op, _ = cast_op(dy, opd, raw=True, act=False)
         alpha = 0.25 if ctx.pool2 else 1.0
         d_bias = None
+        if pc.need_wgrad and ctx.has_bias:  # bias gradient and the dY operand cast in one pass over dY
+            bsum, _, dy_op = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False, cast_to=opd)
+            dy_op = dy_op.view(dy.shape)
+            d_bias = bsum[0][:h.co]
+        else:
+            dy_op, _ = cast_op(dy, opd, raw=True, act=False)
         if pc.need_wgrad:
             wgrad_raw(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
                       flops=ctx.flops)
-            if ctx.has_bias:
-                d_bias = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False)[0][0][:h.co]
         dx = d_mask = d_w = d_b = None
         if need_x or need_mod:
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles

@@ -86,6 +86,27 @@ def test_conv_forward(case, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", [(2, 8, 8, 256, 64, 3, False, False), (4, 4, 4, 512, 136, 3, False, True),
+                                  (3, 4, 4, 256, 128, 3, True, False), (8, 1, 1, 2048, 16, 1, False, False)])
+def test_conv_split_k(case, dt):
+    """small grids with a long reduction take the split-K path (f32 atomics into a zeroed output)"""
+    from layout2img_amd import ops
+    B, H, W, Ci, Co, KH, up2, pool2 = case
+    g = torch.Generator().manual_seed(11)
+    x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    w = _rt(torch.randn(Co, Ci, KH, KH, generator=g) / math.sqrt(Ci * KH * KH), dt)
+    bias = torch.randn(Co, generator=g)
+    ref = _ref_conv(x, w, bias, up2, pool2)
+    res = torch.randn(ref.shape, generator=g)
+    mask = _rt(torch.randn(ref.shape, generator=g), dt)
+    pack, kpad = _pack(w, 64 if dt == torch.bfloat16 else 32)
+    out, _, _ = ops.conv_raw(x.to(_dev(), dt), pack.to(_dev(), dt), kpad, Co, KH, bias=bias.to(_dev()), res=res.to(_dev()),
+                             relu_mask=mask.to(_dev(), dt), up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0)
+    expect = ref * (mask > 0).float() + res
+    assert float((out.cpu() - expect).abs().max()) < 3e-5 * float(expect.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_conv_relu_mask(dt):
     from layout2img_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -181,7 +202,7 @@ def test_weight_arena_spectral_norm(training):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("pro", ["cast", "relu", "isla", "affine", "instance"])
+@pytest.mark.parametrize("pro", ["cast", "relu", "isla", "affine", "instance", "isla_big"])
 def test_fused_conv_fwd_bwd(pro, dt):
     """FusedConvFn (prologue + conv + bias + res [+ up2]) forward and all gradients, incl. the spectral-norm
     backward into the flat gradient buffer, against torch autograd on the oracle formulas."""
@@ -189,7 +210,11 @@ def test_fused_conv_fwd_bwd(pro, dt):
     from layout2img_amd.arena import GemmWeight
     torch.manual_seed(1)
     B, H, W, Ci, Co, O_ = 3, 8, 8, 16, 24, 5
-    up2 = pro in ("isla", "cast")
+    if pro == "isla_big":   # 2 channel chunks (one partial), 2 object chunks, several 32-pixel sub-tiles per block
+        B, H, W, Ci, Co, O_, pro = 40, 32, 32, 136, 8, 11, "isla"
+        if dt == torch.float32:
+            B = 8
+    up2 = pro in ("isla", "cast") and H == 8
     h = GemmWeight("conv", Co, Ci, 3, sn=True, eps=1e-4)
     sd = _sd_of(h)
     net, flat, arena = _mk([h], dt)
