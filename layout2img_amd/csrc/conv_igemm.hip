@@ -18,6 +18,8 @@
 // one quad and the 2x2 pool is an in-register sum.
 #include "igemm.h"
 
+__device__ uint4 g_zero16[1] = {{0u, 0u, 0u, 0u}};  // source of out-of-image im2col taps
+
 struct ConvArgs {
     const void* x;      // T  [B, Hi, Wi, Ci]
     const void* w;      // T  [Npad, Kpad], K order (ky, kx, ci)
@@ -51,9 +53,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int TM = 2, TN = BN / 64;
     constexpr int AP = BM / 32, BP = BN / 32;  // 16-byte loads per thread per K-step
 
+    // LDS: two stages of [A 128 rows | B BN rows], 128-byte rows, filled by LDS-DMA (global_load_lds_dwordx4:
+    // lane i of a wave-instruction lands at base + 16 i, i.e. 8 rows x 8 chunks), no VGPR staging, no ds_write.
+    // Bank conflicts of the ds_read_b128 fragment reads are avoided by an XOR swizzle applied on the SOURCE
+    // side (the lane that fills physical chunk c of row r fetches logical chunk c ^ (r & 7)) and on the read.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;
-    char* Bs = smem + BM * IG_ROWB;
+    constexpr int STAGE = (BM + BN) * IG2_ROWB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = p.tiles_m * p.tiles_n;
@@ -66,7 +71,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int pad = p.KH >> 1;
 
     // ---- per-thread A rows (fixed for the whole K loop)
-    const int lrow = tid >> 3, lgrp = tid & 7;
+    const int lrow = tid >> 3;
+    const int lchunk = (tid & 7) ^ (lrow & 7);  // logical 16-byte chunk this lane fetches
     int a_y[AP], a_x[AP], a_boff[AP];
 #pragma unroll
     for (int q = 0; q < AP; ++q) {
@@ -80,10 +86,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
     const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ W = reinterpret_cast<const T*>(p.w);
+    const T* zsrc = reinterpret_cast<const T*>(g_zero16);
+    const int wbase = __builtin_amdgcn_readfirstlane(wave) * 8 * IG2_ROWB;  // this wave's 8 rows of each 32-row slab
 
-    uint4 areg[AP], breg[BP];
-    auto load_tiles = [&](int ks) {
-        const int k0 = ks * BK + lgrp * EPG;
+    auto issue_tiles = [&](int ks, char* stage) {
+        const int k0 = ks * BK + lchunk * EPG;
         const int tap = k0 / p.Ci, ci = k0 - tap * p.Ci;
         const int ky = tap / p.KH, kx = tap - ky * p.KH;
         const bool kvalid = k0 < p.K;
@@ -93,17 +100,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const bool inb = kvalid && yy >= 0 && yy < p.Ho && xx >= 0 && xx < p.Wo;
             const int ys = yy >> p.up2, xs = xx >> p.up2;
             const int off = a_boff[q] + (ys * p.Wi + xs) * p.Ci + ci;
-            areg[q] = inb ? *reinterpret_cast<const uint4*>(X + off) : make_uint4(0, 0, 0, 0);
+            const T* src = inb ? X + off : zsrc;  // out-of-image taps read a 16-byte zero block
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + q * 32 * IG2_ROWB + wbase), 16, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < BP; ++q)
-            breg[q] = *reinterpret_cast<const uint4*>(W + (size_t)(n0 + lrow + 32 * q) * p.Kpad + ks * BK + lgrp * EPG);
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int q = 0; q < AP; ++q) *reinterpret_cast<uint4*>(As + (lrow + 32 * q) * IG_ROWB + lgrp * 16) = areg[q];
-#pragma unroll
-        for (int q = 0; q < BP; ++q) *reinterpret_cast<uint4*>(Bs + (lrow + 32 * q) * IG_ROWB + lgrp * 16) = breg[q];
+        for (int q = 0; q < BP; ++q) {
+            const T* src = W + (size_t)(n0 + lrow + 32 * q) * p.Kpad + k0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + (BM + q * 32) * IG2_ROWB + wbase), 16, 0, 0);
+        }
     };
 
     f32x16_t acc[TM][TN];
@@ -117,13 +123,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (BN / 2);
     const int ks0 = split * p.ks_per;
     const int nks = min(p.Kpad / BK, ks0 + p.ks_per);
-    load_tiles(ks0);
+    issue_tiles(ks0, smem);
     for (int ks = ks0; ks < nks; ++ks) {
-        store_tiles();
+        char* cur = smem + ((ks - ks0) & 1) * STAGE;
+        // one barrier per K-step: (i) tile ks has landed (hipcc drains vmcnt before the barrier because an LDS-DMA
+        // is in flight), (ii) every wave is done reading the other stage, which the next DMA overwrites.
         __syncthreads();
-        if (ks + 1 < nks) load_tiles(ks + 1);  // in flight under the MFMAs
-        Mma<T>::template step<TM, TN>(As, Bs, wrow, wcol, lane, acc);
-        __syncthreads();
+        if (ks + 1 < nks) issue_tiles(ks + 1, smem + ((ks + 1 - ks0) & 1) * STAGE);  // lands under the MFMAs
+        Mma2<T>::template step<TM, TN>(cur, cur + BM * IG2_ROWB, wrow, wcol, lane, acc);
     }
 
     // ---- epilogue
@@ -235,7 +242,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
         if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     }
-    const size_t lds = (size_t)(128 + BN) * IG_ROWB;
+    const size_t lds = (size_t)2 * (128 + BN) * IG2_ROWB;
     if (BN == 64)
         hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
     else

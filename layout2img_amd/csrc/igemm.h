@@ -66,6 +66,56 @@ template <> struct Mma<float> {
     }
 };
 
+// ---- LDS-DMA image: unpadded 128-byte rows, 16-byte chunks XOR-swizzled by (row & 7)
+#define IG2_ROWB 128
+__device__ __forceinline__ int ig2_off(int row, int chunk) { return row * IG2_ROWB + ((chunk ^ (row & 7)) << 4); }
+
+template <typename T> struct Mma2;
+template <> struct Mma2<bf16_t> {
+    template <int TM, int TN>
+    __device__ static __forceinline__ void step(const char* As, const char* Bs, int wrow, int wcol, int lane,
+                                                f32x16_t (&acc)[TM][TN]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + ig2_off(wrow + i * 32 + r, kk * 2 + h));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + ig2_off(wcol + j * 32 + r, kk * 2 + h));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[i]),
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+};
+template <> struct Mma2<float> {
+    template <int TM, int TN>
+    __device__ static __forceinline__ void step(const char* As, const char* Bs, int wrow, int wcol, int lane,
+                                                f32x16_t (&acc)[TM][TN]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(As + ig2_off(wrow + i * 32 + r, h * 4 + q));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(Bs + ig2_off(wcol + j * 32 + r, h * 4 + q));
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
 // XCD-aware bijective block remap: the dispatcher places block b on XCD b % 8;
 // give each XCD a contiguous run of tiles so neighbouring tiles share its L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
