@@ -137,27 +137,35 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restric
     const float inv = 1.f / sigma;
     const float* W = params + LF(0);
     const int taps = KH * KH;
-    if (kind == 0) {
-        const int Kpad = (int)LF(8);
-        const long long total = LF(9) * Kpad;
-        T* dst = packed + LF(10);
-        for (long long i = (long long)chunk * 2048 + threadIdx.x; i < min(total, (long long)(chunk + 1) * 2048); i += 256) {
-            const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
-            const int tap = k / Ci_p, ci = k - tap * Ci_p;
-            float v = 0.f;
-            if (n < Co && tap < taps && ci < Ci) v = W[((size_t)n * Ci + ci) * taps + tap] * inv;
-            dst[i] = OpT<T>::from(v);
+    // one thread = 8 consecutive packed elements (same tap: Ci_p, Co_p and Kpad are multiples of 8) -> one 16-byte
+    // (bf16) or two 16-byte (f32) stores
+    const bool fwd = kind == 0;
+    const int Kpad = (int)(fwd ? LF(8) : LF(11));
+    const long long total = (fwd ? LF(9) : LF(12)) * Kpad;
+    T* dst = packed + (fwd ? LF(10) : LF(13));
+    const int inner_p = fwd ? Ci_p : Co_p;   // padded channel count of the pack's inner index
+    const int inner = fwd ? Ci : Co, rows = fwd ? Co : Ci;
+    const long long i = (long long)chunk * 2048 + 8 * threadIdx.x;
+    if (i < total) {
+        const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
+        const int tap = k / inner_p, c0 = k - tap * inner_p;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = 0.f;
+            if (n < rows && tap < taps && c0 + j < inner)
+                v[j] = (fwd ? W[((size_t)n * Ci + c0 + j) * taps + tap] : W[((size_t)(c0 + j) * Ci + n) * taps + (taps - 1 - tap)]) * inv;
         }
-    } else {
-        const int Kpad = (int)LF(11);
-        const long long total = LF(12) * Kpad;
-        T* dst = packed + LF(13);
-        for (long long i = (long long)chunk * 2048 + threadIdx.x; i < min(total, (long long)(chunk + 1) * 2048); i += 256) {
-            const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);  // n = ci
-            const int tap = k / Co_p, co = k - tap * Co_p;
-            float v = 0.f;
-            if (n < Ci && tap < taps && co < Co) v = W[((size_t)co * Ci + n) * taps + (taps - 1 - tap)] * inv;
-            dst[i] = OpT<T>::from(v);
+        if constexpr (sizeof(T) == 2) {
+            uint4 pk;
+            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+            pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dst) + i) = pk;
+        } else {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + i) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
     }
 }

@@ -85,6 +85,24 @@ class ISLANorm(nn.Module):
                         momentum=bn.momentum, training=training)
 
 
+_RESAMPLE = {}
+
+
+def resample_matrix(kind, n_in, n_out, device):
+    """(n_out^2, n_in^2) matrix of a fixed spatial resampling (square maps), built once by pushing the identity
+    basis through the torch op it replaces: 'bilinear' (align_corners=False), 'bilinear_ac' (align_corners=True,
+    the PSP upsample, reference :750), 'adaptive_avg' (nn.AdaptiveAvgPool2d, reference :743)."""
+    key = (kind, n_in, n_out, str(device))
+    if key not in _RESAMPLE:
+        eye = torch.eye(n_in * n_in).view(n_in * n_in, 1, n_in, n_in)
+        if kind == "adaptive_avg":
+            out = F.adaptive_avg_pool2d(eye, (n_out, n_out))
+        else:
+            out = F.interpolate(eye, size=(n_out, n_out), mode="bilinear", align_corners=(kind == "bilinear_ac"))
+        _RESAMPLE[key] = out.reshape(n_in * n_in, n_out * n_out).t().contiguous().to(device)
+    return _RESAMPLE[key]
+
+
 def _resize_mask(mask, H, W):
     return mask if mask.shape[-2:] == (H, W) else F.interpolate(mask, size=(H, W), mode="bilinear")
 
@@ -101,11 +119,22 @@ class PSPModule(nn.Module):
                                          BNState(out_features)])
         self.dropout_p = 0.1
 
+    def _stage(self, st, s, flat, B, H, W):
+        """AdaptiveAvgPool(s) -> 1x1 conv -> BatchNorm2d -> ReLU -> bilinear(align_corners=True) back to HxW, with
+        both resamplings expressed as (tiny) matrices so forward and backward are plain GEMMs in NHWC."""
+        conv, bn = st[1], st[2]
+        pooled = torch.matmul(resample_matrix("adaptive_avg", H, s, flat.device), flat)        # (B, s*s, C)
+        y = pooled.reshape(B * s * s, -1) @ conv.weight.view(conv.weight.shape[0], -1).t()       # (B*s*s, 100)
+        y = F.relu(F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps))
+        if bn.training:
+            bn.num_batches_tracked += 1
+        return torch.matmul(resample_matrix("bilinear_ac", s, H, flat.device), y.view(B, s * s, -1)).view(B, H, W, -1)
+
     def forward(self, feats, pc, sync):
         # feats: (B,H,W,C) f32
         B, H, W, C = feats.shape
-        f_nchw = feats.permute(0, 3, 1, 2)
-        priors = [F.interpolate(st(f_nchw), size=(H, W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1) for st in self.stages]
+        flat = feats.view(B, H * W, C)
+        priors = [self._stage(st, s, flat, B, H, W) for st, s in zip(self.stages, (1, 2, 3, 6))]
         cat = torch.cat(priors + [feats], dim=3).contiguous()
         conv, bn = self.bottleneck
         h = fused_conv(cat, conv, pc)
@@ -283,7 +312,7 @@ class MaskRegressNetv2(nn.Module):
             a = ops.norm_act(h, spec, wa, ba)
             if not self.instance:
                 blk_prev[1].commit()
-            a = F.interpolate(a.permute(0, 3, 1, 2), size=size, mode="bilinear").permute(0, 2, 3, 1).contiguous()
+            a = torch.matmul(resample_matrix("bilinear", size // 2, size, a.device), a.view(N, -1, self.ch)).view(N, size, size, self.ch)
             h = fused_conv(a, blk[0], pc)
         spec, wa, ba = self._spec(self.conv3, sync)
         m = fused_conv(h, self.conv3[3], pc, prologue=spec, wproj=wa, bproj=ba)[..., 0]
