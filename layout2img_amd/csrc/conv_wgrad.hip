@@ -182,6 +182,154 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         }
 }
 
+// ---------------------------------------------------------------- bf16 fast path: LDS-DMA + transposing LDS reads
+// Both operands are staged UNTRANSPOSED ([pixel][channel], the layout they have in HBM) by LDS-DMA
+// (global_load_lds_dwordx4, no VGPR round trip, no ds_write), double-buffered with one barrier per 64-pixel step.
+// The MFMA fragments (8 consecutive pixels of one channel per lane) are produced by ds_read_b64_tr_b16, gfx950's
+// transposing LDS read: within a 16-lane group lane t addresses the 8-byte piece (row t>>2, 4-channel block t&3)
+// of a 4-pixel x 16-channel block and lane c receives channel c's 4 pixels. Rows that a half-wave reads together
+// are spread over the 64 banks by XOR-ing the 16-byte chunk index with a function of the pixel row, applied on
+// the DMA source side and on the read. Requires power-of-two Ho, Wo (all layers of this path).
+__device__ uint4 g_wzero16[1] = {{0u, 0u, 0u, 0u}};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <int RS>  // RS = bytes per LDS pixel row (256: 128 channels, 128: 64 channels)
+__device__ __forceinline__ int wg_swz(int p) { return RS == 256 ? ((p & 3) << 2) : (((p >> 1) & 1) << 2); }
+
+template <int RS>
+__device__ __forceinline__ bf16x8_t wg_frag(const char* tile, int pixbase, int chbase, int lane) {
+    const int t = lane & 15, cb = ((lane >> 4) & 1) * 16, h = lane >> 5;
+    const int ch = chbase + cb + (t & 3) * 4;
+    const int L = ch >> 3, half = (ch >> 2) & 1;
+    bf16x8_t out;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int p = pixbase + 8 * h + 4 * r + (t >> 2);
+        const int addr = p * RS + ((L ^ wg_swz<RS>(p)) << 4) + half * 8;
+        const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)((__attribute__((address_space(3))) char*)tile + addr));
+        out[4 * r + 0] = v[0]; out[4 * r + 1] = v[1]; out[4 * r + 2] = v[2]; out[4 * r + 3] = v[3];
+    }
+    return out;
+}
+
+template <int BMO>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lgW, int lgH) {
+    constexpr int BNK = 128, BK = 64;
+    constexpr int RSA = BMO * 2, RSB = BNK * 2;
+    constexpr int TM = BMO / 64, TN = 2;
+    constexpr int STAGE = BK * (RSA + RSB);
+    constexpr int A_ROWS = 1024 / RSA;           // pixel rows per wave-instruction (4 | 8)
+    constexpr int A_Q = BK / (4 * A_ROWS);       // A instructions per wave per step (4 | 2)
+    constexpr int A_CH = RSA / 16;               // 16-byte chunks per A row (16 | 8)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    int bid = blockIdx.x;
+    const int split = bid % p.splits; bid /= p.splits;
+    const int tile_k = bid % p.tiles_k, tile_co = bid / p.tiles_k;
+    const int co0 = tile_co * BMO, kc0 = tile_k * BNK;
+    const int pad = p.KH >> 1;
+    const int Hd = p.Ho >> p.pool2, Wd = p.Wo >> p.pool2;
+    const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(p.x);
+    const bf16_t* __restrict__ DY = reinterpret_cast<const bf16_t*>(p.dy);
+    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_wzero16);
+    const int m_begin = split * p.Mper;
+    const int m_end = min(p.M, m_begin + p.Mper);
+
+    // per-lane constants: A (dY) chunk
+    const int a_row = lane / A_CH;                                     // row within the wave-instruction
+    const int a_lchunk = (lane % A_CH) ^ wg_swz<RSA>(a_row);           // logical chunk (rows bases are multiples of 8)
+    const int a_chan = co0 + a_lchunk * 8;
+    const bool a_on = a_chan < p.Co;
+    // B (im2col) chunk: 16 chunks per row, 4 rows per instruction
+    const int b_row = lane >> 4;
+    const int b_lchunk = (lane & 15) ^ wg_swz<RSB>(b_row);
+    const int kc = kc0 + b_lchunk * 8;
+    const int tap = kc / p.Ci, b_ci = kc - tap * p.Ci;
+    const int b_ky = tap / p.KH, b_kx = tap - b_ky * p.KH;
+    const bool b_on = kc < p.K;
+
+    auto issue = [&](int mstep, char* stage) {
+#pragma unroll
+        for (int q = 0; q < A_Q; ++q) {
+            const int prow = wv * 16 + q * A_ROWS;   // wave-uniform first pixel row of this instruction
+            const int m = mstep + prow + a_row;
+            const bf16_t* src = zsrc;
+            if (a_on && m < m_end) {
+                const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1), b = m >> (lgW + lgH);
+                src = DY + ((size_t)(b * Hd + (y >> p.pool2)) * Wd + (x >> p.pool2)) * p.Co + a_chan;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + prow * RSA), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int prow = wv * 16 + q * 4;
+            const int m = mstep + prow + b_row;
+            const bf16_t* src = zsrc;
+            if (b_on && m < m_end) {
+                const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1), b = m >> (lgW + lgH);
+                const int yy = y + b_ky - pad, xx = x + b_kx - pad;
+                if (yy >= 0 && yy < p.Ho && xx >= 0 && xx < p.Wo)
+                    src = X + ((size_t)(b * p.Hi + (yy >> p.up2)) * p.Wi + (xx >> p.up2)) * p.Ci + b_ci;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + BK * RSA + prow * RSB), 16, 0, 0);
+        }
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int wrow = (wave >> 1) * (BMO / 2), wcol = (wave & 1) * 64;
+    if (m_begin < m_end) {
+        issue(m_begin, smem);
+        int it = 0;
+        for (int ms = m_begin; ms < m_end; ms += BK, ++it) {
+            char* cur = smem + (it & 1) * STAGE;
+            __syncthreads();  // tile `it` landed (vmcnt drained before the barrier), other stage free
+            if (ms + BK < m_end) issue(ms + BK, smem + ((it + 1) & 1) * STAGE);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8_t a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = wg_frag<RSA>(cur, kk * 16, wrow + i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = wg_frag<RSB>(cur + BK * RSA, kk * 16, wcol + j * 32, lane);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[i]),
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[j]), acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = kc0 + wcol + j * 32 + c;
+            if (col >= p.K) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = co0 + wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < p.Co) atomicAdd(p.dw + (size_t)row * p.ldw + col, p.alpha * acc[i][j][e]);
+            }
+        }
+}
+
 template <typename T>
 static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     constexpr int BK = Mma<T>::BK;
@@ -205,8 +353,20 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     int per = (steps + splits - 1) / splits;
     a.Mper = per * BK;
     a.splits = (a.M + a.Mper - 1) / a.Mper;
-    const size_t lds = (size_t)(BMO + 128) * IG_ROWB;
     const int nblk = tiles * a.splits;
+    const bool pow2 = !(a.Ho & (a.Ho - 1)) && !(a.Wo & (a.Wo - 1));
+    if (sizeof(T) == 2 && pow2) {  // bf16: LDS-DMA + transposing-read kernel
+        int lgW = 0, lgH = 0;
+        while ((1 << lgW) < a.Wo) ++lgW;
+        while ((1 << lgH) < a.Ho) ++lgH;
+        const size_t lds2 = (size_t)2 * 64 * (BMO * 2 + 256);
+        if (BMO == 64)
+            hipLaunchKernelGGL((conv_wgrad_dma_kernel<64>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+        else
+            hipLaunchKernelGGL((conv_wgrad_dma_kernel<128>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+        return l2i_check_launch();
+    }
+    const size_t lds = (size_t)(BMO + 128) * IG_ROWB;
     if (BMO == 64)
         hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), dim3(nblk), dim3(256), lds, stream, a);
     else
