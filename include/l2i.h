@@ -41,6 +41,9 @@ int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float*
                    float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                    int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, void* stream);
 
+/* Tuning hook: force one of the forward-kernel tile configurations (see conv_igemm.hip), -1 = built-in heuristic. */
+int l2i_set_conv_config(int cfg);
+
 /* Weight gradient of the same convolution: dw[Co][ldw] += alpha * dYfull^T . im2col(x)
  * (autograd of the layers above). dy [B,Ho>>pool2,Wo>>pool2,Co] T; k order (ky,kx,ci). */
 int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,

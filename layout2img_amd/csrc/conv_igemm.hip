@@ -18,7 +18,12 @@
 // one quad and the 2x2 pool is an in-register sum.
 #include "igemm.h"
 
-__device__ uint4 g_zero16[1] = {{0u, 0u, 0u, 0u}};  // source of out-of-image im2col taps
+// 16-byte LDS-DMA through a buffer descriptor: lane i's data lands at lds_dst + 16 i; an out-of-range byte offset
+// makes the hardware write zeros. (Kept in a __device__ helper: the descriptor type does not exist in the host pass.)
+__device__ __forceinline__ void buf_load_lds16(const void* base, unsigned nbytes, unsigned voff, char* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nbytes, 0x00020000),
+                                             (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
+}
 
 struct ConvArgs {
     const void* x;      // T  [B, Hi, Wi, Ci]
@@ -33,6 +38,9 @@ struct ConvArgs {
     int up2, pool2, relu_op;
     int Kpad, K;
     int PW, PH, hw_shift, lin, tiles_c, tiles_m, tiles_n;
+    int chunk_major;     // K order (see issue_tiles)
+    int nks;             // K-steps in total
+    unsigned x_bytes, w_bytes;
     int splits, ks_per;  // split-K: `out` pre-zeroed, partials combined with f32 atomics
     float alpha;
 };
@@ -45,18 +53,23 @@ __device__ __forceinline__ void idx2pix(int idx, int hw_shift, int lin, int& py,
     px = 2 * qx + (s & 1);
 }
 
-template <typename T, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
-    constexpr int BM = 128;
+// Tile geometry: BM x BN outputs per workgroup of WM x WN waves (each wave a (BM/WM) x (BN/WN) block of 32x32
+// MFMA tiles), NS-stage LDS ring.
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int THREADS = WM * WN * 64;
+    constexpr int RPP = THREADS / 8;  // tile rows filled per DMA pass (8 lanes x 16 B per 128-byte row)
     constexpr int BK = Mma<T>::BK;
     constexpr int EPG = OpT<T>::EPG;
-    constexpr int TM = 2, TN = BN / 64;
-    constexpr int AP = BM / 32, BP = BN / 32;  // 16-byte loads per thread per K-step
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int AP = BM / RPP, BP = BN / RPP;  // LDS-DMA instructions per thread per K-step
+    static_assert(RPP % 16 == 0 && BM % RPP == 0 && BN % RPP == 0, "tile geometry");
 
     // LDS: two stages of [A 128 rows | B BN rows], 128-byte rows, filled by LDS-DMA (global_load_lds_dwordx4:
     // lane i of a wave-instruction lands at base + 16 i, i.e. 8 rows x 8 chunks), no VGPR staging, no ds_write.
+    // (RPP rows per pass: the +RPP*q rows of a thread share (row >> 1) & 7, so one swizzle per thread.)
     // Bank conflicts of the ds_read_b128 fragment reads are avoided by an XOR swizzle applied on the SOURCE
-    // side (the lane that fills physical chunk c of row r fetches logical chunk c ^ (r & 7)) and on the read.
+    // side (the lane that fills physical chunk c of row r fetches logical chunk c ^ ig2_swz(r)) and on the read.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = (BM + BN) * IG2_ROWB;
 
@@ -70,45 +83,92 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int rows_total = p.B * p.Ho;
     const int pad = p.KH >> 1;
 
-    // ---- per-thread A rows (fixed for the whole K loop)
+    // ---- per-thread A rows (fixed for the whole K loop). Loads are buffer_load ... lds: a 32-bit byte offset per
+    // lane, and an out-of-range offset makes the hardware write zeros -- that is how padding taps, rows past the
+    // end and channels past Ci are zero-filled without a branch or a 64-bit address select.
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int SZ = (int)sizeof(T);
     const int lrow = tid >> 3;
-    const int lchunk = (tid & 7) ^ (lrow & 7);  // logical 16-byte chunk this lane fetches
-    int a_y[AP], a_x[AP], a_boff[AP];
+    const int lchunk = (tid & 7) ^ ig2_swz(lrow);  // logical 16-byte chunk this lane fetches (rows +32q: same swizzle)
+    int a_y[AP], a_x[AP];
+    unsigned a_off[AP], a_mask[AP];                 // byte offset of the row's pixel (+ lane chunk); 9-bit tap validity
 #pragma unroll
     for (int q = 0; q < AP; ++q) {
         int py, px;
-        idx2pix(lrow + 32 * q, p.hw_shift, p.lin, py, px);
+        idx2pix(lrow + RPP * q, p.hw_shift, p.lin, py, px);
         const int r = tile_r * p.PH + py;
         const int b = r / p.Ho;
-        a_y[q] = r < rows_total ? r - b * p.Ho : -(1 << 20);  // invalid rows fail the bounds test
-        a_x[q] = tile_c * p.PW + px;
-        a_boff[q] = b * p.Hi * p.Wi * p.Ci;
-    }
-    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.w);
-    const T* zsrc = reinterpret_cast<const T*>(g_zero16);
-    const int wbase = __builtin_amdgcn_readfirstlane(wave) * 8 * IG2_ROWB;  // this wave's 8 rows of each 32-row slab
-
-    auto issue_tiles = [&](int ks, char* stage) {
-        const int k0 = ks * BK + lchunk * EPG;
-        const int tap = k0 / p.Ci, ci = k0 - tap * p.Ci;
-        const int ky = tap / p.KH, kx = tap - ky * p.KH;
-        const bool kvalid = k0 < p.K;
-#pragma unroll
-        for (int q = 0; q < AP; ++q) {
-            const int yy = a_y[q] + ky - pad, xx = a_x[q] + kx - pad;
-            const bool inb = kvalid && yy >= 0 && yy < p.Ho && xx >= 0 && xx < p.Wo;
-            const int ys = yy >> p.up2, xs = xx >> p.up2;
-            const int off = a_boff[q] + (ys * p.Wi + xs) * p.Ci + ci;
-            const T* src = inb ? X + off : zsrc;  // out-of-image taps read a 16-byte zero block
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(stage + q * 32 * IG2_ROWB + wbase), 16, 0, 0);
+        const bool rv = r < rows_total;
+        const int y = r - b * p.Ho, x = tile_c * p.PW + px;
+        a_y[q] = y;
+        a_x[q] = x;
+        a_off[q] = (unsigned)(((b * p.Hi + (y >> p.up2)) * p.Wi + (x >> p.up2)) * p.Ci) * SZ;
+        unsigned m = 0;
+        for (int t = 0; t < p.KH * p.KH; ++t) {
+            const int yy = y + t / p.KH - pad, xx = x + t % p.KH - pad;
+            if (rv && yy >= 0 && yy < p.Ho && xx >= 0 && xx < p.Wo) m |= 1u << t;
         }
+        a_mask[q] = m;
+    }
+    unsigned b_off[BP];
 #pragma unroll
-        for (int q = 0; q < BP; ++q) {
-            const T* src = W + (size_t)(n0 + lrow + 32 * q) * p.Kpad + k0;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(stage + (BM + q * 32) * IG2_ROWB + wbase), 16, 0, 0);
+    for (int q = 0; q < BP; ++q) b_off[q] = (unsigned)((n0 + lrow + RPP * q) * p.Kpad) * SZ;
+    const int wbase = __builtin_amdgcn_readfirstlane(wave) * 8 * IG2_ROWB;  // this wave's 8 rows of each 32-row slab
+    const int lane_c = lchunk * EPG;                                          // first channel of the lane's chunk
+
+    // K traversal. chunk_major (3x3, Ci >= BK): steps run channel-chunk-major, tap-minor -- the 9 taps of one
+    // 64-channel chunk are consecutive, a workgroup re-reads nearly the same input lines 9 steps in a row (L1/L2
+    // hits), and all per-step index arithmetic is scalar (tap counters) plus ~4 VALU per row. Otherwise
+    // (1x1 / linear / Ci < BK) the step covers k = ks*BK.. linearly and a lane derives its own tap.
+    int it_tap, it_cb;  // running (tap, channel-chunk base) of the NEXT tile to issue (chunk_major)
+    {
+        const int taps = p.KH * p.KH;
+        const int ksa = split * p.ks_per;
+        it_cb = (ksa / taps) * BK;
+        it_tap = ksa - (ksa / taps) * taps;
+    }
+    int it_ks = split * p.ks_per;
+    auto issue_tiles = [&](char* stage) {
+        if (p.chunk_major) {
+            const int ky = it_tap / 3, kx = it_tap - ky * 3;
+            const unsigned tapbit = 1u << it_tap;
+            const bool cv = it_cb + lane_c < p.Ci;
+            const unsigned cadd = (unsigned)(it_cb + lane_c) * SZ;
+            const int s_delta = ((ky - 1) * p.Wi + (kx - 1)) * p.Ci * SZ;   // non-up2 tap displacement (scalar)
+#pragma unroll
+            for (int q = 0; q < AP; ++q) {
+                unsigned off;
+                if (p.up2) {
+                    const int dy = (((a_y[q] & 1) + ky - 1) >> 1), dx = (((a_x[q] & 1) + kx - 1) >> 1);
+                    off = a_off[q] + (unsigned)((dy * p.Wi + dx) * p.Ci * SZ) + cadd;
+                } else {
+                    off = a_off[q] + (unsigned)s_delta + cadd;
+                }
+                const unsigned voff = ((a_mask[q] & tapbit) && cv) ? off : OOB;
+                buf_load_lds16(p.x, p.x_bytes, voff, stage + q * RPP * IG2_ROWB + wbase);
+            }
+            const unsigned kadd = (unsigned)(it_tap * p.Ci) * SZ + cadd;
+#pragma unroll
+            for (int q = 0; q < BP; ++q)
+                buf_load_lds16(p.w, p.w_bytes, b_off[q] + kadd, stage + (BM + q * RPP) * IG2_ROWB + wbase);
+            if (++it_tap == 9) { it_tap = 0; it_cb += BK; }
+        } else {
+            const int k0 = it_ks * BK + lane_c;
+            const int tap = k0 / p.Ci, ci = k0 - tap * p.Ci;
+            const int ky = tap / p.KH, kx = tap - ky * p.KH;
+            const bool kvalid = k0 < p.K;
+#pragma unroll
+            for (int q = 0; q < AP; ++q) {
+                const int ys = (a_y[q] + ky - pad) >> p.up2, xs = (a_x[q] + kx - pad) >> p.up2;
+                const int y0 = a_y[q] >> p.up2, x0 = a_x[q] >> p.up2;
+                const unsigned off = a_off[q] + (unsigned)((((ys - y0) * p.Wi + (xs - x0)) * p.Ci + ci) * SZ);
+                const unsigned voff = (kvalid && ((a_mask[q] >> tap) & 1u)) ? off : OOB;
+                buf_load_lds16(p.x, p.x_bytes, voff, stage + q * RPP * IG2_ROWB + wbase);
+            }
+#pragma unroll
+            for (int q = 0; q < BP; ++q)
+                buf_load_lds16(p.w, p.w_bytes, b_off[q] + (unsigned)k0 * SZ, stage + (BM + q * RPP) * IG2_ROWB + wbase);
+            ++it_ks;
         }
     };
 
@@ -120,16 +180,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * (BN / 2);
+    const int wrow = (wave / WN) * (BM / WM), wcol = (wave % WN) * (BN / WN);
     const int ks0 = split * p.ks_per;
-    const int nks = min(p.Kpad / BK, ks0 + p.ks_per);
-    issue_tiles(ks0, smem);
+    const int nks = min(p.nks, ks0 + p.ks_per);
+    // NS-stage LDS ring. Tiles ks .. ks+NS-2 are in flight while tile ks is consumed: each wave waits with a COUNTED
+    // s_waitcnt vmcnt for its own DMA of tile ks (its LPT newest-but-... loads may stay outstanding), then a raw
+    // s_barrier makes every wave's part of the tile visible and proves the stage about to be refilled is no longer
+    // read. (__syncthreads() would drain vmcnt to 0 and serialise the ring.) One K-step of a single workgroup is
+    // otherwise bound by the ~1.5 us DMA round trip, not by its 0.2 us of MFMA work.
+    constexpr int LPT = AP + BP;  // LDS-DMA instructions per thread per tile
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (ks0 + s < nks) issue_tiles(smem + s * STAGE);
     for (int ks = ks0; ks < nks; ++ks) {
-        char* cur = smem + ((ks - ks0) & 1) * STAGE;
-        // one barrier per K-step: (i) tile ks has landed (hipcc drains vmcnt before the barrier because an LDS-DMA
-        // is in flight), (ii) every wave is done reading the other stage, which the next DMA overwrites.
-        __syncthreads();
-        if (ks + 1 < nks) issue_tiles(ks + 1, smem + ((ks + 1 - ks0) & 1) * STAGE);  // lands under the MFMAs
+        const int it = ks - ks0;
+        const int ahead = min(NS - 2, nks - 1 - ks);  // tiles allowed to stay in flight behind tile ks
+        if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (NS >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ks + NS - 1 < nks) issue_tiles(smem + ((it + NS - 1) % NS) * STAGE);
+        char* cur = smem + (it % NS) * STAGE;
         Mma2<T>::template step<TM, TN>(cur, cur + BM * IG2_ROWB, wrow, wcol, lane, acc);
     }
 
@@ -199,36 +271,18 @@ static int ilog2(int v) {
     return s;
 }
 
-template <typename T>
-static int launch_conv(ConvArgs& a, hipStream_t stream) {
+// Launch one instantiation; LDS rings above 64 KB need the opt-in attribute (set once per instantiation).
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+static int launch_cfg(ConvArgs a, hipStream_t stream) {
     constexpr int BK = Mma<T>::BK;
-    constexpr int EPG = OpT<T>::EPG;
-    if (a.KH != 1 && a.KH != 3) return L2I_ERR_ARG;
-    if (a.Ci % EPG) return L2I_ERR_ARG;
-    if (a.up2 && (a.Ho != 2 * a.Hi || a.Wo != 2 * a.Wi)) return L2I_ERR_ARG;
-    if (!a.up2 && (a.Ho != a.Hi || a.Wo != a.Wi)) return L2I_ERR_ARG;
-    if (a.pool2 && ((a.Ho & 1) || (a.Wo & 1))) return L2I_ERR_ARG;
-    a.K = a.KH * a.KH * a.Ci;
-    if (a.Kpad < a.K || a.Kpad % BK) return L2I_ERR_ARG;
-    a.lin = a.Wo < 2;
-    if (a.lin) {
-        if (a.Ho != 1 || a.pool2) return L2I_ERR_ARG;
-        a.PW = 1;
-        a.hw_shift = 0;
-    } else {
-        if (a.Wo & (a.Wo - 1)) return L2I_ERR_ARG;  // power-of-two widths (4..128 on this path)
-        if (a.Ho & 1) return L2I_ERR_ARG;
-        a.PW = a.Wo < 16 ? a.Wo : 16;
-        a.hw_shift = ilog2(a.PW >> 1);
-    }
-    a.PH = 128 / a.PW;
-    a.tiles_c = a.Wo / a.PW;
+    constexpr size_t lds = (size_t)NS * (BM + BN) * IG2_ROWB;
+    a.PH = BM / a.PW;
+    if (!a.lin && (a.PH & 1)) return L2I_ERR_ARG;
     const int rows = a.B * a.Ho;
     a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
-    const int BN = a.Co <= 64 ? 64 : 128;
     a.tiles_n = (a.Co + BN - 1) / BN;
     const int nblk = a.tiles_m * a.tiles_n;
-    const int nks = a.Kpad / BK;
+    const int nks = a.nks;
     // split-K for small grids with a long reduction (D block5/6, G res1/res2, ROI heads): fill the 256 CUs
     int splits = 1;
     if (a.out && !a.out_op && !a.out_op_raw && nblk < 192 && nks >= 16) {
@@ -242,12 +296,75 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
         if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     }
-    const size_t lds = (size_t)2 * (128 + BN) * IG2_ROWB;
-    if (BN == 64)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 128>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
+    static bool ready = false;
+    if (!ready) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN, NS>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ready = true;
+    }
+    (void)BK;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, NS>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
     return l2i_check_launch();
+}
+
+static int g_conv_cfg_override = -1;  // tuning hook (l2i_set_conv_config): -1 = heuristic
+extern "C" int l2i_set_conv_config(int cfg) { g_conv_cfg_override = cfg; return L2I_OK; }
+
+template <typename T>
+static int launch_conv(ConvArgs& a, hipStream_t stream) {
+    constexpr int BK = Mma<T>::BK;
+    constexpr int EPG = OpT<T>::EPG;
+    if (a.KH != 1 && a.KH != 3) return L2I_ERR_ARG;
+    if (a.Ci % EPG) return L2I_ERR_ARG;
+    if (a.up2 && (a.Ho != 2 * a.Hi || a.Wo != 2 * a.Wi)) return L2I_ERR_ARG;
+    if (!a.up2 && (a.Ho != a.Hi || a.Wo != a.Wi)) return L2I_ERR_ARG;
+    if (a.pool2 && ((a.Ho & 1) || (a.Wo & 1))) return L2I_ERR_ARG;
+    a.K = a.KH * a.KH * a.Ci;
+    if (a.Kpad < a.K || a.Kpad % BK) return L2I_ERR_ARG;
+    a.chunk_major = (a.KH == 3 && a.Ci >= BK) ? 1 : 0;
+    a.nks = a.chunk_major ? 9 * ((a.Ci + BK - 1) / BK) : a.Kpad / BK;
+    a.x_bytes = (unsigned)((size_t)a.B * a.Hi * a.Wi * a.Ci * sizeof(T));
+    a.w_bytes = (unsigned)((size_t)((a.Co + 127) / 128 * 128) * a.Kpad * sizeof(T));
+    a.lin = a.Wo < 2;
+    if (a.lin) {
+        if (a.Ho != 1 || a.pool2) return L2I_ERR_ARG;
+        a.PW = 1;
+        a.hw_shift = 0;
+    } else {
+        if (a.Wo & (a.Wo - 1)) return L2I_ERR_ARG;  // power-of-two widths (4..128 on this path)
+        if (a.Ho & 1) return L2I_ERR_ARG;
+        a.PW = a.Wo < 16 ? a.Wo : 16;
+        a.hw_shift = ilog2(a.PW >> 1);
+    }
+    a.tiles_c = a.Wo / a.PW;
+    // Configurations (see DESIGN.md for the measurements behind the choice):
+    //  0: 128x128 tile, 4 waves, 2 stages (two workgroups per CU)      1: 128x64, 4 waves, 2 stages (Co <= 64)
+    //  2: 128x128, 8 waves (64x32 each), 4 stages                       3: 256x128, 8 waves (64x64 each), 3 stages
+    //  4: 256x256, 8 waves (64x128 each), 2 stages
+    // Heuristic from scratch/conv_tune.py on MI355X (TFLOP/s, bf16): big-tile configs pay only when their grid still
+    // fills the 256 CUs; a single wave of 128x128 tiles (one workgroup per CU) prefers the 8-wave deep ring.
+    const long long M = (long long)a.B * a.Ho * a.Wo;
+    const long long t128 = ((M + 127) / 128) * ((a.Co + 127) / 128);
+    const long long t256x128 = ((M + 255) / 256) * ((a.Co + 127) / 128);
+    const long long t256x256 = ((M + 255) / 256) * ((a.Co + 255) / 256);
+    int cfg;
+    if (a.Co <= 64) cfg = 1;
+    else if (!a.lin && a.Co >= 256 && t256x256 >= 240) cfg = 4;
+    else if (!a.lin && t256x128 >= 384 && a.nks >= 36) cfg = 3;
+    else if (t128 >= 192 && t128 <= 288) cfg = 2;
+    else cfg = 0;
+    if (g_conv_cfg_override >= 0 && a.Co > 64) {
+        cfg = g_conv_cfg_override;
+        if ((cfg == 3 || cfg == 4) && (a.lin || t256x128 < 128)) cfg = 0;  // too few tiles to be meaningful
+    }
+    switch (cfg) {
+        case 1: return launch_cfg<T, 128, 64, 2, 2, 2>(a, stream);
+        case 2: return launch_cfg<T, 128, 128, 2, 4, 4>(a, stream);
+        case 3: return launch_cfg<T, 256, 128, 4, 2, 3>(a, stream);
+        case 4: return launch_cfg<T, 256, 256, 4, 2, 2>(a, stream);
+        default: return launch_cfg<T, 128, 128, 2, 2, 2>(a, stream);
+    }
 }
 
 // C ABI -- see include/l2i.h
