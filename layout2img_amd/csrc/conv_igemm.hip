@@ -350,8 +350,8 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     const long long t256x256 = ((M + 255) / 256) * ((a.Co + 255) / 256);
     int cfg;
     if (a.Co <= 64) cfg = 1;
-    else if (!a.lin && a.Co >= 256 && t256x256 >= 240) cfg = 4;
-    else if (!a.lin && t256x128 >= 384 && a.nks >= 36) cfg = 3;
+    else if (!a.lin && a.Co % 256 == 0 && t256x256 >= 240 && a.nks >= 144) cfg = 4;   // 1024-channel 3x3 ROI heads
+    else if (!a.lin && a.Co % 128 == 0 && t256x128 >= 384 && a.nks >= 72) cfg = 3;
     else if (t128 >= 192 && t128 <= 288) cfg = 2;
     else cfg = 0;
     if (g_conv_cfg_override >= 0 && a.Co > 64) {

@@ -34,6 +34,43 @@ def _chk(t, dtype=None):
     return t
 
 
+# ----------------------------------------------------------------------------- zero pool
+class ZeroPool:
+    """One pre-zeroed slab per training step for the many small atomically-accumulated outputs (channel sums,
+    s1/s2, projection gradients): one memset instead of hundreds of tiny fill launches. Slices stay valid until the
+    next begin(); outside a step (inactive) callers fall back to torch.zeros."""
+
+    def __init__(self):
+        self.buf, self.off, self.active = None, 0, False
+
+    def begin(self, device, nfloats=8 << 20):
+        if self.buf is None or self.buf.device != torch.device(device) or self.buf.numel() != nfloats:
+            self.buf = torch.empty(nfloats, dtype=torch.float32, device=device)
+        self.buf.zero_()
+        self.off, self.active = 0, True
+
+    def end(self):
+        self.active = False
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= d
+        n4 = (n + 3) // 4 * 4
+        if not self.active or n > (1 << 18) or self.off + n4 > self.buf.numel() or self.buf.device != torch.device(device):
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        v = self.buf[self.off:self.off + n].view(shape)
+        self.off += n4
+        return v
+
+
+POOL = ZeroPool()
+
+
+def _zeros(shape, device):
+    return POOL.take(tuple(shape), device)
+
+
 # ----------------------------------------------------------------------------- raw kernels
 def cast_op(x, op_dtype, raw=True, act=False):
     """f32 stream -> operand copies. Returns (raw_copy | None, relu_copy | None)."""
@@ -111,14 +148,19 @@ def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0
         end.record()
 
 
-def channel_stats(x2d, rows_per_group=None, want_sq=True, cast_to=None):
-    """x2d: (rows, C) f32 view. Returns sums (G, C), sqsums (G, C)|None [, operand-dtype copy if cast_to]."""
+def channel_stats(x2d, rows_per_group=None, want_sq=True, cast_to=None, accumulate_into=None):
+    """x2d: (rows, C) f32 view. Returns sums (G, C), sqsums (G, C)|None [, operand-dtype copy if cast_to].
+    accumulate_into: an existing (C,) f32 tensor the sums are atomically ADDED to (e.g. a bias .grad view)."""
     _chk(x2d, torch.float32)
     rows, C = x2d.shape
     rpg = rows if rows_per_group is None else rows_per_group
     G = rows // rpg
-    buf = torch.zeros((2 if want_sq else 1, G, C), dtype=torch.float32, device=x2d.device)
-    sums, sq = buf[0], (buf[1] if want_sq else None)
+    if accumulate_into is not None:
+        assert G == 1 and not want_sq and accumulate_into.numel() == C and accumulate_into.is_contiguous()
+        sums, sq = accumulate_into.view(1, C), None
+    else:
+        buf = _zeros((2 if want_sq else 1, G, C), x2d.device)
+        sums, sq = buf[0], (buf[1] if want_sq else None)
     raw = torch.empty(x2d.shape, dtype=cast_to, device=x2d.device) if cast_to is not None else None
     _lib.call("l2i_channel_stats", x2d.data_ptr(), rows, C, rpg, sums.data_ptr(), _p(sq), _p(raw),
               _code(cast_to) if cast_to is not None else _lib.F32, _stream())
@@ -191,16 +233,16 @@ def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, 
     O = mask.shape[1] if mask is not None else 0
     dev = x.device
     G = sums.shape[0]
-    s1 = torch.zeros((G, C), dtype=torch.float32, device=dev)
-    s2 = torch.zeros((G, C), dtype=torch.float32, device=dev)
+    s1 = _zeros((G, C), dev)
+    s2 = _zeros((G, C), dev)
     dw = db = dm = None
     psb = pso = 0
     if spec.mode == 0:
-        dw, db = torch.zeros_like(wproj), torch.zeros_like(bproj)
+        dw, db = _zeros(wproj.shape, dev), _zeros(bproj.shape, dev)
         dm = torch.zeros_like(mask) if need_mask_grad else None
         psb, pso = O * C, C
     elif spec.mode == 1:
-        dw, db = torch.zeros_like(wproj), torch.zeros_like(bproj)
+        dw, db = _zeros(wproj.shape, dev), _zeros(bproj.shape, dev)
     keep = torch.empty_like(dy) if (spec.mode == 0 and O > 8) else None
     _lib.call("l2i_norm_mod_bwd_a", x.data_ptr(), dy.data_ptr(), B, H * W, C, sums.data_ptr(), sq.data_ptr(), float(count),
               float(spec.eps), stat_stride, _p(mask), O, _p(wproj), _p(bproj), psb, pso, spec.mode, int(spec.relu),
@@ -266,9 +308,12 @@ class FusedConvFn(Function):
         alpha = 0.25 if ctx.pool2 else 1.0
         d_bias = None
         if pc.need_wgrad and ctx.has_bias:  # bias gradient and the dY operand cast in one pass over dY
-            bsum, _, dy_op = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False, cast_to=opd)
+            bg = h.bias.grad
+            direct = bg is not None and h.co == h.co_p and bg.is_contiguous() and bg.dtype == torch.float32
+            bsum, _, dy_op = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False, cast_to=opd,
+                                           accumulate_into=bg if direct else None)
             dy_op = dy_op.view(dy.shape)
-            d_bias = bsum[0][:h.co]
+            d_bias = None if direct else bsum[0][:h.co]   # direct: summed straight into the flat gradient buffer
         else:
             dy_op, _ = cast_op(dy, opd, raw=True, act=False)
         if pc.need_wgrad:

@@ -66,6 +66,7 @@ class GanTrainer:
         y = label.view(b, o)
         if z is None:
             z = torch.randn(b, o, self.z_dim, device=real.device)
+        ops.POOL.begin(real.device)
         # ---- D step (reference :156-174)
         netD.zero_grad()
         *outs_r, valid, _ = netD.forward_padded(real, bbox, y)
@@ -85,4 +86,5 @@ class GanTrainer:
         g_loss = g_adv + pixel
         g_loss.backward()
         self.g_opt.step()
+        ops.POOL.end()
         return {"d_loss": d_loss.detach(), "g_loss": g_loss.detach(), "pixel": pixel.detach(), "fake": fake.detach()}
