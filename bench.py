@@ -70,8 +70,12 @@ def main():
     op_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     torch.manual_seed(1234)
-    netG = L.ResnetGenerator128_context(num_classes=184).finalize(dev, op_dtype)
-    netD = L.CombineDiscriminator128_app(num_classes=184).finalize(dev, op_dtype)
+    if args.size == 64:   # BASELINE configs 1-2 (not the headline metric)
+        netG = L.ResnetGenerator64_context(num_classes=184).finalize(dev, op_dtype)
+        netD = L.CombineDiscriminator64(num_classes=184).finalize(dev, op_dtype)
+    else:
+        netG = L.ResnetGenerator128_context(num_classes=184).finalize(dev, op_dtype)
+        netD = L.CombineDiscriminator128_app(num_classes=184).finalize(dev, op_dtype)
     netG.train(), netD.train()
     trainer = L.GanTrainer(netG, netD)
     real, label, bbox, z, z_im = make_batch(args.batch, args.size, "coco", seed=1234 + rank, device=dev)
@@ -112,7 +116,7 @@ def main():
                 roof["wgrad_tflops"] = round(w["work"] / (w["ms"] * 1e-3) / 1e12, 2)
             ops.TIMER = None
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.size == 128:
             cpu = cpu_baseline(netG, netD, args.size)
         out = {
             "metric": "images/sec (G+D fwd+bwd) at 128x128 COCO-layout",

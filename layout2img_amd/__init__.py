@@ -5,6 +5,6 @@ Public surface mirrors the reference's module boundary:
 The compute path is the C-ABI library libl2i_hip.so (include/l2i.h); it must be built first
 (`python -m layout2img_amd.build`) and there is no CPU / PyTorch fallback.
 """
-from .discriminator import CombineDiscriminator128_app, ResnetDiscriminator128_app  # noqa: F401
-from .generator import ResnetGenerator128_context  # noqa: F401
+from .discriminator import CombineDiscriminator64, CombineDiscriminator128_app, ResnetDiscriminator128_app  # noqa: F401
+from .generator import ResnetGenerator64_context, ResnetGenerator128_context, context_aware_generator  # noqa: F401
 from .trainer import FlatAdam, GanTrainer  # noqa: F401

@@ -128,9 +128,9 @@ class CombineDiscriminator128_app(nn.Module):
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()  # pending pass contexts stay: they are consumed by FlatAdam.step()
 
-    def forward_padded(self, images, bbox, label, need_wgrad=True):
-        if not images.is_cuda:
-            raise RuntimeError("layout2img_amd discriminators run on the GPU HIP path only")
+    def _prepare(self, images, bbox, label):
+        """xywh in [0,1] -> (R,5) pixel ROIs with batch index, flat labels, validity, NHWC image padded to 8 channels
+        (reference :402-417 without the host-synchronising nonzero())."""
         b, o = bbox.size(0), bbox.size(1)
         size = images.size(2)
         bb = bbox.to(images.device).float()
@@ -140,7 +140,13 @@ class CombineDiscriminator128_app(nn.Module):
         y = label.reshape(-1)
         valid = (y != 0).to(torch.int32).contiguous()
         x = F.pad(images.permute(0, 2, 3, 1), (0, 8 - images.size(1))).contiguous()
-        pc = self.obD_arena().prepare(training=self.training, need_wgrad=need_wgrad)
+        return rois, y, valid, x
+
+    def forward_padded(self, images, bbox, label, need_wgrad=True):
+        if not images.is_cuda:
+            raise RuntimeError("layout2img_amd discriminators run on the GPU HIP path only")
+        rois, y, valid, x = self._prepare(images, bbox, label)
+        pc = self.arena.prepare(training=self.training, need_wgrad=need_wgrad)
         d_img, d_obj, d_app = self.obD(x, y, rois, valid, pc)
         return d_img, d_obj, d_app, valid, rois
 
@@ -153,3 +159,58 @@ class CombineDiscriminator128_app(nn.Module):
         v = valid.bool()
         order = torch.cat((torch.nonzero(v & ~small).view(-1), torch.nonzero(v & small).view(-1)))
         return d_img, d_obj[order], d_app[order]
+
+
+class ResnetDiscriminator64(nn.Module):
+    """reference model/rcnn_discriminator_orig.py:83-135 (the only working 64x64 discriminator):
+    single-scale RoIAlign((8,8), 1/2, 0) on the 32x32 map, MEAN pooling on the image path (:117), orthogonal init."""
+
+    def __init__(self, num_classes=0, input_dim=3, ch=64):
+        super().__init__()
+        self.block1 = OptimizedBlock(input_dim, ch, downsample=False)
+        self.block2 = ResBlock(ch, ch * 2, downsample=False)
+        self.block3 = ResBlock(ch * 2, ch * 4, downsample=True)
+        self.block4 = ResBlock(ch * 4, ch * 8, downsample=True)
+        self.block5 = ResBlock(ch * 8, ch * 16, downsample=True)
+        self.l_im = GemmWeight("linear", 1, ch * 16, sn=True)
+        self.block_obj4 = ResBlock(ch * 4, ch * 8, downsample=True)
+        self.l_obj = GemmWeight("linear", 1, ch * 8, sn=True)
+        self.l_y = GemmWeight("embedding", num_classes, ch * 8, bias=False, sn=True)
+        for name, p in self.named_parameters():   # :130-135
+            if p.dim() > 1:
+                nn.init.orthogonal_(p)
+            if name[-4:] == "bias":
+                nn.init.constant_(p, 0)
+
+    def forward(self, x, y, rois, valid, pc):
+        x = self.block1(x, pc)
+        x = self.block2(x, pc)
+        x1 = self.block3(x, pc)
+        x = self.block4(x1, pc)
+        x = self.block5(x, pc)
+        out_im = F.linear(F.relu(x).mean(dim=(1, 2)), arena_weight(self.l_im, pc), self.l_im.bias)
+        obj = ops.roi_align(x1, None, rois, valid, 8, 1.0 / 2.0, 1.0, 1e30, 0)
+        f = F.relu(self.block_obj4(obj, pc)).sum(dim=(1, 2))
+        out_obj = F.linear(f, arena_weight(self.l_obj, pc), self.l_obj.bias)
+        out_obj = out_obj + torch.sum(arena_weight(self.l_y, pc)[y] * f, dim=1, keepdim=True)
+        return out_im, out_obj
+
+
+class CombineDiscriminator64(CombineDiscriminator128_app):
+    """reference model/rcnn_discriminator_orig.py:305-325; returns (d_img, d_obj). `bbox` is not modified."""
+
+    def __init__(self, num_classes=81):
+        nn.Module.__init__(self)
+        self.obD = ResnetDiscriminator64(num_classes=num_classes, input_dim=3)
+
+    def forward_padded(self, images, bbox, label, need_wgrad=True):
+        if not images.is_cuda:
+            raise RuntimeError("layout2img_amd discriminators run on the GPU HIP path only")
+        rois, y, valid, x = self._prepare(images, bbox, label)
+        pc = self.arena.prepare(training=self.training, need_wgrad=need_wgrad)
+        d_img, d_obj = self.obD(x, y, rois, valid, pc)
+        return d_img, d_obj, valid, rois
+
+    def forward(self, images, bbox, label, mask=None):
+        d_img, d_obj, valid, _ = self.forward_padded(images, bbox, label)
+        return d_img, d_obj[torch.nonzero(valid).view(-1)]

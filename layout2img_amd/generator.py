@@ -447,3 +447,53 @@ class context_aware_generator(_GeneratorBase):
         pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
         bn.commit()
         return torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()
+
+
+class ResnetGenerator64_context(ResnetGenerator128_context):
+    """64x64 generator for BASELINE configs 1-2. The reference has no working 64x64 `app_v2` generator (SURVEY.md
+    section 0, fact 10); this follows its own pattern for 64x64 models (model/resnet_generator_vg.py:301-355: drop
+    `res1`, blocks named res2..res5) with the app_v2 blocks: fc -> 4x4x16ch -> four up-blocks at 8/16/32/64 px, mask
+    heads on the first three (PSP on the second-to-last, as :411-415 do for their last two blocks), none on the last;
+    the 64x64 regressed masks and rectangle indicators are unchanged. Parity for this class is block-level (every
+    block is the oracle-checked 128x128 block) plus an end-to-end comparison with the oracle's restatement."""
+
+    def __init__(self, ch=64, z_dim=128, num_classes=10, output_dim=3):
+        _GeneratorBase.__init__(self)
+        self.num_classes, self.ch, self.output_dim = num_classes, ch, output_dim
+        self.label_embedding = nn.Embedding(num_classes, 180)
+        num_w = 128 + 180
+        self.context = BoxMultiHeadedAttention(1, num_w)
+        self.fc = GemmWeight("linear", 4 * 4 * 16 * ch, z_dim, sn=True, eps=1e-12)
+        self.res2 = ResBlock(ch * 16, ch * 8, num_w=num_w)
+        self.res3 = ResBlock(ch * 8, ch * 4, num_w=num_w)
+        self.res4 = ResBlock(ch * 4, ch * 2, num_w=num_w, psp_module=True)
+        self.res5 = ResBlock(ch * 2, ch * 1, num_w=num_w, predict_mask=False)
+        self.final = nn.ModuleList([BNState(ch), nn.Identity(), GemmWeight("conv", output_dim, ch, 3, sn=True, eps=1e-4), nn.Identity()])
+        self.alpha1 = nn.Parameter(torch.zeros(1, 184, 1))
+        self.alpha2 = nn.Parameter(torch.zeros(1, 184, 1))
+        self.alpha3 = nn.Parameter(torch.zeros(1, 184, 1))
+        self.mask_regress = MaskRegressNetv2(num_w)
+        self.init_parameter()
+
+    def forward(self, z, bbox, z_im=None, y=None, taps=None):
+        if not z.is_cuda:
+            raise RuntimeError("layout2img_amd generators run on the GPU HIP path only")
+        b, o = z.size(0), z.size(1)
+        bbox = bbox.to(z.device).float()
+        pc = self.arena.prepare(training=self.training)
+        w = self.context(self._latent(z, y), bbox, y, pc)
+        wp = _pad_last(w.reshape(b * o, -1), self.res2.b1.weight_proj.ci_p).reshape(b * o, 1, 1, -1).contiguous()
+        bmask = self.mask_regress(wp, bbox, pc, self.sync)
+        if z_im is None:
+            z_im = torch.randn((b, 128), device=z.device)
+        bbox_mask_ = bbox_mask(bbox, 64, 64)
+        x = fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc).view(b, 16 * self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
+        x, m = self.res2(x, wp, bmask, pc, self.sync)
+        for blk, alpha in ((self.res3, self.alpha1), (self.res4, self.alpha2), (self.res5, self.alpha3)):
+            stage = self._stage_mask(m, bmask, bbox_mask_, alpha, y)
+            x, m = blk(x, wp, stage, pc, self.sync)
+        bn, _, conv, _ = self.final
+        spec, wa, ba = bn.spec(self.training, self.sync)
+        pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
+        bn.commit()
+        return torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()

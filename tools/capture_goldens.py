@@ -151,6 +151,33 @@ def capture_discriminator():
     print("D captured", [tuple(t.shape) for t in o1])
 
 
+def capture_discriminator64():
+    """model/rcnn_discriminator_orig.CombineDiscriminator64 at 64x64 (it mutates bbox in place: pass a clone)."""
+    from model.rcnn_discriminator_orig import CombineDiscriminator64 as D
+    torch.manual_seed(0)
+    d = load(D(num_classes=184), 41)
+    inp = recipe.make_inputs(2, 8, 184, 141, size=64)
+    ks, shp = keys_blob(shapes_of(d))
+    rec = dict(keys=ks, shapes=shp, **{k: v.numpy() for k, v in inp.items()})
+    d.train()
+    label = inp["y"].unsqueeze(-1)
+    real = inp["real"].clone().requires_grad_(True)
+    o1 = d(real, inp["bbox"].clone(), label)
+    d.zero_grad()
+    g = torch.Generator().manual_seed(6)
+    sum((t * torch.randn(t.shape, generator=g)).sum() for t in o1).backward()
+    gn_names, gn = grad_norms(d)
+    rec.update(train1_img=o1[0].detach().numpy(), train1_obj=o1[1].detach().numpy(), grad_names=gn_names, grad_norms=gn,
+               grad_input_sub=real.grad.numpy()[:, :, ::2, ::2].copy())
+    o2 = d(inp["real"], inp["bbox"].clone(), label)
+    d.eval()
+    oe = d(inp["real"], inp["bbox"].clone(), label)
+    rec.update(train2_img=o2[0].detach().numpy(), train2_obj=o2[1].detach().numpy(), eval_img=oe[0].detach().numpy(),
+               eval_obj=oe[1].detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "d64.npz"), **rec)
+    print("D64 captured", [tuple(t.shape) for t in o1])
+
+
 def capture_train_loop():
     """Two iterations of train_context_app_v2.py:148-189 (VGG term omitted) on reference modules."""
     from model.rcnn_discriminator_app import CombineDiscriminator128_app as D
@@ -209,7 +236,7 @@ def capture_small_ops():
 if __name__ == "__main__":
     patch_env()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["small", "g_coco", "g_vg", "d", "loop"]
+    which = sys.argv[1:] or ["small", "g_coco", "g_vg", "d", "d64", "loop"]
     with torch.random.fork_rng():
         if "small" in which:
             capture_small_ops()
@@ -219,5 +246,7 @@ if __name__ == "__main__":
             capture_generator("vg")
         if "d" in which:
             capture_discriminator()
+        if "d64" in which:
+            capture_discriminator64()
         if "loop" in which:
             capture_train_loop()
