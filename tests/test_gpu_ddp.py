@@ -1,0 +1,87 @@
+"""GPU: the full data-parallel training iteration (GanTrainer under torch.distributed) with world_size 2 equals the
+single-process iteration on the concatenated batch -- DataParallel semantics of the reference
+(train_context_app_v2.py:50-57,108-110; model/sync_batchnorm/batchnorm.py:59-125).
+
+Only one GPU is available to the tests, and RCCL refuses two ranks on one device, so the two ranks share cuda:0 and
+use the gloo backend (which all-reduces CUDA tensors through the host). The code path is the one `bench.py --gpus N`
+runs over RCCL: SyncBN statistic exchange in forward and backward, global-count loss normalisation, flat gradient
+all-reduce, parameter broadcast.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build():
+    import layout2img_amd as L
+    torch.manual_seed(7)
+    g = L.ResnetGenerator64_context(num_classes=184)
+    d = L.CombineDiscriminator64(num_classes=184)
+    g.finalize(DEV, torch.float32), d.finalize(DEV, torch.float32)
+    for m in g.modules():
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = 0.0
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()  # the PSP stage norms are per-replica (un-synchronised) in the reference too: freeze them
+    return g, d, L.GanTrainer(g, d)
+
+
+def _batch():
+    from layout2img_amd.synthetic import make_batch
+    return make_batch(4, 64, "coco", seed=11, device="cpu")
+
+
+def _run(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from layout2img_amd import parallel
+    if world > 1:
+        parallel.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    g, d, tr = _build()
+    real, label, bbox, z, z_im = _batch()
+    n = 4 // world
+    sl = slice(rank * n, (rank + 1) * n)
+    args = [t[sl].to(DEV) for t in (real, label, bbox, z, z_im)]
+    for _ in range(2):
+        r = tr.step(*args)
+    torch.cuda.synchronize()
+    if rank == 0:
+        out["g"] = g.flat.data.detach().cpu()
+        out["d"] = d.flat.data.detach().cpu()
+        out["d_loss"] = float(r["d_loss"])
+        out["g_loss"] = float(r["g_loss"])
+        out["bn_mean"] = g.res5.b2.batch_norm2d.running_mean.detach().cpu()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process():
+    mgr = mp.Manager()
+    single, multi = mgr.dict(), mgr.dict()
+    mp.spawn(_run, args=(1, _free_port(), single), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), multi), nprocs=2, join=True)
+    # global-count losses: rank 0 holds its share of the global mean; the sum over ranks is the global loss, so
+    # compare parameters (which see the all-reduced gradients) and synchronised BN statistics instead.
+    assert torch.allclose(multi["bn_mean"], single["bn_mean"], atol=2e-3)   # second step sees 1-step-old Adam sign noise
+    for k in ("g", "d"):
+        a, b = multi[k], single[k]
+        # Adam (beta1 = 0) moves each element by ~lr*sign(g): identical gradients up to round-off except at
+        # elements whose gradient is round-off noise; require 99 % of the elements to agree to 2e-5 after 2 steps
+        frac = float(((a - b).abs() < 2e-5).float().mean())
+        assert frac > 0.99, (k, frac)
+        assert float((a - b).abs().max()) <= 1e-3   # a few opposite-sign Adam steps of <= sqrt(2) * lr each
