@@ -20,9 +20,28 @@
 
 // 16-byte LDS-DMA through a buffer descriptor: lane i's data lands at lds_dst + 16 i; an out-of-range byte offset
 // makes the hardware write zeros. (Kept in a __device__ helper: the descriptor type does not exist in the host pass.)
-__device__ __forceinline__ void buf_load_lds16(const void* base, unsigned nbytes, unsigned voff, char* lds_dst) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nbytes, 0x00020000),
-                                             (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
+//
+// Issued through inline asm on purpose: hipcc tracks a builtin LDS-DMA as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read of the same __shared__ array -- i.e. right after the tile for a
+// LATER K-step was issued -- which serialises "issue, wait for everything, compute" and leaves no DMA in flight under
+// the MFMAs. An asm load is invisible to that bookkeeping; its completion is counted by hand (s_waitcnt vmcnt(N)
+// before the barrier of the K-step that consumes it). M0 (LDS base of the wave-instruction) is written in the same
+// statement that uses it.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t make_rsrc(const void* base, unsigned nbytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4_t r;
+    r[0] = (unsigned)a;
+    r[1] = (unsigned)(a >> 32) & 0xffffu;  // stride 0
+    r[2] = nbytes;
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void buf_load_lds16(u32x4_t rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
 }
 
 struct ConvArgs {
@@ -55,11 +74,15 @@ __device__ __forceinline__ void idx2pix(int idx, int hw_shift, int lin, int& py,
 
 // Tile geometry: BM x BN outputs per workgroup of WM x WN waves (each wave a (BM/WM) x (BN/WN) block of 32x32
 // MFMA tiles), NS-stage LDS ring.
-template <typename T, int BM, int BN, int WM, int WN, int NS>
+// HK = 1 halves the K-step (64-byte LDS rows): twice as many, half as large ring stages, so that two workgroups per
+// CU can each keep three tiles in flight within the 160 KB of LDS (the DMA round trip under load is ~1.5 us).
+template <typename T, int BM, int BN, int WM, int WN, int NS, int HK>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
     constexpr int THREADS = WM * WN * 64;
-    constexpr int RPP = THREADS / 8;  // tile rows filled per DMA pass (8 lanes x 16 B per 128-byte row)
-    constexpr int BK = Mma<T>::BK;
+    constexpr int ROWB = HK ? 64 : 128;     // bytes per LDS tile row
+    constexpr int CPR = ROWB / 16;        // 16-byte chunks per LDS row
+    constexpr int RPP = THREADS / CPR;        // tile rows filled per DMA pass
+    constexpr int BK = Mma<T>::BK >> HK;
     constexpr int EPG = OpT<T>::EPG;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int AP = BM / RPP, BP = BN / RPP;  // LDS-DMA instructions per thread per K-step
@@ -71,7 +94,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
     // Bank conflicts of the ds_read_b128 fragment reads are avoided by an XOR swizzle applied on the SOURCE
     // side (the lane that fills physical chunk c of row r fetches logical chunk c ^ ig2_swz(r)) and on the read.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = (BM + BN) * IG2_ROWB;
+    constexpr int STAGE = (BM + BN) * ROWB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = p.tiles_m * p.tiles_n;
@@ -88,8 +111,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
     // end and channels past Ci are zero-filled without a branch or a 64-bit address select.
     constexpr unsigned OOB = 0x80000000u;
     constexpr int SZ = (int)sizeof(T);
-    const int lrow = tid >> 3;
-    const int lchunk = (tid & 7) ^ ig2_swz(lrow);  // logical 16-byte chunk this lane fetches (rows +32q: same swizzle)
+    const int lrow = tid / CPR;
+    const int lchunk = (tid % CPR) ^ ig2_swz_t<HK>(lrow);  // logical 16-byte chunk this lane fetches (rows +RPP*q: same swizzle)
     int a_y[AP], a_x[AP];
     unsigned a_off[AP], a_mask[AP];                 // byte offset of the row's pixel (+ lane chunk); 9-bit tap validity
 #pragma unroll
@@ -113,22 +136,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
     unsigned b_off[BP];
 #pragma unroll
     for (int q = 0; q < BP; ++q) b_off[q] = (unsigned)((n0 + lrow + RPP * q) * p.Kpad) * SZ;
-    const int wbase = __builtin_amdgcn_readfirstlane(wave) * 8 * IG2_ROWB;  // this wave's 8 rows of each 32-row slab
+    const int wbase = __builtin_amdgcn_readfirstlane(wave) * 1024;  // one wave-instruction fills 1 KB = this wave's rows of a pass
     const int lane_c = lchunk * EPG;                                          // first channel of the lane's chunk
 
     // K traversal. chunk_major (3x3, Ci >= BK): steps run channel-chunk-major, tap-minor -- the 9 taps of one
     // 64-channel chunk are consecutive, a workgroup re-reads nearly the same input lines 9 steps in a row (L1/L2
     // hits), and all per-step index arithmetic is scalar (tap counters) plus ~4 VALU per row. Otherwise
     // (1x1 / linear / Ci < BK) the step covers k = ks*BK.. linearly and a lane derives its own tap.
-    int it_tap, it_cb;  // running (tap, channel-chunk base) of the NEXT tile to issue (chunk_major)
+    int nx_tap, nx_cb;  // running (tap, channel-chunk base) of the NEXT tile to issue (chunk_major)
     {
         const int taps = p.KH * p.KH;
         const int ksa = split * p.ks_per;
-        it_cb = (ksa / taps) * BK;
-        it_tap = ksa - (ksa / taps) * taps;
+        nx_cb = (ksa / taps) * BK;
+        nx_tap = ksa - (ksa / taps) * taps;
     }
-    int it_ks = split * p.ks_per;
-    auto issue_tiles = [&](char* stage) {
+    int nx_ks = split * p.ks_per;
+    auto advance = [](int& tap, int& cb, int& ks, int bk) {
+        ++ks;
+        if (++tap == 9) { tap = 0; cb += bk; }
+    };
+    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
+    const unsigned smem_addr = lds_addr_of(smem);
+    // (iterator state is passed by value: captured-by-reference counters ended up in scratch memory, and scratch
+    // loads count on vmcnt just like the DMA)
+    auto issue_tiles = [&](unsigned stage, const int it_tap, const int it_cb, const int it_ks) {  // stage: LDS byte address
         if (p.chunk_major) {
             const int ky = it_tap / 3, kx = it_tap - ky * 3;
             const unsigned tapbit = 1u << it_tap;
@@ -145,13 +176,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
                     off = a_off[q] + (unsigned)s_delta + cadd;
                 }
                 const unsigned voff = ((a_mask[q] & tapbit) && cv) ? off : OOB;
-                buf_load_lds16(p.x, p.x_bytes, voff, stage + q * RPP * IG2_ROWB + wbase);
+                buf_load_lds16(rsrc_x, voff, stage + q * RPP * ROWB + wbase);
             }
             const unsigned kadd = (unsigned)(it_tap * p.Ci) * SZ + cadd;
 #pragma unroll
             for (int q = 0; q < BP; ++q)
-                buf_load_lds16(p.w, p.w_bytes, b_off[q] + kadd, stage + (BM + q * RPP) * IG2_ROWB + wbase);
-            if (++it_tap == 9) { it_tap = 0; it_cb += BK; }
+                buf_load_lds16(rsrc_w, b_off[q] + kadd, stage + (BM + q * RPP) * ROWB + wbase);
         } else {
             const int k0 = it_ks * BK + lane_c;
             const int tap = k0 / p.Ci, ci = k0 - tap * p.Ci;
@@ -163,12 +193,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
                 const int y0 = a_y[q] >> p.up2, x0 = a_x[q] >> p.up2;
                 const unsigned off = a_off[q] + (unsigned)((((ys - y0) * p.Wi + (xs - x0)) * p.Ci + ci) * SZ);
                 const unsigned voff = (kvalid && ((a_mask[q] >> tap) & 1u)) ? off : OOB;
-                buf_load_lds16(p.x, p.x_bytes, voff, stage + q * RPP * IG2_ROWB + wbase);
+                buf_load_lds16(rsrc_x, voff, stage + q * RPP * ROWB + wbase);
             }
 #pragma unroll
             for (int q = 0; q < BP; ++q)
-                buf_load_lds16(p.w, p.w_bytes, b_off[q] + (unsigned)k0 * SZ, stage + (BM + q * RPP) * IG2_ROWB + wbase);
-            ++it_ks;
+                buf_load_lds16(rsrc_w, b_off[q] + (unsigned)k0 * SZ, stage + (BM + q * RPP) * ROWB + wbase);
         }
     };
 
@@ -191,7 +220,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
     constexpr int LPT = AP + BP;  // LDS-DMA instructions per thread per tile
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (ks0 + s < nks) issue_tiles(smem + s * STAGE);
+        if (ks0 + s < nks) {
+            issue_tiles(smem_addr + s * STAGE, nx_tap, nx_cb, nx_ks);
+            advance(nx_tap, nx_cb, nx_ks, BK);
+        }
     for (int ks = ks0; ks < nks; ++ks) {
         const int it = ks - ks0;
         const int ahead = min(NS - 2, nks - 1 - ks);  // tiles allowed to stay in flight behind tile ks
@@ -200,9 +232,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (ks + NS - 1 < nks) issue_tiles(smem + ((it + NS - 1) % NS) * STAGE);
+        if (ks + NS - 1 < nks) {
+            issue_tiles(smem_addr + ((it + NS - 1) % NS) * STAGE, nx_tap, nx_cb, nx_ks);
+            advance(nx_tap, nx_cb, nx_ks, BK);
+        }
         char* cur = smem + (it % NS) * STAGE;
-        Mma2<T>::template step<TM, TN>(cur, cur + BM * IG2_ROWB, wrow, wcol, lane, acc);
+        Mma2<T>::template step<TM, TN, HK>(cur, cur + BM * ROWB, wrow, wcol, lane, acc);
     }
 
     // ---- epilogue
@@ -272,10 +307,12 @@ static int ilog2(int v) {
 }
 
 // Launch one instantiation; LDS rings above 64 KB need the opt-in attribute (set once per instantiation).
-template <typename T, int BM, int BN, int WM, int WN, int NS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int HK = 0>
 static int launch_cfg(ConvArgs a, hipStream_t stream) {
-    constexpr int BK = Mma<T>::BK;
-    constexpr size_t lds = (size_t)NS * (BM + BN) * IG2_ROWB;
+    constexpr int BK = Mma<T>::BK >> HK;
+    constexpr size_t lds = (size_t)NS * (BM + BN) * (HK ? 64 : 128);
+    a.chunk_major = (a.KH == 3 && a.Ci >= BK) ? 1 : 0;
+    a.nks = a.chunk_major ? 9 * ((a.Ci + BK - 1) / BK) : a.Kpad / BK;
     a.PH = BM / a.PW;
     if (!a.lin && (a.PH & 1)) return L2I_ERR_ARG;
     const int rows = a.B * a.Ho;
@@ -299,12 +336,12 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     static bool ready = false;
     if (!ready) {
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN, NS>,
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN, NS, HK>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         ready = true;
     }
     (void)BK;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, NS>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, NS, HK>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
     return l2i_check_launch();
 }
 
@@ -341,7 +378,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     // Configurations (see DESIGN.md for the measurements behind the choice):
     //  0: 128x128 tile, 4 waves, 2 stages (two workgroups per CU)      1: 128x64, 4 waves, 2 stages (Co <= 64)
     //  2: 128x128, 8 waves (64x32 each), 4 stages                       3: 256x128, 8 waves (64x64 each), 3 stages
-    //  4: 256x256, 8 waves (64x128 each), 2 stages
+    //  4: 256x256, 8 waves (64x128 each), 2 stages                      5/6: as 0/1 with half K-steps and a 4-stage ring
     // Heuristic from scratch/conv_tune.py on MI355X (TFLOP/s, bf16): big-tile configs pay only when their grid still
     // fills the 256 CUs; a single wave of 128x128 tiles (one workgroup per CU) prefers the 8-wave deep ring.
     const long long M = (long long)a.B * a.Ho * a.Wo;
@@ -354,6 +391,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     else if (!a.lin && a.Co % 128 == 0 && t256x128 >= 384 && a.nks >= 72) cfg = 3;
     else if (t128 >= 192 && t128 <= 288) cfg = 2;
     else cfg = 0;
+    if (g_conv_cfg_override == 5 && a.Co <= 64) cfg = 6;
     if (g_conv_cfg_override >= 0 && a.Co > 64) {
         cfg = g_conv_cfg_override;
         if ((cfg == 3 || cfg == 4) && (a.lin || t256x128 < 128)) cfg = 0;  // too few tiles to be meaningful
@@ -363,6 +401,8 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         case 2: return launch_cfg<T, 128, 128, 2, 4, 4>(a, stream);
         case 3: return launch_cfg<T, 256, 128, 4, 2, 3>(a, stream);
         case 4: return launch_cfg<T, 256, 256, 4, 2, 2>(a, stream);
+        case 5: return launch_cfg<T, 128, 128, 2, 2, 4, 1>(a, stream);   // half K-steps, 4-stage ring, two workgroups per CU
+        case 6: return launch_cfg<T, 128, 64, 2, 2, 4, 1>(a, stream);
         default: return launch_cfg<T, 128, 128, 2, 2, 2>(a, stream);
     }
 }

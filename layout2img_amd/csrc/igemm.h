@@ -71,23 +71,28 @@ template <> struct Mma<float> {
 // (= two 128-byte tile rows): the row's parity picks the half, so the 8 same-parity rows of a group must get 8
 // different chunk positions; their (row >> 1) & 7 are all different, their row & 7 are not (measured: 50 % of the
 // LDS cycles were bank conflicts with the row & 7 form).
+// Half K-step (HK = 1): 64-byte rows, four rows per 256-byte bank row; the 4 rows of a 16-lane group that share a
+// quarter have distinct (row >> 2) & 3, which is the swizzle there.
 #define IG2_ROWB 128
 __device__ __forceinline__ int ig2_swz(int row) { return (row >> 1) & 7; }
-__device__ __forceinline__ int ig2_off(int row, int chunk) { return row * IG2_ROWB + ((chunk ^ ig2_swz(row)) << 4); }
+template <int HK> __device__ __forceinline__ int ig2_swz_t(int row) { return HK ? ((row >> 2) & 3) : ((row >> 1) & 7); }
+template <int HK> __device__ __forceinline__ int ig2_off(int row, int chunk) {
+    return row * (HK ? 64 : 128) + ((chunk ^ ig2_swz_t<HK>(row)) << 4);
+}
 
 template <typename T> struct Mma2;
 template <> struct Mma2<bf16_t> {
-    template <int TM, int TN>
+    template <int TM, int TN, int HK>
     __device__ static __forceinline__ void step(const char* As, const char* Bs, int wrow, int wcol, int lane,
                                                 f32x16_t (&acc)[TM][TN]) {
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < (HK ? 2 : 4); ++kk) {
             bf16x8_t a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + ig2_off(wrow + i * 32 + r, kk * 2 + h));
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + ig2_off<HK>(wrow + i * 32 + r, kk * 2 + h));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + ig2_off(wcol + j * 32 + r, kk * 2 + h));
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + ig2_off<HK>(wcol + j * 32 + r, kk * 2 + h));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -99,17 +104,18 @@ template <> struct Mma2<bf16_t> {
     }
 };
 template <> struct Mma2<float> {
-    template <int TM, int TN>
+    template <int TM, int TN, int HK>
     __device__ static __forceinline__ void step(const char* As, const char* Bs, int wrow, int wcol, int lane,
                                                 f32x16_t (&acc)[TM][TN]) {
         const int r = lane & 31, h = lane >> 5;
+        constexpr int NQ = HK ? 2 : 4;  // float4 chunks per lane half
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             f32x4_t a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(As + ig2_off(wrow + i * 32 + r, h * 4 + q));
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(As + ig2_off<HK>(wrow + i * 32 + r, h * NQ + q));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(Bs + ig2_off(wcol + j * 32 + r, h * 4 + q));
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(Bs + ig2_off<HK>(wcol + j * 32 + r, h * NQ + q));
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
