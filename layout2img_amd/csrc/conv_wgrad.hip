@@ -23,6 +23,7 @@ struct WgradArgs {
     int B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2;
     int K, ldw, M, Mper, tiles_co, tiles_k, splits;
     float alpha;
+    unsigned x_bytes, dy_bytes;   // buffer-descriptor ranges of x and dy
 };
 
 template <typename T> struct Tr;
@@ -190,7 +191,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 // of a 4-pixel x 16-channel block and lane c receives channel c's 4 pixels. Rows that a half-wave reads together
 // are spread over the 64 banks by XOR-ing the 16-byte chunk index with a function of the pixel row, applied on
 // the DMA source side and on the read. Requires power-of-two Ho, Wo (all layers of this path).
-__device__ uint4 g_wzero16[1] = {{0u, 0u, 0u, 0u}};
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -233,9 +233,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
     const int co0 = tile_co * BMO, kc0 = tile_k * BNK;
     const int pad = p.KH >> 1;
     const int Hd = p.Ho >> p.pool2, Wd = p.Wo >> p.pool2;
-    const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(p.x);
-    const bf16_t* __restrict__ DY = reinterpret_cast<const bf16_t*>(p.dy);
-    const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_wzero16);
     const int m_begin = split * p.Mper;
     const int m_end = min(p.M, m_begin + p.Mper);
 
@@ -252,32 +249,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
     const int b_ky = tap / p.KH, b_kx = tap - b_ky * p.KH;
     const bool b_on = kc < p.K;
 
-    auto issue = [&](int mstep, char* stage) {
+    // LDS-DMA through buffer descriptors (inline asm, see igemm.h): masked lanes use an out-of-range offset -> zeros.
+    const u32x4_t rs_dy = make_rsrc(p.dy, p.dy_bytes), rs_x = make_rsrc(p.x, p.x_bytes);
+    const unsigned smem_addr = lds_addr_of(smem);
+    constexpr unsigned OOB = 0x80000000u;
+    auto issue = [&](int mstep, unsigned stage) {   // stage: LDS byte address of the stage
 #pragma unroll
         for (int q = 0; q < A_Q; ++q) {
             const int prow = wv * 16 + q * A_ROWS;   // wave-uniform first pixel row of this instruction
             const int m = mstep + prow + a_row;
-            const bf16_t* src = zsrc;
+            unsigned voff = OOB;
             if (a_on && m < m_end) {
                 const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1), b = m >> (lgW + lgH);
-                src = DY + ((size_t)(b * Hd + (y >> p.pool2)) * Wd + (x >> p.pool2)) * p.Co + a_chan;
+                voff = (unsigned)(((b * Hd + (y >> p.pool2)) * Wd + (x >> p.pool2)) * p.Co + a_chan) * 2u;
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(stage + prow * RSA), 16, 0, 0);
+            buf_load_lds16(rs_dy, voff, stage + prow * RSA);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int prow = wv * 16 + q * 4;
             const int m = mstep + prow + b_row;
-            const bf16_t* src = zsrc;
+            unsigned voff = OOB;
             if (b_on && m < m_end) {
                 const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1), b = m >> (lgW + lgH);
                 const int yy = y + b_ky - pad, xx = x + b_kx - pad;
                 if (yy >= 0 && yy < p.Ho && xx >= 0 && xx < p.Wo)
-                    src = X + ((size_t)(b * p.Hi + (yy >> p.up2)) * p.Wi + (xx >> p.up2)) * p.Ci + b_ci;
+                    voff = (unsigned)(((b * p.Hi + (yy >> p.up2)) * p.Wi + (xx >> p.up2)) * p.Ci + b_ci) * 2u;
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(stage + BK * RSA + prow * RSB), 16, 0, 0);
+            buf_load_lds16(rs_x, voff, stage + BK * RSA + prow * RSB);
         }
     };
 
@@ -291,12 +290,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
 
     const int wrow = (wave >> 1) * (BMO / 2), wcol = (wave & 1) * 64;
     if (m_begin < m_end) {
-        issue(m_begin, smem);
+        issue(m_begin, smem_addr);
         int it = 0;
         for (int ms = m_begin; ms < m_end; ms += BK, ++it) {
             char* cur = smem + (it & 1) * STAGE;
-            __syncthreads();  // tile `it` landed (vmcnt drained before the barrier), other stage free
-            if (ms + BK < m_end) issue(ms + BK, smem + ((it + 1) & 1) * STAGE);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile `it` landed ...
+            __builtin_amdgcn_s_barrier();                       // ... everyone's did, and the other stage is free
+            if (ms + BK < m_end) issue(ms + BK, smem_addr + ((it + 1) & 1) * STAGE);   // in flight under the MFMAs below
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 bf16x8_t a[TM], b[TN];
@@ -355,6 +355,12 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.splits = (a.M + a.Mper - 1) / a.Mper;
     const int nblk = tiles * a.splits;
     const bool pow2 = !(a.Ho & (a.Ho - 1)) && !(a.Wo & (a.Wo - 1));
+    {
+        const size_t xb = (size_t)a.B * a.Hi * a.Wi * a.Ci * sizeof(T);
+        const size_t yb = (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co * sizeof(T);
+        if (xb >= 0x80000000ull || yb >= 0x80000000ull) return L2I_ERR_ARG;   // 32-bit buffer offsets
+        a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+    }
     if (sizeof(T) == 2 && pow2) {  // bf16: LDS-DMA + transposing-read kernel
         int lgW = 0, lgH = 0;
         while ((1 << lgW) < a.Wo) ++lgW;

@@ -134,3 +134,30 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + k;
 }
+
+// 16-byte LDS-DMA through a buffer descriptor: lane i's data lands at lds_dst + 16 i; an out-of-range byte offset
+// makes the hardware write zeros. (Kept in a __device__ helper: the descriptor type does not exist in the host pass.)
+//
+// Issued through inline asm on purpose: hipcc tracks a builtin LDS-DMA as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read of the same __shared__ array -- i.e. right after the tile for a
+// LATER K-step was issued -- which serialises "issue, wait for everything, compute" and leaves no DMA in flight under
+// the MFMAs. An asm load is invisible to that bookkeeping; its completion is counted by hand (s_waitcnt vmcnt(N)
+// before the barrier of the K-step that consumes it). M0 (LDS base of the wave-instruction) is written in the same
+// statement that uses it.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t make_rsrc(const void* base, unsigned nbytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4_t r;
+    r[0] = (unsigned)a;
+    r[1] = (unsigned)(a >> 32) & 0xffffu;  // stride 0
+    r[2] = nbytes;
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void buf_load_lds16(u32x4_t rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
+}
+
