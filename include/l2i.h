@@ -70,9 +70,13 @@ int l2i_weights_backward(const long long* layers, int n_layers, const int* tab_d
 /* Per-channel sum / sum of squares over rows of x [rows][C] (grouped): sums/sqsums [G][C] +=.
  * Batch statistics of SynchronizedBatchNorm2d (model/sync_batchnorm/batchnorm.py:51-68), of
  * nn.InstanceNorm2d (rows_per_group = H*W) and bias gradients. raw (optional): operand-dtype copy of x written in
- * the same pass (the dY cast of a convolution's backward). */
+ * the same pass (the dY cast of a convolution's backward).
+ * ws (optional, here and in l2i_norm_mod_bwd_a): all-zero f32 workspace of L2I_WS_FLOATS floats, left all-zero;
+ * kernels sharing one workspace must be ordered on one stream. With it the many workgroups of a single-group
+ * reduction add into 32 replicas that a small fold kernel sums, instead of serialising on one address per channel. */
+#define L2I_WS_FLOATS (32 * 4 * 1024)
 int l2i_channel_stats(const float* x, long long rows, int C, long long rows_per_group, float* sums, float* sqsums,
-                      void* raw, int dtype, void* stream);
+                      void* raw, int dtype, float* ws, void* stream);
 
 /* Normalise + modulate + ReLU in one pass. mode 0: ISLA (SpatialAdaptiveSynBatchNorm2d.forward,
  * model/norm_module.py:163-186); mode 1: per-channel affine; mode 2: none.
@@ -88,7 +92,8 @@ int l2i_norm_mod_fwd(const float* x, int B, int HW, int C, const float* sums, co
 int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW, int C, const float* sums, const float* sqsums,
                        float count, float eps, int stat_stride, const float* mask, int O, const float* wproj,
                        const float* bproj, long long pstride_b, long long pstride_o, int mode, int relu, float* dxhat,
-                       float* s1, float* s2, float* dwproj, float* dbproj, float* dmask, float* dy_keep, void* stream);
+                       float* s1, float* s2, float* dwproj, float* dbproj, float* dmask, float* dy_keep, float* ws,
+                       void* stream);
 
 /* Backward, second pass: dx (+)= invstd * (dxhat - s1/count - xhat*s2/count). */
 int l2i_norm_bwd_b(const float* x, const float* dxhat, const float* sums, const float* sqsums, const float* s1,

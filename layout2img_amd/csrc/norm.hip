@@ -22,26 +22,30 @@
 // x [rows][C] f32, rows grouped in consecutive runs of rows_per_group. sums/sqsums [G][C] += .
 // Optionally also writes the operand-dtype copy of x (the cast a following MFMA kernel needs), so the
 // bias-gradient reduction and the dY cast of a convolution's backward are one pass over dY.
-// ~512 blocks in total: each block's per-channel partials end in one atomic per channel, and many more
-// blocks than that serialise on the same few addresses in L2.
+// ~1024 blocks in total (4 per CU, 8 x 16-byte loads in flight per thread). Each block's per-channel partials end in
+// one atomic per channel: into `sums`/`sqsums` directly when few blocks share an address (many groups), otherwise into
+// the replicated workspace `ws` (common.h) that the last block folds into `sums`/`sqsums`.
 template <typename T>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, long long rows, int C,
                                                             long long rows_per_group, int slabs_per_group,
                                                             float* __restrict__ sums, float* __restrict__ sqsums,
-                                                            T* __restrict__ raw) {
+                                                            T* __restrict__ raw, float* __restrict__ ws) {
     __shared__ float4 red[2][256];
     const int cols4 = C >> 2;
     const int group = blockIdx.x / slabs_per_group, slab = blockIdx.x % slabs_per_group;
     const long long slab_rows = (rows_per_group + slabs_per_group - 1) / slabs_per_group;
     const long long r0 = group * rows_per_group + slab * slab_rows;
     const long long r1 = min(group * rows_per_group + rows_per_group, r0 + slab_rows);
+    const int L = sqsums ? 2 * C : C;
+    float* const sdst = ws ? ws_replica(ws, slab % L2I_WS_R, L) : sums + (size_t)group * C;
+    float* const qdst = !sqsums ? nullptr : ws ? sdst + C : sqsums + (size_t)group * C;
     for (int cbase = 0; cbase < cols4; cbase += 256) {
         const int ncol = min(256, cols4 - cbase);
         const int TY = 256 / ncol;
         const int tx = threadIdx.x % ncol, ty = threadIdx.x / ncol;
         float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
         if (ty < TY) {
-#pragma unroll 4
+#pragma unroll 8
             for (long long r = r0 + ty; r < r1; r += TY) {
                 const size_t off = (size_t)r * C + 4 * (cbase + tx);
                 const float4 v = *reinterpret_cast<const float4*>(x + off);
@@ -69,10 +73,10 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
                 s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
                 q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
             }
-            float* so = sums + (size_t)group * C + 4 * (cbase + tx);
+            float* so = sdst + 4 * (cbase + tx);
             atomicAdd(so + 0, s.x); atomicAdd(so + 1, s.y); atomicAdd(so + 2, s.z); atomicAdd(so + 3, s.w);
-            if (sqsums) {
-                float* qo = sqsums + (size_t)group * C + 4 * (cbase + tx);
+            if (qdst) {
+                float* qo = qdst + 4 * (cbase + tx);
                 atomicAdd(qo + 0, q.x); atomicAdd(qo + 1, q.y); atomicAdd(qo + 2, q.z); atomicAdd(qo + 3, q.w);
             }
         }
@@ -80,22 +84,24 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 }
 
 extern "C" int l2i_channel_stats(const float* x, long long rows, int C, long long rows_per_group, float* sums,
-                                 float* sqsums, void* raw, int dtype, void* stream) {
+                                 float* sqsums, void* raw, int dtype, float* ws, void* stream) {
     if (!x || !sums || C % 4 || rows_per_group <= 0 || rows % rows_per_group) return L2I_ERR_ARG;
     const long long G = rows / rows_per_group;
-    long long slabs = (512 + G - 1) / G;
+    long long slabs = (1024 + G - 1) / G;
     const long long max_slabs = (rows_per_group + 63) / 64;
     if (slabs > max_slabs) slabs = max_slabs;
     if (slabs < 1) slabs = 1;
+    if (G != 1 || slabs <= 32) ws = nullptr;   // few workgroups per address: atomics straight into sums / sqsums
     const dim3 grid((unsigned)(G * slabs));
     if (dtype == 1)
         hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, C, rows_per_group,
-                           (int)slabs, sums, sqsums, (bf16_t*)raw);
+                           (int)slabs, sums, sqsums, (bf16_t*)raw, ws);
     else if (dtype == 0)
         hipLaunchKernelGGL(channel_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, C, rows_per_group,
-                           (int)slabs, sums, sqsums, (float*)raw);
+                           (int)slabs, sums, sqsums, (float*)raw, ws);
     else
         return L2I_ERR_ARG;
+    if (ws) ws_fold(ws, sqsums ? 2 * C : C, C, sums, sqsums, nullptr, nullptr, (hipStream_t)stream);
     return l2i_check_launch();
 }
 
@@ -113,6 +119,7 @@ struct NormArgs {
     float* out_f32;        // fwd: optional f32 copy; bwd: dxhat
     float* s1; float* s2;  // bwd: [G][C]
     float* dwproj; float* dbproj; float* dmask;
+    float* ws;             // bwd: replicated workspace for the per-channel totals (common.h) or null
     long long pstride_b, pstride_o;
     int B, HW, C, O, mode, relu, stat_stride;
     float count, eps;
@@ -536,7 +543,8 @@ __global__ __launch_bounds__(256) void norm_bwd_a_kernel(NormArgs p, int nseg, i
             } else {
                 if (p.mode == 0) kk -= 2 * NB_OC;
                 const size_t so = (size_t)b * p.stat_stride + cch;
-                dst = kk == 0 ? p.s1 + so : kk == 1 ? p.s2 + so : kk == 2 ? p.dwproj + cch : p.dbproj + cch;
+                if (p.ws) dst = ws_replica(p.ws, (blockIdx.x / tiles_c) % L2I_WS_R, (p.mode == 1 ? 4 : 2) * p.C) + kk * p.C + cch;
+                else dst = kk == 0 ? p.s1 + so : kk == 1 ? p.s2 + so : kk == 2 ? p.dwproj + cch : p.dbproj + cch;
             }
             atomicAdd(dst + 0, a.x); atomicAdd(dst + 1, a.y); atomicAdd(dst + 2, a.z); atomicAdd(dst + 3, a.w);
         }
@@ -584,7 +592,7 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
                                   const float* sqsums, float count, float eps, int stat_stride, const float* mask, int O,
                                   const float* wproj, const float* bproj, long long pstride_b, long long pstride_o,
                                   int mode, int relu, float* dxhat, float* s1, float* s2, float* dwproj, float* dbproj,
-                                  float* dmask, float* dy_keep, void* stream) {
+                                  float* dmask, float* dy_keep, float* ws, void* stream) {
     NormArgs a = {};
     a.x = x; a.dy = dy; a.B = B; a.HW = HW; a.C = C; a.sums = sums; a.sqsums = sqsums; a.count = count; a.eps = eps;
     a.stat_stride = stat_stride; a.mask = mask; a.O = O; a.wproj = wproj; a.bproj = bproj;
@@ -600,8 +608,10 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
     if (nseg < 1) nseg = 1;
     const int seg_pixels = ((subtiles + nseg - 1) / nseg) * NB_PX;
     nseg = (HW + seg_pixels - 1) / seg_pixels;
+    a.ws = (stat_stride == 0 && B * nseg > 32) ? ws : nullptr;   // batch statistics shared by many workgroups
     hipLaunchKernelGGL(norm_bwd_a_kernel, dim3(B * nseg * tiles_c), dim3(256), norm_bwd_lds(a), (hipStream_t)stream, a, nseg,
                        seg_pixels);
+    if (a.ws) ws_fold(a.ws, (mode == 1 ? 4 : 2) * C, C, s1, s2, dwproj, dbproj, (hipStream_t)stream);
     return l2i_check_launch();
 }
 

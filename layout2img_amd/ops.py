@@ -67,6 +67,19 @@ class ZeroPool:
 POOL = ZeroPool()
 
 
+WS_FLOATS = 32 * 4 * 1024   # L2I_WS_FLOATS of include/l2i.h
+_WS = {}
+
+
+def _ws(device):
+    """Per-(device, stream) all-zero reduction workspace of the library (self-cleaning; see csrc/common.h)."""
+    key = (device.index, _stream())
+    w = _WS.get(key)
+    if w is None:
+        w = _WS[key] = torch.zeros(WS_FLOATS, dtype=torch.float32, device=device)
+    return w.data_ptr()
+
+
 def _zeros(shape, device):
     return POOL.take(tuple(shape), device)
 
@@ -163,7 +176,7 @@ def channel_stats(x2d, rows_per_group=None, want_sq=True, cast_to=None, accumula
         sums, sq = buf[0], (buf[1] if want_sq else None)
     raw = torch.empty(x2d.shape, dtype=cast_to, device=x2d.device) if cast_to is not None else None
     _lib.call("l2i_channel_stats", x2d.data_ptr(), rows, C, rpg, sums.data_ptr(), _p(sq), _p(raw),
-              _code(cast_to) if cast_to is not None else _lib.F32, _stream())
+              _code(cast_to) if cast_to is not None else _lib.F32, _ws(x2d.device) if C <= 1024 else None, _stream())
     if cast_to is not None:
         return sums, sq, raw
     return sums, sq
@@ -246,7 +259,8 @@ def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, 
     keep = torch.empty_like(dy) if (spec.mode == 0 and O > 8) else None
     _lib.call("l2i_norm_mod_bwd_a", x.data_ptr(), dy.data_ptr(), B, H * W, C, sums.data_ptr(), sq.data_ptr(), float(count),
               float(spec.eps), stat_stride, _p(mask), O, _p(wproj), _p(bproj), psb, pso, spec.mode, int(spec.relu),
-              dy.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(dw), _p(db), _p(dm), _p(keep), _stream())
+              dy.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(dw), _p(db), _p(dm), _p(keep),
+              _ws(dev) if C <= 1024 else None, _stream())
     frozen = (not spec.training) and spec.running is not None and not spec.instance
     if frozen:
         raise RuntimeError("backward through eval-mode batch norm is not part of the hot path")
