@@ -56,16 +56,19 @@ int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B,
  * nn.utils.spectral_norm(nn.Linear/nn.Embedding) (model/norm_module.py:158-159,
  * model/mask_regression.py:64-81, model/rcnn_discriminator_app.py:95,104-109).
  * layers: 20 x int64 per layer row, tables built by layout2img_amd/arena.py; one call per round (a weight the
- * reference applies twice per forward is iterated twice, second round with clear = 0). */
+ * reference applies twice per forward is iterated twice, second round with clear = 0).
+ * packed: only elements with co < Co_p, ci < Ci_p are written -- padding rows / K tails must already be zero
+ * (allocate the buffer zero-filled once; it may be reused for later passes). */
 int l2i_weights_prepare(const long long* layers, int n_layers, const int* tab_wtu, int n_wtu, const int* tab_wv, int n_wv,
-                        const int* tab_pack, int n_pack, const float* params, float* sn_state, float* pass_uv,
-                        long long uv_len, float* norms, void* packed, int dtype, int training, int clear,
-                        void* stream);
+                        const int* tab_pack, int n_pack, const int* tab_fin, int n_fin, const float* params,
+                        float* sn_state, float* pass_uv, long long uv_len, float* norms, void* packed, int dtype,
+                        int training, int clear, void* stream);
 
-/* Backward of the above: grads[w] += (G - <G,Wbar> u v^T) / sigma for every layer (G = dwbar). */
+/* Backward of the above: grads[w] += (G - <G,Wbar> u v^T) / sigma for every layer (G = dwbar).
+ * ws: the all-zero workspace described at l2i_channel_stats (required; left all-zero). */
 int l2i_weights_backward(const long long* layers, int n_layers, const int* tab_dot, int n_dot, const int* tab_apply,
                          int n_apply, const float* params, const float* dwbar, const float* pass_uv, float* norms,
-                         float* grads, void* stream);
+                         float* grads, float* ws, void* stream);
 
 /* Per-channel sum / sum of squares over rows of x [rows][C] (grouped): sums/sqsums [G][C] +=.
  * Batch statistics of SynchronizedBatchNorm2d (model/sync_batchnorm/batchnorm.py:51-68), of

@@ -17,8 +17,8 @@ SIGNATURES = {
     "l2i_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "l2i_set_conv_config": [_i],
     "l2i_conv2d_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
-    "l2i_weights_prepare": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p],
-    "l2i_weights_backward": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p],
+    "l2i_weights_prepare": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p],
+    "l2i_weights_backward": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "l2i_channel_stats": [_p, _ll, _i, _ll, _p, _p, _p, _i, _p, _p],
     "l2i_norm_mod_fwd": [_p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _i, _p],
     "l2i_norm_mod_bwd_a": [_p, _p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
@@ -59,3 +59,17 @@ def call(name, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed with code {rc} ({'bad argument' if rc == -1 else 'HIP launch error'})")
+
+
+WS_FLOATS = 32 * 4 * 1024   # L2I_WS_FLOATS of include/l2i.h
+_WS = {}
+
+
+def workspace(device):
+    """Pointer to the (device, current stream)'s all-zero reduction workspace (self-cleaning; csrc/common.h)."""
+    import torch
+    key = (torch.device(device).index or 0, torch.cuda.current_stream().cuda_stream)
+    w = _WS.get(key)
+    if w is None:
+        w = _WS[key] = torch.zeros(WS_FLOATS, dtype=torch.float32, device=device)
+    return w.data_ptr()

@@ -186,6 +186,7 @@ class WeightArena:
         t_wtu = [[] for _ in range(self.rounds)]
         t_wv = [[] for _ in range(self.rounds)]
         t_pack = [[] for _ in range(self.rounds)]
+        t_fin = [[] for _ in range(self.rounds)]
         t_dot, t_apply = [], []
         for i, (h, use) in enumerate(rows):
             taps = h.kh * h.kh
@@ -218,20 +219,21 @@ class WeightArena:
                 h.use_rows = [h]
             else:
                 h.use_rows.append(LayerUse(h, **attrs))
+            row[18] = 1 if h.uses > 1 else 0
+            pair_chunks = (h.co * h.ci + 255) // 256      # csrc/weights.hip: BW_PAIRS
             if h.sn:
-                for cc in range((kt + 255) // 256):
-                    for rc in range((h.co + 255) // 256):
+                for cc in range((kt + 1023) // 1024):
+                    for rc in range((h.co + 63) // 64):   # WTU_ROWS
                         t_wtu[use].append((i, cc, rc))
                 for rc in range((h.co + 15) // 16):
                     t_wv[use].append((i, rc))
-                for c in range((h.co * kt + 4095) // 4096):
-                    t_dot.append((i, c))
-            for c in range((npad * kpad + 2047) // 2048):
-                t_pack[use].append((i, 0, c))
-            for c in range((npad_d * kpad_d + 2047) // 2048):
-                t_pack[use].append((i, 1, c))
-            for c in range((h.co * kt + 4095) // 4096):
-                t_apply.append((i, c))
+                t_dot += [(i, c) for c in range(pair_chunks)]
+            tci = 256 if taps == 1 else 32
+            for ct in range((h.co_p + 63) // 64):         # PK_TCO
+                for cc in range((h.ci_p + tci - 1) // tci):
+                    t_pack[use].append((i, ct, cc))
+            t_fin[use].append((i,))
+            t_apply += [(i, c) for c in range(pair_chunks)]
         self.n_layers = L
         self.packed_len, self.dw_len = packed_len, max(dw_len, ALIGN)
         self.uv_len = max(uv_len, ALIGN)
@@ -243,19 +245,21 @@ class WeightArena:
         self.t_wtu = [dev(t, 3) for t in t_wtu]
         self.t_wv = [dev(t, 2) for t in t_wv]
         self.t_pack = [dev(t, 3) for t in t_pack]
+        self.t_fin = [dev(t, 1) for t in t_fin]
         self.t_dot, self.n_dot = dev(t_dot, 2)
         self.t_apply, self.n_apply = dev(t_apply, 2)
         self.pending = []
+        self.free_packs = []   # zero-padded pack buffers of finished passes (see PassCtx)
 
     def prepare(self, training=True, need_wgrad=True):
         """Run the power iteration(s) (train mode) and pack all weights; returns the pass context."""
         p = PassCtx(self, training, need_wgrad)
         for r in range(self.rounds):
-            (wtu, n_wtu), (wv, n_wv), (pk, n_pk) = self.t_wtu[r], self.t_wv[r], self.t_pack[r]
+            (wtu, n_wtu), (wv, n_wv), (pk, n_pk), (fin, n_fin) = self.t_wtu[r], self.t_wv[r], self.t_pack[r], self.t_fin[r]
             if n_pk == 0:
                 continue
             _lib.call("l2i_weights_prepare", self.layers.data_ptr(), self.n_layers, wtu.data_ptr(), n_wtu, wv.data_ptr(), n_wv,
-                      pk.data_ptr(), n_pk, self.flat.data.data_ptr(), self.sn_flat.data.data_ptr(), p.pass_uv.data_ptr(),
+                      pk.data_ptr(), n_pk, fin.data_ptr(), n_fin, self.flat.data.data_ptr(), self.sn_flat.data.data_ptr(), p.pass_uv.data_ptr(),
                       self.uv_len, p.norms.data_ptr(), p.packed.data_ptr(), self.dtype_code, 1 if training else 0,
                       1 if r == 0 else 0, torch.cuda.current_stream().cuda_stream)
         if need_wgrad and torch.is_grad_enabled():
@@ -271,7 +275,7 @@ class WeightArena:
                 continue
             _lib.call("l2i_weights_backward", self.layers.data_ptr(), self.n_layers, self.t_dot.data_ptr(), self.n_dot,
                       self.t_apply.data_ptr(), self.n_apply, self.flat.data.data_ptr(), p.dwbar.data_ptr(),
-                      p.pass_uv.data_ptr(), p.norms.data_ptr(), self.flat.grad.data_ptr(),
+                      p.pass_uv.data_ptr(), p.norms.data_ptr(), self.flat.grad.data_ptr(), _lib.workspace(self.device),
                       torch.cuda.current_stream().cuda_stream)
         self.pending = []
 
@@ -287,10 +291,19 @@ class PassCtx:
         self.training = training
         self.need_wgrad = need_wgrad
         dev = arena.device
-        self.packed = torch.empty(arena.packed_len, dtype=arena.op_dtype, device=dev)
+        # The pack kernel writes only the true (co < Co_p, ci < Ci_p) elements; padding rows and K tails must be
+        # zero, so buffers are zero-filled once and recycled through the arena when their pass dies.
+        self.packed = arena.free_packs.pop() if arena.free_packs else torch.zeros(arena.packed_len, dtype=arena.op_dtype, device=dev)
         self.pass_uv = torch.empty(arena.uv_len, dtype=torch.float32, device=dev)
         self.norms = torch.empty(4 * arena.n_layers, dtype=torch.float32, device=dev)
         self.dwbar = None
+
+    def __del__(self):
+        try:
+            if len(self.arena.free_packs) < 4:
+                self.arena.free_packs.append(self.packed)
+        except Exception:
+            pass
 
     def dw(self):
         if self.dwbar is None:

@@ -10,12 +10,17 @@
 //   normalize(x, eps) = x / max(||x||_2, eps).   eval mode: sigma = u . (W v) with the stored u, v.
 //   backward: dW = (G - <G, Wbar> u v^T) / sigma,  G = dL/dWbar.
 //
+// All of it is HBM-bound streaming over the f32 master weights (D: ~60 M, G: ~35 M parameters): every kernel
+// reads W in its natural [Co][Ci][taps] order with coalesced loads and goes through LDS where the destination
+// order differs (the two packs, the gradient), so that each phase moves its bytes once.
+//
 // Layer table: L2I_LSTRIDE (20) int64 per layer row (see layout2img_amd/arena.py); a weight that the reference
 // applies k times per forward (block_obj4, model/rcnn_discriminator_app.py:137,141 -- each application runs its own
 // power iteration) has k rows sharing w/u/v offsets and is processed in k sequential rounds:
 //   0 w_off  1 u_off(-1 = no SN)  2 v_off  3 Co  4 Ci  5 KH  6 Co_p  7 Ci_p
 //   8 Kpad  9 Npad  10 fwd_off  11 Kpad_d  12 Npad_d  13 dg_off  14 dw_off  15 eps(float bits)
-//   16 pass_u_off  17 pass_v_off (offsets into the per-pass u/v snapshot)  18,19 reserved
+//   16 pass_u_off  17 pass_v_off (offsets into the per-pass u/v snapshot)  18 multi-use (gradient needs atomics)
+//   19 reserved
 // norms: f32 [L][4] = {||W^T u||^2, ||W v||^2 (eval: u.Wv), sigma, <G, W>}
 #include "common.h"
 
@@ -24,25 +29,46 @@
 
 __device__ __forceinline__ float layer_eps(const long long* L) { return __uint_as_float((uint32_t)L[15]); }
 
-// phase 1: t = W^T u, partial over a 256-row slab, 256 columns per block. table: (layer, colchunk, rowchunk)
+// ---------------------------------------------------------------- phase 1: t = W^T u
+// table (layer, colchunk, rowchunk): 1024 columns (4 per thread, one 16-byte load per row) x 64 rows per block.
+#define WTU_ROWS 64
 __global__ __launch_bounds__(256) void sn_wtu_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                      const float* __restrict__ params, const float* __restrict__ sn_state,
                                                      float* __restrict__ pass_uv) {
     const int* e = table + 3 * blockIdx.x;
     const long long* L = layers + L2I_LSTRIDE * e[0];
     const int Co = (int)LF(3), Kt = (int)(LF(4) * LF(5) * LF(5));
-    const int col = e[1] * 256 + threadIdx.x;
-    const int r0 = e[2] * 256, r1 = min(Co, r0 + 256);
-    if (col >= Kt) return;
+    const int r0 = e[2] * WTU_ROWS, r1 = min(Co, r0 + WTU_ROWS);
     const float* W = params + LF(0);
     const float* u = sn_state + LF(1);
-    float t = 0.f;
-    for (int r = r0; r < r1; ++r) t += u[r] * W[(size_t)r * Kt + col];
-    atomicAdd(pass_uv + LF(17) + col, t);
+    float* t_out = pass_uv + LF(17);
+    if ((Kt & 3) == 0) {
+        const int col = e[1] * 1024 + 4 * threadIdx.x;
+        if (col >= Kt) return;
+        float4 t = make_float4(0, 0, 0, 0);
+#pragma unroll 8
+        for (int r = r0; r < r1; ++r) {
+            const float4 w = *reinterpret_cast<const float4*>(W + (size_t)r * Kt + col);
+            const float ur = u[r];
+            t.x = fmaf(ur, w.x, t.x); t.y = fmaf(ur, w.y, t.y); t.z = fmaf(ur, w.z, t.z); t.w = fmaf(ur, w.w, t.w);
+        }
+        atomicAdd(t_out + col + 0, t.x); atomicAdd(t_out + col + 1, t.y);
+        atomicAdd(t_out + col + 2, t.z); atomicAdd(t_out + col + 3, t.w);
+    } else {   // rows not 16-byte aligned (Ci = 3, odd class counts): scalar columns
+        for (int c = 0; c < 4; ++c) {
+            const int col = e[1] * 1024 + c * 256 + threadIdx.x;
+            if (col >= Kt) continue;
+            float t = 0.f;
+#pragma unroll 8
+            for (int r = r0; r < r1; ++r) t = fmaf(u[r], W[(size_t)r * Kt + col], t);
+            atomicAdd(t_out + col, t);
+        }
+    }
 }
 
-// phase 2: s = W vhat (train: vhat = t / max(||t||, eps); eval: vhat = stored v). 16 rows per block.
-// table: (layer, rowchunk)
+// ---------------------------------------------------------------- phase 2: s = W vhat
+// (train: vhat = t / max(||t||, eps); eval: vhat = stored v). 16 rows per block, 4 per wave read together so the
+// vector chunk is loaded once per 4 rows. table: (layer, rowchunk)
 __global__ __launch_bounds__(256) void sn_wv_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                     const float* __restrict__ params, const float* __restrict__ sn_state,
                                                     float* __restrict__ pass_uv, float* __restrict__ norms, int training) {
@@ -54,176 +80,262 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const long long* __restrict_
     const float* W = params + LF(0);
     const float* vsrc = training ? pass_uv + LF(17) : sn_state + LF(2);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float blk = 0.f;
-    float tn2_keep = 0.f;
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = e[1] * 16 + wave * 4 + rr;
-        if (r >= Co) break;
-        float dot = 0.f, tn2 = 0.f;
+    const int rbase = e[1] * 16 + wave * 4;
+    float dot[4] = {0.f, 0.f, 0.f, 0.f}, tn2 = 0.f;
+    const float* Wr[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Wr[rr] = W + (size_t)min(rbase + rr, Co - 1) * Kt;   // clamped rows are discarded below
+    if ((Kt & 3) == 0) {
+#pragma unroll 2
+        for (int k = 4 * lane; k < Kt; k += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(vsrc + k);
+            tn2 += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float4 w = *reinterpret_cast<const float4*>(Wr[rr] + k);
+                dot[rr] += w.x * t.x + w.y * t.y + w.z * t.z + w.w * t.w;
+            }
+        }
+    } else {
         for (int k = lane; k < Kt; k += 64) {
             const float t = vsrc[k];
-            dot += W[(size_t)r * Kt + k] * t;
             tn2 += t * t;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) dot[rr] += Wr[rr][k] * t;
         }
-        dot = wave_sum(dot);
-        tn2 = wave_sum(tn2);
-        tn2_keep = tn2;
+    }
+    tn2 = wave_sum(tn2);
+    float blk = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = rbase + rr;
+        const float d = wave_sum(dot[rr]);
+        if (r >= Co) continue;
         float s;
         if (training) {
-            s = dot / fmaxf(sqrtf(tn2), layer_eps(L));
-            if (lane == 0) blk += s * s;
+            s = d / fmaxf(sqrtf(tn2), layer_eps(L));
+            blk += s * s;
         } else {
-            s = dot;
-            if (lane == 0) blk += s * sn_state[LF(1) + r];  // sigma = u . (W v)
+            s = d;
+            blk += s * sn_state[LF(1) + r];  // sigma = u . (W v)
         }
         if (lane == 0) pass_uv[LF(16) + r] = s;
     }
-    // one atomic per block
     __syncthreads();
     if (lane == 0) red[wave] = blk;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {   // one atomic per block (<= 64 per layer)
         atomicAdd(norms + 4 * layer + 1, red[0] + red[1] + red[2] + red[3]);
-        if (e[1] == 0) norms[4 * layer + 0] = tn2_keep;
+        if (e[1] == 0) norms[4 * layer + 0] = tn2;
     }
 }
 
-// phase 3: sigma; normalise u, v (pass copy + persistent state); write the packed weights.
-// table: (layer, kind, chunk) kind 0 = forward pack [Npad][Kpad] (k = ky,kx,ci), kind 1 = dgrad pack
-// [Npad_d][Kpad_d] (rows ci, k = ky',kx',co with the taps flipped). 2048 packed elements per block.
+__device__ __forceinline__ float layer_sigma(const long long* L, const float* norms, int layer, int training) {
+    if (LF(1) < 0) return 1.f;
+    const float sn2 = norms[4 * layer + 1];
+    return training ? sn2 / fmaxf(sqrtf(sn2), layer_eps(L)) : sn2;
+}
+
+// ---------------------------------------------------------------- phase 3a: packs
+// One block = a tile of 64 output channels x TCI input channels x all taps of one layer (TCI = 32 for 3x3, 256 for
+// 1x1 / linear). The tile is read in W's own order (per co a contiguous run of TCI*taps floats), scaled by 1/sigma
+// into LDS, and written twice: forward pack [n = co][k = tap*Ci_p + ci] (runs of TCI elements) and dgrad pack
+// [n = ci][k = (taps-1-tap)*Co_p + co] (runs of 64 elements). Only elements with co < Co_p / ci < Ci_p are written:
+// the pack buffer's padding rows and K tails are zero from its allocation (arena.py pools the buffers) and stay zero.
+// table: (layer, cotile, cichunk)
+#define PK_TCO 64
+template <typename T>
+__device__ __forceinline__ void store8(T* dst, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        uint4 pk;
+        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>(dst) = pk;
+    } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
-                                                      const float* __restrict__ params, float* __restrict__ sn_state,
-                                                      float* __restrict__ pass_uv, float* __restrict__ norms,
+                                                      const float* __restrict__ params, const float* __restrict__ norms,
                                                       T* __restrict__ packed, int training) {
+    extern __shared__ float tile[];   // [64][RUN + 1]
     const int* e = table + 3 * blockIdx.x;
-    const int layer = e[0], kind = e[1], chunk = e[2];
+    const int layer = e[0];
     const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Co_p = (int)LF(6), Ci_p = (int)LF(7);
-    const int Kt = Ci * KH * KH;
-    const bool sn = LF(1) >= 0;
-    float sigma = 1.f;
-    if (sn) {
-        const float eps = layer_eps(L);
-        const float sn2 = norms[4 * layer + 1];
-        if (training) {
-            const float snorm = sqrtf(sn2), tnorm = sqrtf(norms[4 * layer + 0]);
-            sigma = sn2 / fmaxf(snorm, eps);
-            if (kind == 0) {
-                for (int i = chunk * 2048 + threadIdx.x; i < min(Co, (chunk + 1) * 2048); i += 256) {
-                    const float u = pass_uv[LF(16) + i] / fmaxf(snorm, eps);
-                    pass_uv[LF(16) + i] = u;
-                    sn_state[LF(1) + i] = u;
-                }
-                for (int i = chunk * 2048 + threadIdx.x; i < min(Kt, (chunk + 1) * 2048); i += 256) {
-                    const float v = pass_uv[LF(17) + i] / fmaxf(tnorm, eps);
-                    pass_uv[LF(17) + i] = v;
-                    sn_state[LF(2) + i] = v;
-                }
-            }
-        } else {
-            sigma = sn2;
-            if (kind == 0) {
-                for (int i = chunk * 2048 + threadIdx.x; i < min(Co, (chunk + 1) * 2048); i += 256)
-                    pass_uv[LF(16) + i] = sn_state[LF(1) + i];
-                for (int i = chunk * 2048 + threadIdx.x; i < min(Kt, (chunk + 1) * 2048); i += 256)
-                    pass_uv[LF(17) + i] = sn_state[LF(2) + i];
-            }
-        }
-        if (kind == 0 && chunk == 0 && threadIdx.x == 0) norms[4 * layer + 2] = sigma;
-    } else if (kind == 0 && chunk == 0 && threadIdx.x == 0) {
-        norms[4 * layer + 2] = 1.f;
-    }
-    const float inv = 1.f / sigma;
-    const float* W = params + LF(0);
     const int taps = KH * KH;
-    // one thread = 8 consecutive packed elements (same tap: Ci_p, Co_p and Kpad are multiples of 8) -> one 16-byte
-    // (bf16) or two 16-byte (f32) stores
-    const bool fwd = kind == 0;
-    const int Kpad = (int)(fwd ? LF(8) : LF(11));
-    const long long total = (fwd ? LF(9) : LF(12)) * Kpad;
-    T* dst = packed + (fwd ? LF(10) : LF(13));
-    const int inner_p = fwd ? Ci_p : Co_p;   // padded channel count of the pack's inner index
-    const int inner = fwd ? Ci : Co, rows = fwd ? Co : Ci;
-    const long long i = (long long)chunk * 2048 + 8 * threadIdx.x;
-    if (i < total) {
-        const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
-        const int tap = k / inner_p, c0 = k - tap * inner_p;
-        float v[8];
+    const int TCI = taps == 1 ? 256 : 32;
+    const int RUN = TCI * taps, RUNP = RUN + 1;
+    const int co0 = e[1] * PK_TCO, ci0 = e[2] * TCI;
+    const int nco = min(PK_TCO, Co - co0), nrun = min(TCI, Ci - ci0) * taps;   // valid rows / valid floats per row (may be <= 0)
+    const float inv = 1.f / layer_sigma(L, norms, layer, training);
+    const float* W = params + LF(0);
+#pragma unroll 8
+    for (int idx = threadIdx.x; idx < PK_TCO * RUN; idx += 256) {
+        const int row = idx / RUN, j = idx - row * RUN;
+        float v = 0.f;
+        if (row < nco && j < nrun) v = W[((size_t)(co0 + row) * Ci + ci0) * taps + j] * inv;
+        tile[row * RUNP + j] = v;
+    }
+    __syncthreads();
+    // forward pack
+    {
+        const int Kpad = (int)LF(8);
+        T* dst = packed + LF(10);
+        const int c8n = TCI / 8;
+        for (int u = threadIdx.x; u < PK_TCO * taps * c8n; u += 256) {
+            const int c8 = u % c8n, rest = u / c8n;
+            const int tap = rest % taps, row = rest / taps;
+            const int co = co0 + row, ci = ci0 + 8 * c8;
+            if (co >= Co || ci >= Ci_p) continue;
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] = 0.f;
-            if (n < rows && tap < taps && c0 + j < inner)
-                v[j] = (fwd ? W[((size_t)n * Ci + c0 + j) * taps + tap] : W[((size_t)(c0 + j) * Ci + n) * taps + (taps - 1 - tap)]) * inv;
+            for (int j = 0; j < 8; ++j) v[j] = tile[row * RUNP + (8 * c8 + j) * taps + tap];
+            store8<T>(dst + (size_t)co * Kpad + tap * Ci_p + ci, v);
         }
-        if constexpr (sizeof(T) == 2) {
-            uint4 pk;
-            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-            pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dst) + i) = pk;
-        } else {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + i) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    // dgrad pack (taps flipped)
+    {
+        const int Kpad_d = (int)LF(11);
+        T* dst = packed + LF(13);
+        for (int u = threadIdx.x; u < TCI * taps * (PK_TCO / 8); u += 256) {
+            const int co8 = u % (PK_TCO / 8), rest = u / (PK_TCO / 8);
+            const int tap = rest % taps, cil = rest / taps;
+            const int ci = ci0 + cil, co = co0 + 8 * co8;
+            if (ci >= Ci || co >= Co_p) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[(8 * co8 + j) * RUNP + cil * taps + tap];
+            store8<T>(dst + (size_t)ci * Kpad_d + (taps - 1 - tap) * Co_p + co, v);
         }
     }
 }
 
-// backward phase a: <G, W> per SN layer. table: (layer, chunk) over Co*Kt true elements, 4096 per block
+// ---------------------------------------------------------------- phase 3b: sigma, normalised u / v
+// One block per layer row of the round: writes sigma, and (train) u <- s/||s||, v <- t/||t|| into the pass snapshot
+// and the persistent state; (eval) copies the stored u, v into the snapshot. table: (layer)
+__global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
+                                                        float* __restrict__ sn_state, float* __restrict__ pass_uv,
+                                                        float* __restrict__ norms, int training) {
+    const int layer = table[blockIdx.x];
+    const long long* L = layers + L2I_LSTRIDE * layer;
+    if (LF(1) < 0) {
+        if (threadIdx.x == 0) norms[4 * layer + 2] = 1.f;
+        return;
+    }
+    const int Co = (int)LF(3), Kt = (int)(LF(4) * LF(5) * LF(5));
+    const float eps = layer_eps(L);
+    const float sn2 = norms[4 * layer + 1], tn2 = norms[4 * layer + 0];
+    if (training) {
+        const float iu = 1.f / fmaxf(sqrtf(sn2), eps), iv = 1.f / fmaxf(sqrtf(tn2), eps);
+        for (int i = threadIdx.x; i < Co; i += 256) {
+            const float u = pass_uv[LF(16) + i] * iu;
+            pass_uv[LF(16) + i] = u;
+            sn_state[LF(1) + i] = u;
+        }
+        for (int i = threadIdx.x; i < Kt; i += 256) {
+            const float v = pass_uv[LF(17) + i] * iv;
+            pass_uv[LF(17) + i] = v;
+            sn_state[LF(2) + i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < Co; i += 256) pass_uv[LF(16) + i] = sn_state[LF(1) + i];
+        for (int i = threadIdx.x; i < Kt; i += 256) pass_uv[LF(17) + i] = sn_state[LF(2) + i];
+    }
+    __syncthreads();   // every thread has read sn2 before sigma's slot (a different one) is written
+    if (threadIdx.x == 0) norms[4 * layer + 2] = layer_sigma(L, norms, layer, training);
+}
+
+// ---------------------------------------------------------------- backward
+// Both backward kernels walk W's (co, ci) pairs in chunks of 256: the chunk's W / gradient run (256*taps floats) is
+// contiguous, and the matching entries of G = dWbar ([co][tap][Ci_p] order) are contiguous in ci per tap; LDS
+// converts between the two orders so that every global access is a run. table: (layer, pairchunk)
+#define BW_PAIRS 256
+
+// phase a: <G, W> per SN layer, one atomic per block into replica (block % 32) of ws[r * n_layers + layer].
 __global__ __launch_bounds__(256) void sn_dot_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                      const float* __restrict__ params, const float* __restrict__ dwbar,
-                                                     float* __restrict__ norms) {
+                                                     float* __restrict__ ws, int n_layers) {
     __shared__ float red[16];
+    __shared__ float wl[BW_PAIRS * 9];
     const int* e = table + 2 * blockIdx.x;
     const int layer = e[0];
     const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Ci_p = (int)LF(7);
-    const int taps = KH * KH, Kt = Ci * taps, Kp = taps * Ci_p;
-    const float* W = params + LF(0);
+    const int taps = KH * KH, Kp = taps * Ci_p;
+    const long long p0 = (long long)e[1] * BW_PAIRS;
+    const int np = (int)min((long long)BW_PAIRS, (long long)Co * Ci - p0);
+    const float* W = params + LF(0) + p0 * taps;
     const float* G = dwbar + LF(14);
-    const long long total = (long long)Co * Kt;
+    for (int j = threadIdx.x; j < np * taps; j += 256) wl[j] = W[j];
+    __syncthreads();
     float acc = 0.f;
-    for (long long i = (long long)e[1] * 4096 + threadIdx.x; i < min(total, (long long)(e[1] + 1) * 4096); i += 256) {
-        const int co = (int)(i / Kt), kt = (int)(i - (long long)co * Kt);
-        const int ci = kt / taps, tap = kt - ci * taps;
-        acc += W[i] * G[(size_t)co * Kp + tap * Ci_p + ci];
+    if ((int)threadIdx.x < np) {
+        const long long pr = p0 + threadIdx.x;
+        const int co = (int)(pr / Ci), ci = (int)(pr - (long long)co * Ci);
+        const float* g = G + (size_t)co * Kp + ci;
+        for (int tap = 0; tap < taps; ++tap) acc = fmaf(wl[threadIdx.x * taps + tap], g[tap * Ci_p], acc);
     }
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(norms + 4 * layer + 3, acc);
+    if (threadIdx.x == 0) atomicAdd(ws + (size_t)(blockIdx.x % L2I_WS_R) * n_layers + layer, acc);
 }
 
-// backward phase b: grads[w] += (G - <G,Wbar> u v^T) / sigma   (non-SN layers: grads[w] += G)
+// phase b: grads[w] += (G - <G,Wbar> u v^T) / sigma   (non-SN layers: grads[w] += G)
 __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                        const float* __restrict__ dwbar, const float* __restrict__ pass_uv,
-                                                       const float* __restrict__ norms, float* __restrict__ grads) {
+                                                       float* __restrict__ norms, const float* __restrict__ ws, int n_layers,
+                                                       float* __restrict__ grads) {
+    __shared__ float gl[BW_PAIRS * 9];
     const int* e = table + 2 * blockIdx.x;
     const int layer = e[0];
     const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Ci_p = (int)LF(7);
-    const int taps = KH * KH, Kt = Ci * taps, Kp = taps * Ci_p;
+    const int taps = KH * KH, Kp = taps * Ci_p;
+    const long long p0 = (long long)e[1] * BW_PAIRS;
+    const int np = (int)min((long long)BW_PAIRS, (long long)Co * Ci - p0);
     const float* G = dwbar + LF(14);
-    float* dst = grads + LF(0);
     const bool sn = LF(1) >= 0;
-    const float sigma = norms[4 * layer + 2];
-    const float inv = 1.f / sigma;
-    const float gw = sn ? norms[4 * layer + 3] * inv : 0.f;  // <G, Wbar>
-    const long long total = (long long)Co * Kt;
-    for (long long i = (long long)e[1] * 4096 + threadIdx.x; i < min(total, (long long)(e[1] + 1) * 4096); i += 256) {
-        const int co = (int)(i / Kt), kt = (int)(i - (long long)co * Kt);
-        const int ci = kt / taps, tap = kt - ci * taps;
-        float g = G[(size_t)co * Kp + tap * Ci_p + ci];
-        if (sn) g = (g - gw * pass_uv[LF(16) + co] * pass_uv[LF(17) + kt]) * inv;
-        atomicAdd(dst + i, g);  // rows of a multiply-applied weight update the same gradient concurrently
+    const float inv = 1.f / norms[4 * layer + 2];
+    float gw = 0.f;
+    if (sn) {
+        float d = 0.f;
+        for (int r = 0; r < L2I_WS_R; ++r) d += ws[(size_t)r * n_layers + layer];
+        gw = d * inv;  // <G, Wbar>
+        if (e[1] == 0 && threadIdx.x == 0) norms[4 * layer + 3] = d;
+    }
+    if ((int)threadIdx.x < np) {
+        const long long pr = p0 + threadIdx.x;
+        const int co = (int)(pr / Ci), ci = (int)(pr - (long long)co * Ci);
+        const float* g = G + (size_t)co * Kp + ci;
+        const float uc = sn ? pass_uv[LF(16) + co] * gw : 0.f;
+        const float* v = pass_uv + LF(17) + (size_t)ci * taps;
+        for (int tap = 0; tap < taps; ++tap) {
+            float x = g[tap * Ci_p];
+            if (sn) x = (x - uc * v[tap]) * inv;
+            gl[threadIdx.x * taps + tap] = x;
+        }
+    }
+    __syncthreads();
+    float* dst = grads + LF(0) + p0 * taps;
+    if (LF(18)) {   // rows of a multiply-applied weight update the same gradient concurrently
+        for (int j = threadIdx.x; j < np * taps; j += 256) atomicAdd(dst + j, gl[j]);
+    } else {
+        for (int j = threadIdx.x; j < np * taps; j += 256) dst[j] += gl[j];
     }
 }
 
 extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const int* tab_wtu, int n_wtu,
-                                   const int* tab_wv, int n_wv, const int* tab_pack, int n_pack, const float* params,
-                                   float* sn_state, float* pass_uv, long long uv_len, float* norms, void* packed,
-                                   int dtype, int training, int clear, void* stream_) {
+                                   const int* tab_wv, int n_wv, const int* tab_pack, int n_pack, const int* tab_fin,
+                                   int n_fin, const float* params, float* sn_state, float* pass_uv, long long uv_len,
+                                   float* norms, void* packed, int dtype, int training, int clear, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!layers || !params || !packed || !norms) return L2I_ERR_ARG;
+    if (dtype != 0 && dtype != 1) return L2I_ERR_ARG;
     if (clear) {  // first round of a pass
         if (hipMemsetAsync(norms, 0, sizeof(float) * 4 * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
         if (uv_len > 0 && hipMemsetAsync(pass_uv, 0, sizeof(float) * uv_len, stream) != hipSuccess) return L2I_ERR_LAUNCH;
@@ -233,27 +345,38 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
     if (n_wv > 0)
         hipLaunchKernelGGL(sn_wv_kernel, dim3(n_wv), dim3(256), 0, stream, layers, tab_wv, params, sn_state, pass_uv, norms,
                            training);
-    if (dtype == 0)
-        hipLaunchKernelGGL(sn_pack_kernel<float>, dim3(n_pack), dim3(256), 0, stream, layers, tab_pack, params, sn_state,
-                           pass_uv, norms, (float*)packed, training);
-    else if (dtype == 1)
-        hipLaunchKernelGGL(sn_pack_kernel<bf16_t>, dim3(n_pack), dim3(256), 0, stream, layers, tab_pack, params, sn_state,
-                           pass_uv, norms, (bf16_t*)packed, training);
-    else
-        return L2I_ERR_ARG;
+    if (n_pack > 0) {
+        constexpr size_t lds = sizeof(float) * PK_TCO * (32 * 9 + 1);   // >= 64 * (256 + 1)
+        static bool ready = false;
+        if (!ready) {
+            (void)hipFuncSetAttribute((const void*)sn_pack_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)sn_pack_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            ready = true;
+        }
+        if (dtype == 0)
+            hipLaunchKernelGGL(sn_pack_kernel<float>, dim3(n_pack), dim3(256), lds, stream, layers, tab_pack, params, norms,
+                               (float*)packed, training);
+        else
+            hipLaunchKernelGGL(sn_pack_kernel<bf16_t>, dim3(n_pack), dim3(256), lds, stream, layers, tab_pack, params, norms,
+                               (bf16_t*)packed, training);
+    }
+    if (n_fin > 0)
+        hipLaunchKernelGGL(sn_finish_kernel, dim3(n_fin), dim3(256), 0, stream, layers, tab_fin, sn_state, pass_uv, norms,
+                           training);
     return l2i_check_launch();
 }
 
 extern "C" int l2i_weights_backward(const long long* layers, int n_layers, const int* tab_dot, int n_dot,
                                     const int* tab_apply, int n_apply, const float* params, const float* dwbar,
-                                    const float* pass_uv, float* norms, float* grads, void* stream_) {
+                                    const float* pass_uv, float* norms, float* grads, float* ws, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!layers || !params || !dwbar || !norms || !grads) return L2I_ERR_ARG;
-    (void)n_layers;
+    if (!layers || !params || !dwbar || !norms || !grads || !ws) return L2I_ERR_ARG;
+    if ((long long)n_layers * L2I_WS_R > 32 * 4 * 1024) return L2I_ERR_ARG;   // L2I_WS_FLOATS
     if (n_dot > 0)
-        hipLaunchKernelGGL(sn_dot_kernel, dim3(n_dot), dim3(256), 0, stream, layers, tab_dot, params, dwbar, norms);
+        hipLaunchKernelGGL(sn_dot_kernel, dim3(n_dot), dim3(256), 0, stream, layers, tab_dot, params, dwbar, ws, n_layers);
     if (n_apply > 0)
-        hipLaunchKernelGGL(sn_apply_kernel, dim3(n_apply), dim3(256), 0, stream, layers, tab_apply, dwbar, pass_uv, norms,
-                           grads);
+        hipLaunchKernelGGL(sn_apply_kernel, dim3(n_apply), dim3(256), 0, stream, layers, tab_apply, dwbar, pass_uv, norms, ws,
+                           n_layers, grads);
+    if (n_dot > 0 && hipMemsetAsync(ws, 0, sizeof(float) * L2I_WS_R * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     return l2i_check_launch();
 }

@@ -67,17 +67,7 @@ class ZeroPool:
 POOL = ZeroPool()
 
 
-WS_FLOATS = 32 * 4 * 1024   # L2I_WS_FLOATS of include/l2i.h
-_WS = {}
-
-
-def _ws(device):
-    """Per-(device, stream) all-zero reduction workspace of the library (self-cleaning; see csrc/common.h)."""
-    key = (device.index, _stream())
-    w = _WS.get(key)
-    if w is None:
-        w = _WS[key] = torch.zeros(WS_FLOATS, dtype=torch.float32, device=device)
-    return w.data_ptr()
+_ws = _lib.workspace
 
 
 def _zeros(shape, device):
