@@ -139,6 +139,15 @@ int l2i_cast_op(const float* x, void* raw, void* act, long long n, int dtype, vo
 /* ReLU backward on f32 streams: out = g*[mask>0] (+ add). */
 int l2i_relu_bwd(const float* g, const float* mask, const float* add, float* out, long long n, void* stream);
 
+/* Appearance head of the discriminator without the (R, C, C) Gram matrices
+ * (model/rcnn_discriminator_app.py:148-157; see csrc/misc.hip): x [R][HW][C] pre-ReLU features, w [C] the first half
+ * of the head's Linear(2C -> 1) weight. fwd: out[r] += (1/C^2) sum_p (sum_c a)(sum_c a w), a = relu(x); keeps the two
+ * per-position sums s, t [R][HW]. bwd: dx [R][HW][C] (written), dw [C] += ; ws as at l2i_channel_stats (required). */
+int l2i_gram_head_fwd(const float* x, const float* w, float* out, float* s_keep, float* t_keep, int R, int HW, int C,
+                      void* stream);
+int l2i_gram_head_bwd(const float* x, const float* w, const float* s_keep, const float* t_keep, const float* g, float* dx,
+                      float* dw, float* ws, int R, int HW, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

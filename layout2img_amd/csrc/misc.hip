@@ -169,4 +169,94 @@ extern "C" int l2i_relu_bwd(const float* g, const float* mask, const float* add,
     return l2i_check_launch();
 }
 
+// ---------------------------------------------------------------- appearance head: Gram term without the Gram matrices
+// Reference model/rcnn_discriminator_app.py:148-157: per ROI, F = relu(app_conv(obj)) viewed as (C, hw), Gram =
+// F F^T / C (C x C), and the head applies Linear(2C -> 1) to [sum_rows(Gram)/C... ] -- only  w1 . (Gram 1) / C  of the
+// Gram matrix ever reaches the output:  gram_term[r] = (1/C^2) sum_p (sum_c a[r,p,c]) (sum_c a[r,p,c] w1[c]),
+// a = relu(x). One pass over x forward (keeping s[r,p], t[r,p]), one pass backward (dx, dw1).
+//   x [R][HW][C] f32 (pre-ReLU), w [C];  fwd: out[r] += gram_term (out pre-zeroed), s,t [R][HW]
+#define GH_POS 16   // positions per block (4 per wave)
+__global__ __launch_bounds__(256) void gram_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ out, float* __restrict__ s_keep,
+                                                            float* __restrict__ t_keep, int HW, int C, int parts) {
+    __shared__ float red[16];
+    const int r = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float blk = 0.f;
+    for (int pi = wave; pi < GH_POS; pi += 4) {
+        const int pos = part * GH_POS + pi;
+        if (pos >= HW) break;
+        const float* row = x + ((size_t)r * HW + pos) * C;
+        float s = 0.f, t = 0.f;
+        for (int c = 4 * lane; c < C; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(row + c);
+            const float4 ww = *reinterpret_cast<const float4*>(w + c);
+            const float a0 = fmaxf(v.x, 0.f), a1 = fmaxf(v.y, 0.f), a2 = fmaxf(v.z, 0.f), a3 = fmaxf(v.w, 0.f);
+            s += a0 + a1 + a2 + a3;
+            t += a0 * ww.x + a1 * ww.y + a2 * ww.z + a3 * ww.w;
+        }
+        s = wave_sum(s);
+        t = wave_sum(t);
+        if (lane == 0) { s_keep[(size_t)r * HW + pos] = s; t_keep[(size_t)r * HW + pos] = t; }
+        blk += s * t;
+    }
+    __syncthreads();
+    if (lane == 0) red[wave] = blk;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + r, (red[0] + red[1] + red[2] + red[3]) / ((float)C * (float)C));
+}
+
+//   bwd: dx[r,p,c] = [x>0] g[r]/C^2 (t[r,p] + s[r,p] w[c]);  dw[c] += sum_{r,p} g[r]/C^2 s[r,p] a[r,p,c]  (via ws replicas)
+__global__ __launch_bounds__(256) void gram_head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ s_keep, const float* __restrict__ t_keep,
+                                                            const float* __restrict__ g, float* __restrict__ dx,
+                                                            float* __restrict__ ws, int HW, int C, int parts) {
+    extern __shared__ float dwl[];   // [4 waves][C]
+    const int r = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float gs = g[r] / ((float)C * (float)C);
+    for (int c = 4 * lane; c < C; c += 256) {
+        const float4 ww = *reinterpret_cast<const float4*>(w + c);
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int pi = wave; pi < GH_POS; pi += 4) {
+            const int pos = part * GH_POS + pi;
+            if (pos >= HW) break;
+            const size_t off = ((size_t)r * HW + pos) * C + c;
+            const float4 v = *reinterpret_cast<const float4*>(x + off);
+            const float s = s_keep[(size_t)r * HW + pos] * gs, t = t_keep[(size_t)r * HW + pos] * gs;
+            float4 d;
+            d.x = v.x > 0.f ? fmaf(s, ww.x, t) : 0.f; d.y = v.y > 0.f ? fmaf(s, ww.y, t) : 0.f;
+            d.z = v.z > 0.f ? fmaf(s, ww.z, t) : 0.f; d.w = v.w > 0.f ? fmaf(s, ww.w, t) : 0.f;
+            *reinterpret_cast<float4*>(dx + off) = d;
+            acc.x = fmaf(s, fmaxf(v.x, 0.f), acc.x); acc.y = fmaf(s, fmaxf(v.y, 0.f), acc.y);
+            acc.z = fmaf(s, fmaxf(v.z, 0.f), acc.z); acc.w = fmaf(s, fmaxf(v.w, 0.f), acc.w);
+        }
+        *reinterpret_cast<float4*>(dwl + wave * C + c) = acc;
+    }
+    __syncthreads();
+    float* rep = ws_replica(ws, blockIdx.x % L2I_WS_R, C);
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(rep + c, dwl[c] + dwl[C + c] + dwl[2 * C + c] + dwl[3 * C + c]);
+}
+
+extern "C" int l2i_gram_head_fwd(const float* x, const float* w, float* out, float* s_keep, float* t_keep, int R, int HW,
+                                 int C, void* stream) {
+    if (!x || !w || !out || !s_keep || !t_keep || C % 4 || R < 0) return L2I_ERR_ARG;
+    if (R == 0) return L2I_OK;
+    const int parts = (HW + GH_POS - 1) / GH_POS;
+    hipLaunchKernelGGL(gram_head_fwd_kernel, dim3(R * parts), dim3(256), 0, (hipStream_t)stream, x, w, out, s_keep, t_keep, HW,
+                       C, parts);
+    return l2i_check_launch();
+}
+
+extern "C" int l2i_gram_head_bwd(const float* x, const float* w, const float* s_keep, const float* t_keep, const float* g,
+                                 float* dx, float* dw, float* ws, int R, int HW, int C, void* stream) {
+    if (!x || !w || !s_keep || !t_keep || !g || !dx || !dw || !ws || C % 4 || C > 4096 || R < 0) return L2I_ERR_ARG;
+    if (R == 0) return L2I_OK;
+    const int parts = (HW + GH_POS - 1) / GH_POS;
+    hipLaunchKernelGGL(gram_head_bwd_kernel, dim3(R * parts), dim3(256), sizeof(float) * 4 * C, (hipStream_t)stream, x, w,
+                       s_keep, t_keep, g, dx, ws, HW, C, parts);
+    ws_fold(ws, C, C, dw, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    return l2i_check_launch();
+}
+
 extern "C" int l2i_version(void) { return 1; }

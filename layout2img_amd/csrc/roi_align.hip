@@ -118,16 +118,22 @@ extern "C" int l2i_roi_align_fwd(const float* feat_s, const float* feat_l, const
     return l2i_check_launch();
 }
 
-// Backward, LDS-accumulating form: one workgroup per (ROI, 32-channel chunk). The ROI's footprint on the feature map
-// (at most RB_F x RB_F pixels: an ROI spans <= 16 feature pixels on either map by the routing rule) is accumulated
-// in LDS with ds_add_f32 over all bins / samples / corners, then flushed with ONE global atomic per touched
-// (pixel, channel) -- ~100x fewer global atomics than scattering every corner of every sample. ROIs with a larger
-// footprint (not produced by this path's routing) fall back to the scattering kernel above.
+// Backward, separable form: one workgroup per (ROI, 32-channel chunk). The bilinear scatter of ROIAlign is separable
+// -- every sample's weight on feature pixel (y, x) is hat_y * hat_x, bins form a regular grid, and a sample is
+// dropped iff its y OR its x is outside [-1, size] -- so with
+//   Wy[y][ph] = sum over the gh sample rows of bin row ph of their weight on feature row y   (Wx likewise)
+// the gradient of the ROI's footprint is  D[y][x][c] = sum_pw Wx[x][pw] * ( sum_ph Wy[y][ph] * G[ph][pw][c] ) / count:
+// two small dense products out of LDS, no LDS atomics, and ONE global atomic per touched (pixel, channel). The
+// footprint is at most RB_F x RB_F pixels (an ROI spans <= 16 feature pixels on either map by the routing rule);
+// larger ones (not produced by this path) scatter sample by sample.
 #define RB_F 20
 #define RB_C 32
+#define RB_P 8
 
-__global__ __launch_bounds__(256) void roi_align_bwd_lds_kernel(RoiArgs p, int chunks) {
-    __shared__ float tile[RB_F * RB_F * RB_C];
+__global__ __launch_bounds__(256) void roi_align_bwd_sep_kernel(RoiArgs p, int chunks) {
+    __shared__ float G[RB_P * RB_P * RB_C];   // [bin][c], already / count
+    __shared__ float T[RB_F * RB_P * RB_C];   // [y][pw][c]
+    __shared__ float Wy[RB_F * RB_P], Wx[RB_F * RB_P];
     const int r = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * RB_C;
     if (p.valid && p.valid[r] == 0) return;
     const float* roi = p.rois + 5 * r;
@@ -145,13 +151,14 @@ __global__ __launch_bounds__(256) void roi_align_bwd_lds_kernel(RoiArgs p, int c
     const int fy0 = max((int)floorf(y1), 0), fx0 = max((int)floorf(x1), 0);
     const int fy1 = min((int)floorf(y1 + roi_h) + 1, H - 1), fx1 = min((int)floorf(x1 + roi_w) + 1, W - 1);
     const int fh = fy1 - fy0 + 1, fw = fx1 - fx0 + 1;
-    const int c = threadIdx.x & (RB_C - 1), part = threadIdx.x / RB_C;  // 8 bin groups
-    const bool con = c0 + c < p.C;
+    const int P = p.P;
     if (fh <= 0 || fw <= 0) return;
     if (fh > RB_F || fw > RB_F) {  // oversize footprint: scatter directly (never taken on this path)
-        for (int bin = part; bin < p.P * p.P; bin += 256 / RB_C) {
-            const int ph = bin / p.P, pw = bin % p.P;
-            const float g = con ? p.out[((size_t)r * p.P * p.P + bin) * p.C + c0 + c] * inv_count : 0.f;
+        const int c = threadIdx.x & (RB_C - 1), part = threadIdx.x / RB_C;
+        const bool con = c0 + c < p.C;
+        for (int bin = part; bin < P * P; bin += 256 / RB_C) {
+            const int ph = bin / P, pw = bin % P;
+            const float g = con ? p.out[((size_t)r * P * P + bin) * p.C + c0 + c] * inv_count : 0.f;
             for (int iy = 0; iy < gh; ++iy)
                 for (int ix = 0; ix < gw; ++ix) {
                     const float y = y1 + ph * bin_h + (iy + 0.5f) * bin_h / gh, x = x1 + pw * bin_w + (ix + 0.5f) * bin_w / gw;
@@ -169,33 +176,45 @@ __global__ __launch_bounds__(256) void roi_align_bwd_lds_kernel(RoiArgs p, int c
         }
         return;
     }
-    for (int i = threadIdx.x; i < fh * fw * RB_C; i += 256) tile[i] = 0.f;
-    __syncthreads();
-    for (int bin = part; bin < p.P * p.P; bin += 256 / RB_C) {
-        const int ph = bin / p.P, pw = bin % p.P;
-        const float g = con ? p.out[((size_t)r * p.P * p.P + bin) * p.C + c0 + c] * inv_count : 0.f;
-        for (int iy = 0; iy < gh; ++iy) {
-            const float y = y1 + ph * bin_h + (iy + 0.5f) * bin_h / gh;
-            for (int ix = 0; ix < gw; ++ix) {
-                const float x = x1 + pw * bin_w + (ix + 0.5f) * bin_w / gw;
-                if (y < -1.f || y > (float)H || x < -1.f || x > (float)W) continue;
-                float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
-                int yl = (int)yy, xl = (int)xx, yh, xh;
-                if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
-                if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
-                const float ly = yy - yl, lx = xx - xl, hy = 1.f - ly, hx = 1.f - lx;
-                atomicAdd(&tile[((yl - fy0) * fw + (xl - fx0)) * RB_C + c], hy * hx * g);
-                atomicAdd(&tile[((yl - fy0) * fw + (xh - fx0)) * RB_C + c], hy * lx * g);
-                atomicAdd(&tile[((yh - fy0) * fw + (xl - fx0)) * RB_C + c], ly * hx * g);
-                atomicAdd(&tile[((yh - fy0) * fw + (xh - fx0)) * RB_C + c], ly * lx * g);
+    for (int i = threadIdx.x; i < P * P * RB_C; i += 256) {
+        const int bin = i / RB_C, c = i - bin * RB_C;
+        G[i] = c0 + c < p.C ? p.out[((size_t)r * P * P + bin) * p.C + c0 + c] * inv_count : 0.f;
+    }
+    for (int i = threadIdx.x; i < 2 * RB_F * RB_P; i += 256) {
+        const bool isx = i >= RB_F * RB_P;
+        const int j = isx ? i - RB_F * RB_P : i;
+        const int pix = j / RB_P, pb = j - pix * RB_P;
+        const int n = isx ? fw : fh, g = isx ? gw : gh, lim = isx ? W : H, f0 = isx ? fx0 : fy0;
+        const float start = isx ? x1 : y1, bsz = isx ? bin_w : bin_h;
+        float w = 0.f;
+        if (pix < n && pb < P)
+            for (int s = 0; s < g; ++s) {
+                const float v = start + pb * bsz + (s + 0.5f) * bsz / g;
+                if (v < -1.f || v > (float)lim) continue;
+                float vv = fmaxf(v, 0.f);
+                int lo = (int)vv, hi;
+                if (lo >= lim - 1) { hi = lo = lim - 1; vv = (float)lo; } else hi = lo + 1;
+                const float l = vv - lo, h = 1.f - l;
+                if (lo - f0 == pix) w += h;
+                if (hi - f0 == pix) w += l;
             }
-        }
+        (isx ? Wx : Wy)[j] = w;
     }
     __syncthreads();
-    if (!con) return;
-    for (int px = part; px < fh * fw; px += 256 / RB_C) {
-        const float v = tile[px * RB_C + c];
-        if (v != 0.f) atomicAdd(dfeat + ((size_t)(fy0 + px / fw) * W + fx0 + px % fw) * p.C + c0 + c, v);
+    for (int i = threadIdx.x; i < fh * P * RB_C; i += 256) {
+        const int c = i & (RB_C - 1), rest = i / RB_C;
+        const int pw = rest % P, y = rest / P;
+        float acc = 0.f;
+        for (int ph = 0; ph < P; ++ph) acc = fmaf(Wy[y * RB_P + ph], G[(ph * P + pw) * RB_C + c], acc);
+        T[(y * RB_P + pw) * RB_C + c] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < fh * fw * RB_C; i += 256) {
+        const int c = i & (RB_C - 1), px = i / RB_C;
+        const int y = px / fw, x = px - y * fw;
+        float acc = 0.f;
+        for (int pw = 0; pw < P; ++pw) acc = fmaf(Wx[x * RB_P + pw], T[(y * RB_P + pw) * RB_C + c], acc);
+        if (acc != 0.f && c0 + c < p.C) atomicAdd(dfeat + ((size_t)(fy0 + y) * W + fx0 + x) * p.C + c0 + c, acc);
     }
 }
 
@@ -208,7 +227,8 @@ extern "C" int l2i_roi_align_bwd(const float* rois, const int* valid, const floa
         return L2I_ERR_ARG;
     a.dfeat_s = dfeat_s; a.dfeat_l = dfeat_l; a.out = const_cast<float*>(dout);
     if (R == 0) return L2I_OK;
+    if (P > RB_P) return L2I_ERR_ARG;
     const int chunks = (C + RB_C - 1) / RB_C;
-    hipLaunchKernelGGL(roi_align_bwd_lds_kernel, dim3(R * chunks), dim3(256), 0, (hipStream_t)stream, a, chunks);
+    hipLaunchKernelGGL(roi_align_bwd_sep_kernel, dim3(R * chunks), dim3(256), 0, (hipStream_t)stream, a, chunks);
     return l2i_check_launch();
 }

@@ -92,14 +92,13 @@ class ResnetDiscriminator128_app(nn.Module):
         obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0)  # (R,8,8,C)
 
         # appearance head (reference :148-157): Gram of the ROI features + class embedding
-        a = F.relu(self.app_conv(obj, pc))
-        R, s2 = a.shape[0], a.shape[3]
-        A = a.view(R, -1, s2)                                             # (R, hw, C) = F^T of the reference's (C, hw)
+        a = self.app_conv(obj, pc)                                        # (R, 8, 8, C) pre-ReLU
+        s2 = a.shape[3]
         wa = arena_weight(self.app, pc)                                   # (1, 2C)
         emb_app = arena_weight(self.l_y_app, pc)[y]                       # (R, C)
-        # sum_rows(Gram @ wa1)/C with Gram = F F^T / C, without materialising the (R,C,C) Gram matrices:
-        #   sum_i sum_j G_ij wa1_j = (1/C) sum_p (sum_i F_ip) (sum_j F_jp wa1_j)
-        gram_term = ((A.sum(dim=2) * (A @ wa[0, :s2])).sum(dim=1, keepdim=True)) / (s2 * s2)
+        # w1 . sum_rows(Gram) / C with Gram = F F^T / C, F = relu(a): only this contraction of the (R,C,C) Gram
+        # matrices reaches the output, so they are never formed (ops.GramHeadFn / csrc/misc.hip)
+        gram_term = ops.gram_head(a, wa[0, :s2].contiguous())
         out_app = gram_term + emb_app @ wa[0, s2:].unsqueeze(1) + self.app.bias
 
         # projection head (reference :160-166)

@@ -495,6 +495,37 @@ def hinge(x, valid, mode, weight=1.0, count=None):
     return HingeFn.apply(x, valid, mode, weight, count)
 
 
+class GramHeadFn(Function):
+    """gram_term[r] = w1 . (Gram_r 1) / C with Gram_r = F F^T / C, F = relu(x_r) -- the only part of the Gram matrix the
+    appearance head reads (reference model/rcnn_discriminator_app.py:148-157) -- in one pass over x, both ways."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _chk(x, torch.float32), _chk(w, torch.float32)
+        R, H, W, C = x.shape
+        out = _zeros((R, 1), x.device)
+        keep = torch.empty((2, R, H * W), dtype=torch.float32, device=x.device)
+        _lib.call("l2i_gram_head_fwd", x.data_ptr(), w.data_ptr(), out.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(),
+                  R, H * W, C, _stream())
+        ctx.save_for_backward(x, w, keep)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, keep = ctx.saved_tensors
+        R, H, W, C = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        dw = _zeros((C,), x.device)
+        _lib.call("l2i_gram_head_bwd", x.data_ptr(), w.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), g.data_ptr(),
+                  dx.data_ptr(), dw.data_ptr(), _ws(x.device), R, H * W, C, _stream())
+        return dx, dw
+
+
+def gram_head(x, w):
+    return GramHeadFn.apply(x, w)
+
+
 class L1Fn(Function):
     @staticmethod
     def forward(ctx, a, b, weight):
