@@ -334,13 +334,30 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(NormArgs p) {
 }
 
 // ---------------------------------------------------------------- modulated norm, backward pass A
-// One block = (image b, 128-channel chunk, a run of 32-pixel sub-tiles). Per-channel sums (s1, s2, affine
-// grads) and the per-object projection grads dW[b,o,c], dB[b,o,c] are accumulated in REGISTERS across the
-// whole run and leave the block as one atomic per value; the per-pixel mask gradient needs a sum over the
-// channels held by the 32 lanes of a half-wave, done as a 32-value reduce-scatter (31 shuffles instead of
-// 5 per value). Objects are processed in chunks of 8 (o > 8 re-walks the run; only VG has o = 31).
+// One block = (image b, 128-channel chunk, a run of 32-pixel sub-tiles), two phases per sub-tile with different
+// thread roles so that neither needs many registers (the block keeps 3 workgroups per CU resident; a single-role
+// version needed 255 VGPRs = one wave per SIMD and ran at a tenth of the speed):
+//   phase 1, thread = (pixel row, 4 channels): x-hat, gamma/beta, the ReLU gate, g = gated dy, gx = g * x-hat;
+//            writes dxhat = g * gamma, accumulates the per-channel sums (s1, s2, affine grads) in registers and parks
+//            g, gx in LDS;
+//   phase 2, thread = (object, 4 channels), ISLA only: dW[b,o,c] += sum_p mn_o(p) gx(p,c), dB likewise with g --
+//            each thread owns its accumulators for the whole run, no reduction -- and
+//            part[o,p] = sum_c gx W_o + g B_o reduced over the 32 channel lanes (4 DPP steps + one permute);
+//   then dmask[b,o,p] = (part[o,p] - sum_o' mn_o'(p) part[o',p]) / S(p)   (the second term is the "-1/S^2" path of
+//   the mask normalisation, since gamma - 1 = sum_o mn_o W_o and beta = sum_o mn_o B_o).
+// More than 8 objects (VG: 31) repeat phase 2 per chunk of 8 on the same parked tile.
 #define NB_PX 32
 #define NB_OC 8
+#define NB_MAXCH 4   // object chunks (NM_MAXO / NB_OC)
+
+__device__ __forceinline__ float sum32(float v) {   // sum over the 32 lanes of a half-wave, result in every lane
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
 
 __global__ __launch_bounds__(256) void norm_bwd_a_kernel(NormArgs p, int nseg, int seg_pixels) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -349,7 +366,10 @@ __global__ __launch_bounds__(256) void norm_bwd_a_kernel(NormArgs p, int nseg, i
     float* Bl = Wl + O * NM_CC;
     float* mn = Bl + O * NM_CC;          // [O][NB_PX]
     float* sinv = mn + O * NB_PX;        // [NB_PX]
-    float4* red = reinterpret_cast<float4*>(sinv + NB_PX);  // [4 waves][20 values][32 cv]
+    float* partl = sinv + NB_PX;         // [O][NB_PX]
+    float* gl = partl + O * NB_PX;       // [NB_PX][NM_CC]  (mode 0) -- also the end-of-run reduction buffer
+    float* gxl = gl + NB_PX * NM_CC;     // [NB_PX][NM_CC]
+    float4* red = reinterpret_cast<float4*>(gl);  // [4 values][8 pixel rows][32 cv]
 
     const int tiles_c = (p.C + NM_CC - 1) / NM_CC;
     int bid = blockIdx.x;
@@ -358,7 +378,7 @@ __global__ __launch_bounds__(256) void norm_bwd_a_kernel(NormArgs p, int nseg, i
     const int b = bid / nseg;
     const int c0 = tc * NM_CC;
     const int cc = min(NM_CC, p.C - c0);
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int px_begin = seg * seg_pixels, px_end = min(p.HW, px_begin + seg_pixels);
 
     for (int i = tid; i < O * NM_CC; i += 256) {
@@ -395,165 +415,162 @@ __global__ __launch_bounds__(256) void norm_bwd_a_kernel(NormArgs p, int nseg, i
     }
     const float4 z4 = make_float4(0, 0, 0, 0);
     float4 acc_s1 = z4, acc_s2 = z4, acc_aw = z4, acc_ab = z4;
-    const int nchunk = p.mode == 0 ? (O + NB_OC - 1) / NB_OC : 1;
+    // phase-2 role: object (tid >> 5) of each chunk, channels 4 * cv
+    const int o2 = tid >> 5;
+    float4 adw[NB_MAXCH], adb[NB_MAXCH];
+#pragma unroll
+    for (int k = 0; k < NB_MAXCH; ++k) { adw[k] = z4; adb[k] = z4; }
 
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        float4 adw[NB_OC], adb[NB_OC];
+    for (int p0 = px_begin; p0 < px_end; p0 += NB_PX) {
+        __syncthreads();   // previous sub-tile's LDS fully consumed (and Wl/Bl written, first time)
+        if (O > 0 && tid < NB_PX) {
+            const int px = p0 + tid;
+            float S = 1e-6f;
+            if (px < px_end)
+                for (int o = 0; o < O; ++o) S += p.mask[((size_t)b * O + o) * p.HW + px];
+            const float inv = 1.f / S;
+            sinv[tid] = inv;
+            for (int o = 0; o < O; ++o)
+                mn[o * NB_PX + tid] = px < px_end ? p.mask[((size_t)b * O + o) * p.HW + px] * inv : 0.f;
+        }
+        // the x / dy loads of phase 1 do not depend on the mask: issue them before the barrier
+        float4 xv[4], dv[4];
 #pragma unroll
-        for (int k = 0; k < NB_OC; ++k) { adw[k] = z4; adb[k] = z4; }
-        for (int p0 = px_begin; p0 < px_end; p0 += NB_PX) {
-            __syncthreads();
-            if (O > 0 && tid < NB_PX) {
-                const int px = p0 + tid;
-                float S = 1e-6f;
-                if (px < px_end)
-                    for (int o = 0; o < O; ++o) S += p.mask[((size_t)b * O + o) * p.HW + px];
-                const float inv = 1.f / S;
-                sinv[tid] = inv;
-                for (int o = 0; o < O; ++o)
-                    mn[o * NB_PX + tid] = px < px_end ? p.mask[((size_t)b * O + o) * p.HW + px] * inv : 0.f;
-            }
-            __syncthreads();
-            float4 g[4], gx[4];
-            float t0[4];
-#pragma unroll
-            for (int pi = 0; pi < 4; ++pi) {
-                const int pl = prow + 8 * pi, px = p0 + pl;
-                const bool on = con && px < px_end;
+        for (int pi = 0; pi < 4; ++pi) {
+            const int px = p0 + prow + 8 * pi;
+            xv[pi] = z4; dv[pi] = z4;
+            if (con && px < px_end) {
                 const size_t off = ((size_t)b * p.HW + px) * p.C + c;
-                g[pi] = z4; gx[pi] = z4; t0[pi] = 0.f;
-                if (on) {
-                    const float4 xv = *reinterpret_cast<const float4*>(p.x + off);
-                    const float4 xh = make_float4((xv.x - mean.x) * istd.x, (xv.y - mean.y) * istd.y,
-                                                  (xv.z - mean.z) * istd.z, (xv.w - mean.w) * istd.w);
-                    float4 ga = aw, be = ab;
-                    if (p.mode == 0) {
-                        ga = make_float4(1, 1, 1, 1);
-                        be = z4;
-                        for (int o = 0; o < O; ++o) {
-                            const float m = mn[o * NB_PX + pl];
-                            ga = f4mad(m, *reinterpret_cast<const float4*>(Wl + o * NM_CC + 4 * cv), ga);
-                            be = f4mad(m, *reinterpret_cast<const float4*>(Bl + o * NM_CC + 4 * cv), be);
-                        }
+                xv[pi] = *reinterpret_cast<const float4*>(p.x + off);
+                dv[pi] = *reinterpret_cast<const float4*>(p.dy + off);
+            }
+        }
+        __syncthreads();
+        // ---- phase 1
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            const int pl = prow + 8 * pi, px = p0 + pl;
+            const bool on = con && px < px_end;
+            float4 gg = z4, gxv = z4;
+            if (on) {
+                const float4 xh = make_float4((xv[pi].x - mean.x) * istd.x, (xv[pi].y - mean.y) * istd.y,
+                                              (xv[pi].z - mean.z) * istd.z, (xv[pi].w - mean.w) * istd.w);
+                float4 ga = aw, be = ab;
+                if (p.mode == 0) {
+                    ga = make_float4(1, 1, 1, 1);
+                    be = z4;
+                    for (int o = 0; o < O; ++o) {
+                        const float m = mn[o * NB_PX + pl];
+                        ga = f4mad(m, *reinterpret_cast<const float4*>(Wl + o * NM_CC + 4 * cv), ga);
+                        be = f4mad(m, *reinterpret_cast<const float4*>(Bl + o * NM_CC + 4 * cv), be);
                     }
-                    const float4 y = make_float4(fmaf(ga.x, xh.x, be.x), fmaf(ga.y, xh.y, be.y), fmaf(ga.z, xh.z, be.z),
-                                                 fmaf(ga.w, xh.w, be.w));
-                    // dy may alias the dxhat output: each element is read here before this thread overwrites it,
-                    // and later object chunks re-read x but take g from dy only in chunk 0 ... so for chunk > 0
-                    // the gate and gamma are recomputed and g is recovered as dxhat / gamma is NOT safe; instead
-                    // chunk > 0 reads the saved dy copy below.
-                    const float4 d = *reinterpret_cast<const float4*>((chunk == 0 ? p.dy : p.dy_keep) + off);
-                    float4 gg;
-                    gg.x = (!p.relu || y.x > 0.f) ? d.x : 0.f;
-                    gg.y = (!p.relu || y.y > 0.f) ? d.y : 0.f;
-                    gg.z = (!p.relu || y.z > 0.f) ? d.z : 0.f;
-                    gg.w = (!p.relu || y.w > 0.f) ? d.w : 0.f;
-                    g[pi] = gg;
-                    gx[pi] = make_float4(gg.x * xh.x, gg.y * xh.y, gg.z * xh.z, gg.w * xh.w);
-                    if (chunk == 0) {
-                        const float4 dxh = make_float4(gg.x * ga.x, gg.y * ga.y, gg.z * ga.z, gg.w * ga.w);
-                        if (p.dy_keep && nchunk > 1) *reinterpret_cast<float4*>(p.dy_keep + off) = d;
-                        *reinterpret_cast<float4*>(p.out_f32 + off) = dxh;
-                        acc_s1.x += dxh.x; acc_s1.y += dxh.y; acc_s1.z += dxh.z; acc_s1.w += dxh.w;
-                        acc_s2.x += dxh.x * xh.x; acc_s2.y += dxh.y * xh.y; acc_s2.z += dxh.z * xh.z; acc_s2.w += dxh.w * xh.w;
-                        if (p.mode == 1) {
-                            acc_aw.x += gx[pi].x; acc_aw.y += gx[pi].y; acc_aw.z += gx[pi].z; acc_aw.w += gx[pi].w;
-                            acc_ab.x += gg.x; acc_ab.y += gg.y; acc_ab.z += gg.z; acc_ab.w += gg.w;
-                        }
-                    }
-                    t0[pi] = gx[pi].x * (ga.x - 1.f) + gg.x * be.x + gx[pi].y * (ga.y - 1.f) + gg.y * be.y +
-                             gx[pi].z * (ga.z - 1.f) + gg.z * be.z + gx[pi].w * (ga.w - 1.f) + gg.w * be.w;
+                }
+                const float4 d = dv[pi];
+                gg.x = (!p.relu || fmaf(ga.x, xh.x, be.x) > 0.f) ? d.x : 0.f;
+                gg.y = (!p.relu || fmaf(ga.y, xh.y, be.y) > 0.f) ? d.y : 0.f;
+                gg.z = (!p.relu || fmaf(ga.z, xh.z, be.z) > 0.f) ? d.z : 0.f;
+                gg.w = (!p.relu || fmaf(ga.w, xh.w, be.w) > 0.f) ? d.w : 0.f;
+                gxv = make_float4(gg.x * xh.x, gg.y * xh.y, gg.z * xh.z, gg.w * xh.w);
+                const float4 dxh = make_float4(gg.x * ga.x, gg.y * ga.y, gg.z * ga.z, gg.w * ga.w);
+                *reinterpret_cast<float4*>(p.out_f32 + ((size_t)b * p.HW + px) * p.C + c) = dxh;
+                acc_s1.x += dxh.x; acc_s1.y += dxh.y; acc_s1.z += dxh.z; acc_s1.w += dxh.w;
+                acc_s2.x += dxh.x * xh.x; acc_s2.y += dxh.y * xh.y; acc_s2.z += dxh.z * xh.z; acc_s2.w += dxh.w * xh.w;
+                if (p.mode == 1) {
+                    acc_aw.x += gxv.x; acc_aw.y += gxv.y; acc_aw.z += gxv.z; acc_aw.w += gxv.w;
+                    acc_ab.x += gg.x; acc_ab.y += gg.y; acc_ab.z += gg.z; acc_ab.w += gg.w;
                 }
             }
             if (p.mode == 0) {
-                float v[NB_OC * 4];
+                *reinterpret_cast<float4*>(gl + pl * NM_CC + 4 * cv) = gg;
+                *reinterpret_cast<float4*>(gxl + pl * NM_CC + 4 * cv) = gxv;
+            }
+        }
+        if (p.mode != 0) continue;
+        __syncthreads();
+        // ---- phase 2
 #pragma unroll
-                for (int ol = 0; ol < NB_OC; ++ol) {
-                    const int o = chunk * NB_OC + ol;
-                    float4 wv = z4, bv = z4;
-                    const bool oon = o < O;
-                    if (oon) {
-                        wv = *reinterpret_cast<const float4*>(Wl + o * NM_CC + 4 * cv);
-                        bv = *reinterpret_cast<const float4*>(Bl + o * NM_CC + 4 * cv);
-                    }
-#pragma unroll
-                    for (int pi = 0; pi < 4; ++pi) {
-                        const float m = oon ? mn[o * NB_PX + prow + 8 * pi] : 0.f;
-                        adw[ol] = f4mad(m, gx[pi], adw[ol]);
-                        adb[ol] = f4mad(m, g[pi], adb[ol]);
-                        v[ol * 4 + pi] = oon ? gx[pi].x * wv.x + gx[pi].y * wv.y + gx[pi].z * wv.z + gx[pi].w * wv.w +
-                                                   g[pi].x * bv.x + g[pi].y * bv.y + g[pi].z * bv.z + g[pi].w * bv.w - t0[pi]
-                                             : 0.f;
-                    }
-                }
+        for (int k = 0; k < NB_MAXCH; ++k) {
+            const int o = k * NB_OC + o2;
+            if (k * NB_OC >= O) break;
+            const bool oon = o < O;
+            const int oc = oon ? o : 0;
+            const float4 wv = *reinterpret_cast<const float4*>(Wl + oc * NM_CC + 4 * cv);
+            const float4 bv = *reinterpret_cast<const float4*>(Bl + oc * NM_CC + 4 * cv);
+#pragma unroll 4
+            for (int pl = 0; pl < NB_PX; ++pl) {
+                const float4 gxv = *reinterpret_cast<const float4*>(gxl + pl * NM_CC + 4 * cv);
+                const float4 gv = *reinterpret_cast<const float4*>(gl + pl * NM_CC + 4 * cv);
+                const float m = oon ? mn[oc * NB_PX + pl] : 0.f;
+                adw[k] = f4mad(m, gxv, adw[k]);
+                adb[k] = f4mad(m, gv, adb[k]);
                 if (p.dmask) {
-                    // reduce-scatter of v[32] over the 32 channel lanes of this pixel row: lane l ends with sum_j-th value j = l
-                    const int l = tid & 31;
-#define L2I_RS(N, S)                                                                 \
-                    _Pragma("unroll") for (int k = 0; k < N; ++k) {                  \
-                        const bool hi = (l & S) != 0;                                \
-                        const float send = hi ? v[k] : v[k + N];                     \
-                        const float keep = hi ? v[k + N] : v[k];                     \
-                        v[k] = keep + __shfl_xor(send, S, 64);                       \
-                    }
-                    L2I_RS(16, 16) L2I_RS(8, 8) L2I_RS(4, 4) L2I_RS(2, 2) L2I_RS(1, 1)
-#undef L2I_RS
-                    const int ol = l >> 2, pi = l & 3;
-                    const int o = chunk * NB_OC + ol, pl = prow + 8 * pi, px = p0 + pl;
-                    if (o < O && px < px_end) atomicAdd(p.dmask + ((size_t)b * O + o) * p.HW + px, v[0] * sinv[pl]);
+                    float part = gxv.x * wv.x + gxv.y * wv.y + gxv.z * wv.z + gxv.w * wv.w +
+                                 gv.x * bv.x + gv.y * bv.y + gv.z * bv.z + gv.w * bv.w;
+                    part = sum32(part);
+                    if (cv == 0 && oon) partl[o * NB_PX + pl] = part;
                 }
             }
         }
-        // ---- block-level reduction of this chunk's per-object gradients (and, in chunk 0, the channel sums)
-        __syncthreads();
-        const int nval = (p.mode == 0 ? 2 * NB_OC : 0) + (chunk == 0 ? (p.mode == 1 ? 4 : 2) : 0);
-        {
-            int k = 0;
-            auto put = [&](float4 a) {
-                a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64);
-                a.z += __shfl_xor(a.z, 32, 64); a.w += __shfl_xor(a.w, 32, 64);
-                if ((tid & 32) == 0) red[(wave * 20 + k) * 32 + cv] = a;
-                ++k;
-            };
-            if (p.mode == 0) {
+        if (p.dmask) {
+            __syncthreads();
+            for (int i = tid; i < O * NB_PX; i += 256) {
+                const int o = i / NB_PX, pl = i - o * NB_PX;
+                const int px = p0 + pl;
+                if (px >= px_end) continue;
+                float t0 = 0.f;
+                for (int oo = 0; oo < O; ++oo) t0 = fmaf(mn[oo * NB_PX + pl], partl[oo * NB_PX + pl], t0);
+                atomicAdd(p.dmask + ((size_t)b * O + o) * p.HW + px, (partl[i] - t0) * sinv[pl]);
+            }
+        }
+    }
+
+    // ---- per-object gradients: each thread owns (object, 4 channels) -- one atomic per value per block
+    if (p.mode == 0 && con) {
 #pragma unroll
-                for (int ol = 0; ol < NB_OC; ++ol) { put(adw[ol]); put(adb[ol]); }
-            }
-            if (chunk == 0) {
-                put(acc_s1); put(acc_s2);
-                if (p.mode == 1) { put(acc_aw); put(acc_ab); }
-            }
+        for (int k = 0; k < NB_MAXCH; ++k) {
+            const int o = k * NB_OC + o2;
+            if (o >= O) continue;
+            const size_t off = (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + c;
+            atomicAdd(p.dwproj + off + 0, adw[k].x); atomicAdd(p.dwproj + off + 1, adw[k].y);
+            atomicAdd(p.dwproj + off + 2, adw[k].z); atomicAdd(p.dwproj + off + 3, adw[k].w);
+            atomicAdd(p.dbproj + off + 0, adb[k].x); atomicAdd(p.dbproj + off + 1, adb[k].y);
+            atomicAdd(p.dbproj + off + 2, adb[k].z); atomicAdd(p.dbproj + off + 3, adb[k].w);
         }
-        __syncthreads();
-        for (int i = tid; i < nval * 32; i += 256) {
-            const int k = i >> 5, lc = i & 31;
-            if (4 * lc >= cc) continue;
-            float4 a = red[(0 * 20 + k) * 32 + lc];
-            for (int w = 1; w < 4; ++w) {
-                const float4 t = red[(w * 20 + k) * 32 + lc];
-                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-            }
-            float* dst;
-            const int cch = c0 + 4 * lc;
-            int kk = k;
-            if (p.mode == 0 && kk < 2 * NB_OC) {
-                const int o = chunk * NB_OC + (kk >> 1);
-                if (o >= O) continue;
-                dst = ((kk & 1) ? p.dbproj : p.dwproj) + (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + cch;
-            } else {
-                if (p.mode == 0) kk -= 2 * NB_OC;
-                const size_t so = (size_t)b * p.stat_stride + cch;
-                if (p.ws) dst = ws_replica(p.ws, (blockIdx.x / tiles_c) % L2I_WS_R, (p.mode == 1 ? 4 : 2) * p.C) + kk * p.C + cch;
-                else dst = kk == 0 ? p.s1 + so : kk == 1 ? p.s2 + so : kk == 2 ? p.dwproj + cch : p.dbproj + cch;
-            }
-            atomicAdd(dst + 0, a.x); atomicAdd(dst + 1, a.y); atomicAdd(dst + 2, a.z); atomicAdd(dst + 3, a.w);
+    }
+    // ---- per-channel sums: reduce the 8 pixel rows through LDS, then one atomic per value per block
+    __syncthreads();
+    const int nval = p.mode == 1 ? 4 : 2;
+    red[(0 * 8 + prow) * 32 + cv] = acc_s1;
+    red[(1 * 8 + prow) * 32 + cv] = acc_s2;
+    if (p.mode == 1) {
+        red[(2 * 8 + prow) * 32 + cv] = acc_aw;
+        red[(3 * 8 + prow) * 32 + cv] = acc_ab;
+    }
+    __syncthreads();
+    for (int i = tid; i < nval * 32; i += 256) {
+        const int k = i >> 5, lc = i & 31;
+        if (4 * lc >= cc) continue;
+        float4 a = red[(k * 8) * 32 + lc];
+        for (int w = 1; w < 8; ++w) {
+            const float4 t = red[(k * 8 + w) * 32 + lc];
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
+        const int cch = c0 + 4 * lc;
+        float* dst;
+        if (p.ws) {
+            dst = ws_replica(p.ws, (blockIdx.x / tiles_c) % L2I_WS_R, nval * p.C) + k * p.C + cch;
+        } else {
+            const size_t so = (size_t)b * p.stat_stride + cch;
+            dst = k == 0 ? p.s1 + so : k == 1 ? p.s2 + so : k == 2 ? p.dwproj + cch : p.dbproj + cch;
+        }
+        atomicAdd(dst + 0, a.x); atomicAdd(dst + 1, a.y); atomicAdd(dst + 2, a.z); atomicAdd(dst + 3, a.w);
     }
 }
 
 static size_t norm_bwd_lds(const NormArgs& a) {
     const int O = a.mode == 0 ? a.O : 0;
-    return sizeof(float) * ((size_t)2 * O * NM_CC + (size_t)O * NB_PX + NB_PX) + sizeof(float4) * 4 * 20 * 32 + 16;
+    const size_t tile = a.mode == 0 ? (size_t)2 * NB_PX * NM_CC : (size_t)4 * 4 * 8 * 32;   // g, gx | reduction buffer (float4 x 4 x 8 x 32)
+    return sizeof(float) * ((size_t)2 * O * NM_CC + (size_t)2 * O * NB_PX + NB_PX + tile) + 16;
 }
 
 static size_t norm_lds(const NormArgs& a) {
@@ -600,7 +617,7 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
     a.s1 = s1; a.s2 = s2; a.dwproj = dwproj; a.dbproj = dbproj; a.dmask = dmask; a.dy_keep = dy_keep;
     if (norm_check(a) != L2I_OK || !dy || !dxhat || !s1 || !s2) return L2I_ERR_ARG;
     if (mode != 2 && (!dwproj || !dbproj)) return L2I_ERR_ARG;
-    if (mode == 0 && O > NB_OC && !dy_keep) return L2I_ERR_ARG;  // more than one object chunk needs the dy copy
+    (void)dy_keep;   // (formerly a scratch copy of dy for O > 8; object chunks now share the LDS tile)
     const int tiles_c = (C + NM_CC - 1) / NM_CC;
     const int subtiles = (HW + NB_PX - 1) / NB_PX;
     int nseg = 2048 / (B * tiles_c);
@@ -609,6 +626,11 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
     const int seg_pixels = ((subtiles + nseg - 1) / nseg) * NB_PX;
     nseg = (HW + seg_pixels - 1) / seg_pixels;
     a.ws = (stat_stride == 0 && B * nseg > 32) ? ws : nullptr;   // batch statistics shared by many workgroups
+    static bool ready = false;
+    if (!ready) {   // up to 31 objects: ~72 KB of dynamic LDS
+        (void)hipFuncSetAttribute((const void*)norm_bwd_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        ready = true;
+    }
     hipLaunchKernelGGL(norm_bwd_a_kernel, dim3(B * nseg * tiles_c), dim3(256), norm_bwd_lds(a), (hipStream_t)stream, a, nseg,
                        seg_pixels);
     if (a.ws) ws_fold(a.ws, (mode == 1 ? 4 : 2) * C, C, s1, s2, dwproj, dbproj, (hipStream_t)stream);

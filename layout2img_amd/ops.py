@@ -246,7 +246,7 @@ def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, 
         psb, pso = O * C, C
     elif spec.mode == 1:
         dw, db = _zeros(wproj.shape, dev), _zeros(bproj.shape, dev)
-    keep = torch.empty_like(dy) if (spec.mode == 0 and O > 8) else None
+    keep = None
     _lib.call("l2i_norm_mod_bwd_a", x.data_ptr(), dy.data_ptr(), B, H * W, C, sums.data_ptr(), sq.data_ptr(), float(count),
               float(spec.eps), stat_stride, _p(mask), O, _p(wproj), _p(bproj), psb, pso, spec.mode, int(spec.relu),
               dy.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(dw), _p(db), _p(dm), _p(keep),
