@@ -48,6 +48,9 @@ int l2i_set_conv_config(int cfg);
  * (autograd of the layers above). dy [B,Ho>>pool2,Wo>>pool2,Co] T; k order (ky,kx,ci). */
 int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                      int Co, int KH, int up2, int pool2, int ldw, float alpha, void* stream);
+/* Tuning hook: co-resident workgroups a weight-gradient launch is sized for (0 = derive from the tile: default). */
+int l2i_set_wgrad_blocks(int n);
+
 
 /* Weight arena: spectral-norm power iteration (one step, train mode), sigma, and the forward /
  * dgrad packs of every GEMM-shaped weight of a network in three multi-tensor launches.

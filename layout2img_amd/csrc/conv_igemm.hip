@@ -280,6 +280,7 @@ static int ilog2(int v) {
     return s;
 }
 
+static int g_split_target = 512;   // tuning hook: workgroups a split-K launch aims for
 // Launch one instantiation; LDS rings above 64 KB need the opt-in attribute (set once per instantiation).
 template <typename T, int BM, int BN, int WM, int WN, int NS, int HK = 0>
 static int launch_cfg(ConvArgs a, hipStream_t stream) {
@@ -297,8 +298,8 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     // split-K for small grids with a long reduction (D block5/6, G res1/res2, ROI heads): fill the 256 CUs
     int splits = 1;
     if (a.out && !a.out_op && !a.out_op_raw && nblk < 192 && nks >= 16) {
-        splits = (512 + nblk - 1) / nblk;
-        if (splits > nks / 4) splits = nks / 4;
+        splits = (g_split_target + nblk - 1) / nblk;
+        if (splits > nks / 16) splits = nks / 16;   // >= 16 K-steps per split: shorter ones are all prologue + atomic epilogue
         if (splits < 1) splits = 1;
     }
     a.ks_per = (nks + splits - 1) / splits;
@@ -320,7 +321,11 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
 }
 
 static int g_conv_cfg_override = -1;  // tuning hook (l2i_set_conv_config): -1 = heuristic
-extern "C" int l2i_set_conv_config(int cfg) { g_conv_cfg_override = cfg; return L2I_OK; }
+extern "C" int l2i_set_conv_config(int cfg) {
+    if (cfg >= 1000) { g_split_target = cfg - 1000; return L2I_OK; }   // 1000 + n: split-K target (tuning only)
+    g_conv_cfg_override = cfg;
+    return L2I_OK;
+}
 
 template <typename T>
 static int launch_conv(ConvArgs& a, hipStream_t stream) {

@@ -330,6 +330,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
         }
 }
 
+static int g_wgrad_blocks = 0;   // tuning hook l2i_set_wgrad_blocks: workgroups per wave of the grid (0 = from the tile's occupancy)
+extern "C" int l2i_set_wgrad_blocks(int n) { g_wgrad_blocks = n > 0 ? n : 0; return L2I_OK; }
+
 template <typename T>
 static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     constexpr int BK = Mma<T>::BK;
@@ -347,7 +350,15 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.tiles_k = (a.K + 127) / 128;
     const int tiles = a.tiles_co * a.tiles_k;
     const int steps = (a.M + BK - 1) / BK;
-    int splits = 1024 / tiles;
+    // Split the pixel (reduction) dimension so that the grid is ONE full wave of co-resident workgroups (2 per CU for
+    // the 128-row tile, 3 for the 64-row one: LDS-limited) -- every extra split costs Co*K atomics, and a grid of 1.1-1.9
+    // waves leaves half the chip idle in its second round. Tile counts too large for that go to >= 3 waves instead.
+    const int cap = g_wgrad_blocks > 0 ? g_wgrad_blocks : (BMO == 64 ? 768 : 512);
+    int splits = cap / tiles;
+    if (splits < 1 || (long long)splits * tiles * 5 < (long long)cap * 4) {
+        splits = (3 * cap + tiles - 1) / tiles;
+        if (splits > steps / 32) splits = steps / 32;   // short reductions: extra splits are all prologue + atomics
+    }
     if (splits > steps / 4) splits = steps / 4;
     if (splits < 1) splits = 1;
     int per = (steps + splits - 1) / splits;
