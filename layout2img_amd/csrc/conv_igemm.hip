@@ -35,6 +35,9 @@ struct ConvArgs {
     int nks;             // K-steps in total
     unsigned x_bytes, w_bytes;
     int splits, ks_per;  // split-K: `out` pre-zeroed, partials combined with f32 atomics
+    // halo kernel geometry (conv_halo_kernel): sub-patches of PHs x PW pixels, halo rows h = sp*SUBH + hy*P + hx
+    int PHs, sub_shift, P, SUBH, HR, HWd, halo_pieces;
+    unsigned long long* dbg;   // profiling build only: per-wave phase cycle totals
     float alpha;
 };
 
@@ -44,6 +47,70 @@ __device__ __forceinline__ void idx2pix(int idx, int hw_shift, int lin, int& py,
     const int qy = q >> hw_shift, qx = q & ((1 << hw_shift) - 1);
     py = 2 * qy + (s >> 1);
     px = 2 * qx + (s & 1);
+}
+
+// Epilogue shared by the convolution kernels: alpha, bias, ReLU-backward mask, residual, optional operand copies,
+// optional 2x2 average pool (in-register: the 4 GEMM rows of a quad are one lane's registers 4g..4g+3), split-K atomics.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane,
+                                              int tile_r, int tile_c, int n0, int split, int rows_total) {
+    const int c = lane & 31, h = lane >> 5;
+    T* __restrict__ OutOp = reinterpret_cast<T*>(p.out_op);
+    T* __restrict__ OutRaw = reinterpret_cast<T*>(p.out_op_raw);
+    const T* __restrict__ Mask = reinterpret_cast<const T*>(p.relu_mask);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int idx0 = wrow + i * 32 + 8 * g + 4 * h;  // first GEMM row of this lane's quad
+            if (p.pool2) {
+                const int q = idx0 >> 2;
+                const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
+                const int r2 = tile_r * (p.PH >> 1) + qy;
+                const int Hq = p.Ho >> 1, Wq = p.Wo >> 1;
+                if (r2 >= p.B * Hq) continue;
+                const int b = r2 / Hq, y2 = r2 - b * Hq, x2 = tile_c * (p.PW >> 1) + qx;
+                const size_t rowoff = ((size_t)(b * Hq + y2) * Wq + x2) * p.Co;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wcol + j * 32 + c;
+                    if (n >= p.Co) continue;
+                    float v = acc[i][j][4 * g] + acc[i][j][4 * g + 1] + acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3];
+                    v *= p.alpha;
+                    if (p.bias && split == 0) v += p.bias[n];
+                    if (Mask && !(OpT<T>::to(Mask[rowoff + n]) > 0.f)) v = 0.f;
+                    if (p.res && split == 0) v += p.res[rowoff + n];
+                    if (p.splits > 1) { atomicAdd(p.out + rowoff + n, v); continue; }
+                    if (p.out) p.out[rowoff + n] = v;
+                    if (OutOp) OutOp[rowoff + n] = OpT<T>::from(p.relu_op ? fmaxf(v, 0.f) : v);
+                    if (OutRaw) OutRaw[rowoff + n] = OpT<T>::from(v);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int py, px;
+                    idx2pix(idx0 + e, p.hw_shift, p.lin, py, px);
+                    const int r = tile_r * p.PH + py;
+                    if (r >= rows_total) continue;
+                    const int x = tile_c * p.PW + px;
+                    const size_t rowoff = ((size_t)r * p.Wo + x) * p.Co;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + wcol + j * 32 + c;
+                        if (n >= p.Co) continue;
+                        float v = acc[i][j][4 * g + e] * p.alpha;
+                        if (p.bias && split == 0) v += p.bias[n];
+                        if (Mask && !(OpT<T>::to(Mask[rowoff + n]) > 0.f)) v = 0.f;
+                        if (p.res && split == 0) v += p.res[rowoff + n];
+                        if (p.splits > 1) { atomicAdd(p.out + rowoff + n, v); continue; }
+                        if (p.out) p.out[rowoff + n] = v;
+                        if (OutOp) OutOp[rowoff + n] = OpT<T>::from(p.relu_op ? fmaxf(v, 0.f) : v);
+                        if (OutRaw) OutRaw[rowoff + n] = OpT<T>::from(v);
+                    }
+                }
+            }
+        }
+    }
 }
 
 // Tile geometry: BM x BN outputs per workgroup of WM x WN waves (each wave a (BM/WM) x (BN/WN) block of 32x32
@@ -214,64 +281,234 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
         Mma2<T>::template step<TM, TN, HK>(cur, cur + BM * ROWB, wrow, wcol, lane, acc);
     }
 
-    // ---- epilogue
-    const int c = lane & 31, h = lane >> 5;
-    T* __restrict__ OutOp = reinterpret_cast<T*>(p.out_op);
-    T* __restrict__ OutRaw = reinterpret_cast<T*>(p.out_op_raw);
-    const T* __restrict__ Mask = reinterpret_cast<const T*>(p.relu_mask);
+    conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total);
+}
+
+// ---------------------------------------------------------------- 3x3 convolution with an LDS-resident input halo
+// The implicit-GEMM kernel above re-fetches the A tile for each of the 9 taps, and with 128x128 tiles its LDS-DMA traffic
+// (32 KB per 64-MFMA K-step = 64 B/clk/CU) sits exactly at the CU's vector-memory peak: measured 30-38 % of the MFMA
+// peak, L1-bound. Here a workgroup's output pixels are spatial patches (sub-patches of PHs x PW pixels, never crossing an
+// image), so the inputs of ALL 9 taps of one 64-channel chunk are the patch plus a one-pixel border: that halo is
+// DMA'd into LDS ONCE per chunk (double-buffered, one 1 KB piece per wave per tap step while the previous chunk
+// computes), and a tap's A fragment is a ds_read_b128 at a shifted halo row. Per chunk a 128x128 tile moves
+// 23 KB (halo) + 9 x 16 KB (weights) instead of 9 x 32 KB. With the nearest-2x upsample fused (up2) the halo is held at
+// INPUT resolution (PHs/2+2 x PW/2+2) and the shift is ((y + ky - 1) >> 1).
+//
+// Halo row h = sp*SUBH + hy*P + hx (P, SUBH even); its eight 16-byte channel chunks are stored XOR-swizzled with
+// ((hx >> 1) + 4 hy + 2 sp) & 7, which makes every 16-lane phase of the fragment reads hit 16 distinct bank groups
+// for all taps and tile shapes used (exhaustive check: scratch/halo_check.py). B tiles: as in the kernel above.
+template <int BM, int BN, int WM, int WN, int NSB>
+__global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(ConvArgs p) {
+    typedef bf16_t T;
+    constexpr int THREADS = WM * WN * 64, NW = WM * WN;
+    constexpr int BK = 64, SZ = 2;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int RPP = THREADS / 8, BP = BN / RPP;
+    constexpr int HPMAX = 7;   // halo pieces per wave (1 KB each): <= 50 pieces / 8 waves, 23 / 4 waves
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(BN % RPP == 0, "tile geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int split = blockIdx.x / nblk;
+    const int bid = xcd_remap(blockIdx.x - split * nblk, nblk);
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
+    const int n0 = tile_n * BN;
+    const int rows_total = p.B * p.Ho;
+    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
+    const unsigned smem_addr = lds_addr_of(smem);
+    const unsigned halo_bytes = (unsigned)p.halo_pieces * 1024u;
+    const unsigned bring_addr = smem_addr + 2u * halo_bytes;
+    const char* bring = smem + 2u * halo_bytes;
+
+    // ---- this thread's lane of each halo piece (fixed for the whole K loop; the chunk base is added per chunk)
+    unsigned hoff[HPMAX];
+    int hlim[HPMAX];
+#pragma unroll
+    for (int q = 0; q < HPMAX; ++q) {
+        const int piece = wv + NW * q;
+        const int h = piece * 8 + (lane >> 3), pch = lane & 7;
+        const int sp = h / p.SUBH, rem = h - sp * p.SUBH;
+        const int hy = rem / p.P, hx = rem - hy * p.P;
+        const int gr0 = tile_r * p.PH + sp * p.PHs;          // global output row (b*Ho + y) of the sub-patch origin
+        const int b = gr0 / p.Ho, y0 = gr0 - b * p.Ho, x0 = tile_c * p.PW;
+        const int iy = (y0 >> p.up2) + hy - 1, ix = (x0 >> p.up2) + hx - 1;
+        const bool ok = h < p.HR && hx < p.HWd && gr0 < rows_total && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const int lch = pch ^ (((hx >> 1) + 4 * hy + 2 * sp) & 7);
+        hoff[q] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.Ci + lch * 8) * SZ : OOB;
+        hlim[q] = p.Ci - lch * 8;   // this lane's channels exist in chunk cb iff cb < hlim
+    }
+    // ---- B rows (weights): as in conv_igemm_kernel
+    const int lrow = tid >> 3;
+    const int lchunk = (tid & 7) ^ ig2_swz(lrow);
+    unsigned b_off[BP];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) b_off[q] = (unsigned)((n0 + lrow + RPP * q) * p.Kpad + lchunk * 8) * SZ;
+    const unsigned wbase = (unsigned)wv * 1024u;
+
+    // ---- A fragment rows of this lane: pixel (sub-patch, y, x) of GEMM row wrow + 32 i + (lane & 31)
+    const int wrow = (wave / WN) * (BM / WM), wcol = (wave % WN) * (BN / WN);
+    int a_sp[TM], a_py[TM], a_px[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        int py, px;
+        idx2pix(wrow + i * 32 + (lane & 31), p.hw_shift, 0, py, px);
+        a_sp[i] = py >> p.sub_shift;
+        a_py[i] = py & (p.PHs - 1);
+        a_px[i] = px;
+    }
+    const int hh = lane >> 5;
+    const int brow = wcol + (lane & 31);
+
+    f32x16_t acc[TM][TN];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int idx0 = wrow + i * 32 + 8 * g + 4 * h;  // first GEMM row of this lane's quad
-            if (p.pool2) {
-                const int q = idx0 >> 2;
-                const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
-                const int r2 = tile_r * (p.PH >> 1) + qy;
-                const int Hq = p.Ho >> 1, Wq = p.Wo >> 1;
-                if (r2 >= p.B * Hq) continue;
-                const int b = r2 / Hq, y2 = r2 - b * Hq, x2 = tile_c * (p.PW >> 1) + qx;
-                const size_t rowoff = ((size_t)(b * Hq + y2) * Wq + x2) * p.Co;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wcol + j * 32 + c;
-                    if (n >= p.Co) continue;
-                    float v = acc[i][j][4 * g] + acc[i][j][4 * g + 1] + acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3];
-                    v *= p.alpha;
-                    if (p.bias && split == 0) v += p.bias[n];
-                    if (Mask && !(OpT<T>::to(Mask[rowoff + n]) > 0.f)) v = 0.f;
-                    if (p.res && split == 0) v += p.res[rowoff + n];
-                    if (p.splits > 1) { atomicAdd(p.out + rowoff + n, v); continue; }
-                    if (p.out) p.out[rowoff + n] = v;
-                    if (OutOp) OutOp[rowoff + n] = OpT<T>::from(p.relu_op ? fmaxf(v, 0.f) : v);
-                    if (OutRaw) OutRaw[rowoff + n] = OpT<T>::from(v);
-                }
-            } else {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int py, px;
-                    idx2pix(idx0 + e, p.hw_shift, p.lin, py, px);
-                    const int r = tile_r * p.PH + py;
-                    if (r >= rows_total) continue;
-                    const int x = tile_c * p.PW + px;
-                    const size_t rowoff = ((size_t)r * p.Wo + x) * p.Co;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto issue_halo_piece = [&](int q, unsigned buf_addr, int cb) {   // piece q of this wave, chunk base cb
+        if (wv + NW * q < p.halo_pieces)
+            buf_load_lds16(rsrc_x, cb < hlim[q] ? hoff[q] + (unsigned)cb * SZ : OOB, buf_addr + (unsigned)(wv + NW * q) * 1024u);
+    };
+    auto issue_b = [&](unsigned stage_addr, int tap, int cb) {
+        const unsigned kadd = (unsigned)(tap * p.Ci + cb) * SZ;
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int n = n0 + wcol + j * 32 + c;
-                        if (n >= p.Co) continue;
-                        float v = acc[i][j][4 * g + e] * p.alpha;
-                        if (p.bias && split == 0) v += p.bias[n];
-                        if (Mask && !(OpT<T>::to(Mask[rowoff + n]) > 0.f)) v = 0.f;
-                        if (p.res && split == 0) v += p.res[rowoff + n];
-                        if (p.splits > 1) { atomicAdd(p.out + rowoff + n, v); continue; }
-                        if (p.out) p.out[rowoff + n] = v;
-                        if (OutOp) OutOp[rowoff + n] = OpT<T>::from(p.relu_op ? fmaxf(v, 0.f) : v);
-                        if (OutRaw) OutRaw[rowoff + n] = OpT<T>::from(v);
-                    }
+        for (int q = 0; q < BP; ++q) buf_load_lds16(rsrc_w, b_off[q] + kadd, stage_addr + (unsigned)(q * RPP) * 128u + wbase);
+    };
+
+    // K range of this split: whole chunks (ks_per is a multiple of 9)
+    const int ks0 = split * p.ks_per, ks1 = min(p.nks, ks0 + p.ks_per);
+    if (ks0 < ks1) {
+        int cb = (ks0 / 9) * BK, tap = 0, cpar = 0;
+#pragma unroll
+        for (int q = 0; q < HPMAX; ++q) issue_halo_piece(q, smem_addr, cb);
+        // B ring of NSB stages: tiles ks+1 .. ks+NSB-1 are in flight while tile ks is consumed. c1 / c2 = LDS-DMA
+        // instructions this wave issued one / two steps ago: they may still be outstanding at the next wait.
+        int pf_tap = 0, pf_cb = cb;   // (tap, chunk base) of the next B tile to issue
+        int c1 = 0, c2 = 0;
+#pragma unroll
+        for (int s = 0; s < NSB - 1; ++s) {
+            int n = 0;
+            if (ks0 + s < ks1) {
+                issue_b(bring_addr + (unsigned)s * (BN * 128u), pf_tap, pf_cb);
+                n = BP;
+                if (++pf_tap == 9) { pf_tap = 0; pf_cb += BK; }
+            }
+            if (s > 0) { c2 = c1; c1 = n; }   // tile 0 itself must have landed at the first wait
+        }
+#ifdef L2I_PROF
+        unsigned long long pa = 0, pb = 0, pc = 0, pd = 0;
+#endif
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int it = ks - ks0;
+#ifdef L2I_PROF
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+            {
+                const int allow = NSB >= 4 ? c1 + c2 : NSB == 3 ? c1 : 0;
+                switch (allow) {   // s_waitcnt takes an immediate
+                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
                 }
             }
+#ifdef L2I_PROF
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+            __builtin_amdgcn_s_barrier();   // everyone's part of tile ks (and, at tap 0, of the halo) landed; the stage and halo buffer refilled below are free
+            asm volatile("" ::: "memory");
+#ifdef L2I_PROF
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+            // weights NSB-1 taps ahead, and one piece per wave of the NEXT chunk's halo
+            {
+                int n = 0;
+                if (ks + NSB - 1 < ks1) {
+                    issue_b(bring_addr + (unsigned)((it + NSB - 1) % NSB) * (BN * 128u), pf_tap, pf_cb);
+                    n = BP;
+                    if (++pf_tap == 9) { pf_tap = 0; pf_cb += BK; }
+                }
+                if (ks + 9 - tap < ks1 && tap < HPMAX && wv + NW * tap < p.halo_pieces) {   // a next chunk exists and this wave has a piece `tap`
+                    const unsigned nbuf = smem_addr + (unsigned)(cpar ^ 1) * halo_bytes;
+                    ++n;
+                    switch (tap) {   // (constant indices keep hoff / hlim in registers)
+                        case 0: issue_halo_piece(0, nbuf, cb + BK); break;
+                        case 1: issue_halo_piece(1, nbuf, cb + BK); break;
+                        case 2: issue_halo_piece(2, nbuf, cb + BK); break;
+                        case 3: issue_halo_piece(3, nbuf, cb + BK); break;
+                        case 4: issue_halo_piece(4, nbuf, cb + BK); break;
+                        case 5: issue_halo_piece(5, nbuf, cb + BK); break;
+                        default: issue_halo_piece(6, nbuf, cb + BK); break;
+                    }
+                }
+                c2 = c1; c1 = n;
+            }
+#ifdef L2I_PROF
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
+            // ---- MFMA step for (tap, chunk): A from the halo at the tap's shift, B from the ring
+            const char* hb = smem + (unsigned)cpar * halo_bytes;
+            const char* bs = bring + (unsigned)(it % NSB) * (BN * 128u);
+            const int ky = tap / 3, kx = tap - ky * 3;
+            int a_row[TM], a_swz[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int hy, hx;
+                if (p.up2) { hy = ((a_py[i] + ky - 1) >> 1) + 1; hx = ((a_px[i] + kx - 1) >> 1) + 1; }
+                else { hy = a_py[i] + ky; hx = a_px[i] + kx; }
+                a_row[i] = (a_sp[i] * p.SUBH + hy * p.P + hx) * 128;
+                a_swz[i] = ((hx >> 1) + 4 * hy + 2 * a_sp[i]) & 7;
+            }
+            {   // all 16 fragment reads first, then the MFMAs (see Mma2::step)
+                bf16x8_t a[4][TM], b[4][TN];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[kk][i] = *reinterpret_cast<const bf16x8_t*>(hb + a_row[i] + (((kk * 2 + hh) ^ a_swz[i]) << 4));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[kk][j] = *reinterpret_cast<const bf16x8_t*>(bs + ig2_off<0>(brow + j * 32, kk * 2 + hh));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[kk][i]),
+                                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[kk][j]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifdef L2I_PROF
+            {
+                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+                pa += t1 - t0; pb += t2 - t1; pc += t3 - t2; pd += t4 - t3;
+            }
+#endif
+            if (++tap == 9) { tap = 0; cb += BK; cpar ^= 1; }
         }
+#ifdef L2I_PROF
+        if (p.dbg && lane == 0) {
+            unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
+            d[0] = pa; d[1] = pb; d[2] = pc; d[3] = pd;
+        }
+#endif
     }
+    conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total);
 }
 
 static int ilog2(int v) {
@@ -280,6 +517,8 @@ static int ilog2(int v) {
     return s;
 }
 
+static unsigned long long* g_conv_dbg = nullptr;   // profiling builds (-DL2I_PROF): per-wave phase cycle totals of the halo kernel
+extern "C" int l2i_debug_set_buffer(void* p) { g_conv_dbg = (unsigned long long*)p; return L2I_OK; }
 static int g_split_target = 512;   // tuning hook: workgroups a split-K launch aims for
 // Launch one instantiation; LDS rings above 64 KB need the opt-in attribute (set once per instantiation).
 template <typename T, int BM, int BN, int WM, int WN, int NS, int HK = 0>
@@ -317,6 +556,51 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     }
     (void)BK;
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, NS, HK>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+    return l2i_check_launch();
+}
+
+// Halo kernel launch (bf16, 3x3, Ci >= 64, Wo >= 8, no upsample into 8-wide maps). Returns -100 when the shape is
+// not covered so that the caller falls through to the generic kernel.
+template <int BM, int BN, int WM, int WN, int NSB>
+static int launch_halo(ConvArgs a, hipStream_t stream) {
+    a.PH = BM / a.PW;
+    a.PHs = a.PH < a.Ho ? a.PH : a.Ho;
+    a.sub_shift = ilog2(a.PHs);
+    const int nsp = a.PH / a.PHs;
+    a.HWd = (a.up2 ? a.PW / 2 : a.PW) + 2;
+    const int hh = (a.up2 ? a.PHs / 2 : a.PHs) + 2;
+    a.P = (a.HWd + 1) & ~1;
+    a.SUBH = hh * a.P;
+    a.HR = nsp * a.SUBH;
+    a.halo_pieces = (a.HR + 7) / 8;
+    if (a.halo_pieces > 7 * WM * WN) return -100;
+    const size_t lds = (size_t)2 * a.halo_pieces * 1024 + (size_t)NSB * BN * 128;
+    if (lds > 160 * 1024) return -100;
+    const int nchunks = (a.Ci + 63) / 64;
+    a.nks = 9 * nchunks;
+    const int rows = a.B * a.Ho;
+    a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
+    a.tiles_n = (a.Co + BN - 1) / BN;
+    const int nblk = a.tiles_m * a.tiles_n;
+    int splits = 1;
+    if (a.out && !a.out_op && !a.out_op_raw && nblk < 192 && nchunks >= 4) {
+        splits = (g_split_target + nblk - 1) / nblk;
+        if (splits > nchunks / 2) splits = nchunks / 2;   // >= 18 K-steps per split
+        if (splits < 1) splits = 1;
+    }
+    const int cper = (nchunks + splits - 1) / splits;
+    a.ks_per = 9 * cper;
+    a.splits = (nchunks + cper - 1) / cper;
+    if (a.splits > 1) {
+        const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
+        if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+    }
+    static bool ready = false;
+    if (!ready) {
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BM, BN, WM, WN, NSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        ready = true;
+    }
+    hipLaunchKernelGGL((conv_halo_kernel<BM, BN, WM, WN, NSB>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
     return l2i_check_launch();
 }
 
@@ -361,6 +645,25 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     // Heuristic from scratch/conv_tune.py on MI355X (TFLOP/s, bf16): big-tile configs pay only when their grid still
     // fills the 256 CUs; a single wave of 128x128 tiles (one workgroup per CU) prefers the 8-wave deep ring.
     const long long M = (long long)a.B * a.Ho * a.Wo;
+    if (sizeof(T) == 2 && a.KH == 3 && a.Ci >= 64 && !a.lin && a.Wo >= 8 && !(a.up2 && a.Wo < 16) && a.Ho >= 2 &&
+        (g_conv_cfg_override < 0 || g_conv_cfg_override >= 10)) {
+        // halo kernel: 256x128 / 8 waves where its grid still fills the chip (and always for 8-wide maps, whose
+        // 128-row tile would not fit two workgroups per CU), else 128x128 or 128x64 / 4 waves, two workgroups per CU
+        const long long t256 = ((M + 255) / 256) * ((a.Co + 127) / 128);
+        int hc = a.Co <= 64 ? 1 : ((a.Wo < 16 || t256 >= 256) ? 2 : 0);
+        if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
+        if (a.Wo < 16 && hc < 2) hc = 2;
+        int rc;
+        switch (hc) {
+            case 1: rc = launch_halo<128, 64, 2, 2, 2>(a, stream); break;
+            case 2: rc = launch_halo<256, 128, 4, 2, 2>(a, stream); break;
+            case 3: rc = launch_halo<256, 128, 4, 2, 4>(a, stream); break;    // 3 weight tiles in flight
+            case 4: rc = launch_halo<128, 128, 2, 2, 4>(a, stream); break;    // one workgroup per CU, deep ring
+            case 5: rc = launch_halo<256, 128, 4, 2, 3>(a, stream); break;
+            default: rc = launch_halo<128, 128, 2, 2, 2>(a, stream); break;
+        }
+        if (rc != -100) return rc;
+    }
     const long long t128 = ((M + 127) / 128) * ((a.Co + 127) / 128);
     const long long t256x128 = ((M + 255) / 256) * ((a.Co + 127) / 128);
     const long long t256x256 = ((M + 255) / 256) * ((a.Co + 255) / 256);
@@ -395,8 +698,21 @@ extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, c
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out; a.out_op = out_op; a.out_op_raw = out_op_raw; a.relu_mask = relu_mask;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.relu_op = relu_op ? 1 : 0;
-    a.Kpad = Kpad; a.alpha = alpha;
+    a.Kpad = Kpad; a.alpha = alpha; a.dbg = g_conv_dbg;
     if (dtype == 0) return launch_conv<float>(a, (hipStream_t)stream);
     if (dtype == 1) return launch_conv<bf16_t>(a, (hipStream_t)stream);
     return L2I_ERR_ARG;
+}
+
+// Debug aid: co-resident workgroups per CU the runtime computes for a few instantiations (scratch/occupancy.py).
+extern "C" int l2i_debug_occupancy(int which, int lds_bytes) {
+    int n = -1;
+    hipError_t e = hipSuccess;
+    switch (which) {
+        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_igemm_kernel<bf16_t, 128, 128, 2, 2, 2, 0>, 256, lds_bytes); break;
+        case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_halo_kernel<128, 128, 2, 2, 2>, 256, lds_bytes); break;
+        case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_halo_kernel<256, 128, 4, 2, 2>, 512, lds_bytes); break;
+        default: break;
+    }
+    return e == hipSuccess ? n : -(int)e;
 }

@@ -86,20 +86,32 @@ template <> struct Mma2<bf16_t> {
     __device__ static __forceinline__ void step(const char* As, const char* Bs, int wrow, int wcol, int lane,
                                                 f32x16_t (&acc)[TM][TN]) {
         const int r = lane & 31, h = lane >> 5;
+        // All fragment reads of a batch of k16 sub-steps are issued BEFORE its MFMAs (sched_barrier keeps hipcc from
+        // sinking them back): left alone it keeps 16 fragment registers and alternates "4 reads, wait, 4 MFMAs", which
+        // exposes the ~150-cycle LDS latency four times per K-step (measured: 1500 cycles per 512 cycles of MFMA).
+        constexpr int NKK = HK ? 2 : 4;
+        constexpr int KB = (TM + TN) * NKK <= 16 ? NKK : 2;   // sub-steps per batch: <= 64 fragment VGPRs
 #pragma unroll
-        for (int kk = 0; kk < (HK ? 2 : 4); ++kk) {
-            bf16x8_t a[TM], b[TN];
+        for (int k0 = 0; k0 < NKK; k0 += KB) {
+            bf16x8_t a[KB][TM], b[KB][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + ig2_off<HK>(wrow + i * 32 + r, kk * 2 + h));
+            for (int kk = 0; kk < KB; ++kk) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + ig2_off<HK>(wcol + j * 32 + r, kk * 2 + h));
+                for (int i = 0; i < TM; ++i) a[kk][i] = *reinterpret_cast<const bf16x8_t*>(As + ig2_off<HK>(wrow + i * 32 + r, (k0 + kk) * 2 + h));
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) b[kk][j] = *reinterpret_cast<const bf16x8_t*>(Bs + ig2_off<HK>(wcol + j * 32 + r, (k0 + kk) * 2 + h));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[i]),
-                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[j]), acc[i][j], 0, 0, 0);
+            for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[kk][i]),
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[kk][j]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 };

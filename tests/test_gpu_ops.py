@@ -50,6 +50,15 @@ CONV_CASES = [
     (2, 8, 8, 16, 16, 3, False, True),
     (3, 8, 8, 16, 32, 1, False, True),
     (2, 32, 32, 8, 8, 3, True, True),
+    # 3x3 with >= 64 input channels on maps >= 8 wide: the halo-resident kernel (bf16)
+    (2, 16, 16, 64, 72, 3, False, False),
+    (1, 32, 32, 128, 136, 3, False, True),
+    (2, 16, 16, 64, 64, 3, True, False),
+    (3, 8, 8, 136, 128, 3, False, False),
+    (1, 64, 64, 64, 8, 3, False, False),
+    (9, 16, 16, 192, 128, 3, False, False),
+    (2, 32, 32, 72, 64, 3, True, True),
+    (5, 8, 8, 64, 264, 3, False, True),
 ]
 
 
@@ -104,6 +113,30 @@ def test_conv_split_k(case, dt):
                              relu_mask=mask.to(_dev(), dt), up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0)
     expect = ref * (mask > 0).float() + res
     assert float((out.cpu() - expect).abs().max()) < 3e-5 * float(expect.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 72, 3, False, False), (1, 32, 32, 128, 136, 3, False, True),
+                                  (2, 16, 16, 64, 64, 3, True, False), (9, 16, 16, 192, 128, 3, False, False),
+                                  (5, 8, 8, 64, 264, 3, False, True), (1, 64, 64, 64, 8, 3, True, False)])
+def test_conv_halo_tiles(case, cfg):
+    """every tile shape of the halo kernel (128x128, 128x64, 256x128) on every geometry, forced through the tuning hook"""
+    from layout2img_amd import ops, _lib
+    B, H, W, Ci, Co, KH, up2, pool2 = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    w = _rt(torch.randn(Co, Ci, KH, KH, generator=g) / math.sqrt(Ci * KH * KH), dt)
+    bias = torch.randn(Co, generator=g)
+    ref = _ref_conv(x, w, bias, up2, pool2)
+    pack, kpad = _pack(w, 64)
+    _lib.call("l2i_set_conv_config", cfg)
+    try:
+        out, _, _ = ops.conv_raw(x.to(_dev(), dt), pack.to(_dev(), dt), kpad, Co, KH, bias=bias.to(_dev()), up2=up2, pool2=pool2,
+                                 alpha=0.25 if pool2 else 1.0)
+    finally:
+        _lib.call("l2i_set_conv_config", -1)
+    assert float((out.cpu() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("dt", DTYPES)
