@@ -52,8 +52,6 @@ int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B,
 int l2i_set_wgrad_blocks(int n);
 /* Debug aid: co-resident workgroups per CU for conv instantiation `which` with lds_bytes of dynamic LDS. */
 int l2i_debug_occupancy(int which, int lds_bytes);
-/* Debug aid (library built with -DL2I_PROF): buffer of 4 uint64 per wave receiving the halo kernel's phase cycles. */
-int l2i_debug_set_buffer(void* buf);
 
 
 /* Weight arena: spectral-norm power iteration (one step, train mode), sigma, and the forward /

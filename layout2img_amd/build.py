@@ -11,8 +11,6 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libl2i_hip.so")
 SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "weights.hip", "norm.hip", "roi_align.hip", "attention.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
-if os.environ.get("L2I_PROF"):   # phase-timing instrumentation of the halo conv kernel (scratch/phase_prof.py)
-    FLAGS.append("-DL2I_PROF")
 
 
 def _stale():

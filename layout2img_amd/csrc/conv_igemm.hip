@@ -37,7 +37,6 @@ struct ConvArgs {
     int splits, ks_per;  // split-K: `out` pre-zeroed, partials combined with f32 atomics
     // halo kernel geometry (conv_halo_kernel): sub-patches of PHs x PW pixels, halo rows h = sp*SUBH + hy*P + hx
     int PHs, sub_shift, P, SUBH, HR, HWd, halo_pieces;
-    unsigned long long* dbg;   // profiling build only: per-wave phase cycle totals
     float alpha;
 };
 
@@ -50,63 +49,167 @@ __device__ __forceinline__ void idx2pix(int idx, int hw_shift, int lin, int& py,
 }
 
 // Epilogue shared by the convolution kernels: alpha, bias, ReLU-backward mask, residual, optional operand copies,
-// optional 2x2 average pool (in-register: the 4 GEMM rows of a quad are one lane's registers 4g..4g+3), split-K atomics.
+// optional 2x2 average pool, split-K atomics.
+// The MFMAs are issued with the operands swapped (weights as "A", pixels as "B"), so an accumulator tile is the
+// TRANSPOSE of the output tile: lane l holds pixel (l & 31) of the 32-row tile and its 16 registers are output channels
+// 8g + 4(l >> 5) + {0..3}, g = 0..3 -- four CONSECUTIVE channels per register group. Every global access of the epilogue
+// is therefore 16 bytes per lane (8 for bf16 operands) instead of 4: a quarter of the instructions of the row-per-
+// register layout. The 2x2 pool sums the 4 pixels of a quad = 4 adjacent lanes (quad-major pixel enumeration) with two
+// DPP quad permutes.
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+template <typename T> struct Op4;
+template <> struct Op4<bf16_t> {
+    __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+    __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+        uint2 u;
+        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+};
+template <> struct Op4<float> {
+    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 u = *reinterpret_cast<const float4*>(p);
+        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+    }
+    __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+
+// Split-K partial tiles are combined with f32 atomics, which only run at speed when a wave's 64 addresses are
+// contiguous runs; the transposed accumulator would scatter them over 32 rows. Each wave therefore turns its 32x32
+// tiles back through a private 32 x 36-float LDS patch (the ring is idle by then) and adds 128-byte row segments.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_splitk(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane,
+                                                     int wave, int tile_r, int tile_c, int n0, int split, int rows_total,
+                                                     char* smem) {
+    constexpr int LD = 36;
+    float* patch = reinterpret_cast<float*>(smem) + wave * 32 * LD;
+    const T* __restrict__ Mask = reinterpret_cast<const T*>(p.relu_mask);
+    const int m = lane & 31, h = lane >> 5;
+    __syncthreads();   // every wave is done reading the ring
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(patch + m * LD + 8 * g + 4 * h) =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            // (same wave wrote and reads: LDS operations of a wave complete in order)
+            const int n = n0 + wcol + j * 32 + m;
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = 2 * rr + h;               // pixel within the 32-row tile
+                float v = patch[row * LD + m] * p.alpha;
+                const int idx = wrow + i * 32 + row;
+                size_t rowoff;
+                bool live;
+                if (p.pool2) {   // the 4 pixels of a quad all add (x alpha = 1/4) into the pooled pixel
+                    const int q = idx >> 2;
+                    const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
+                    const int r2 = tile_r * (p.PH >> 1) + qy;
+                    const int Hq = p.Ho >> 1, Wq = p.Wo >> 1;
+                    const int b = r2 / Hq, y2 = r2 - b * Hq, x2 = tile_c * (p.PW >> 1) + qx;
+                    rowoff = ((size_t)(b * Hq + y2) * Wq + x2) * p.Co;
+                    live = r2 < p.B * Hq;
+                } else {
+                    int py, px;
+                    idx2pix(idx, p.hw_shift, p.lin, py, px);
+                    const int r = tile_r * p.PH + py;
+                    rowoff = ((size_t)r * p.Wo + tile_c * p.PW + px) * p.Co;
+                    live = r < rows_total;
+                }
+                if (!live || n >= p.Co) continue;
+                // out = mask * (sum of partials + bias) + res: bias and res enter once (first split, first pixel of a quad)
+                const bool once = split == 0 && (!p.pool2 || (idx & 3) == 0);
+                if (p.bias && once) v += p.bias[n];
+                if (Mask && !(OpT<T>::to(Mask[rowoff + n]) > 0.f)) v = 0.f;
+                if (p.res && once) v += p.res[rowoff + n];
+                atomicAdd(p.out + rowoff + n, v);
+            }
+        }
+}
+
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane,
                                               int tile_r, int tile_c, int n0, int split, int rows_total) {
-    const int c = lane & 31, h = lane >> 5;
+    const int m = lane & 31, h = lane >> 5;
     T* __restrict__ OutOp = reinterpret_cast<T*>(p.out_op);
     T* __restrict__ OutRaw = reinterpret_cast<T*>(p.out_op_raw);
     const T* __restrict__ Mask = reinterpret_cast<const T*>(p.relu_mask);
+    const bool lead = split == 0;   // bias and residual are added by the first split only
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int idx = wrow + i * 32 + m;   // this lane's pixel (GEMM row)
+        size_t rowoff;
+        bool live;
+        if (p.pool2) {
+            const int q = idx >> 2;
+            const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
+            const int r2 = tile_r * (p.PH >> 1) + qy;
+            const int Hq = p.Ho >> 1, Wq = p.Wo >> 1;
+            const int b = r2 / Hq, y2 = r2 - b * Hq, x2 = tile_c * (p.PW >> 1) + qx;
+            rowoff = ((size_t)(b * Hq + y2) * Wq + x2) * p.Co;
+            live = r2 < p.B * Hq && (lane & 3) == 0;   // one lane of the quad writes the pooled pixel
+        } else {
+            int py, px;
+            idx2pix(idx, p.hw_shift, p.lin, py, px);
+            const int r = tile_r * p.PH + py;
+            rowoff = ((size_t)r * p.Wo + tile_c * p.PW + px) * p.Co;
+            live = r < rows_total;
+        }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int idx0 = wrow + i * 32 + 8 * g + 4 * h;  // first GEMM row of this lane's quad
-            if (p.pool2) {
-                const int q = idx0 >> 2;
-                const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
-                const int r2 = tile_r * (p.PH >> 1) + qy;
-                const int Hq = p.Ho >> 1, Wq = p.Wo >> 1;
-                if (r2 >= p.B * Hq) continue;
-                const int b = r2 / Hq, y2 = r2 - b * Hq, x2 = tile_c * (p.PW >> 1) + qx;
-                const size_t rowoff = ((size_t)(b * Hq + y2) * Wq + x2) * p.Co;
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wcol + j * 32 + c;
-                    if (n >= p.Co) continue;
-                    float v = acc[i][j][4 * g] + acc[i][j][4 * g + 1] + acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3];
-                    v *= p.alpha;
-                    if (p.bias && split == 0) v += p.bias[n];
-                    if (Mask && !(OpT<T>::to(Mask[rowoff + n]) > 0.f)) v = 0.f;
-                    if (p.res && split == 0) v += p.res[rowoff + n];
-                    if (p.splits > 1) { atomicAdd(p.out + rowoff + n, v); continue; }
-                    if (p.out) p.out[rowoff + n] = v;
-                    if (OutOp) OutOp[rowoff + n] = OpT<T>::from(p.relu_op ? fmaxf(v, 0.f) : v);
-                    if (OutRaw) OutRaw[rowoff + n] = OpT<T>::from(v);
-                }
-            } else {
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wcol + j * 32 + 8 * g + 4 * h;
+                float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    int py, px;
-                    idx2pix(idx0 + e, p.hw_shift, p.lin, py, px);
-                    const int r = tile_r * p.PH + py;
-                    if (r >= rows_total) continue;
-                    const int x = tile_c * p.PW + px;
-                    const size_t rowoff = ((size_t)r * p.Wo + x) * p.Co;
+                    v[e] = acc[i][j][4 * g + e];
+                    if (p.pool2) v[e] = quad_sum(v[e]);
+                    v[e] *= p.alpha;
+                }
+                if (!live || n >= p.Co) continue;
+                const size_t off = rowoff + n;
+                if (p.bias && lead) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (Mask) {
+                    float mk[4];
+                    Op4<T>::load(Mask + off, mk);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int n = n0 + wcol + j * 32 + c;
-                        if (n >= p.Co) continue;
-                        float v = acc[i][j][4 * g + e] * p.alpha;
-                        if (p.bias && split == 0) v += p.bias[n];
-                        if (Mask && !(OpT<T>::to(Mask[rowoff + n]) > 0.f)) v = 0.f;
-                        if (p.res && split == 0) v += p.res[rowoff + n];
-                        if (p.splits > 1) { atomicAdd(p.out + rowoff + n, v); continue; }
-                        if (p.out) p.out[rowoff + n] = v;
-                        if (OutOp) OutOp[rowoff + n] = OpT<T>::from(p.relu_op ? fmaxf(v, 0.f) : v);
-                        if (OutRaw) OutRaw[rowoff + n] = OpT<T>::from(v);
+                    for (int e = 0; e < 4; ++e)
+                        if (!(mk[e] > 0.f)) v[e] = 0.f;
+                }
+                if (p.res && lead) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.res + off);
+                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                }
+                if (p.splits > 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(p.out + off + e, v[e]);
+                    continue;
+                }
+                if (p.out) *reinterpret_cast<float4*>(p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+                if (OutRaw) Op4<T>::store(OutRaw + off, v);
+                if (OutOp) {
+                    if (p.relu_op) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
+                    Op4<T>::store(OutOp + off, v);
                 }
             }
         }
@@ -281,7 +384,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
         Mma2<T>::template step<TM, TN, HK>(cur, cur + BM * ROWB, wrow, wcol, lane, acc);
     }
 
-    conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total);
+    if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_total, smem);
+    else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total);
 }
 
 // ---------------------------------------------------------------- 3x3 convolution with an LDS-resident input halo
@@ -297,16 +401,39 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
 // Halo row h = sp*SUBH + hy*P + hx (P, SUBH even); its eight 16-byte channel chunks are stored XOR-swizzled with
 // ((hx >> 1) + 4 hy + 2 sp) & 7, which makes every 16-lane phase of the fragment reads hit 16 distinct bank groups
 // for all taps and tile shapes used (exhaustive check: scratch/halo_check.py). B tiles: as in the kernel above.
-template <int BM, int BN, int WM, int WN, int NSB>
-__global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(ConvArgs p) {
+// Main loop. A first version of this kernel kept tap, ring stage and addresses as run-time state: per 16 MFMAs a
+// wave also issued ~90 SALU,
+// ~90 VALU, 16 LDS and 5 VMEM instructions -- 12.7 other instructions per MFMA. A wave issues at most one instruction
+// per 4 cycles, so the K-step cost ~900 issue cycles against 512 cycles of MFMA work: the loop was ISSUE-bound (and the
+// LDS, L2 and DMA counters all sat below 25 %). This form removes the bookkeeping instead of hiding it:
+//   * the 9 taps of two consecutive chunks (18 K-steps) are fully unrolled, so tap, halo buffer, ring stage (9 % 3 == 0)
+//     and fragment-register set are compile-time constants;
+//   * every LDS address is precomputed: a_addr[i][tap] holds the swizzled byte address of the lane's A row for each tap
+//     (the k16 sub-step only XORs bits 5-6: ((2kk + h) ^ swz) << 4 == ((h ^ swz) << 4) ^ (kk << 5)), b_addr[j][kk] the
+//     B row, with the ring stage as the instruction's immediate offset; the halo buffer flip is one add per address
+//     per chunk;
+//   * DMA instructions take the per-tap part of their source offset as the SGPR soffset operand (no VALU), are spread
+//     between the MFMAs, and the ring is 3 stages with a constant s_waitcnt vmcnt(BP) (each step issues its optional
+//     halo piece BEFORE its weight pieces, so "all but the newest BP" always covers the tile about to be read); tiles
+//     past the end of the reduction are issued anyway (clamped to the last chunk) to keep the count constant;
+//   * PIPE (one wave per SIMD, 128x128 tile): the fragment reads of step s are issued before the MFMAs of step s-1
+//     (two register sets), so LDS latency never stalls the MFMA pipe.
+#define H2_DMA(rsrc, voff, soff, ldsaddr)                                                                             \
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), \
+                 "s"(soff), "s"(ldsaddr)                                                                              \
+                 : "memory")
+
+template <int BM, int BN, int WM, int WN, int NSB, bool PIPE>
+__global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
     typedef bf16_t T;
     constexpr int THREADS = WM * WN * 64, NW = WM * WN;
     constexpr int BK = 64, SZ = 2;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int RPP = THREADS / 8, BP = BN / RPP;
-    constexpr int HPMAX = 7;   // halo pieces per wave (1 KB each): <= 50 pieces / 8 waves, 23 / 4 waves
+    constexpr int HPMAX = 7;
     constexpr unsigned OOB = 0x80000000u;
-    static_assert(BN % RPP == 0, "tile geometry");
+    constexpr unsigned BSTAGE = BN * 128u;
+    static_assert(BN % RPP == 0 && BP >= 1 && BP <= 4, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -321,10 +448,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(ConvArgs p) {
     const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
     const unsigned smem_addr = lds_addr_of(smem);
     const unsigned halo_bytes = (unsigned)p.halo_pieces * 1024u;
-    const unsigned bring_addr = smem_addr + 2u * halo_bytes;
-    const char* bring = smem + 2u * halo_bytes;
+    const unsigned ring_off = 2u * halo_bytes;
 
-    // ---- this thread's lane of each halo piece (fixed for the whole K loop; the chunk base is added per chunk)
+    // ---- halo pieces of this wave (piece q = wv + NW q; lane -> halo row / chunk), as in conv_halo_kernel
     unsigned hoff[HPMAX];
     int hlim[HPMAX];
 #pragma unroll
@@ -333,35 +459,50 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(ConvArgs p) {
         const int h = piece * 8 + (lane >> 3), pch = lane & 7;
         const int sp = h / p.SUBH, rem = h - sp * p.SUBH;
         const int hy = rem / p.P, hx = rem - hy * p.P;
-        const int gr0 = tile_r * p.PH + sp * p.PHs;          // global output row (b*Ho + y) of the sub-patch origin
+        const int gr0 = tile_r * p.PH + sp * p.PHs;
         const int b = gr0 / p.Ho, y0 = gr0 - b * p.Ho, x0 = tile_c * p.PW;
         const int iy = (y0 >> p.up2) + hy - 1, ix = (x0 >> p.up2) + hx - 1;
         const bool ok = h < p.HR && hx < p.HWd && gr0 < rows_total && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         const int lch = pch ^ (((hx >> 1) + 4 * hy + 2 * sp) & 7);
         hoff[q] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.Ci + lch * 8) * SZ : OOB;
-        hlim[q] = p.Ci - lch * 8;   // this lane's channels exist in chunk cb iff cb < hlim
+        hlim[q] = p.Ci - lch * 8;
     }
-    // ---- B rows (weights): as in conv_igemm_kernel
+    const int nq = (p.halo_pieces - wv + NW - 1) / NW;   // pieces this wave owns (wave-uniform)
+    // ---- B rows
     const int lrow = tid >> 3;
     const int lchunk = (tid & 7) ^ ig2_swz(lrow);
     unsigned b_off[BP];
 #pragma unroll
     for (int q = 0; q < BP; ++q) b_off[q] = (unsigned)((n0 + lrow + RPP * q) * p.Kpad + lchunk * 8) * SZ;
-    const unsigned wbase = (unsigned)wv * 1024u;
+    const unsigned ring_w = smem_addr + ring_off + (unsigned)wv * 1024u;   // this wave's 1 KB slot of a pass
+    const unsigned halo_w = smem_addr + (unsigned)wv * 1024u;
 
-    // ---- A fragment rows of this lane: pixel (sub-patch, y, x) of GEMM row wrow + 32 i + (lane & 31)
+    // ---- LDS addresses of the fragments
     const int wrow = (wave / WN) * (BM / WM), wcol = (wave % WN) * (BN / WN);
-    int a_sp[TM], a_py[TM], a_px[TM];
+    const int hh = lane >> 5;
+    unsigned a_addr[TM][9];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         int py, px;
         idx2pix(wrow + i * 32 + (lane & 31), p.hw_shift, 0, py, px);
-        a_sp[i] = py >> p.sub_shift;
-        a_py[i] = py & (p.PHs - 1);
-        a_px[i] = px;
+        const int sp = py >> p.sub_shift, pyl = py & (p.PHs - 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            int hy, hx;
+            if (p.up2) { hy = ((pyl + ky - 1) >> 1) + 1; hx = ((px + kx - 1) >> 1) + 1; }
+            else { hy = pyl + ky; hx = px + kx; }
+            const int swz = ((hx >> 1) + 4 * hy + 2 * sp) & 7;
+            a_addr[i][tap] = (unsigned)((sp * p.SUBH + hy * p.P + hx) * 128 + ((hh ^ swz) << 4));
+        }
     }
-    const int hh = lane >> 5;
-    const int brow = wcol + (lane & 31);
+    unsigned b_addr[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wcol + j * 32 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b_addr[j][kk] = ring_off + (unsigned)(row * 128 + (((kk * 2 + hh) ^ ig2_swz(row)) << 4));
+    }
 
     f32x16_t acc[TM][TN];
 #pragma unroll
@@ -371,144 +512,134 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto issue_halo_piece = [&](int q, unsigned buf_addr, int cb) {   // piece q of this wave, chunk base cb
-        if (wv + NW * q < p.halo_pieces)
-            buf_load_lds16(rsrc_x, cb < hlim[q] ? hoff[q] + (unsigned)cb * SZ : OOB, buf_addr + (unsigned)(wv + NW * q) * 1024u);
-    };
-    auto issue_b = [&](unsigned stage_addr, int tap, int cb) {
-        const unsigned kadd = (unsigned)(tap * p.Ci + cb) * SZ;
-#pragma unroll
-        for (int q = 0; q < BP; ++q) buf_load_lds16(rsrc_w, b_off[q] + kadd, stage_addr + (unsigned)(q * RPP) * 128u + wbase);
-    };
+    // ---- reduction range of this split: chunks [c_begin, c_end)
+    const int nchunks_all = (p.Ci + BK - 1) / BK, cper = p.ks_per / 9;
+    const int c_begin = split * cper, c_end = min(nchunks_all, c_begin + cper);
+    const int last_cb = (c_end - 1) * BK;
+    const int ci2 = p.Ci * SZ;
 
-    // K range of this split: whole chunks (ks_per is a multiple of 9)
-    const int ks0 = split * p.ks_per, ks1 = min(p.nks, ks0 + p.ks_per);
-    if (ks0 < ks1) {
-        int cb = (ks0 / 9) * BK, tap = 0, cpar = 0;
-#pragma unroll
-        for (int q = 0; q < HPMAX; ++q) issue_halo_piece(q, smem_addr, cb);
-        // B ring of NSB stages: tiles ks+1 .. ks+NSB-1 are in flight while tile ks is consumed. c1 / c2 = LDS-DMA
-        // instructions this wave issued one / two steps ago: they may still be outstanding at the next wait.
-        int pf_tap = 0, pf_cb = cb;   // (tap, chunk base) of the next B tile to issue
-        int c1 = 0, c2 = 0;
-#pragma unroll
-        for (int s = 0; s < NSB - 1; ++s) {
-            int n = 0;
-            if (ks0 + s < ks1) {
-                issue_b(bring_addr + (unsigned)s * (BN * 128u), pf_tap, pf_cb);
-                n = BP;
-                if (++pf_tap == 9) { pf_tap = 0; pf_cb += BK; }
-            }
-            if (s > 0) { c2 = c1; c1 = n; }   // tile 0 itself must have landed at the first wait
-        }
-#ifdef L2I_PROF
-        unsigned long long pa = 0, pb = 0, pc = 0, pd = 0;
-#endif
-        for (int ks = ks0; ks < ks1; ++ks) {
-            const int it = ks - ks0;
-#ifdef L2I_PROF
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-#endif
-            {
-                const int allow = NSB >= 4 ? c1 + c2 : NSB == 3 ? c1 : 0;
-                switch (allow) {   // s_waitcnt takes an immediate
-                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-                    default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-                }
-            }
-#ifdef L2I_PROF
-            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-#endif
-            __builtin_amdgcn_s_barrier();   // everyone's part of tile ks (and, at tap 0, of the halo) landed; the stage and halo buffer refilled below are free
-            asm volatile("" ::: "memory");
-#ifdef L2I_PROF
-            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-#endif
-            // weights NSB-1 taps ahead, and one piece per wave of the NEXT chunk's halo
-            {
-                int n = 0;
-                if (ks + NSB - 1 < ks1) {
-                    issue_b(bring_addr + (unsigned)((it + NSB - 1) % NSB) * (BN * 128u), pf_tap, pf_cb);
-                    n = BP;
-                    if (++pf_tap == 9) { pf_tap = 0; pf_cb += BK; }
-                }
-                if (ks + 9 - tap < ks1 && tap < HPMAX && wv + NW * tap < p.halo_pieces) {   // a next chunk exists and this wave has a piece `tap`
-                    const unsigned nbuf = smem_addr + (unsigned)(cpar ^ 1) * halo_bytes;
-                    ++n;
-                    switch (tap) {   // (constant indices keep hoff / hlim in registers)
-                        case 0: issue_halo_piece(0, nbuf, cb + BK); break;
-                        case 1: issue_halo_piece(1, nbuf, cb + BK); break;
-                        case 2: issue_halo_piece(2, nbuf, cb + BK); break;
-                        case 3: issue_halo_piece(3, nbuf, cb + BK); break;
-                        case 4: issue_halo_piece(4, nbuf, cb + BK); break;
-                        case 5: issue_halo_piece(5, nbuf, cb + BK); break;
-                        default: issue_halo_piece(6, nbuf, cb + BK); break;
-                    }
-                }
-                c2 = c1; c1 = n;
-            }
-#ifdef L2I_PROF
-            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-#endif
-            // ---- MFMA step for (tap, chunk): A from the halo at the tap's shift, B from the ring
-            const char* hb = smem + (unsigned)cpar * halo_bytes;
-            const char* bs = bring + (unsigned)(it % NSB) * (BN * 128u);
-            const int ky = tap / 3, kx = tap - ky * 3;
-            int a_row[TM], a_swz[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                int hy, hx;
-                if (p.up2) { hy = ((a_py[i] + ky - 1) >> 1) + 1; hx = ((a_px[i] + kx - 1) >> 1) + 1; }
-                else { hy = a_py[i] + ky; hx = a_px[i] + kx; }
-                a_row[i] = (a_sp[i] * p.SUBH + hy * p.P + hx) * 128;
-                a_swz[i] = ((hx >> 1) + 4 * hy + 2 * a_sp[i]) & 7;
-            }
-            {   // all 16 fragment reads first, then the MFMAs (see Mma2::step)
-                bf16x8_t a[4][TM], b[4][TN];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[kk][i] = *reinterpret_cast<const bf16x8_t*>(hb + a_row[i] + (((kk * 2 + hh) ^ a_swz[i]) << 4));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[kk][j] = *reinterpret_cast<const bf16x8_t*>(bs + ig2_off<0>(brow + j * 32, kk * 2 + hh));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[kk][i]),
-                                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[kk][j]), acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#ifdef L2I_PROF
-            {
-                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-                pa += t1 - t0; pb += t2 - t1; pc += t3 - t2; pd += t4 - t3;
-            }
-#endif
-            if (++tap == 9) { tap = 0; cb += BK; cpar ^= 1; }
-        }
-#ifdef L2I_PROF
-        if (p.dbg && lane == 0) {
-            unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
-            d[0] = pa; d[1] = pb; d[2] = pc; d[3] = pd;
-        }
-#endif
+    bf16x8_t fa[2][4][TM], fb[2][4][TN];   // fragment register sets (only set 0 without PIPE)
+
+#define H2_READS(SET, TAP, STG)                                                                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                                 \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                 \
+            fa[SET][kk][i] = *reinterpret_cast<const bf16x8_t*>(smem + (a_addr[i][TAP] ^ (unsigned)(kk << 5)));        \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                 \
+            fb[SET][kk][j] = *reinterpret_cast<const bf16x8_t*>(smem + b_addr[j][kk] + (STG) * BSTAGE);                \
     }
-    conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total);
+#define H2_MFMA(SET, KK, I, J)                                                                                         \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                               \
+        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[SET][KK][J]),   /* weights first: transposed tile, see conv_epilogue */ \
+        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[SET][KK][I]), acc[I][J], 0, 0, 0)
+#define H2_MFMA4(SET, KK)                                                                                              \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) H2_MFMA(SET, KK, i_, j_); \
+    }
+    // One K-step. S = step within the unrolled pair of chunks (0..17): tap = S % 9, halo buffer = S / 9, stage = tap % 3.
+    // cb_cur: channel base of the current chunk; cb_nxt: of the chunk after it (clamped).
+#define H2_STEP(S, cb_cur, cb_nxt, DO_MFMA_PREV)                                                                       \
+    {                                                                                                                  \
+        constexpr int TAP = (S) % 9, HB = (S) / 9, STG = (S) % NSB;            /* 18 % NSB == 0 for NSB 2, 3 */        \
+        constexpr int AHEAD = NSB - 1;                                                                                 \
+        constexpr int TAP2 = (TAP + AHEAD) % 9, STG2 = ((S) + AHEAD) % NSB;                                            \
+        constexpr int SET = PIPE ? ((S)&1) : 0, PSET = PIPE ? (((S) + 1) & 1) : 0;                                     \
+        if (PIPE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSB == 3 ? BP : 0) : "memory");                                       \
+        if (!PIPE) { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) asm volatile("" : "+v"(a_addr[i_][TAP])); }   /* keep the 72 XOR-ed copies out of registers */ \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        H2_READS(SET, TAP, STG)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        const int cb2 = TAP + AHEAD >= 9 ? (cb_nxt) : (cb_cur);                                                        \
+        const unsigned kadd = (unsigned)(TAP2 * ci2 + cb2 * SZ);                                                       \
+        if (!PIPE || (DO_MFMA_PREV)) { H2_MFMA4(PSET, 0); }                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (TAP < HPMAX && TAP < nq) {                                                                                 \
+            const unsigned vo = (cb_nxt) < hlim[TAP] ? hoff[TAP] : OOB;                                                \
+            H2_DMA(rsrc_x, vo, (unsigned)((cb_nxt)*SZ), halo_w + (unsigned)(1 - HB) * halo_bytes + (unsigned)(NW * TAP) * 1024u); \
+        }                                                                                                              \
+        H2_DMA(rsrc_w, b_off[0], kadd, ring_w + STG2 * BSTAGE);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (!PIPE || (DO_MFMA_PREV)) { H2_MFMA4(PSET, 1); }                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (BP > 1) H2_DMA(rsrc_w, b_off[BP > 1 ? 1 : 0], kadd, ring_w + STG2 * BSTAGE + 1u * RPP * 128u);              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (!PIPE || (DO_MFMA_PREV)) { H2_MFMA4(PSET, 2); }                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (BP > 2) H2_DMA(rsrc_w, b_off[BP > 2 ? 2 : 0], kadd, ring_w + STG2 * BSTAGE + 2u * RPP * 128u);              \
+        if (BP > 3) H2_DMA(rsrc_w, b_off[BP > 3 ? 3 : 0], kadd, ring_w + STG2 * BSTAGE + 3u * RPP * 128u);              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (!PIPE || (DO_MFMA_PREV)) { H2_MFMA4(PSET, 3); }                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
+
+    if (c_begin < c_end) {
+        // prologue: the whole first halo, then the weight tiles of taps 0 and 1
+        {
+            const int cb0 = c_begin * BK;
+#pragma unroll
+            for (int q = 0; q < HPMAX; ++q)
+                if (q < nq) {
+                    const unsigned vo = cb0 < hlim[q] ? hoff[q] : OOB;
+                    H2_DMA(rsrc_x, vo, (unsigned)(cb0 * SZ), halo_w + (unsigned)(NW * q) * 1024u);
+                }
+#pragma unroll
+            for (int t = 0; t < NSB - 1; ++t) {
+                const unsigned kadd = (unsigned)(t * ci2 + cb0 * SZ);
+#pragma unroll
+                for (int q = 0; q < BP; ++q) H2_DMA(rsrc_w, b_off[q], kadd, ring_w + (unsigned)t * BSTAGE + (unsigned)(q * RPP) * 128u);
+            }
+        }
+        bool first = true;
+        int pending = 0;   // PIPE: fragment set holding the not-yet-multiplied last step
+        for (int c = c_begin; c < c_end; c += 2) {
+            const int cbA = c * BK;
+            const int cbB = min(cbA + BK, last_cb), cbC = min(cbA + 2 * BK, last_cb);
+            H2_STEP(0, cbA, cbB, !first)
+            H2_STEP(1, cbA, cbB, true)
+            H2_STEP(2, cbA, cbB, true)
+            H2_STEP(3, cbA, cbB, true)
+            H2_STEP(4, cbA, cbB, true)
+            H2_STEP(5, cbA, cbB, true)
+            H2_STEP(6, cbA, cbB, true)
+            H2_STEP(7, cbA, cbB, true)
+            H2_STEP(8, cbA, cbB, true)
+            first = false;
+            pending = 0;
+            // halo buffer flip for the second chunk of the pair (and back afterwards)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) a_addr[i][tap] += halo_bytes;
+            if (c + 1 < c_end) {
+                H2_STEP(9, cbB, cbC, true)
+                H2_STEP(10, cbB, cbC, true)
+                H2_STEP(11, cbB, cbC, true)
+                H2_STEP(12, cbB, cbC, true)
+                H2_STEP(13, cbB, cbC, true)
+                H2_STEP(14, cbB, cbC, true)
+                H2_STEP(15, cbB, cbC, true)
+                H2_STEP(16, cbB, cbC, true)
+                H2_STEP(17, cbB, cbC, true)
+                pending = 1;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) a_addr[i][tap] -= halo_bytes;
+        }
+        if (PIPE) {   // the last step's fragments are still waiting for their MFMAs
+            if (pending) { H2_MFMA4(1, 0); H2_MFMA4(1, 1); H2_MFMA4(1, 2); H2_MFMA4(1, 3); }
+            else { H2_MFMA4(0, 0); H2_MFMA4(0, 1); H2_MFMA4(0, 2); H2_MFMA4(0, 3); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped extra tiles must not land after the LDS is reused / the wave ends
+    }
+#undef H2_STEP
+#undef H2_MFMA4
+#undef H2_MFMA
+#undef H2_READS
+    if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_total, smem);
+    else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total);
 }
 
 static int ilog2(int v) {
@@ -517,8 +648,6 @@ static int ilog2(int v) {
     return s;
 }
 
-static unsigned long long* g_conv_dbg = nullptr;   // profiling builds (-DL2I_PROF): per-wave phase cycle totals of the halo kernel
-extern "C" int l2i_debug_set_buffer(void* p) { g_conv_dbg = (unsigned long long*)p; return L2I_OK; }
 static int g_split_target = 512;   // tuning hook: workgroups a split-K launch aims for
 // Launch one instantiation; LDS rings above 64 KB need the opt-in attribute (set once per instantiation).
 template <typename T, int BM, int BN, int WM, int WN, int NS, int HK = 0>
@@ -561,8 +690,8 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
 
 // Halo kernel launch (bf16, 3x3, Ci >= 64, Wo >= 8, no upsample into 8-wide maps). Returns -100 when the shape is
 // not covered so that the caller falls through to the generic kernel.
-template <int BM, int BN, int WM, int WN, int NSB>
-static int launch_halo(ConvArgs a, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, int NSB, bool PIPE>
+static int launch_halo2(ConvArgs a, hipStream_t stream) {
     a.PH = BM / a.PW;
     a.PHs = a.PH < a.Ho ? a.PH : a.Ho;
     a.sub_shift = ilog2(a.PHs);
@@ -597,10 +726,10 @@ static int launch_halo(ConvArgs a, hipStream_t stream) {
     }
     static bool ready = false;
     if (!ready) {
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BM, BN, WM, WN, NSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ready = true;
     }
-    hipLaunchKernelGGL((conv_halo_kernel<BM, BN, WM, WN, NSB>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL((conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
     return l2i_check_launch();
 }
 
@@ -647,20 +776,17 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     const long long M = (long long)a.B * a.Ho * a.Wo;
     if (sizeof(T) == 2 && a.KH == 3 && a.Ci >= 64 && !a.lin && a.Wo >= 8 && !(a.up2 && a.Wo < 16) && a.Ho >= 2 &&
         (g_conv_cfg_override < 0 || g_conv_cfg_override >= 10)) {
-        // halo kernel: 256x128 / 8 waves where its grid still fills the chip (and always for 8-wide maps, whose
-        // 128-row tile would not fit two workgroups per CU), else 128x128 or 128x64 / 4 waves, two workgroups per CU
-        const long long t256 = ((M + 255) / 256) * ((a.Co + 127) / 128);
-        int hc = a.Co <= 64 ? 1 : ((a.Wo < 16 || t256 >= 256) ? 2 : 0);
+        // 128x128 tiles (two workgroups per CU, 2-stage weight ring) when they make at least one full wave of
+        // workgroups; otherwise 128x64 tiles (twice the workgroups, 3-stage ring). Measured: scratch/conv_tune.py.
+        const long long t128h = ((M + 127) / 128) * ((a.Co + 127) / 128);
+        int hc = (a.Co <= 64 || t128h < 512 || a.Wo < 16) ? 1 : 0;   // (8-wide maps: two 8x8 sub-patch halos + a 128-wide ring exceed 80 KB)
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
-        if (a.Wo < 16 && hc < 2) hc = 2;
         int rc;
         switch (hc) {
-            case 1: rc = launch_halo<128, 64, 2, 2, 2>(a, stream); break;
-            case 2: rc = launch_halo<256, 128, 4, 2, 2>(a, stream); break;
-            case 3: rc = launch_halo<256, 128, 4, 2, 4>(a, stream); break;    // 3 weight tiles in flight
-            case 4: rc = launch_halo<128, 128, 2, 2, 4>(a, stream); break;    // one workgroup per CU, deep ring
-            case 5: rc = launch_halo<256, 128, 4, 2, 3>(a, stream); break;
-            default: rc = launch_halo<128, 128, 2, 2, 2>(a, stream); break;
+            case 1: rc = launch_halo2<128, 64, 2, 2, 3, false>(a, stream); break;
+            case 2: rc = launch_halo2<256, 128, 4, 2, 2, false>(a, stream); break;
+            case 3: rc = launch_halo2<128, 128, 2, 2, 3, false>(a, stream); break;   // one workgroup per CU
+            default: rc = launch_halo2<128, 128, 2, 2, 2, false>(a, stream); break;
         }
         if (rc != -100) return rc;
     }
@@ -698,7 +824,7 @@ extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, c
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out; a.out_op = out_op; a.out_op_raw = out_op_raw; a.relu_mask = relu_mask;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.relu_op = relu_op ? 1 : 0;
-    a.Kpad = Kpad; a.alpha = alpha; a.dbg = g_conv_dbg;
+    a.Kpad = Kpad; a.alpha = alpha;
     if (dtype == 0) return launch_conv<float>(a, (hipStream_t)stream);
     if (dtype == 1) return launch_conv<bf16_t>(a, (hipStream_t)stream);
     return L2I_ERR_ARG;
@@ -710,8 +836,8 @@ extern "C" int l2i_debug_occupancy(int which, int lds_bytes) {
     hipError_t e = hipSuccess;
     switch (which) {
         case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_igemm_kernel<bf16_t, 128, 128, 2, 2, 2, 0>, 256, lds_bytes); break;
-        case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_halo_kernel<128, 128, 2, 2, 2>, 256, lds_bytes); break;
-        case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_halo_kernel<256, 128, 4, 2, 2>, 512, lds_bytes); break;
+        case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_halo2_kernel<128, 128, 2, 2, 2, false>, 256, lds_bytes); break;
+        case 11: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_halo2_kernel<128, 64, 2, 2, 3, false>, 256, lds_bytes); break;
         default: break;
     }
     return e == hipSuccess ? n : -(int)e;

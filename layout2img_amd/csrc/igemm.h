@@ -109,8 +109,8 @@ template <> struct Mma2<bf16_t> {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[kk][i]),
-                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[kk][j]), acc[i][j], 0, 0, 0);
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[kk][j]),   // weights first: the accumulator is
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[kk][i]), acc[i][j], 0, 0, 0);   // the transposed tile (conv_epilogue)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -134,7 +134,7 @@ template <> struct Mma2<float> {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][t], a[i][t], acc[i][j], 0, 0, 0);   // transposed tile
         }
     }
 };
