@@ -214,7 +214,7 @@ __device__ __forceinline__ bf16x8_t wg_frag(const char* tile, int pixbase, int c
     return out;
 }
 
-template <int BMO>
+template <int BMO, bool FAST>   // FAST: no pool / upsample and M a multiple of 64 (straight-line address code)
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lgW, int lgH) {
     constexpr int BNK = 128, BK = 64;
     constexpr int RSA = BMO * 2, RSB = BNK * 2;
@@ -250,33 +250,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
     const bool b_on = kc < p.K;
 
     // LDS-DMA through buffer descriptors (inline asm, see igemm.h): masked lanes use an out-of-range offset -> zeros.
+    // The loop below is written to ISSUE few instructions (a wave issues one per ~4 cycles; the first version spent
+    // 16.6 VALU/SALU/LDS/VMEM instructions per MFMA against the ~5 that fit under a 32-cycle MFMA):
+    //  * dY rows are contiguous in the pixel index (no pool): the per-lane offset is a constant and the step's base goes
+    //    in the instruction's SGPR offset; rows past the end of the tensor are out of the descriptor's range = zeros,
+    //    which also zeroes the products of whatever the im2col side fetches there;
+    //  * the im2col offset is linear in the pixel index, only the border test needs the pixel's (x, y);
+    //  * two steps are unrolled so the LDS stage is an immediate; fragment addresses are loop constants; all 32
+    //    transposing reads of a step are issued before its 16 MFMAs.
     const u32x4_t rs_dy = make_rsrc(p.dy, p.dy_bytes), rs_x = make_rsrc(p.x, p.x_bytes);
+    // The range check of a buffer access looks at the LANE offset only (not at the SGPR offset), so fast-path lane
+    // offsets must be non-negative and may not rely on the check for the step base: the im2col descriptor starts
+    // (Wo + 1) pixels BEFORE x (lanes that would read there are masked by the border test), and steps that cross the
+    // end of the tensor take the general path.
+    const unsigned x_shift = (unsigned)((p.Wo + 1) * p.Ci) * 2u;
+    const u32x4_t rs_xs = make_rsrc(reinterpret_cast<const char*>(p.x) - x_shift, p.x_bytes + x_shift);
     const unsigned smem_addr = lds_addr_of(smem);
     constexpr unsigned OOB = 0x80000000u;
+    unsigned a_base[A_Q];      // fast path: byte offset of this lane's chunk for pixel (prow + a_row), without the step base
+    int b_mlane[4];
+    unsigned b_base[4];        // fast path: ((ky-1)*Wo + (kx-1) + prow + b_row) * Ci + b_ci, in bytes (may wrap below 0)
+#pragma unroll
+    for (int q = 0; q < A_Q; ++q)
+        a_base[q] = a_on ? (unsigned)((wv * 16 + q * A_ROWS + a_row) * p.Co + a_chan) * 2u : OOB;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        b_mlane[q] = wv * 16 + q * 4 + b_row;
+        b_base[q] = (unsigned)(((b_ky - pad) * p.Wo + (b_kx - pad) + b_mlane[q]) * p.Ci + b_ci) * 2u + x_shift;
+    }
+    const unsigned co2 = (unsigned)p.Co * 2u, ci2 = (unsigned)p.Ci * 2u;
     auto issue = [&](int mstep, unsigned stage) {   // stage: LDS byte address of the stage
 #pragma unroll
         for (int q = 0; q < A_Q; ++q) {
-            const int prow = wv * 16 + q * A_ROWS;   // wave-uniform first pixel row of this instruction
-            const int m = mstep + prow + a_row;
-            unsigned voff = OOB;
-            if (a_on && m < m_end) {
+            const unsigned dst = stage + (unsigned)(wv * 16 + q * A_ROWS) * RSA;
+            if constexpr (FAST) {
+                L2I_DMA16_S(rs_dy, a_base[q], (unsigned)mstep * co2, dst);
+            } else {
+                const int m = mstep + wv * 16 + q * A_ROWS + a_row;
                 const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1), b = m >> (lgW + lgH);
-                voff = (unsigned)(((b * Hd + (y >> p.pool2)) * Wd + (x >> p.pool2)) * p.Co + a_chan) * 2u;
+                const unsigned off = (unsigned)(((b * Hd + (y >> p.pool2)) * Wd + (x >> p.pool2)) * p.Co + a_chan) * 2u;
+                L2I_DMA16_S(rs_dy, (a_on && m < m_end) ? off : OOB, 0u, dst);   // (select, not a branch: keeps the loop straight-line)
             }
-            buf_load_lds16(rs_dy, voff, stage + prow * RSA);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int prow = wv * 16 + q * 4;
-            const int m = mstep + prow + b_row;
-            unsigned voff = OOB;
-            if (b_on && m < m_end) {
-                const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1), b = m >> (lgW + lgH);
-                const int yy = y + b_ky - pad, xx = x + b_kx - pad;
-                if (yy >= 0 && yy < p.Ho && xx >= 0 && xx < p.Wo)
-                    voff = (unsigned)(((b * p.Hi + (yy >> p.up2)) * p.Wi + (xx >> p.up2)) * p.Ci + b_ci) * 2u;
+            const unsigned dst = stage + BK * RSA + (unsigned)(wv * 16 + q * 4) * RSB;
+            const int m = mstep + b_mlane[q];
+            const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1);
+            const int yy = y + b_ky - pad, xx = x + b_kx - pad;
+            const bool in = b_on && (unsigned)yy < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo;
+            if constexpr (FAST) {
+                L2I_DMA16_S(rs_xs, in ? b_base[q] : OOB, (unsigned)mstep * ci2, dst);
+            } else {
+                const int b = m >> (lgW + lgH);
+                const unsigned off = (unsigned)(((b * p.Hi + (yy >> p.up2)) * p.Wi + (xx >> p.up2)) * p.Ci + b_ci) * 2u;
+                L2I_DMA16_S(rs_x, (in && m < m_end) ? off : OOB, 0u, dst);
             }
-            buf_load_lds16(rs_x, voff, stage + BK * RSA + prow * RSB);
         }
     };
 
@@ -289,31 +318,73 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int wrow = (wave >> 1) * (BMO / 2), wcol = (wave & 1) * 64;
-    if (m_begin < m_end) {
-        issue(m_begin, smem_addr);
-        int it = 0;
-        for (int ms = m_begin; ms < m_end; ms += BK, ++it) {
-            char* cur = smem + (it & 1) * STAGE;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile `it` landed ...
-            __builtin_amdgcn_s_barrier();                       // ... everyone's did, and the other stage is free
-            if (ms + BK < m_end) issue(ms + BK, smem_addr + ((it + 1) & 1) * STAGE);   // in flight under the MFMAs below
+    // fragment read addresses (stage-relative): piece (row 8h + (t>>2), 4-channel block) of the k16 sub-step 0, r = 0;
+    // sub-step kk adds 16 rows and r adds 4 rows -- neither changes the row's swizzle, so they are immediates
+    unsigned fa_addr[TM], fb_addr[TN];
+    {
+        const int t = lane & 15, cb = ((lane >> 4) & 1) * 16, h = lane >> 5;
+        const int prow0 = 8 * h + (t >> 2);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bf16x8_t a[TM], b[TN];
+        for (int i = 0; i < TM; ++i) {
+            const int ch = wrow + i * 32 + cb + (t & 3) * 4;
+            fa_addr[i] = (unsigned)(prow0 * RSA + (((ch >> 3) ^ wg_swz<RSA>(prow0)) << 4) + ((ch >> 2) & 1) * 8);
+        }
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = wg_frag<RSA>(cur, kk * 16, wrow + i * 32, lane);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = wg_frag<RSB>(cur + BK * RSA, kk * 16, wcol + j * 32, lane);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a[i]),
-                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b[j]), acc[i][j], 0, 0, 0);
-            }
+        for (int j = 0; j < TN; ++j) {
+            const int ch = wcol + j * 32 + cb + (t & 3) * 4;
+            fb_addr[j] = (unsigned)(BK * RSA + prow0 * RSB + (((ch >> 3) ^ wg_swz<RSB>(prow0)) << 4) + ((ch >> 2) & 1) * 8);
         }
     }
+#define WG_TR(ADDR) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)((__attribute__((address_space(3))) char*)smem + (ADDR)))
+#define WG_STEP(STG)                                                                                                  \
+    {                                                                                                                 \
+        s16x4_t ra[4][TM][2], rb[4][TN][2];                                                                           \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int r = 0; r < 2; ++r)              \
+                ra[kk][i][r] = WG_TR(fa_addr[i] + (STG) * STAGE + (kk * 16 + 4 * r) * RSA);                           \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int r = 0; r < 2; ++r)              \
+                rb[kk][j][r] = WG_TR(fb_addr[j] + (STG) * STAGE + (kk * 16 + 4 * r) * RSB);                           \
+        }                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                              \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {           \
+                bf16x8_t fa, fb;                                                                                      \
+                fa[0] = ra[kk][i][0][0]; fa[1] = ra[kk][i][0][1]; fa[2] = ra[kk][i][0][2]; fa[3] = ra[kk][i][0][3];   \
+                fa[4] = ra[kk][i][1][0]; fa[5] = ra[kk][i][1][1]; fa[6] = ra[kk][i][1][2]; fa[7] = ra[kk][i][1][3];   \
+                fb[0] = rb[kk][j][0][0]; fb[1] = rb[kk][j][0][1]; fb[2] = rb[kk][j][0][2]; fb[3] = rb[kk][j][0][3];   \
+                fb[4] = rb[kk][j][1][0]; fb[5] = rb[kk][j][1][1]; fb[6] = rb[kk][j][1][2]; fb[7] = rb[kk][j][1][3];   \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                  \
+                    __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa),                               \
+                    __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb), acc[i][j], 0, 0, 0);          \
+            }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
+    if (m_begin < m_end) {
+        // (whole pairs of steps in the loop, an odd last step after it: a conditional second step inside the loop makes
+        // the compiler merge two accumulator register sets with 64 AGPR<->VGPR copies per iteration)
+        issue(m_begin, smem_addr);
+        int ms = m_begin;
+        for (; ms + 2 * BK <= m_end; ms += 2 * BK) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tile landed ...
+            __builtin_amdgcn_s_barrier();                       // ... everyone's did, and the other stage is free
+            asm volatile("" ::: "memory");
+            issue(ms + BK, smem_addr + STAGE);                  // in flight under the MFMAs below
+            WG_STEP(0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ms + 2 * BK < m_end) issue(ms + 2 * BK, smem_addr);
+            WG_STEP(1)
+        }
+        if (ms < m_end) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            WG_STEP(0)
+        }
+    }
+#undef WG_STEP
+#undef WG_TR
 
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -377,10 +448,14 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
         while ((1 << lgW) < a.Wo) ++lgW;
         while ((1 << lgH) < a.Ho) ++lgH;
         const size_t lds2 = (size_t)2 * 64 * (BMO * 2 + 256);
-        if (BMO == 64)
-            hipLaunchKernelGGL((conv_wgrad_dma_kernel<64>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
-        else
-            hipLaunchKernelGGL((conv_wgrad_dma_kernel<128>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+        const bool fast = !a.pool2 && !a.up2 && a.M % 64 == 0;
+        if (BMO == 64) {
+            if (fast) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, true>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, false>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+        } else {
+            if (fast) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, true>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, false>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+        }
         return l2i_check_launch();
     }
     const size_t lds = (size_t)(BMO + 128) * IG_ROWB;

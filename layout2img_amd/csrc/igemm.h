@@ -169,6 +169,11 @@ __device__ __forceinline__ u32x4_t make_rsrc(const void* base, unsigned nbytes) 
 __device__ __forceinline__ void buf_load_lds16(u32x4_t rsrc, unsigned voff, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
 }
+// the same with an SGPR byte offset added to the lane offset (no VALU for the per-step part of an address)
+#define L2I_DMA16_S(rsrc, voff, soff, ldsaddr)                                                                        \
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), \
+                 "s"(soff), "s"(ldsaddr)                                                                              \
+                 : "memory")
 __device__ __forceinline__ unsigned lds_addr_of(const char* p) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
 }
