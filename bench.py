@@ -107,8 +107,16 @@ def main():
             s = ops.TIMER.summary()["conv_igemm"]
             peak = 2500.0 if op_dtype == torch.bfloat16 else 157.3
             ach = s["work"] / (s["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="conv_igemm_kernel (fwd + dgrad launches)", achieved=round(ach, 2), peak=peak,
-                        unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None, launches_per_step=s["launches"], timed_steps=1,
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")   # PMC pass of this same command (scratch/traffic.sh)
+            if op_dtype == torch.bfloat16 and args.size == 128 and os.path.exists(tpath):
+                traffic = round(json.load(open(tpath))["conv(fwd+dgrad)"]["traffic_bytes_per_launch"])
+                traffic_src = "profiles/r01_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE; separate passes)"
+            roof = dict(bound="mfma", kernel="l2i_conv2d_fwd launches (conv_halo2_kernel + conv_igemm_kernel), forward and data-gradient",
+                        achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
+                        traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
+                        algorithmic_bytes_per_launch=round(s["bytes"] / s["launches"]),
+                        launches_per_step=s["launches"], timed_steps=1,
                         avg_launch_us=round(1e3 * s["ms"] / s["launches"], 2),
                         gflop_per_launch=round(s["work"] / s["launches"] / 1e9, 3))
             w = ops.TIMER.summary().get("conv_wgrad")

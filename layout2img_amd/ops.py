@@ -91,9 +91,9 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
 
-    def time(self, name, work):
+    def time(self, name, work, nbytes=0.0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.setdefault(name, []).append((a, b, work))
+        self.records.setdefault(name, []).append((a, b, work, nbytes))
         a.record()
         return b
 
@@ -101,8 +101,8 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for name, recs in self.records.items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-            out[name] = dict(launches=len(recs), ms=ms, work=float(sum(w for _, _, w in recs)))
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            out[name] = dict(launches=len(recs), ms=ms, work=float(sum(r[2] for r in recs)), bytes=float(sum(r[3] for r in recs)))
         return out
 
 
@@ -128,7 +128,10 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
         assert relu_mask.shape == (B, Hq, Wq, co), (relu_mask.shape, (B, Hq, Wq, co))
     end = None
     if TIMER is not None:
-        end = TIMER.time("conv_igemm", flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci)
+        esz = x_op.element_size()   # algorithmic bytes: every operand and result once
+        nbytes = (x_op.numel() + wpack.numel()) * esz + B * Hq * Wq * co * (
+            4 * (want_f32 + (res is not None)) + esz * (want_op + want_raw + (relu_mask is not None)))
+        end = TIMER.time("conv_igemm", flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci, nbytes)
     _lib.call("l2i_conv2d_fwd", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
               _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
               float(alpha), _stream())
