@@ -239,8 +239,8 @@ def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, 
     O = mask.shape[1] if mask is not None else 0
     dev = x.device
     G = sums.shape[0]
-    s1 = _zeros((G, C), dev)
-    s2 = _zeros((G, C), dev)
+    s12 = _zeros((2, G, C), dev)   # one buffer: the data-parallel exchange reduces both halves in one message, in place
+    s1, s2 = s12[0], s12[1]
     dw = db = dm = None
     psb = pso = 0
     if spec.mode == 0:

@@ -58,10 +58,17 @@ def sync_bn_stats(a, b, count):
     ws = world_size()
     if ws == 1:
         return count
-    buf = torch.cat((a.reshape(-1), b.reshape(-1)))
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-    a.copy_(buf[:a.numel()].view_as(a))
-    b.copy_(buf[a.numel():].view_as(b))
+    adjacent = (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.device == b.device and
+                a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and
+                b.storage_offset() == a.storage_offset() + a.numel())
+    if adjacent:   # the usual case: both halves of one statistics buffer -> reduce it in place, no staging copies
+        both = a.new_empty(0).set_(a.untyped_storage(), a.storage_offset(), (a.numel() + b.numel(),), (1,))
+        dist.all_reduce(both, op=dist.ReduceOp.SUM)
+    else:
+        buf = torch.cat((a.reshape(-1), b.reshape(-1)))
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        a.copy_(buf[:a.numel()].view_as(a))
+        b.copy_(buf[a.numel():].view_as(b))
     return None if count is None else count * ws
 
 
