@@ -144,6 +144,10 @@ int l2i_cast_op(const float* x, void* raw, void* act, long long n, int dtype, vo
 /* ReLU backward on f32 streams: out = g*[mask>0] (+ add). */
 int l2i_relu_bwd(const float* g, const float* mask, const float* add, float* out, long long n, void* stream);
 
+/* Bilinear resize (align_corners = False) of N planar h x w maps to H x W: F.interpolate(mask, size, mode="bilinear")
+ * on the object masks (model/norm_module.py:172-173, model/resnet_generator_app_v2.py:465-470). */
+int l2i_resize_bilinear(const float* in, float* out, long long N, int h, int w, int H, int W, void* stream);
+
 /* Appearance head of the discriminator without the (R, C, C) Gram matrices
  * (model/rcnn_discriminator_app.py:148-157; see csrc/misc.hip): x [R][HW][C] pre-ReLU features, w [C] the first half
  * of the head's Linear(2C -> 1) weight. fwd: out[r] += (1/C^2) sum_p (sum_c a)(sum_c a w), a = relu(x); keeps the two

@@ -33,6 +33,7 @@ SIGNATURES = {
     "l2i_cast_op": [_p, _p, _p, _ll, _i, _p],
     "l2i_set_wgrad_blocks": [_i],
     "l2i_debug_occupancy": [_i, _i],
+    "l2i_resize_bilinear": [_p, _p, _ll, _i, _i, _i, _i, _p],
     "l2i_gram_head_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "l2i_gram_head_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "l2i_relu_bwd": [_p, _p, _p, _p, _ll, _p],

@@ -667,7 +667,8 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     int splits = 1;
     if (a.out && !a.out_op && !a.out_op_raw && nblk < 192 && nks >= 16) {
         splits = (g_split_target + nblk - 1) / nblk;
-        if (splits > nks / 16) splits = nks / 16;   // >= 16 K-steps per split: shorter ones are all prologue + atomic epilogue
+        const int min_steps = nblk < 32 ? 4 : 16;   // >= 16 K-steps per split (shorter ones are all prologue + atomic epilogue), except for the
+        if (splits > nks / min_steps) splits = nks / min_steps;   // handful-of-tiles Linear layers, which otherwise run on 6 CUs
         if (splits < 1) splits = 1;
     }
     a.ks_per = (nks + splits - 1) / splits;

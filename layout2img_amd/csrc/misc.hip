@@ -259,4 +259,36 @@ extern "C" int l2i_gram_head_bwd(const float* x, const float* w, const float* s_
     return l2i_check_launch();
 }
 
+// ---------------------------------------------------------------- bilinear resize of planar maps (align_corners = False)
+// F.interpolate(mask, size=(H, W), mode="bilinear") as used on the (b, o, 64, 64) object masks at every ISLA norm and
+// stage-mask blend (reference model/norm_module.py:172-173, model/resnet_generator_app_v2.py:465-470):
+//   src = max((dst + 0.5) * in/out - 0.5, 0); i0 = floor(src); i1 = min(i0 + 1, in - 1); lerp.
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, long long N,
+                                                              int h, int w, int H, int W) {
+    const long long total = N * H * W;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const long long n = i / ((long long)W * H);
+        const float fy = fmaxf(((float)y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)x + 0.5f) * sx - 0.5f, 0.f);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* p = in + n * h * w;
+        const float top = p[y0 * w + x0] * (1.f - lx) + p[y0 * w + x1] * lx;
+        const float bot = p[y1 * w + x0] * (1.f - lx) + p[y1 * w + x1] * lx;
+        out[i] = top * (1.f - ly) + bot * ly;
+    }
+}
+
+extern "C" int l2i_resize_bilinear(const float* in, float* out, long long N, int h, int w, int H, int W, void* stream) {
+    if (!in || !out || N < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return L2I_ERR_ARG;
+    const long long total = N * H * W;
+    if (total == 0) return L2I_OK;
+    long long nblk = (total + 255) / 256;
+    if (nblk > 8192) nblk = 8192;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, in, out, N, h, w, H, W);
+    return l2i_check_launch();
+}
+
 extern "C" int l2i_version(void) { return 1; }

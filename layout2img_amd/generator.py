@@ -104,7 +104,7 @@ def resample_matrix(kind, n_in, n_out, device):
 
 
 def _resize_mask(mask, H, W):
-    return mask if mask.shape[-2:] == (H, W) else F.interpolate(mask, size=(H, W), mode="bilinear")
+    return mask if mask.shape[-2:] == (H, W) else ops.resize_bilinear(mask, H, W)
 
 
 class PSPModule(nn.Module):
@@ -378,7 +378,7 @@ class ResnetGenerator128_context(_GeneratorBase):
         seman = torch.sigmoid(torch.gather(stage_logits, 3, idx)).permute(0, 3, 1, 2)
         seman = seman * F.interpolate(bbox_mask_, size=(H, W), mode="nearest")
         a = torch.gather(torch.sigmoid(alpha).expand(b, -1, -1), dim=1, index=y.view(b, o, 1)).unsqueeze(-1)
-        return (F.interpolate(bmask, size=(H, W), mode="bilinear") * (1 - a) + seman * a).contiguous()
+        return (_resize_mask(bmask, H, W) * (1 - a) + seman * a).contiguous()
 
     def forward(self, z, bbox, z_im=None, y=None, taps=None):
         if not z.is_cuda:

@@ -529,6 +529,29 @@ def gram_head(x, w):
     return GramHeadFn.apply(x, w)
 
 
+class ResizeBilinearFn(Function):
+    """F.interpolate(x, size=(H, W), mode="bilinear") for planar (b, o, h, w) f32 maps; the (cheap) backward is
+    torch's own adjoint kernel."""
+
+    @staticmethod
+    def forward(ctx, x, H, W):
+        _chk(x, torch.float32)
+        b, o, h, w = x.shape
+        out = torch.empty((b, o, H, W), dtype=torch.float32, device=x.device)
+        _lib.call("l2i_resize_bilinear", x.data_ptr(), out.data_ptr(), b * o, h, w, H, W, _stream())
+        ctx.in_shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, o, h, w = ctx.in_shape
+        return torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), [g.shape[2], g.shape[3]], [b, o, h, w], False), None, None
+
+
+def resize_bilinear(x, H, W):
+    return ResizeBilinearFn.apply(x.contiguous(), H, W)
+
+
 class L1Fn(Function):
     @staticmethod
     def forward(ctx, a, b, weight):

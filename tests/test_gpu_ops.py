@@ -513,3 +513,21 @@ def test_norm_act_standalone():
     xm = x.reshape(-1, 104)
     assert float((rm.cpu() - 0.1 * xm.mean(0)).abs().max()) < 1e-5
     assert float((rv.cpu() - (0.9 + 0.1 * xm.var(0, unbiased=True))).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("case", [(3, 5, 64, 64, 128, 128), (2, 8, 64, 64, 32, 32), (1, 2, 64, 64, 4, 4), (2, 3, 16, 16, 64, 64)])
+def test_resize_bilinear(case):
+    """l2i_resize_bilinear == F.interpolate(mode="bilinear", align_corners=False), forward and backward"""
+    from layout2img_amd import ops
+    b, o, h, w, H, W = case
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(b, o, h, w, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr, size=(H, W), mode="bilinear")
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xg = x.to(_dev()).requires_grad_(True)
+    out = ops.resize_bilinear(xg, H, W)
+    out.backward(dy.to(_dev()))
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-6
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) < 1e-5
