@@ -160,27 +160,43 @@ __device__ __forceinline__ void store8(T* dst, const float (&v)[8]) {
 }
 
 template <typename T>
+__device__ __forceinline__ void store8t(T* dst, const T (&v)[8]) {   // 8 already-converted operand values
+    if constexpr (sizeof(T) == 2) {
+        uint4 pk;
+        pk.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+        pk.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+        pk.z = (uint32_t)v[4] | ((uint32_t)v[5] << 16);
+        pk.w = (uint32_t)v[6] | ((uint32_t)v[7] << 16);
+        *reinterpret_cast<uint4*>(dst) = pk;
+    } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                       const float* __restrict__ params, const float* __restrict__ norms,
                                                       T* __restrict__ packed, int training) {
-    extern __shared__ float tile[];   // [64][RUN + 1]
+    extern __shared__ __attribute__((aligned(16))) char tile_raw[];
+    T* tile = reinterpret_cast<T*>(tile_raw);   // [64][RUN + 2] in the OPERAND type: 37 KB for bf16 -> four workgroups per CU in flight
     const int* e = table + 3 * blockIdx.x;
     const int layer = e[0];
     const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Co_p = (int)LF(6), Ci_p = (int)LF(7);
     const int taps = KH * KH;
     const int TCI = taps == 1 ? 256 : 32;
-    const int RUN = TCI * taps, RUNP = RUN + 1;
+    const int RUN = TCI * taps, RUNP = RUN + 2;
     const int co0 = e[1] * PK_TCO, ci0 = e[2] * TCI;
     const int nco = min(PK_TCO, Co - co0), nrun = min(TCI, Ci - ci0) * taps;   // valid rows / valid floats per row (may be <= 0)
     const float inv = 1.f / layer_sigma(L, norms, layer, training);
     const float* W = params + LF(0);
-#pragma unroll 8
+#pragma unroll 12
     for (int idx = threadIdx.x; idx < PK_TCO * RUN; idx += 256) {
         const int row = idx / RUN, j = idx - row * RUN;
         float v = 0.f;
         if (row < nco && j < nrun) v = W[((size_t)(co0 + row) * Ci + ci0) * taps + j] * inv;
-        tile[row * RUNP + j] = v;
+        tile[row * RUNP + j] = OpT<T>::from(v);
     }
     __syncthreads();
     // forward pack
@@ -193,10 +209,10 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restric
             const int tap = rest % taps, row = rest / taps;
             const int co = co0 + row, ci = ci0 + 8 * c8;
             if (co >= Co || ci >= Ci_p) continue;
-            float v[8];
+            T v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = tile[row * RUNP + (8 * c8 + j) * taps + tap];
-            store8<T>(dst + (size_t)co * Kpad + tap * Ci_p + ci, v);
+            store8t<T>(dst + (size_t)co * Kpad + tap * Ci_p + ci, v);
         }
     }
     // dgrad pack (taps flipped)
@@ -208,10 +224,10 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restric
             const int tap = rest % taps, cil = rest / taps;
             const int ci = ci0 + cil, co = co0 + 8 * co8;
             if (ci >= Ci || co >= Co_p) continue;
-            float v[8];
+            T v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = tile[(8 * co8 + j) * RUNP + cil * taps + tap];
-            store8<T>(dst + (size_t)ci * Kpad_d + (taps - 1 - tap) * Co_p + co, v);
+            store8t<T>(dst + (size_t)ci * Kpad_d + (taps - 1 - tap) * Co_p + co, v);
         }
     }
 }
@@ -346,7 +362,7 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
         hipLaunchKernelGGL(sn_wv_kernel, dim3(n_wv), dim3(256), 0, stream, layers, tab_wv, params, sn_state, pass_uv, norms,
                            training);
     if (n_pack > 0) {
-        constexpr size_t lds = sizeof(float) * PK_TCO * (32 * 9 + 1);   // >= 64 * (256 + 1)
+        const size_t lds = (dtype == 0 ? sizeof(float) : sizeof(bf16_t)) * PK_TCO * (32 * 9 + 2);   // >= 64 * (256 + 2) elements
         static bool ready = false;
         if (!ready) {
             (void)hipFuncSetAttribute((const void*)sn_pack_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
