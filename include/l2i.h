@@ -134,9 +134,11 @@ int l2i_hinge_fwd_bwd(const float* x, const int* valid, int n, int mode, float w
 /* L1 pixel loss with fused backward (train_context_app_v2.py:143,184). */
 int l2i_l1_fwd_bwd(const float* a, const float* b, long long n, float weight, float* loss_out, float* grad, void* stream);
 
-/* torch.optim.Adam step over one flat buffer (train_context_app_v2.py:121,127,174,189). */
+/* torch.optim.Adam step over one flat buffer (train_context_app_v2.py:121,127,174,189). step_ptr (optional): device
+ * int holding the step count t >= 1, read by the kernel instead of `step` -- lets a captured HIP graph of the whole
+ * iteration be replayed with the correct bias corrections. */
 int l2i_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
-                  int step, float grad_scale, void* stream);
+                  int step, float grad_scale, const int* step_ptr, void* stream);
 
 /* f32 stream -> T operand copies (raw and/or ReLU'd). */
 int l2i_cast_op(const float* x, void* raw, void* act, long long n, int dtype, void* stream);

@@ -71,7 +71,13 @@ extern "C" int l2i_l1_fwd_bwd(const float* a, const float* b, long long n, float
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n4, float b1, float b2, float eps,
-                                                   float step_size, float inv_sqrt_bc2, float grad_scale) {
+                                                   float step_size, float inv_sqrt_bc2, float grad_scale, float lr,
+                                                   const int* __restrict__ step_ptr) {
+    if (step_ptr) {   // step count kept on the device (graph-captured iterations): same double-precision bias corrections
+        const double t = (double)*step_ptr;
+        step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -93,14 +99,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 extern "C" int l2i_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                             float eps, int step, float grad_scale, void* stream) {
-    if (!p || !g || !m || !v || n <= 0 || n % 4 || step < 1) return L2I_ERR_ARG;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+                             float eps, int step, float grad_scale, const int* step_ptr, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || n % 4 || (!step_ptr && step < 1)) return L2I_ERR_ARG;
+    float step_size = 0.f, inv_sqrt_bc2 = 0.f;
+    if (!step_ptr) {
+        const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+        step_size = (float)(lr / bc1);
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    }
     long long nblk = (n / 4 + 255) / 256;
     if (nblk > 2048) nblk = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, beta1, beta2,
-                       eps, step_size, inv_sqrt_bc2, grad_scale);
+                       eps, step_size, inv_sqrt_bc2, grad_scale, lr, step_ptr);
     return l2i_check_launch();
 }
 

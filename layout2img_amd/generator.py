@@ -218,7 +218,7 @@ def box_relational_embedding(f_g, dim_g=64, wave_len=1000.0):
     dh = torch.log(h / h.view(B, 1, -1))
     pos = torch.stack((dx, dy, dw, dh), dim=-1)  # (B,O,O,4)
     feat_range = torch.arange(dim_g / 8, device=f_g.device)
-    dim_mat = 1.0 / torch.pow(torch.tensor(wave_len, device=f_g.device), feat_range / (dim_g / 8))
+    dim_mat = 1.0 / torch.pow(float(wave_len), feat_range / (dim_g / 8))   # (scalar base: no host-to-device copy, graph-capturable)
     mul = (100.0 * pos).unsqueeze(-1) * dim_mat.view(1, 1, 1, 1, -1)
     mul = mul.reshape(B, pos.size(1), pos.size(2), -1)
     return torch.cat((torch.sin(mul), torch.cos(mul)), -1)

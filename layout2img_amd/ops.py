@@ -573,6 +573,7 @@ def l1_loss(a, b, weight=1.0):
     return L1Fn.apply(a, b, weight)
 
 
-def adam_step(flat, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+def adam_step(flat, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=None):
+    """step_dev: 1-element int32 device tensor with the step count (read on the device; graph-capturable)."""
     _lib.call("l2i_adam_step", flat.data.data_ptr(), flat.grad.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel, float(lr),
-              float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())
+              float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _p(step_dev), _stream())

@@ -134,3 +134,38 @@ def test_train_step_64():
     r = tr.step(real, label, bbox, z, z_im)
     torch.cuda.synchronize()
     assert torch.isfinite(r["d_loss"]) and torch.isfinite(r["g_loss"]) and r["fake"].shape == (64, 3, 64, 64)
+
+
+@pytest.mark.gpu
+def test_graph_replay_matches_eager():
+    """GanTrainer.capture / step_graphed (the whole iteration as one HIP graph) trains like the eager loop: same losses,
+    parameters equal up to the sign noise of Adam(beta1 = 0) on round-off-sized gradients (atomics reorder sums)."""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_batch
+    dev = torch.device("cuda:0")
+
+    def build():
+        torch.manual_seed(5)
+        g = L.ResnetGenerator64_context(num_classes=184).finalize(dev, torch.float32)
+        d = L.CombineDiscriminator64(num_classes=184).finalize(dev, torch.float32)
+        for m in g.modules():
+            if hasattr(m, "dropout_p"):
+                m.dropout_p = 0.0
+        return g, d, L.GanTrainer(g, d)
+
+    real, label, bbox, z, z_im = make_batch(4, 64, "coco", seed=3, device=dev)
+    ga, da, ta = build()
+    for _ in range(5):
+        oa = ta.step(real, label, bbox, z, z_im)
+    gb, db, tb = build()
+    assert tb.capture(real, label, bbox, z, z_im)      # two eager warm-up iterations inside
+    for _ in range(3):
+        ob = tb.step_graphed(real, label, bbox, z, z_im)
+    torch.cuda.synchronize()
+    assert int(tb.d_opt.t_dev) == 5 and int(tb.g_opt.t_dev) == 5
+    for k in ("d_loss", "g_loss"):
+        assert abs(float(oa[k]) - float(ob[k])) <= 2e-2 * max(1.0, abs(float(oa[k]))), (k, float(oa[k]), float(ob[k]))
+    for a, b in ((ga.flat.data, gb.flat.data), (da.flat.data, db.flat.data)):
+        diff = (a - b).abs()
+        assert float((diff < 1e-4).float().mean()) > 0.95
+        assert float(diff.max()) <= 2e-3
