@@ -5,6 +5,8 @@ train_context_app_v2.py:148-189 with the VGG term omitted -- its weights cannot 
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
+At N = 1 the iteration is captured once as a HIP graph and replayed (GanTrainer.capture); --no-graph runs eagerly.
+
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline     -- the implicit-GEMM conv kernel (forward + data-gradient launches): algorithmic FLOPs
                   (2*M*N*K of the unpadded layer shapes) / launch time measured with HIP events on the
