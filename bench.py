@@ -123,7 +123,7 @@ def main():
             peak = 2500.0 if op_dtype == torch.bfloat16 else 157.3
             ach = s["work"] / (s["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")   # PMC pass of this same command (scratch/traffic.sh)
+            tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")   # PMC pass of this same command (tools/perf/traffic.sh)
             if op_dtype == torch.bfloat16 and args.size == 128 and os.path.exists(tpath):
                 traffic = round(json.load(open(tpath))["conv(fwd+dgrad)"]["traffic_bytes_per_launch"])
                 traffic_src = "profiles/r01_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE; separate passes)"

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
 //
 // Halo row h = sp*SUBH + hy*P + hx (P, SUBH even); its eight 16-byte channel chunks are stored XOR-swizzled with
 // ((hx >> 1) + 4 hy + 2 sp) & 7, which makes every 16-lane phase of the fragment reads hit 16 distinct bank groups
-// for all taps and tile shapes used (exhaustive check: scratch/halo_check.py). B tiles: as in the kernel above.
+// for all taps and tile shapes used (exhaustive check: tools/perf/halo_check.py). B tiles: as in the kernel above.
 // Main loop. A first version of this kernel kept tap, ring stage and addresses as run-time state: per 16 MFMAs a
 // wave also issued ~90 SALU,
 // ~90 VALU, 16 LDS and 5 VMEM instructions -- 12.7 other instructions per MFMA. A wave issues at most one instruction
@@ -772,13 +772,13 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     //  0: 128x128 tile, 4 waves, 2 stages (two workgroups per CU)      1: 128x64, 4 waves, 2 stages (Co <= 64)
     //  2: 128x128, 8 waves (64x32 each), 4 stages                       3: 256x128, 8 waves (64x64 each), 3 stages
     //  4: 256x256, 8 waves (64x128 each), 2 stages                      5/6: as 0/1 with half K-steps and a 4-stage ring
-    // Heuristic from scratch/conv_tune.py on MI355X (TFLOP/s, bf16): big-tile configs pay only when their grid still
+    // Heuristic from tools/perf/conv_tune.py on MI355X (TFLOP/s, bf16): big-tile configs pay only when their grid still
     // fills the 256 CUs; a single wave of 128x128 tiles (one workgroup per CU) prefers the 8-wave deep ring.
     const long long M = (long long)a.B * a.Ho * a.Wo;
     if (sizeof(T) == 2 && a.KH == 3 && a.Ci >= 64 && !a.lin && a.Wo >= 8 && !(a.up2 && a.Wo < 16) && a.Ho >= 2 &&
         (g_conv_cfg_override < 0 || g_conv_cfg_override >= 10)) {
         // 128x128 tiles (two workgroups per CU, 2-stage weight ring) when they make at least one full wave of
-        // workgroups; otherwise 128x64 tiles (twice the workgroups, 3-stage ring). Measured: scratch/conv_tune.py.
+        // workgroups; otherwise 128x64 tiles (twice the workgroups, 3-stage ring). Measured: tools/perf/conv_tune.py.
         const long long t128h = ((M + 127) / 128) * ((a.Co + 127) / 128);
         int hc = (a.Co <= 64 || t128h < 512 || a.Wo < 16) ? 1 : 0;   // (8-wide maps: two 8x8 sub-patch halos + a 128-wide ring exceed 80 KB)
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
@@ -831,7 +831,7 @@ extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, c
     return L2I_ERR_ARG;
 }
 
-// Debug aid: co-resident workgroups per CU the runtime computes for a few instantiations (scratch/occupancy.py).
+// Debug aid: co-resident workgroups per CU the runtime computes for a few instantiations (tools/perf/occupancy.py).
 extern "C" int l2i_debug_occupancy(int which, int lds_bytes) {
     int n = -1;
     hipError_t e = hipSuccess;
