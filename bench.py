@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--layout", default="coco", choices=["coco", "vg"],
+                    help="coco: BASELINE config 3/4 (o = 8, 184 classes, ResnetGenerator128_context); "
+                         "vg: config 5 (o = 31, 179 classes, context_aware_generator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run every iteration eagerly (default: replay a captured HIP graph at N=1)")
@@ -76,12 +79,15 @@ def main():
     if args.size == 64:   # BASELINE configs 1-2 (not the headline metric)
         netG = L.ResnetGenerator64_context(num_classes=184).finalize(dev, op_dtype)
         netD = L.CombineDiscriminator64(num_classes=184).finalize(dev, op_dtype)
+    elif args.layout == "vg":   # BASELINE config 5 (not the headline metric)
+        netG = L.context_aware_generator(num_classes=179).finalize(dev, op_dtype)
+        netD = L.CombineDiscriminator128_app(num_classes=179).finalize(dev, op_dtype)
     else:
         netG = L.ResnetGenerator128_context(num_classes=184).finalize(dev, op_dtype)
         netD = L.CombineDiscriminator128_app(num_classes=184).finalize(dev, op_dtype)
     netG.train(), netD.train()
     trainer = L.GanTrainer(netG, netD)
-    real, label, bbox, z, z_im = make_batch(args.batch, args.size, "coco", seed=1234 + rank, device=dev)
+    real, label, bbox, z, z_im = make_batch(args.batch, args.size, args.layout, seed=1234 + rank, device=dev)
 
     def sync():
         torch.cuda.synchronize()
@@ -138,23 +144,37 @@ def main():
             if w:
                 roof["wgrad_tflops"] = round(w["work"] / (w["ms"] * 1e-3) / 1e12, 2)
             ops.TIMER = None
+        # secondary figure of SURVEY section 8d: generator forward alone (train-mode statistics, no autograd tape)
+        g_fwd = None
+        if world == 1:
+            with torch.no_grad():
+                for _ in range(2):
+                    netG(z, bbox, z_im=z_im, y=label)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    netG(z, bbox, z_im=z_im, y=label)
+                torch.cuda.synchronize()
+                g_fwd = round(args.batch * 5 / (time.perf_counter() - t1), 1)
         cpu = None
-        if not args.no_cpu_baseline and world == 1 and args.size == 128:
+        if not args.no_cpu_baseline and world == 1 and args.size == 128 and args.layout == "coco":
             cpu = cpu_baseline(netG, netD, args.size)
         out = {
-            "metric": "images/sec (G+D fwd+bwd) at 128x128 COCO-layout",
+            "metric": f"images/sec (G+D fwd+bwd) at {args.size}x{args.size} {'COCO' if args.layout == 'coco' else 'VG'}-layout",
             "value": round(args.batch * world * args.steps / elapsed, 2),
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.size}x{args.size}, batch {args.batch}/GPU, COCO-stuff layouts (8 slots, 3-8 objects), "
-                                   "ResnetGenerator128_context + CombineDiscriminator128_app, full D-step + G-step with Adam, "
+            "config": {"workload": f"{args.size}x{args.size}, batch {args.batch}/GPU, "
+                                   + ("COCO-stuff layouts (8 slots, 3-8 objects), ResnetGenerator128_context" if args.layout == "coco"
+                                      else "VG layouts (31 slots, 3-30 objects), context_aware_generator")
+                                   + " + CombineDiscriminator128_app, full D-step + G-step with Adam, "
                                    "VGG loss term omitted, random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": "HIP graph replay (last timed step eager, with HIP events)" if graphed else "eager"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "g_forward_images_per_sec": g_fwd,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

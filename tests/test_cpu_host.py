@@ -1,6 +1,8 @@
 """CPU: host-side logic of the HIP package -- module/state_dict layout against the reference's keys,
 flat parameter storage, arena tables, synthetic layouts, and that the product path refuses to run
 without a GPU (no silent fallback)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -89,3 +91,35 @@ def test_synthetic_layout_statistics():
     real, label, bbox, z, z_im = make_batch(4, 128)
     assert real.shape == (4, 3, 128, 128) and z.shape == (4, 8, 128) and z_im.shape == (4, 128)
     assert float(real.min()) >= -1 and float(real.max()) <= 1
+
+
+def test_truncated_normal_matches_the_rejection_sampler_distribution():
+    """sampling.truncated_normal == N(0,1) restricted to [-t, t] (reference utils/util.py:39-45 draws it by rejection)"""
+    from layout2img_amd.sampling import truncated_normal
+    g = torch.Generator().manual_seed(0)
+    for t in (1.0, 2.0):
+        z = truncated_normal((200000,), t, "cpu", g)
+        assert float(z.abs().max()) <= t
+        # moments of the truncated normal: mean 0, var = 1 - 2 t phi(t) / (2 Phi(t) - 1)
+        phi = math.exp(-t * t / 2) / math.sqrt(2 * math.pi)
+        var = 1 - 2 * t * phi / math.erf(t / math.sqrt(2))
+        assert abs(float(z.mean())) < 1e-2 and abs(float(z.var()) - var) < 1e-2
+        ref = torch.randn(400000, generator=g)
+        ref = ref[ref.abs() <= t][:200000]                 # the rejection sampler
+        q = torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95])
+        assert float((torch.quantile(z, q) - torch.quantile(ref, q)).abs().max()) < 2e-2
+
+
+def test_reference_checkpoint_loading_strips_the_dataparallel_prefix():
+    """load_reference_checkpoint == test_context_app_v2.py:44-59 (keys `module.<name>`, unknown / mis-shaped keys ignored)"""
+    import layout2img_amd as L
+    torch.manual_seed(0)
+    src = L.ResnetGenerator64_context(num_classes=10)
+    dst = L.ResnetGenerator64_context(num_classes=10)
+    ckpt = {"module." + k: v.clone() + 1.0 for k, v in src.state_dict().items() if v.dtype.is_floating_point}
+    ckpt["module.not_a_key"] = torch.zeros(3)
+    loaded, ignored = L.load_reference_checkpoint(dst, ckpt)
+    assert ignored == ["module.not_a_key"] and len(loaded) == len(ckpt) - 1
+    sd, ss = dst.state_dict(), src.state_dict()
+    for k in loaded:
+        assert torch.equal(sd[k], ss[k] + 1.0), k
