@@ -60,6 +60,7 @@ def main():
                          "vg: config 5 (o = 31, 179 classes, context_aware_generator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-g-forward", action="store_true", help="skip the secondary generator-forward measurement (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="run every iteration eagerly (default: replay a captured HIP graph at N=1)")
     args = ap.parse_args()
 
@@ -146,7 +147,7 @@ def main():
             ops.TIMER = None
         # secondary figure of SURVEY section 8d: generator forward alone (train-mode statistics, no autograd tape)
         g_fwd = None
-        if world == 1:
+        if world == 1 and not args.no_g_forward:
             with torch.no_grad():
                 for _ in range(2):
                     netG(z, bbox, z_im=z_im, y=label)

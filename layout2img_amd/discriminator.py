@@ -95,7 +95,7 @@ class ResnetDiscriminator128_app(nn.Module):
         a = self.app_conv(obj, pc)                                        # (R, 8, 8, C) pre-ReLU
         s2 = a.shape[3]
         wa = arena_weight(self.app, pc)                                   # (1, 2C)
-        emb_app = arena_weight(self.l_y_app, pc)[y]                       # (R, C)
+        emb_app = arena_weight(self.l_y_app, pc).index_select(0, y)                     # (R, C)
         # w1 . sum_rows(Gram) / C with Gram = F F^T / C, F = relu(a): only this contraction of the (R,C,C) Gram
         # matrices reaches the output, so they are never formed (ops.GramHeadFn / csrc/misc.hip)
         gram_term = ops.gram_head(a, wa[0, :s2].contiguous())
@@ -104,7 +104,7 @@ class ResnetDiscriminator128_app(nn.Module):
         # projection head (reference :160-166)
         f = F.relu(self.block_obj5(obj, pc)).sum(dim=(1, 2))              # (R, 16ch)
         out_obj = F.linear(f, arena_weight(self.l_obj, pc), self.l_obj.bias)
-        out_obj = out_obj + torch.sum(arena_weight(self.l_y, pc)[y] * f, dim=1, keepdim=True)
+        out_obj = out_obj + torch.sum(arena_weight(self.l_y, pc).index_select(0, y) * f, dim=1, keepdim=True)
         return out_im, out_obj, out_app
 
 
@@ -191,7 +191,7 @@ class ResnetDiscriminator64(nn.Module):
         obj = ops.roi_align(x1, None, rois, valid, 8, 1.0 / 2.0, 1.0, 1e30, 0)
         f = F.relu(self.block_obj4(obj, pc)).sum(dim=(1, 2))
         out_obj = F.linear(f, arena_weight(self.l_obj, pc), self.l_obj.bias)
-        out_obj = out_obj + torch.sum(arena_weight(self.l_y, pc)[y] * f, dim=1, keepdim=True)
+        out_obj = out_obj + torch.sum(arena_weight(self.l_y, pc).index_select(0, y) * f, dim=1, keepdim=True)
         return out_im, out_obj
 
 
