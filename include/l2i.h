@@ -93,7 +93,9 @@ int l2i_channel_stats(const float* x, long long rows, int C, long long rows_per_
 int l2i_norm_mod_fwd(const float* x, int B, int HW, int C, const float* sums, const float* sqsums, float count, float eps,
                      int stat_stride, const float* mask, int O, const float* wproj, const float* bproj,
                      long long pstride_b, long long pstride_o, int mode, int relu, void* out_op, float* out_f32, int dtype,
-                     void* stream);
+                     float* run_mean, float* run_var, float momentum, void* stream);
+/* (run_mean / run_var, optional, batch statistics only: nn.BatchNorm2d's train-mode running-statistics update
+ *  r = (1 - momentum) r + momentum * {mean, unbiased var}, done by the same launch.) */
 
 /* Backward, first pass: dxhat = dy*[y>0]*gamma (may alias dy); s1 += sum dxhat, s2 += sum dxhat*xhat;
  * dwproj/dbproj += ; dmask += (all pre-zeroed by the caller). dy_keep: scratch of dy's size, needed when O > 8. */

@@ -120,6 +120,7 @@ struct NormArgs {
     float* s1; float* s2;  // bwd: [G][C]
     float* dwproj; float* dbproj; float* dmask;
     float* ws;             // bwd: replicated workspace for the per-channel totals (common.h) or null
+    float* run_mean; float* run_var; float momentum;   // fwd, train mode: running statistics updated in the same launch (or null)
     long long pstride_b, pstride_o;
     int B, HW, C, O, mode, relu, stat_stride;
     float count, eps;
@@ -192,6 +193,19 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(NormArgs p) {
         if (p.mode == 1) {
             aw = *reinterpret_cast<const float4*>(p.wproj + c);
             ab = *reinterpret_cast<const float4*>(p.bproj + c);
+        }
+        if (!BWD && p.run_mean && b == 0 && tp == 0 && prow == 0) {
+            // nn.BatchNorm2d train-mode side effect (momentum update with the UNBIASED batch variance), once per channel
+            const float ub = p.count / fmaxf(p.count - 1.f, 1.f), mo = p.momentum;
+            float4 rm = *reinterpret_cast<float4*>(p.run_mean + c), rv = *reinterpret_cast<float4*>(p.run_var + c);
+            rm.x = (1.f - mo) * rm.x + mo * mean.x; rm.y = (1.f - mo) * rm.y + mo * mean.y;
+            rm.z = (1.f - mo) * rm.z + mo * mean.z; rm.w = (1.f - mo) * rm.w + mo * mean.w;
+            rv.x = (1.f - mo) * rv.x + mo * ub * fmaxf(q.x * ic - mean.x * mean.x, 0.f);
+            rv.y = (1.f - mo) * rv.y + mo * ub * fmaxf(q.y * ic - mean.y * mean.y, 0.f);
+            rv.z = (1.f - mo) * rv.z + mo * ub * fmaxf(q.z * ic - mean.z * mean.z, 0.f);
+            rv.w = (1.f - mo) * rv.w + mo * ub * fmaxf(q.w * ic - mean.w * mean.w, 0.f);
+            *reinterpret_cast<float4*>(p.run_mean + c) = rm;
+            *reinterpret_cast<float4*>(p.run_var + c) = rv;
         }
     }
     float4 acc_s1 = make_float4(0, 0, 0, 0), acc_s2 = make_float4(0, 0, 0, 0);
@@ -589,8 +603,10 @@ static int norm_check(const NormArgs& a) {
 extern "C" int l2i_norm_mod_fwd(const float* x, int B, int HW, int C, const float* sums, const float* sqsums, float count,
                                 float eps, int stat_stride, const float* mask, int O, const float* wproj,
                                 const float* bproj, long long pstride_b, long long pstride_o, int mode, int relu,
-                                void* out_op, float* out_f32, int dtype, void* stream) {
+                                void* out_op, float* out_f32, int dtype, float* run_mean, float* run_var, float momentum,
+                                void* stream) {
     NormArgs a = {};
+    a.run_mean = stat_stride == 0 ? run_mean : nullptr; a.run_var = run_var; a.momentum = momentum;
     a.x = x; a.B = B; a.HW = HW; a.C = C; a.sums = sums; a.sqsums = sqsums; a.count = count; a.eps = eps;
     a.stat_stride = stat_stride; a.mask = mask; a.O = O; a.wproj = wproj; a.bproj = bproj;
     a.pstride_b = pstride_b; a.pstride_o = pstride_o; a.mode = mode; a.relu = relu; a.out_op = out_op; a.out_f32 = out_f32;

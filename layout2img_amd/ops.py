@@ -206,17 +206,11 @@ def _norm_stats(x, spec: NormSpec):
     count = float(B * H * W)
     if spec.sync is not None:
         count = spec.sync(sums, sq, count)
-    if spec.running is not None:
-        rm, rv = spec.running
-        with torch.no_grad():
-            mean = sums[0] / count
-            var = (sq[0] / count - mean * mean).clamp_min_(0)
-            rm.mul_(1 - spec.momentum).add_(mean, alpha=spec.momentum)
-            rv.mul_(1 - spec.momentum).add_(var * (count / max(count - 1.0, 1.0)), alpha=spec.momentum)
+    # (train-mode running statistics are updated by the normalisation launch itself: norm_fwd_raw(update_running=True))
     return sums, sq, count, 0
 
 
-def norm_fwd_raw(x, sums, sq, count, stat_stride, spec, mask, wproj, bproj, op_dtype, want_f32=False):
+def norm_fwd_raw(x, sums, sq, count, stat_stride, spec, mask, wproj, bproj, op_dtype, want_f32=False, update_running=True):
     B, H, W, C = x.shape
     O = mask.shape[1] if mask is not None else 0
     if spec.mode == 0:
@@ -227,9 +221,13 @@ def norm_fwd_raw(x, sums, sq, count, stat_stride, spec, mask, wproj, bproj, op_d
         psb = pso = 0
     out_op = torch.empty((B, H, W, C), dtype=op_dtype, device=x.device)
     out_f = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device) if want_f32 else None
+    rm = rv = None
+    if update_running and spec.training and spec.running is not None and not spec.instance:
+        rm, rv = spec.running   # nn.BatchNorm2d's momentum update, fused into this launch
+        _chk(rm, torch.float32), _chk(rv, torch.float32)
     _lib.call("l2i_norm_mod_fwd", x.data_ptr(), B, H * W, C, sums.data_ptr(), sq.data_ptr(), float(count), float(spec.eps),
               stat_stride, _p(mask), O, _p(wproj), _p(bproj), psb, pso, spec.mode, int(spec.relu), out_op.data_ptr(),
-              _p(out_f), _code(op_dtype), _stream())
+              _p(out_f), _code(op_dtype), _p(rm), _p(rv), float(spec.momentum), _stream())
     return out_op, out_f
 
 
