@@ -51,6 +51,8 @@ class ResBlock(nn.Module):
     def forward(self, x, pc, use=0):
         """`use`: index of this application within the forward pass (each application of a spectral-normed
         module runs its own power iteration in the reference)."""
+        if self.learnable_sc:
+            ops.precast(x, pc.arena.op_dtype)   # conv1 reads relu(x), the shortcut reads x: one cast launch for both
         h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU)
         sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample) if self.learnable_sc else x
         return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample)

@@ -285,9 +285,13 @@ class FusedConvFn(Function):
             x_op, _ = norm_fwd_raw(x, sums, sq, count, sstride, pro, mask, wproj, bproj, opd)
             stats = (sums, sq, count, sstride)
         elif pro.kind == "relu":
-            _, x_op = cast_op(x, opd, raw=False, act=True)
+            x_op = _sibling(x, "relu", opd)
+            if x_op is None:
+                _, x_op = cast_op(x, opd, raw=False, act=True)
         else:
-            x_op, _ = cast_op(x, opd, raw=True, act=False)
+            x_op = _sibling(x, "raw", opd)
+            if x_op is None:
+                x_op, _ = cast_op(x, opd, raw=True, act=False)
         bias_p = None
         if bias is not None:
             bias_p = bias if bias.numel() == holder.co_p else torch.nn.functional.pad(bias, (0, holder.co_p - bias.numel()))
@@ -338,6 +342,22 @@ class FusedConvFn(Function):
                 dx = dxo
         d_res = dy if ctx.has_res else None
         return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None
+
+
+def _sibling(t, kind, dtype):
+    """Operand-dtype copy of stream `t` made by `precast` (it rides on the tensor object), or None."""
+    d = getattr(t, "_l2i_ops", None)
+    v = d.get(kind) if d else None
+    return v if v is not None and v.dtype == dtype and v.shape == t.shape else None
+
+
+def precast(x, op_dtype):
+    """One launch producing BOTH operand copies of a stream (raw and ReLU'd) for a block whose two branches read it
+    through different prologues (pre-activation conv + shortcut conv); the following fused_conv calls pick them up."""
+    if getattr(x, "_l2i_ops", None) is None:
+        raw, act = cast_op(x, op_dtype, raw=True, act=True)
+        x._l2i_ops = {"raw": raw, "relu": act}
+    return x
 
 
 def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False):

@@ -531,3 +531,26 @@ def test_resize_bilinear(case):
     out.backward(dy.to(_dev()))
     assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-6
     assert float((xg.grad.cpu() - xr.grad).abs().max()) < 1e-5
+
+
+def test_gram_head_matches_the_explicit_gram_matrices():
+    """ops.gram_head == w1 . sum_rows(F F^T / C) / C with F = relu(x) viewed (C, hw) (reference
+    model/rcnn_discriminator_app.py:148-157), forward and both gradients"""
+    from layout2img_amd import ops
+    g = torch.Generator().manual_seed(9)
+    R, H, C = 5, 8, 72
+    x = torch.randn(R, H, H, C, generator=g)
+    w = torch.randn(C, generator=g)
+    dy = torch.randn(R, 1, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    Fm = F.relu(xr).permute(0, 3, 1, 2).reshape(R, C, H * H)
+    gram = torch.bmm(Fm, Fm.transpose(1, 2)) / C                 # (R, C, C)
+    ref = (gram.sum(dim=1) / C) @ wr                               # rows summed, then the head's first-half weight
+    ref.view(R, 1).backward(dy)
+    xg, wg = x.to(_dev()).requires_grad_(True), w.to(_dev()).requires_grad_(True)
+    out = ops.gram_head(xg, wg)
+    out.backward(dy.to(_dev()))
+    s = float(ref.abs().max())
+    assert float((out.detach().cpu().view(-1) - ref.detach()).abs().max()) < 1e-5 * s
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) < 1e-5 * float(xr.grad.abs().max())
+    assert float((wg.grad.cpu() - wr.grad).abs().max()) < 1e-5 * float(wr.grad.abs().max())
