@@ -754,8 +754,13 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     if (a.Kpad < a.K || a.Kpad % BK) return L2I_ERR_ARG;
     a.chunk_major = (a.KH == 3 && a.Ci >= BK) ? 1 : 0;
     a.nks = a.chunk_major ? 9 * ((a.Ci + BK - 1) / BK) : a.Kpad / BK;
-    a.x_bytes = (unsigned)((size_t)a.B * a.Hi * a.Wi * a.Ci * sizeof(T));
-    a.w_bytes = (unsigned)((size_t)((a.Co + 127) / 128 * 128) * a.Kpad * sizeof(T));
+    {   // buffer descriptors and lane offsets are 32-bit (and 0x80000000 is the "out of range" marker)
+        const size_t xb = (size_t)a.B * a.Hi * a.Wi * a.Ci * sizeof(T);
+        const size_t wb = (size_t)((a.Co + 127) / 128 * 128) * a.Kpad * sizeof(T);
+        if (xb >= 0x80000000ull || wb >= 0x80000000ull) return L2I_ERR_ARG;
+        a.x_bytes = (unsigned)xb;
+        a.w_bytes = (unsigned)wb;
+    }
     a.lin = a.Wo < 2;
     if (a.lin) {
         if (a.Ho != 1 || a.pool2) return L2I_ERR_ARG;
