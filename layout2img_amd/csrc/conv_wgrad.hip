@@ -214,8 +214,13 @@ __device__ __forceinline__ bf16x8_t wg_frag(const char* tile, int pixbase, int c
     return out;
 }
 
-template <int BMO, bool FAST>   // FAST: no pool / upsample and M a multiple of 64 (straight-line address code)
+// MODE 1 (FAST): no pool / upsample, M % 64 == 0: all addresses are lane constants + an SGPR step base.
+// MODE 2 (SEMI): pool and/or upsample, M % 64 == 0 and Ho*Wo % 64 == 0: a 64-pixel step lies inside one image and starts
+//   on a row (or half-row) boundary, so image / row / column of the step are SCALARS and a lane adds its constant (dx, dy).
+// MODE 0: general (any size), per-lane decode of the pixel index.
+template <int BMO, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lgW, int lgH) {
+    constexpr bool FAST = MODE == 1, SEMI = MODE == 2;
     constexpr int BNK = 128, BK = 64;
     constexpr int RSA = BMO * 2, RSB = BNK * 2;
     constexpr int TM = BMO / 64, TN = 2;
@@ -279,12 +284,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
         b_base[q] = (unsigned)(((b_ky - pad) * p.Wo + (b_kx - pad) + b_mlane[q]) * p.Ci + b_ci) * 2u + x_shift;
     }
     const unsigned co2 = (unsigned)p.Co * 2u, ci2 = (unsigned)p.Ci * 2u;
+    // SEMI: lane constants -- position (xl, yl) of the lane's pixel within a step, folded into offsets
+    unsigned a_semi[A_Q];
+    int b_cy[4], b_cx[4];
+#pragma unroll
+    for (int q = 0; q < A_Q; ++q) {
+        const int pl = wv * 16 + q * A_ROWS + a_row;
+        const int xl = pl & (p.Wo - 1), yl = pl >> lgW;
+        a_semi[q] = a_on ? (unsigned)(((yl >> p.pool2) * Wd + (xl >> p.pool2)) * p.Co + a_chan) * 2u : OOB;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int pl = b_mlane[q];
+        b_cx[q] = (pl & (p.Wo - 1)) + b_kx - pad;
+        b_cy[q] = (pl >> lgW) + b_ky - pad;
+    }
     auto issue = [&](int mstep, unsigned stage) {   // stage: LDS byte address of the stage
+        // SEMI: scalar image / row / column of the step
+        const int sb = mstep >> (lgW + lgH), sy = (mstep >> lgW) & (p.Ho - 1), sx = mstep & (p.Wo - 1);
+        const unsigned soff_a = (unsigned)(((sb * Hd + (sy >> p.pool2)) * Wd + (sx >> p.pool2)) * p.Co) * 2u;
+        const unsigned soff_b = (unsigned)(sb * p.Hi * p.Wi) * ci2;
 #pragma unroll
         for (int q = 0; q < A_Q; ++q) {
             const unsigned dst = stage + (unsigned)(wv * 16 + q * A_ROWS) * RSA;
             if constexpr (FAST) {
                 L2I_DMA16_S(rs_dy, a_base[q], (unsigned)mstep * co2, dst);
+            } else if constexpr (SEMI) {
+                L2I_DMA16_S(rs_dy, a_semi[q], soff_a, dst);
             } else {
                 const int m = mstep + wv * 16 + q * A_ROWS + a_row;
                 const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1), b = m >> (lgW + lgH);
@@ -295,6 +321,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned dst = stage + BK * RSA + (unsigned)(wv * 16 + q * 4) * RSB;
+            if constexpr (SEMI) {
+                const int yy = sy + b_cy[q], xx = sx + b_cx[q];
+                const bool in = b_on && (unsigned)yy < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo;
+                const unsigned off = (unsigned)(((yy >> p.up2) * p.Wi + (xx >> p.up2)) * p.Ci + b_ci) * 2u;
+                L2I_DMA16_S(rs_x, in ? off : OOB, soff_b, dst);
+                continue;
+            }
             const int m = mstep + b_mlane[q];
             const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1);
             const int yy = y + b_ky - pad, xx = x + b_kx - pad;
@@ -448,13 +481,16 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
         while ((1 << lgW) < a.Wo) ++lgW;
         while ((1 << lgH) < a.Ho) ++lgH;
         const size_t lds2 = (size_t)2 * 64 * (BMO * 2 + 256);
-        const bool fast = !a.pool2 && !a.up2 && a.M % 64 == 0;
+        const bool whole = a.M % 64 == 0;
+        const int mode = !whole ? 0 : (!a.pool2 && !a.up2) ? 1 : ((a.Ho * a.Wo) % 64 == 0 ? 2 : 0);
         if (BMO == 64) {
-            if (fast) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, true>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
-            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, false>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            if (mode == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 1>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else if (mode == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
         } else {
-            if (fast) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, true>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
-            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, false>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            if (mode == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 1>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else if (mode == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
         }
         return l2i_check_launch();
     }
