@@ -83,7 +83,7 @@ static __global__ __launch_bounds__(256) void ws_fold_kernel(WsFoldArgs p) {
     for (int r = 0; r < L2I_WS_R; ++r) { t += v[r]; q[(size_t)r * p.L] = 0.f; }
     const int k = i / p.C;
     float* d = p.dst[k];
-    if (d) d[i - k * p.C] += t;
+    if (d) atomicAdd(d + (i - k * p.C), t);   // (atomic: two passes of one network may fold into the same gradient from two streams)
 }
 static inline void ws_fold(float* ws, int L, int C, float* d0, float* d1, float* d2, float* d3, hipStream_t stream) {
     WsFoldArgs a;

@@ -10,6 +10,8 @@ Differences from the reference that do not change the mathematics:
   * ROI rows are a fixed b*o with a validity mask, losses average over valid rows;
   * under data parallelism losses divide by global counts and gradients are SUM all-reduced.
 """
+import os
+
 import torch
 
 from . import ops, parallel
@@ -41,6 +43,9 @@ class GanTrainer:
         self.g_opt, self.d_opt = FlatAdam(netG, g_lr), FlatAdam(netD, d_lr)
         self.l_obj, self.l_app, self.l_img, self.z_dim = lamb_obj, lamb_app, lamb_img, z_dim
         self.world = parallel.world_size()
+        # D(real) on a side stream next to G's forward (single-process runs; L2I_OVERLAP=0 turns it off)
+        self.overlap = os.environ.get("L2I_OVERLAP", "1") != "0"
+        self._side = None
         if self.world > 1:
             netG.sync = parallel.sync_bn_stats
             parallel.broadcast_flat_(netG.flat.data)
@@ -73,10 +78,24 @@ class GanTrainer:
         ops.POOL.begin(real.device)
         # ---- D step (reference :156-174)
         netD.zero_grad()
-        *outs_r, valid, _ = netD.forward_padded(real, bbox, y)
-        n_roi, n_img = self._counts(valid, b)
-        d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
-        fake = netG(z, bbox, z_im=z_im, y=y)
+        if self.overlap and self.world == 1:
+            # D(real) does not depend on the generator: it runs on a side stream next to G's forward (and, through
+            # autograd's stream bookkeeping, its backward runs next to D(fake)'s)
+            cur = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                *outs_r, valid, _ = netD.forward_padded(real, bbox, y)
+                n_roi, n_img = self._counts(valid, b)
+                d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
+            fake = netG(z, bbox, z_im=z_im, y=y)
+            cur.wait_stream(self._side)
+        else:
+            *outs_r, valid, _ = netD.forward_padded(real, bbox, y)
+            n_roi, n_img = self._counts(valid, b)
+            d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
+            fake = netG(z, bbox, z_im=z_im, y=y)
         *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y)
         d_loss_fake = self._d_terms(outs_f, valid, 1, n_roi, n_img)
         d_loss = d_loss_real + d_loss_fake

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools/perf/prof.sh <tag>  -> gpurun_out/r01_kernel_stats_<tag>.csv
 cd /tmp && export TMPDIR=/tmp
+export L2I_OVERLAP=0   # one stream: per-kernel durations are those of a kernel that owns the GPU
 rm -rf /tmp/prof
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-g-forward > /tmp/b.log 2>&1
 tail -1 /tmp/b.log | cut -c1-160

@@ -1,6 +1,7 @@
 #!/bin/bash
 # HBM traffic of the conv kernels from PMC (separate passes, --kernel-trace only), averaged per launch.
 cd /tmp && export TMPDIR=/tmp
+export L2I_OVERLAP=0   # one stream: per-kernel durations are those of a kernel that owns the GPU
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/tr_$c
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/tr_$c -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-g-forward > /tmp/tr_$c.log 2>&1
