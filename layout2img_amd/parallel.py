@@ -21,6 +21,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: L2I_DIST_BACKEND=gloo and L2I_FORCE_DEVICE=0 let several ranks share one GPU (RCCL refuses that), which
+    # is how the multi-process path of bench.py is exercised on a single-GPU box
+    backend = os.environ.get("L2I_DIST_BACKEND", backend)
+    if "L2I_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["L2I_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
