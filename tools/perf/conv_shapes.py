@@ -41,5 +41,5 @@ for key, (n, ms) in agg.items():
 rows.sort(key=lambda r: -r[0])
 tot = sum(r[0] for r in rows)
 print("total conv ms/step", tot)
-for ms, n, key, tf in rows[:45]:
+for ms, n, key, tf in rows[:120]:
     print(f"{ms:7.3f} ms/step x{n:3d}  {tf:7.1f} TF/s  {key}")
