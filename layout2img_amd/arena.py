@@ -261,7 +261,7 @@ class WeightArena:
             _lib.call("l2i_weights_prepare", self.layers.data_ptr(), self.n_layers, wtu.data_ptr(), n_wtu, wv.data_ptr(), n_wv,
                       pk.data_ptr(), n_pk, fin.data_ptr(), n_fin, self.flat.data.data_ptr(), self.sn_flat.data.data_ptr(), p.pass_uv.data_ptr(),
                       self.uv_len, p.norms.data_ptr(), p.packed.data_ptr(), self.dtype_code, 1 if training else 0,
-                      1 if r == 0 else 0, torch.cuda.current_stream().cuda_stream)
+                      1 if r == 0 else 0, _lib.raw_stream())
         if need_wgrad and torch.is_grad_enabled():
             self.pending.append(p)
             if len(self.pending) > 8:  # forwards that were never followed by an optimiser step
@@ -276,7 +276,7 @@ class WeightArena:
             _lib.call("l2i_weights_backward", self.layers.data_ptr(), self.n_layers, self.t_dot.data_ptr(), self.n_dot,
                       self.t_apply.data_ptr(), self.n_apply, self.flat.data.data_ptr(), p.dwbar.data_ptr(),
                       p.pass_uv.data_ptr(), p.norms.data_ptr(), self.flat.grad.data_ptr(), _lib.workspace(self.device),
-                      torch.cuda.current_stream().cuda_stream)
+                      _lib.raw_stream())
         self.pending = []
 
     def drop_pending(self):

@@ -17,7 +17,7 @@ def _p(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.raw_stream()
 
 
 def _code(dtype):
