@@ -786,8 +786,8 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // workgroups; otherwise 128x64 tiles (twice the workgroups, 3-stage ring). Measured: tools/perf/conv_tune.py.
         const long long t128h = ((M + 127) / 128) * ((a.Co + 127) / 128);
         int hc = (a.Co <= 64 || t128h < 512 || a.Wo < 16) ? 1 : 0;   // (8-wide maps: two 8x8 sub-patch halos + a 128-wide ring exceed 80 KB)
-        // the 1024-channel ROI-head layers on 8x8 maps: 256x128 tiles (8 waves) measured ~10 % faster than 128x64
-        if (a.Wo < 16 && (a.Ci >= 1024 || a.Co >= 1024) && ((M + 255) / 256) * ((a.Co + 127) / 128) >= 256) hc = 2;
+        // (256x128 / 8-wave tiles are ~10 % faster on the 1024-channel ROI-head layers in isolation but not inside the
+        //  iteration -- rocprofv3: 1.90 vs 1.77 ms for those 9 launches -- so they stay a tuning option: cfg 12)
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
         int rc;
         switch (hc) {
