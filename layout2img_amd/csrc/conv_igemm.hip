@@ -423,7 +423,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
                  "s"(soff), "s"(ldsaddr)                                                                              \
                  : "memory")
 
-template <int BM, int BN, int WM, int WN, int NSB, bool PIPE>
+template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false>   // H1: ONE halo buffer, refilled at each chunk boundary
 __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
     typedef bf16_t T;
     constexpr int THREADS = WM * WN * 64, NW = WM * WN;
@@ -448,7 +448,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
     const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
     const unsigned smem_addr = lds_addr_of(smem);
     const unsigned halo_bytes = (unsigned)p.halo_pieces * 1024u;
-    const unsigned ring_off = 2u * halo_bytes;
+    const unsigned ring_off = (H1 ? 1u : 2u) * halo_bytes;
+    const unsigned halo_flip = H1 ? 0u : halo_bytes;
 
     // ---- halo pieces of this wave (piece q = wv + NW q; lane -> halo row / chunk), as in conv_halo_kernel
     unsigned hoff[HPMAX];
@@ -548,13 +549,22 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
         if (!PIPE) { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) asm volatile("" : "+v"(a_addr[i_][TAP])); }   /* keep the 72 XOR-ed copies out of registers */ \
         __builtin_amdgcn_s_barrier();                                                                                  \
         asm volatile("" ::: "memory");                                                                                 \
+        if (H1 && TAP == 0 && (DO_MFMA_PREV)) {   /* single halo buffer: everyone is past tap 8, refill and wait */      \
+            _Pragma("unroll") for (int q_ = 0; q_ < HPMAX; ++q_) if (q_ < nq) {                                        \
+                const unsigned vo_ = (cb_cur) < hlim[q_] ? hoff[q_] : OOB;                                             \
+                H2_DMA(rsrc_x, vo_, (unsigned)((cb_cur)*SZ), halo_w + (unsigned)(NW * q_) * 1024u);                     \
+            }                                                                                                          \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+            __builtin_amdgcn_s_barrier();                                                                              \
+            asm volatile("" ::: "memory");                                                                             \
+        }                                                                                                              \
         H2_READS(SET, TAP, STG)                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         const int cb2 = TAP + AHEAD >= 9 ? (cb_nxt) : (cb_cur);                                                        \
         const unsigned kadd = (unsigned)(TAP2 * ci2 + cb2 * SZ);                                                       \
         if (!PIPE || (DO_MFMA_PREV)) { H2_MFMA4(PSET, 0); }                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (TAP < HPMAX && TAP < nq) {                                                                                 \
+        if (!H1 && TAP < HPMAX && TAP < nq) {                                                                          \
             const unsigned vo = (cb_nxt) < hlim[TAP] ? hoff[TAP] : OOB;                                                \
             H2_DMA(rsrc_x, vo, (unsigned)((cb_nxt)*SZ), halo_w + (unsigned)(1 - HB) * halo_bytes + (unsigned)(NW * TAP) * 1024u); \
         }                                                                                                              \
@@ -610,7 +620,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) a_addr[i][tap] += halo_bytes;
+                for (int tap = 0; tap < 9; ++tap) a_addr[i][tap] += halo_flip;
             if (c + 1 < c_end) {
                 H2_STEP(9, cbB, cbC, true)
                 H2_STEP(10, cbB, cbC, true)
@@ -626,7 +636,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) a_addr[i][tap] -= halo_bytes;
+                for (int tap = 0; tap < 9; ++tap) a_addr[i][tap] -= halo_flip;
         }
         if (PIPE) {   // the last step's fragments are still waiting for their MFMAs
             if (pending) { H2_MFMA4(1, 0); H2_MFMA4(1, 1); H2_MFMA4(1, 2); H2_MFMA4(1, 3); }
@@ -691,7 +701,7 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
 
 // Halo kernel launch (bf16, 3x3, Ci >= 64, Wo >= 8, no upsample into 8-wide maps). Returns -100 when the shape is
 // not covered so that the caller falls through to the generic kernel.
-template <int BM, int BN, int WM, int WN, int NSB, bool PIPE>
+template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false>
 static int launch_halo2(ConvArgs a, hipStream_t stream) {
     a.PH = BM / a.PW;
     a.PHs = a.PH < a.Ho ? a.PH : a.Ho;
@@ -704,7 +714,7 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     a.HR = nsp * a.SUBH;
     a.halo_pieces = (a.HR + 7) / 8;
     if (a.halo_pieces > 7 * WM * WN) return -100;
-    const size_t lds = (size_t)2 * a.halo_pieces * 1024 + (size_t)NSB * BN * 128;
+    const size_t lds = (size_t)(H1 ? 1 : 2) * a.halo_pieces * 1024 + (size_t)NSB * BN * 128;
     if (lds > 160 * 1024) return -100;
     const int nchunks = (a.Ci + 63) / 64;
     a.nks = 9 * nchunks;
@@ -727,10 +737,10 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     }
     static bool ready = false;
     if (!ready) {
-        (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ready = true;
     }
-    hipLaunchKernelGGL((conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL((conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
     return l2i_check_launch();
 }
 
@@ -785,7 +795,11 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // 128x128 tiles (two workgroups per CU, 2-stage weight ring) when they make at least one full wave of
         // workgroups; otherwise 128x64 tiles (twice the workgroups, 3-stage ring). Measured: tools/perf/conv_tune.py.
         const long long t128h = ((M + 127) / 128) * ((a.Co + 127) / 128);
-        int hc = (a.Co <= 64 || t128h < 512 || a.Wo < 16) ? 1 : 0;   // (8-wide maps: two 8x8 sub-patch halos + a 128-wide ring exceed 80 KB)
+        // 128x128 tiles need >= 512 workgroups (one full wave at two per CU); with them, the double-buffered halo + 2-stage
+        // ring wins on long reductions, the single halo buffer + 3-stage ring on short ones and on 8-wide maps (whose two
+        // 8x8 sub-patch halos only fit twice per CU single-buffered). Measured: tools/perf/conv_tune.py + in-iteration profile.
+        int hc = 1;
+        if (a.Co > 64 && t128h >= 512) hc = (a.Wo < 16 || a.Ci <= 256) ? 4 : 0;
         // (256x128 / 8-wave tiles are ~10 % faster on the 1024-channel ROI-head layers in isolation but not inside the
         //  iteration -- rocprofv3: 1.90 vs 1.77 ms for those 9 launches -- so they stay a tuning option: cfg 12)
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
@@ -794,6 +808,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
             case 1: rc = launch_halo2<128, 64, 2, 2, 3, false>(a, stream); break;
             case 2: rc = launch_halo2<256, 128, 4, 2, 2, false>(a, stream); break;
             case 3: rc = launch_halo2<128, 128, 2, 2, 3, false>(a, stream); break;   // one workgroup per CU
+            case 4: rc = launch_halo2<128, 128, 2, 2, 3, false, true>(a, stream); break;   // single halo buffer: 72 KB, two per CU, 2 tiles ahead
             default: rc = launch_halo2<128, 128, 2, 2, 2, false>(a, stream); break;
         }
         if (rc != -100) return rc;
