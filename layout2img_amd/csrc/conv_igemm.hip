@@ -798,7 +798,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // 128x128 tiles need >= 512 workgroups (one full wave at two per CU); with them, the double-buffered halo + 2-stage
         // ring wins on long reductions, the single halo buffer + 3-stage ring on short ones and on 8-wide maps (whose two
         // 8x8 sub-patch halos only fit twice per CU single-buffered). Measured: tools/perf/conv_tune.py + in-iteration profile.
-        int hc = 1;
+        int hc = 5;   // 128x64 tiles, single halo buffer: 48 KB, three workgroups per CU
         if (a.Co > 64 && t128h >= 512) hc = (a.Wo < 16 || a.Ci <= 256) ? 4 : 0;
         // (256x128 / 8-wave tiles are ~10 % faster on the 1024-channel ROI-head layers in isolation but not inside the
         //  iteration -- rocprofv3: 1.90 vs 1.77 ms for those 9 launches -- so they stay a tuning option: cfg 12)
@@ -809,6 +809,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
             case 2: rc = launch_halo2<256, 128, 4, 2, 2, false>(a, stream); break;
             case 3: rc = launch_halo2<128, 128, 2, 2, 3, false>(a, stream); break;   // one workgroup per CU
             case 4: rc = launch_halo2<128, 128, 2, 2, 3, false, true>(a, stream); break;   // single halo buffer: 72 KB, two per CU, 2 tiles ahead
+            case 5: rc = launch_halo2<128, 64, 2, 2, 3, false, true>(a, stream); break;    // 48 KB: three per CU
             default: rc = launch_halo2<128, 128, 2, 2, 2, false>(a, stream); break;
         }
         if (rc != -100) return rc;
