@@ -810,6 +810,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
             case 3: rc = launch_halo2<128, 128, 2, 2, 3, false>(a, stream); break;   // one workgroup per CU
             case 4: rc = launch_halo2<128, 128, 2, 2, 3, false, true>(a, stream); break;   // single halo buffer: 72 KB, two per CU, 2 tiles ahead
             case 5: rc = launch_halo2<128, 64, 2, 2, 3, false, true>(a, stream); break;    // 48 KB: three per CU
+            case 6: rc = launch_halo2<128, 64, 2, 2, 2, false, true>(a, stream); break;    // 40 KB: four per CU
             default: rc = launch_halo2<128, 128, 2, 2, 2, false>(a, stream); break;
         }
         if (rc != -100) return rc;

@@ -13,7 +13,7 @@ for (B,H,W,Ci,Co,KH,up2,pool2) in shapes:
     Ho = H*(2 if up2 else 1)
     res = []
     ref = None
-    for cfg in (11,15):
+    for cfg in (15,16):
         _lib.call("l2i_set_conv_config", cfg)
         for _ in range(3): out,_,_ = ops.conv_raw(x,w,kpad,Co,KH,up2=bool(up2),pool2=bool(pool2),alpha=0.25 if pool2 else 1.0)
         torch.cuda.synchronize()
