@@ -435,7 +435,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
 }
 
 static int g_wgrad_blocks = 0;   // tuning hook l2i_set_wgrad_blocks: workgroups per wave of the grid (0 = from the tile's occupancy)
-extern "C" int l2i_set_wgrad_blocks(int n) { g_wgrad_blocks = n > 0 ? n : 0; return L2I_OK; }
+static int g_wgrad_force64 = 0;   // tuning: 64-row tiles for every layer (n = -64), back to the default (n = -128)
+extern "C" int l2i_set_wgrad_blocks(int n) {
+    if (n == -64) { g_wgrad_force64 = 1; return L2I_OK; }
+    if (n == -128) { g_wgrad_force64 = 0; return L2I_OK; }
+    g_wgrad_blocks = n > 0 ? n : 0;
+    return L2I_OK;
+}
 
 template <typename T>
 static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
@@ -449,7 +455,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.K = a.KH * a.KH * a.Ci;
     if (a.ldw < a.K) return L2I_ERR_ARG;
     a.M = a.B * a.Ho * a.Wo;
-    const int BMO = a.Co <= 64 ? 64 : 128;
+    const int BMO = (a.Co <= 64 || g_wgrad_force64) ? 64 : 128;
     a.tiles_co = (a.Co + BMO - 1) / BMO;
     a.tiles_k = (a.K + 127) / 128;
     const int tiles = a.tiles_co * a.tiles_k;

@@ -22,7 +22,7 @@ shapes = [(32,128,128,64,64,3,0,0), (32,64,64,128,128,3,0,0), (32,64,64,128,64,3
           (32,32,32,512,512,3,0,0), (256,8,8,512,512,3,0,0), (256,8,8,1024,1024,3,0,1), (32,8,8,1024,1024,3,0,1), (32,4,4,1024,1024,3,0,0), (32,64,64,528,104,3,0,0), (32,128,128,64,8,3,0,0)]
 for sh in shapes:
     out = []
-    for tgt in (0, 512):
+    for tgt in (-128, -64):
         _lib.call("l2i_set_wgrad_blocks", tgt)
         us, tf = run(*sh)
         out.append(f"{tgt}:{us:6.1f}us/{tf:4.0f}TF")
