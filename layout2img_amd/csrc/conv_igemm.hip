@@ -823,7 +823,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     else if (!a.lin && a.Co % 256 == 0 && t256x256 >= 240 && a.nks >= 144) cfg = 4;   // 1024-channel 3x3 ROI heads
     else if (!a.lin && a.Co % 128 == 0 && t256x128 >= 384 && a.nks >= 72) cfg = 3;
     else if (t128 >= 192 && t128 <= 288) cfg = 2;
-    else cfg = 0;
+    else cfg = t128 < 512 ? 1 : 0;   // small grids: 128x64 tiles (48 KB, three workgroups per CU)
     if (g_conv_cfg_override == 5 && a.Co <= 64) cfg = 6;
     if (g_conv_cfg_override >= 0 && a.Co > 64) {
         cfg = g_conv_cfg_override;
