@@ -87,6 +87,9 @@ def main():
         netG = L.ResnetGenerator128_context(num_classes=184).finalize(dev, op_dtype)
         netD = L.CombineDiscriminator128_app(num_classes=184).finalize(dev, op_dtype)
     netG.train(), netD.train()
+    if "L2I_CONV_CFG" in os.environ:   # tuning hook (tools/perf): force a conv tile configuration
+        from layout2img_amd import _lib
+        _lib.call("l2i_set_conv_config", int(os.environ["L2I_CONV_CFG"]))
     trainer = L.GanTrainer(netG, netD)
     real, label, bbox, z, z_im = make_batch(args.batch, args.size, args.layout, seed=1234 + rank, device=dev)
 

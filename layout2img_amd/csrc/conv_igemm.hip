@@ -791,7 +791,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     // fills the 256 CUs; a single wave of 128x128 tiles (one workgroup per CU) prefers the 8-wave deep ring.
     const long long M = (long long)a.B * a.Ho * a.Wo;
     if (sizeof(T) == 2 && a.KH == 3 && a.Ci >= 64 && !a.lin && a.Wo >= 8 && !(a.up2 && a.Wo < 16) && a.Ho >= 2 &&
-        (g_conv_cfg_override < 0 || g_conv_cfg_override >= 10)) {
+        (g_conv_cfg_override < 0 || g_conv_cfg_override >= 10)) {   // (-2: tuning, single halo buffer for every 128x128 launch)
         // 128x128 tiles (two workgroups per CU, 2-stage weight ring) when they make at least one full wave of
         // workgroups; otherwise 128x64 tiles (twice the workgroups, 3-stage ring). Measured: tools/perf/conv_tune.py.
         const long long t128h = ((M + 127) / 128) * ((a.Co + 127) / 128);
@@ -799,7 +799,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // ring wins on long reductions, the single halo buffer + 3-stage ring on short ones and on 8-wide maps (whose two
         // 8x8 sub-patch halos only fit twice per CU single-buffered). Measured: tools/perf/conv_tune.py + in-iteration profile.
         int hc = 5;   // 128x64 tiles, single halo buffer: 48 KB, three workgroups per CU
-        if (a.Co > 64 && t128h >= 512) hc = (a.Wo < 16 || a.Ci <= 256) ? 4 : 0;
+        if (a.Co > 64 && t128h >= 512) hc = (a.Wo < 16 || a.Ci <= 256 || g_conv_cfg_override == -2) ? 4 : 0;
         // (256x128 / 8-wave tiles are ~10 % faster on the 1024-channel ROI-head layers in isolation but not inside the
         //  iteration -- rocprofv3: 1.90 vs 1.77 ms for those 9 launches -- so they stay a tuning option: cfg 12)
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
