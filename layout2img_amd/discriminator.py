@@ -143,11 +143,14 @@ class CombineDiscriminator128_app(nn.Module):
         x = F.pad(images.permute(0, 2, 3, 1), (0, 8 - images.size(1))).contiguous()
         return rois, y, valid, x
 
-    def forward_padded(self, images, bbox, label, need_wgrad=True):
+    def forward_padded(self, images, bbox, label, need_wgrad=True, pc=None):
+        """pc: a pass context already prepared for this pass (GanTrainer prepares the fake pass's weights on the side
+        stream while the generator is still running), else one is prepared here."""
         if not images.is_cuda:
             raise RuntimeError("layout2img_amd discriminators run on the GPU HIP path only")
         rois, y, valid, x = self._prepare(images, bbox, label)
-        pc = self.arena.prepare(training=self.training, need_wgrad=need_wgrad)
+        if pc is None:
+            pc = self.arena.prepare(training=self.training, need_wgrad=need_wgrad)
         d_img, d_obj, d_app = self.obD(x, y, rois, valid, pc)
         return d_img, d_obj, d_app, valid, rois
 
@@ -204,11 +207,14 @@ class CombineDiscriminator64(CombineDiscriminator128_app):
         nn.Module.__init__(self)
         self.obD = ResnetDiscriminator64(num_classes=num_classes, input_dim=3)
 
-    def forward_padded(self, images, bbox, label, need_wgrad=True):
+    def forward_padded(self, images, bbox, label, need_wgrad=True, pc=None):
+        """pc: a pass context already prepared for this pass (GanTrainer prepares the fake pass's weights on the side
+        stream while the generator is still running), else one is prepared here."""
         if not images.is_cuda:
             raise RuntimeError("layout2img_amd discriminators run on the GPU HIP path only")
         rois, y, valid, x = self._prepare(images, bbox, label)
-        pc = self.arena.prepare(training=self.training, need_wgrad=need_wgrad)
+        if pc is None:
+            pc = self.arena.prepare(training=self.training, need_wgrad=need_wgrad)
         d_img, d_obj = self.obD(x, y, rois, valid, pc)
         return d_img, d_obj, valid, rois
 

@@ -93,14 +93,17 @@ class GanTrainer:
             with torch.cuda.stream(self._side):
                 *outs_r, valid, _ = netD.forward_padded(real, bbox, y)
                 d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
+                # the fake pass's power iteration + weight packs need only D's weights: done here, off the main stream
+                pc_fake = netD.arena.prepare(training=netD.training, need_wgrad=True)
             fake = netG(z, bbox, z_im=z_im, y=y)
             cur.wait_stream(self._side)
         else:
+            pc_fake = None
             *outs_r, valid, _ = netD.forward_padded(real, bbox, y)
             n_roi, n_img = self._counts(valid, b)
             d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
             fake = netG(z, bbox, z_im=z_im, y=y)
-        *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y)
+        *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y, pc=pc_fake)
         d_loss_fake = self._d_terms(outs_f, valid, 1, n_roi, n_img)
         d_loss = d_loss_real + d_loss_fake
         d_loss.backward()
