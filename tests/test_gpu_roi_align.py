@@ -1,0 +1,68 @@
+"""GPU twin of tests/test_oracle_roi_align.py: the HIP ROIAlign (l2i_roi_align_fwd / _bwd through the C ABI) against
+the same hand-derived known answers -- not against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests import roi_cases as RC
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(feat, rois, scale, feat_l=None, scale_l=1.0, thr=1e30, need_grad=False):
+    from layout2img_amd import ops
+    dev = torch.device("cuda:0")
+    f = torch.from_numpy(feat).permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(need_grad)     # NHWC
+    fl = None if feat_l is None else torch.from_numpy(feat_l).permute(0, 2, 3, 1).contiguous().to(dev)
+    out = ops.roi_align(f, fl, torch.from_numpy(rois).to(dev), None, RC.P, scale, scale_l, thr, 0)
+    return out, f
+
+
+def _pad4(feat):
+    """the kernel wants C % 4 == 0: repeat the channels"""
+    c = feat.shape[1]
+    reps = (4 + c - 1) // c
+    return np.concatenate([feat] * reps, axis=1)[:, :max(4, c)]
+
+
+@pytest.mark.parametrize("case", RC.known_answer_cases(), ids=lambda c: c["name"])
+def test_known_answers(case):
+    c = case["feat"].shape[1]
+    out, _ = _run(_pad4(case["feat"]), case["rois"], case["scale"])
+    got = out.permute(0, 3, 1, 2)[:, :c].cpu().numpy().astype(np.float64)
+    assert np.abs(got - case["expected"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("seed,scale,size", [(0, 0.25, 16), (1, 0.125, 16), (2, 0.25, 32), (3, 1.0, 12)])
+def test_random_rois_against_the_tent_function_statement(seed, scale, size):
+    case = RC.random_case(seed, H=size, W=size, scale=scale)
+    out, _ = _run(case["feat"], case["rois"], scale)
+    assert np.abs(out.permute(0, 3, 1, 2).cpu().numpy().astype(np.float64) - case["expected"]).max() < 5e-5
+
+
+def test_backward_is_the_transpose_of_forward():
+    case = RC.known_answer_cases()[1]
+    feat = _pad4(case["feat"])
+    r = case["rois"][0]
+    Ay = RC.tent_weights(r[2], r[4], 32, case["scale"])
+    Ax = RC.tent_weights(r[1], r[3], 32, case["scale"])
+    for c, ph, pw in ((0, 0, 0), (1, 3, 5), (0, 7, 7)):
+        out, f = _run(feat, case["rois"], case["scale"], need_grad=True)
+        (g,) = torch.autograd.grad(out[0, ph, pw, c], f)
+        expect = np.zeros((1, 32, 32, 4))
+        expect[0, :, :, c] = np.outer(Ay[ph], Ax[pw])
+        assert np.abs(g.cpu().numpy() - expect).max() < 1e-6
+
+
+def test_two_scale_routing_and_validity():
+    """fine map = 1, coarse map = 2: the output value says which map an ROI pooled from
+    (model/rcnn_discriminator_app.py:131: fine iff width < 64 AND height < 64); invalid rows give zeros."""
+    from layout2img_amd import ops
+    dev = torch.device("cuda:0")
+    fs, fl = torch.full((1, 32, 32, 4), 1.0, device=dev), torch.full((1, 16, 16, 4), 2.0, device=dev)
+    rois = torch.tensor([[0.0, *box] for box, _ in RC.ROUTING] + [[0.0, 0.0, 0.0, 10.0, 10.0]], device=dev)
+    valid = torch.tensor([1] * len(RC.ROUTING) + [0], dtype=torch.int32, device=dev)
+    out = ops.roi_align(fs, fl, rois, valid, 8, 0.25, 0.125, 64.0, 0)
+    vals = out.mean(dim=(1, 2, 3)).cpu().tolist()
+    assert vals[:-1] == [1.0 if s else 2.0 for _, s in RC.ROUTING]
+    assert vals[-1] == 0.0
