@@ -32,10 +32,10 @@ def _build_g(fx, seed, dt, kind="coco"):
     return g
 
 
-def _build_d(fx, seed, dt):
+def _build_d(fx, seed, dt, num_classes=184):
     import layout2img_amd as L
     torch.manual_seed(0)
-    d = L.CombineDiscriminator128_app(num_classes=184)
+    d = L.CombineDiscriminator128_app(num_classes=num_classes)
     sd = fixture_state(fx, seed)
     assert set(d.state_dict().keys()) == set(sd.keys())
     d.load_state_dict(sd)
@@ -220,3 +220,106 @@ def test_full_size_step_properties():
     assert torch.equal(a[3], b[3])
     assert maxdiff(a[0], b[0]) < 0.2 * float(a[0].abs().max()) + 1.0  # different SN iteration, same images
     assert torch.isfinite(a[1][v]).all() and torch.isfinite(a[2][v]).all()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_vg_models_with_image_slot_vs_reference(dt):
+    """BASELINE config 5 models on layouts with the `__image__` slot (reference data/vg.py:120,135: label 0 and box
+    [0,0,1,1] -- not an attention key, not an ROI, but its mask feeds ISLA): generator and discriminator (o = 31,
+    179 classes, 45 valid of 62 ROI rows, one ROI exactly 64 px wide) against reference outputs."""
+    f32 = dt == torch.float32
+    fx = load_fixture("g_vg_img.npz")
+    g = _build_g(fx, 51, dt, kind="vg")
+    inp = {k: v.to(DEV) for k, v in fixture_inputs(fx).items()}
+    g.train()
+    out1 = g(inp["z"], inp["bbox"], inp["z_im"], inp["y"])
+    assert maxdiff(out1[:, :, ::2, ::2], fx["out_train1_sub"]) < (1e-3 if f32 else 1e-1)
+    proj = torch.randn(out1.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+    g.zero_grad()
+    (out1 * proj).sum().backward()
+    g.arena.flush_grads()
+    _check_grad_norms(dict(g.named_parameters()), fx, f32)
+    with torch.no_grad():
+        g.eval()
+        oe = g(inp["z"], inp["bbox"], inp["z_im"], inp["y"])
+    assert maxdiff(oe[:, :, ::2, ::2], fx["out_eval_sub"]) < (1e-3 if f32 else 1e-1)
+
+    fx = load_fixture("d_vg.npz")
+    d = _build_d(fx, 52, dt, num_classes=179)
+    rel = 2e-4 if f32 else 3e-2
+    d.train()
+    real = inp["real"].clone().requires_grad_(True)
+    o1 = d(real, inp["bbox"], inp["y"].unsqueeze(-1))
+    for t, k in zip(o1, ("img", "obj", "app")):
+        ref = fx[f"train1_{k}"]
+        assert tuple(t.shape) == ref.shape, (k, t.shape, ref.shape)
+        assert maxdiff(t, ref) < rel * max(1.0, float(np.abs(ref).max())), (k, maxdiff(t, ref))
+    gen = torch.Generator().manual_seed(6)
+    d.zero_grad()
+    sum((t * torch.randn(t.shape, generator=gen).to(DEV)).sum() for t in o1).backward()
+    d.arena.flush_grads()
+    _check_grad_norms(dict(d.named_parameters()), fx, f32)
+    gi = torch.from_numpy(fx["grad_input_sub"])
+    assert float((real.grad[:, :, ::4, ::4].cpu() - gi).norm() / gi.norm()) < (1e-2 if f32 else 2e-1)
+    with torch.no_grad():
+        d.eval()
+        oe = d(inp["real"], inp["bbox"], inp["y"].unsqueeze(-1))
+    for e, k in zip(oe, ("img", "obj", "app")):
+        assert maxdiff(e, fx[f"eval_{k}"]) < rel * max(1.0, float(np.abs(fx[f"eval_{k}"]).max())), k
+
+
+def test_vg_train_loop_vs_reference():
+    """Two iterations of the loop with the VG models on `__image__`-slot layouts (f32 operands)."""
+    import layout2img_amd as L
+    fx = load_fixture("train_loop_vg.npz")
+    g = _build_g(load_fixture("g_vg_img.npz"), 53, torch.float32, kind="vg")
+    d = _build_d(load_fixture("d_vg.npz"), 54, torch.float32, num_classes=179)
+    g.train(), d.train()
+    tr = L.GanTrainer(g, d)
+    for it in range(2):
+        inp = {k: v.to(DEV) for k, v in recipe.make_inputs_vg(2, 31, 179, 300 + it).items()}
+        r = tr.step(inp["real"], inp["y"], inp["bbox"], inp["z"], inp["z_im"])
+        rel, tol_img = (5e-4, 1e-3) if it == 0 else (3e-2, 2e-2)
+        for k in ("d_loss", "g_loss"):
+            ref = float(fx[f"{k}{it}"])
+            assert abs(float(r[k]) - ref) < rel * max(1.0, abs(ref)), (k, it, float(r[k]), ref)
+        assert maxdiff(r["fake"][:, :, ::4, ::4], fx[f"fake_sub{it}"]) < tol_img
+    for net, pre in ((g, "g"), (d, "d")):
+        named = dict(net.named_parameters())
+        names = [str(n) for n in fx[f"{pre}_param_names"]]
+        sums = np.array([float(named[n].detach().double().sum()) for n in names])
+        numel = np.array([named[n].numel() for n in names])
+        tol = 1e-3 * (np.abs(fx[f"{pre}_param_sums"]) + 1.0) + 2 * 2e-4 * numel * 0.05
+        bad = np.abs(sums - fx[f"{pre}_param_sums"]) - tol
+        assert np.all(bad < 0), (pre, names[int(bad.argmax())])
+
+
+def test_full_size_vg_step_properties():
+    """BASELINE config 5 at full size (128x128, b = 32, o = 31, 179 classes, bf16): one training iteration -- finite
+    losses, image range, parameters move, and the `__image__` slot is never an ROI while it does change the image."""
+    import layout2img_amd as L
+    from layout2img_amd import generator as G
+    from layout2img_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    g = G.context_aware_generator(num_classes=179).finalize(DEV, torch.bfloat16)
+    d = L.CombineDiscriminator128_app(num_classes=179).finalize(DEV, torch.bfloat16)
+    tr = L.GanTrainer(g, d)
+    real, label, bbox, z, z_im = make_batch(32, 128, "vg", seed=3, device=DEV)
+    n_real = (label != 0).sum(1)
+    assert all(bbox[i, int(n_real[i])].tolist() == [0.0, 0.0, 1.0, 1.0] for i in range(32))
+    p0g, p0d = g.flat.data.clone(), d.flat.data.clone()
+    r = tr.step(real, label, bbox, z, z_im)
+    torch.cuda.synchronize()
+    assert torch.isfinite(r["d_loss"]) and torch.isfinite(r["g_loss"])
+    assert r["fake"].shape == (32, 3, 128, 128) and float(r["fake"].abs().max()) <= 1.0
+    assert float((g.flat.data - p0g).abs().max()) > 0 and float((d.flat.data - p0d).abs().max()) > 0
+    with torch.no_grad():
+        out = d.forward_padded(real, bbox, label)
+        assert int(out[3].sum()) == int(n_real.sum())           # valid ROI rows == real objects: the image slot is none
+        g.eval()
+        a = g(z, bbox, z_im, label)
+        bbox2 = bbox.clone()
+        for i in range(32):
+            bbox2[i, int(n_real[i])] = torch.tensor([-0.6, -0.6, 0.5, 0.5], device=DEV)   # image slot -> plain padding
+        b = g(z, bbox2, z_im, label)
+    assert maxdiff(a, b) > 1e-3   # its full-canvas mask contributes to ISLA (SURVEY App. C.15)

@@ -137,7 +137,8 @@ def test_conv_halo_tiles(case, cfg):
                                  alpha=0.25 if pool2 else 1.0)
     finally:
         _lib.call("l2i_set_conv_config", -1)
-    assert float((out.cpu() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    # operands are pre-rounded to bf16, products are exact in f32: only the accumulation order differs from torch's
+    assert float((out.cpu() - ref).abs().max()) < 3e-5 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -118,3 +118,51 @@ def test_train_loop_matches_reference():
         numel = np.array([sd[n].numel() for n in names])
         tol = 1e-4 * (np.abs(fx[f"{pre}_param_sums"]) + 1.0) + 2 * 2e-4 * numel * 0.05
         assert np.all(np.abs(sums - fx[f"{pre}_param_sums"]) < tol)
+
+
+def test_vg_models_with_image_slot_match_reference():
+    """BASELINE config 5 (o = 31, 179 classes) on layouts with the `__image__` slot of data/vg.py:120,135 (label 0,
+    box [0,0,1,1]): generator, discriminator (45 ROIs incl. one exactly 64 px wide) and two loop iterations."""
+    from tests.golden import recipe
+    fx = load_fixture("g_vg_img.npz")
+    inp = fixture_inputs(fx)
+    n_real = (inp["y"] != 0).sum(1)
+    for i in range(inp["y"].shape[0]):   # the fixture really holds the slot
+        assert inp["bbox"][i, int(n_real[i])].tolist() == [0.0, 0.0, 1.0, 1.0] and int(inp["y"][i, int(n_real[i])]) == 0
+    sd = O.make_trainable(fixture_state(fx, 51))
+    out1 = O.vg_generator_forward(sd, inp["z"], inp["bbox"], inp["z_im"], inp["y"], training=True)
+    assert maxdiff(out1[:, :, ::2, ::2], fx["out_train1_sub"]) < TOL
+    proj = torch.randn(out1.shape, generator=torch.Generator().manual_seed(5))
+    (out1 * proj).sum().backward()
+    assert _norms_close(_grad_norms(sd, [str(n) for n in fx["grad_names"]]), fx["grad_norms"])
+    with torch.no_grad():
+        oe = O.vg_generator_forward(sd, inp["z"], inp["bbox"], inp["z_im"], inp["y"], training=False)
+    assert maxdiff(oe[:, :, ::2, ::2], fx["out_eval_sub"]) < TOL
+
+    fx = load_fixture("d_vg.npz")
+    sd = O.make_trainable(fixture_state(fx, 52))
+    real = inp["real"].clone().requires_grad_(True)
+    o1 = O.discriminator_forward(sd, real, inp["bbox"], inp["y"], training=True)
+    for t, k in zip(o1, ("img", "obj", "app")):
+        ref = fx[f"train1_{k}"]
+        assert t.shape == ref.shape and maxdiff(t, ref) < 1e-4 * max(1.0, float(np.abs(ref).max())), k
+    gen = torch.Generator().manual_seed(6)
+    sum((t * torch.randn(t.shape, generator=gen)).sum() for t in o1).backward()
+    assert _norms_close(_grad_norms(sd, [str(n) for n in fx["grad_names"]]), fx["grad_norms"])
+    assert maxdiff(real.grad[:, :, ::4, ::4], fx["grad_input_sub"]) < 1e-3 * max(1.0, float(np.abs(fx["grad_input_sub"]).max()))
+    with torch.no_grad():
+        oe = O.discriminator_forward(sd, inp["real"], inp["bbox"], inp["y"], training=False)
+    for e, k in zip(oe, ("img", "obj", "app")):
+        assert maxdiff(e, fx[f"eval_{k}"]) < 1e-4 * max(1.0, float(np.abs(fx[f"eval_{k}"]).max()))
+
+    fx = load_fixture("train_loop_vg.npz")
+    sd_g = O.make_trainable(fixture_state(load_fixture("g_vg_img.npz"), 53))
+    sd_d = O.make_trainable(fixture_state(load_fixture("d_vg.npz"), 54))
+    tr = O.OracleTrainer(sd_g, sd_d, vg=True)
+    for it in range(2):
+        inp = recipe.make_inputs_vg(2, 31, 179, 300 + it)
+        r = tr.step(inp["real"], inp["y"], inp["bbox"], inp["z"], inp["z_im"])
+        rel, tol_img = (1e-4, 5e-5) if it == 0 else (2e-2, 1e-2)
+        assert abs(float(r["d_loss"]) - float(fx[f"d_loss{it}"])) < rel * max(1.0, abs(float(fx[f"d_loss{it}"])))
+        assert abs(float(r["g_loss"]) - float(fx[f"g_loss{it}"])) < rel * max(1.0, abs(float(fx[f"g_loss{it}"])))
+        assert maxdiff(r["fake"][:, :, ::4, ::4], fx[f"fake_sub{it}"]) < tol_img

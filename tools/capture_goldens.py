@@ -219,6 +219,83 @@ def capture_train_loop():
     print("loop captured", {k: v for k, v in rec.items() if isinstance(v, float)})
 
 
+def capture_vg():
+    """BASELINE config 5 models (context_aware_generator + rcnn_discriminator_vg, 179 classes, o = 31) on layouts WITH
+    the `__image__` slot (data/vg.py:120,135): a generator golden, a discriminator golden and two loop iterations."""
+    from model.rcnn_discriminator_vg import CombineDiscriminator128_app as D
+    from model.resnet_generator_vg import context_aware_generator as G
+    torch.manual_seed(0)
+    # --- generator
+    g = load(G(num_classes=179, output_dim=3), 51)
+    inp = recipe.make_inputs_vg(2, 31, 179, 151)
+    ks, shp = keys_blob(shapes_of(g))
+    rec = dict(keys=ks, shapes=shp, **{k: v.numpy() for k, v in inp.items()})
+    g.train()
+    out1 = g(inp["z"], inp["bbox"], inp["z_im"], inp["y"])
+    proj = torch.randn(out1.shape, generator=torch.Generator().manual_seed(5))
+    g.zero_grad()
+    (out1 * proj).sum().backward()
+    gn_names, gn = grad_norms(g)
+    g.eval()
+    oe = g(inp["z"], inp["bbox"], inp["z_im"], inp["y"])
+    rec.update(out_train1_sub=out1.detach().numpy()[:, :, ::2, ::2], grad_names=gn_names, grad_norms=gn,
+               out_eval_sub=oe.detach().numpy()[:, :, ::2, ::2])
+    np.savez_compressed(os.path.join(OUT, "g_vg_img.npz"), **rec)
+    print("VG G (image slot) captured", float(out1.abs().max()))
+    # --- discriminator at o = 31 / 179 classes
+    d = load(D(num_classes=179), 52)
+    ks, shp = keys_blob(shapes_of(d))
+    rec = dict(keys=ks, shapes=shp, **{k: v.numpy() for k, v in inp.items()})
+    d.train()
+    label = inp["y"].unsqueeze(-1)
+    real = inp["real"].clone().requires_grad_(True)
+    o1 = d(real, inp["bbox"].clone(), label)
+    d.zero_grad()
+    gen = torch.Generator().manual_seed(6)
+    sum((t * torch.randn(t.shape, generator=gen)).sum() for t in o1).backward()
+    gn_names, gn = grad_norms(d)
+    d.eval()
+    oe = d(inp["real"], inp["bbox"].clone(), label)
+    rec.update(train1_img=o1[0].detach().numpy(), train1_obj=o1[1].detach().numpy(), train1_app=o1[2].detach().numpy(),
+               grad_names=gn_names, grad_norms=gn, grad_input_sub=real.grad.numpy()[:, :, ::4, ::4].copy(),
+               eval_img=oe[0].detach().numpy(), eval_obj=oe[1].detach().numpy(), eval_app=oe[2].detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "d_vg.npz"), **rec)
+    print("VG D captured", [tuple(t.shape) for t in o1])
+    # --- two loop iterations (train_context_app_v2.py:148-189, VGG term omitted)
+    netG, netD = load(G(num_classes=179, output_dim=3), 53), load(D(num_classes=179), 54)
+    netG.train(), netD.train()
+    g_opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in netG.parameters()], betas=(0.0, 0.999))
+    d_opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in netD.parameters()], betas=(0.0, 0.999))
+    relu = torch.nn.ReLU()
+    rec = {}
+    for it in range(2):
+        inp = recipe.make_inputs_vg(2, 31, 179, 300 + it)
+        real, label, bbox = inp["real"], inp["y"].unsqueeze(-1), inp["bbox"]
+        netD.zero_grad()
+        r_im, r_obj, r_app = netD(real, bbox.clone(), label)
+        fake = netG(inp["z"], bbox, inp["z_im"], label.squeeze(-1))
+        f_im, f_obj, f_app = netD(fake.detach(), bbox.clone(), label)
+        d_loss = (1.0 * (relu(1 - r_obj).mean() + relu(1 + f_obj).mean()) + 0.1 * (relu(1 - r_im).mean() + relu(1 + f_im).mean()) +
+                  1.0 * (relu(1 - r_app).mean() + relu(1 + f_app).mean()))
+        d_loss.backward()
+        d_opt.step()
+        netG.zero_grad()
+        g_im, g_obj, g_app = netD(fake, bbox.clone(), label)
+        pixel = torch.nn.L1Loss()(fake, real).mean()
+        g_loss = -g_obj.mean() * 1.0 - g_im.mean() * 0.1 + pixel - 1.0 * g_app.mean()
+        g_loss.backward()
+        g_opt.step()
+        rec[f"d_loss{it}"], rec[f"g_loss{it}"], rec[f"pixel{it}"] = float(d_loss), float(g_loss), float(pixel)
+        rec[f"fake_sub{it}"] = fake.detach().numpy()[:, :, ::4, ::4]
+    for net, pre in ((netG, "g"), (netD, "d")):
+        names = sorted(n for n, _ in net.named_parameters())
+        dd = dict(net.named_parameters())
+        rec[f"{pre}_param_names"] = np.array(names)
+        rec[f"{pre}_param_sums"] = np.array([float(dd[n].detach().double().sum()) for n in names])
+    np.savez_compressed(os.path.join(OUT, "train_loop_vg.npz"), **rec)
+    print("VG loop captured", {k: v for k, v in rec.items() if isinstance(v, float)})
+
+
 def capture_small_ops():
     """Known answers the survey lists for masks_to_layout / bbox_mask."""
     from model.resnet_generator_app_v2 import bbox_mask
@@ -236,7 +313,7 @@ def capture_small_ops():
 if __name__ == "__main__":
     patch_env()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["small", "g_coco", "g_vg", "d", "d64", "loop"]
+    which = sys.argv[1:] or ["small", "g_coco", "g_vg", "d", "d64", "loop", "vg"]
     with torch.random.fork_rng():
         if "small" in which:
             capture_small_ops()
@@ -250,3 +327,5 @@ if __name__ == "__main__":
             capture_discriminator64()
         if "loop" in which:
             capture_train_loop()
+        if "vg" in which:
+            capture_vg()
