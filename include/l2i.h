@@ -36,18 +36,23 @@ int l2i_version(void);
  * fused: pool2, alpha = 0.25) and their input gradients (same kernel on the dgrad weight pack).
  *   out = alpha * pool?(conv(up?(x), w)) + bias ; zeroed where relu_mask <= 0 ; + res
  * x [B,Hi,Wi,Ci] T; w packed [Npad][Kpad] T (l2i_weights_prepare); (Ho,Wo) = conv-output grid
- * (= 2*(Hi,Wi) if up2); out/res/relu_mask/out_op* are [B,Ho>>pool2,Wo>>pool2,Co]. KH in {1,3}. */
+ * (= 2*(Hi,Wi) if up2); out/res/relu_mask/out_op* are [B,Ho>>pool2,Wo>>pool2,Co]. KH in {1,3}.
+ * nimg (optional DEVICE int): only the first *nimg of the B images are live -- workgroups whose rows all belong to
+ * later images skip the reduction, and every row of a later image is written as zeros. This is how the ROI heads of the
+ * discriminator (model/rcnn_discriminator_app.py:148-166) run over the batch's real ROIs only while the launch keeps
+ * the fixed, host-sync-free shape R = b*o: ROIs are compacted to the front (reference order, :145-146, 413-417). */
 int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float* res, const void* relu_mask,
                    float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
-                   int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, void* stream);
+                   int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, void* stream);
 
 /* Tuning hook: force one of the forward-kernel tile configurations (see conv_igemm.hip), -1 = built-in heuristic. */
 int l2i_set_conv_config(int cfg);
 
 /* Weight gradient of the same convolution: dw[Co][ldw] += alpha * dYfull^T . im2col(x)
- * (autograd of the layers above). dy [B,Ho>>pool2,Wo>>pool2,Co] T; k order (ky,kx,ci). */
+ * (autograd of the layers above). dy [B,Ho>>pool2,Wo>>pool2,Co] T; k order (ky,kx,ci).
+ * nimg (optional DEVICE int, needs Ho*Wo % 64 == 0): the reduction covers the first *nimg images only. */
 int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
-                     int Co, int KH, int up2, int pool2, int ldw, float alpha, void* stream);
+                     int Co, int KH, int up2, int pool2, int ldw, float alpha, const int* nimg, void* stream);
 /* Tuning hook: co-resident workgroups a weight-gradient launch is sized for (0 = derive from the tile: default). */
 int l2i_set_wgrad_blocks(int n);
 /* Debug aid: co-resident workgroups per CU for conv instantiation `which` with lds_bytes of dynamic LDS. */

@@ -14,9 +14,9 @@ _p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 SIGNATURES = {
     "l2i_version": [],
-    "l2i_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "l2i_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p],
     "l2i_set_conv_config": [_i],
-    "l2i_conv2d_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "l2i_conv2d_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p],
     "l2i_weights_prepare": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p],
     "l2i_weights_backward": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "l2i_channel_stats": [_p, _ll, _i, _ll, _p, _p, _p, _i, _p, _p],
@@ -70,24 +70,27 @@ WS_FLOATS = 32 * 4 * 1024   # L2I_WS_FLOATS of include/l2i.h
 _WS = {}
 
 
-_DEV_INDEX = None
+def current_device():
+    import torch
+    return torch._C._cuda_getDevice()
 
 
 def raw_stream():
-    """hipStream_t of torch's current stream on this process's GPU (one process drives one GPU). The public
+    """hipStream_t of torch's current stream on the CURRENT device (queried per call: two plain C calls). The public
     torch.cuda.current_stream() costs ~10 us of Python per call, which at ~1000 launches per iteration is a tenth of the
-    host time; the raw accessor is a plain C call."""
-    global _DEV_INDEX
+    host time. ops._chk refuses tensors that live on another device than the current one, so a kernel is never
+    enqueued on a stream of the wrong GPU."""
     import torch
-    if _DEV_INDEX is None:
-        _DEV_INDEX = torch.cuda.current_device()
-    return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def workspace(device):
-    """Pointer to the (device, current stream)'s all-zero reduction workspace (self-cleaning; csrc/common.h)."""
+    """Pointer to the (device, current stream)'s all-zero reduction workspace (self-cleaning; csrc/common.h).
+    Created on first use; GanTrainer.capture creates the ones of its capture streams BEFORE capturing, so none is
+    ever allocated inside a graph's private pool."""
     import torch
-    key = (torch.device(device).index or 0, raw_stream())
+    idx = torch.device(device).index
+    key = (current_device() if idx is None else idx, raw_stream())
     w = _WS.get(key)
     if w is None:
         w = _WS[key] = torch.zeros(WS_FLOATS, dtype=torch.float32, device=device)

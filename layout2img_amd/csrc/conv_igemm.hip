@@ -27,6 +27,7 @@ struct ConvArgs {
     void* out_op;       // T   same shape, optional operand copy (relu'd if relu_op)
     void* out_op_raw;   // T   same shape, optional un-activated operand copy
     const void* relu_mask;  // T, shape of out: result is zeroed where mask <= 0 (ReLU backward), before res is added
+    const int* nimg;        // device int (optional): only the first *nimg images are live; rows of the others are written as zeros
     int B, Hi, Wi, Ci, Ho, Wo, Co, KH;
     int up2, pool2, relu_op;
     int Kpad, K;
@@ -121,7 +122,7 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvArgs& p, f32x16_t
                     const int Hq = p.Ho >> 1, Wq = p.Wo >> 1;
                     const int b = r2 / Hq, y2 = r2 - b * Hq, x2 = tile_c * (p.PW >> 1) + qx;
                     rowoff = ((size_t)(b * Hq + y2) * Wq + x2) * p.Co;
-                    live = r2 < p.B * Hq;
+                    live = 2 * r2 < rows_total;
                 } else {
                     int py, px;
                     idx2pix(idx, p.hw_shift, p.lin, py, px);
@@ -142,7 +143,7 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvArgs& p, f32x16_t
 
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane,
-                                              int tile_r, int tile_c, int n0, int split, int rows_total) {
+                                              int tile_r, int tile_c, int n0, int split, int rows_total, int rows_live) {
     const int m = lane & 31, h = lane >> 5;
     T* __restrict__ OutOp = reinterpret_cast<T*>(p.out_op);
     T* __restrict__ OutRaw = reinterpret_cast<T*>(p.out_op_raw);
@@ -152,7 +153,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)
     for (int i = 0; i < TM; ++i) {
         const int idx = wrow + i * 32 + m;   // this lane's pixel (GEMM row)
         size_t rowoff;
-        bool live;
+        bool live, dead;   // dead: a row of an image past *nimg -- written as zeros
         if (p.pool2) {
             const int q = idx >> 2;
             const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
@@ -161,13 +162,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)
             const int b = r2 / Hq, y2 = r2 - b * Hq, x2 = tile_c * (p.PW >> 1) + qx;
             rowoff = ((size_t)(b * Hq + y2) * Wq + x2) * p.Co;
             live = r2 < p.B * Hq && (lane & 3) == 0;   // one lane of the quad writes the pooled pixel
+            dead = 2 * r2 >= rows_live;
         } else {
             int py, px;
             idx2pix(idx, p.hw_shift, p.lin, py, px);
             const int r = tile_r * p.PH + py;
             rowoff = ((size_t)r * p.Wo + tile_c * p.PW + px) * p.Co;
             live = r < rows_total;
+            dead = r >= rows_live;
         }
+        if (p.splits > 1 && dead) live = false;   // split-K: dead rows keep the zeros of the memset
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -197,6 +201,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)
                     const float4 rr = *reinterpret_cast<const float4*>(p.res + off);
                     v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                 }
+                if (dead) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }   // (a select: whatever was read for a dead row is dropped)
                 if (p.splits > 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) atomicAdd(p.out + off + e, v[e]);
@@ -248,6 +253,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
     const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
     const int n0 = tile_n * BN;
     const int rows_total = p.B * p.Ho;
+    const int rows_live = p.nimg ? min(rows_total, *p.nimg * p.Ho) : rows_total;   // (scalar load)
+    const bool tile_dead = !p.lin && tile_r * p.PH >= rows_live;   // every row belongs to a dead image: no reduction, zeros out
     const int pad = p.KH >> 1;
 
     // ---- per-thread A rows (fixed for the whole K loop). Loads are buffer_load ... lds: a 32-bit byte offset per
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
 
     const int wrow = (wave / WN) * (BM / WM), wcol = (wave % WN) * (BN / WN);
     const int ks0 = split * p.ks_per;
-    const int nks = min(p.nks, ks0 + p.ks_per);
+    const int nks = tile_dead ? ks0 : min(p.nks, ks0 + p.ks_per);
     // NS-stage LDS ring. Tiles ks .. ks+NS-2 are in flight while tile ks is consumed: each wave waits with a COUNTED
     // s_waitcnt vmcnt for its own DMA of tile ks (its LPT newest-but-... loads may stay outstanding), then a raw
     // s_barrier makes every wave's part of the tile visible and proves the stage about to be refilled is no longer
@@ -384,8 +391,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
         Mma2<T>::template step<TM, TN, HK>(cur, cur + BM * ROWB, wrow, wcol, lane, acc);
     }
 
-    if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_total, smem);
-    else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total);
+    if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
+    else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
 }
 
 // ---------------------------------------------------------------- 3x3 convolution with an LDS-resident input halo
@@ -445,6 +452,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
     const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
     const int n0 = tile_n * BN;
     const int rows_total = p.B * p.Ho;
+    const int rows_live = p.nimg ? min(rows_total, *p.nimg * p.Ho) : rows_total;   // (scalar load)
+    const bool tile_dead = tile_r * p.PH >= rows_live;   // every row belongs to a dead image: no reduction, zeros out
     const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
     const unsigned smem_addr = lds_addr_of(smem);
     const unsigned halo_bytes = (unsigned)p.halo_pieces * 1024u;
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
 
     // ---- reduction range of this split: chunks [c_begin, c_end)
     const int nchunks_all = (p.Ci + BK - 1) / BK, cper = p.ks_per / 9;
-    const int c_begin = split * cper, c_end = min(nchunks_all, c_begin + cper);
+    const int c_begin = split * cper, c_end = tile_dead ? c_begin : min(nchunks_all, c_begin + cper);
     const int last_cb = (c_end - 1) * BK;
     const int ci2 = p.Ci * SZ;
 
@@ -648,8 +657,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
 #undef H2_MFMA4
 #undef H2_MFMA
 #undef H2_READS
-    if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_total, smem);
-    else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total);
+    if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
+    else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
 }
 
 static int ilog2(int v) {
@@ -843,9 +852,10 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
 // C ABI -- see include/l2i.h
 extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float* res,
                               const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
-                              int up2, int pool2, int relu_op, int Kpad, float alpha, void* stream) {
+                              int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, void* stream) {
     if (!x || !w || (!out && !out_op && !out_op_raw)) return L2I_ERR_ARG;
     ConvArgs a;
+    a.nimg = nimg;
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out; a.out_op = out_op; a.out_op_raw = out_op_raw; a.relu_mask = relu_mask;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.relu_op = relu_op ? 1 : 0;

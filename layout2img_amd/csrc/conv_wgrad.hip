@@ -24,7 +24,21 @@ struct WgradArgs {
     int K, ldw, M, Mper, tiles_co, tiles_k, splits;
     float alpha;
     unsigned x_bytes, dy_bytes;   // buffer-descriptor ranges of x and dy
+    const int* nimg;              // device int (optional): reduce over the first *nimg images only
 };
+
+// The reduction range [m_begin, m_end) of one split. With a device-side image count the live pixels are divided over
+// the launch's `splits` again on the device (whole 64-pixel steps), so every split still does an equal share.
+__device__ __forceinline__ void wgrad_range(const WgradArgs& p, int split, int& m_begin, int& m_end) {
+    int M = p.M, Mper = p.Mper;
+    if (p.nimg) {
+        M = min(M, *p.nimg * p.Ho * p.Wo);
+        const int steps = (M + 63) >> 6;
+        Mper = ((steps + p.splits - 1) / p.splits) << 6;
+    }
+    m_begin = split * Mper;
+    m_end = min(M, m_begin + Mper);
+}
 
 template <typename T> struct Tr;
 template <> struct Tr<bf16_t> {
@@ -78,8 +92,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
 
-    const int m_begin = split * p.Mper;
-    const int m_end = min(p.M, m_begin + p.Mper);
+    int m_begin, m_end;
+    wgrad_range(p, split, m_begin, m_end);
 
     // per-task constants
     int t_pg[NIT], t_row[NIT], t_chan[NIT], t_ky[NIT], t_kx[NIT];
@@ -238,8 +252,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
     const int co0 = tile_co * BMO, kc0 = tile_k * BNK;
     const int pad = p.KH >> 1;
     const int Hd = p.Ho >> p.pool2, Wd = p.Wo >> p.pool2;
-    const int m_begin = split * p.Mper;
-    const int m_end = min(p.M, m_begin + p.Mper);
+    int m_begin, m_end;
+    wgrad_range(p, split, m_begin, m_end);
 
     // per-lane constants: A (dY) chunk
     const int a_row = lane / A_CH;                                     // row within the wave-instruction
@@ -510,9 +524,11 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
 
 extern "C" int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
                                 int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
-                                void* stream) {
+                                const int* nimg, void* stream) {
     if (!x || !dy || !dw) return L2I_ERR_ARG;
+    if (nimg && (Ho * Wo) % 64) return L2I_ERR_ARG;
     WgradArgs a;
+    a.nimg = nimg;
     a.x = x; a.dy = dy; a.dw = dw;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.ldw = ldw; a.alpha = alpha;

@@ -48,14 +48,14 @@ class ResBlock(nn.Module):
         if self.learnable_sc:
             self.c_sc = _conv(in_ch, out_ch, 1, uses)
 
-    def forward(self, x, pc, use=0):
+    def forward(self, x, pc, use=0, nimg=None):
         """`use`: index of this application within the forward pass (each application of a spectral-normed
-        module runs its own power iteration in the reference)."""
+        module runs its own power iteration in the reference). `nimg`: device count of live leading images (ROI heads)."""
         if self.learnable_sc:
             ops.precast(x, pc.arena.op_dtype)   # conv1 reads relu(x), the shortcut reads x: one cast launch for both
-        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU)
-        sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample) if self.learnable_sc else x
-        return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample)
+        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg)
+        sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg) if self.learnable_sc else x
+        return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample, nimg=nimg)
 
 
 class ResnetDiscriminator128_app(nn.Module):
@@ -78,8 +78,9 @@ class ResnetDiscriminator128_app(nn.Module):
         self.l_y_app = GemmWeight("embedding", num_classes, ch * 8, bias=False, sn=True)
         self.app = GemmWeight("linear", 1, ch * 16, sn=True)
 
-    def forward(self, x, y, rois, valid, pc):
-        """x (b,H,W,8) f32 NHWC (3 real channels); y (R,) labels; rois (R,5); valid (R,) int32."""
+    def forward(self, x, y, rois, valid, pc, nimg=None):
+        """x (b,H,W,8) f32 NHWC (3 real channels); y (R,) labels; rois (R,5); valid (R,) int32; nimg: device int32 =
+        number of valid rows when they are compacted to the front (the ROI heads then skip the rest)."""
         x = self.block1(x, pc)
         x1 = self.block2(x, pc)
         x2 = self.block3(x1, pc)
@@ -94,7 +95,7 @@ class ResnetDiscriminator128_app(nn.Module):
         obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0)  # (R,8,8,C)
 
         # appearance head (reference :148-157): Gram of the ROI features + class embedding
-        a = self.app_conv(obj, pc)                                        # (R, 8, 8, C) pre-ReLU
+        a = self.app_conv(obj, pc, nimg=nimg)                             # (R, 8, 8, C) pre-ReLU
         s2 = a.shape[3]
         wa = arena_weight(self.app, pc)                                   # (1, 2C)
         emb_app = arena_weight(self.l_y_app, pc).index_select(0, y)                     # (R, C)
@@ -104,7 +105,7 @@ class ResnetDiscriminator128_app(nn.Module):
         out_app = gram_term + emb_app @ wa[0, s2:].unsqueeze(1) + self.app.bias
 
         # projection head (reference :160-166)
-        f = F.relu(self.block_obj5(obj, pc)).sum(dim=(1, 2))              # (R, 16ch)
+        f = F.relu(self.block_obj5(obj, pc, nimg=nimg)).sum(dim=(1, 2))   # (R, 16ch)
         out_obj = F.linear(f, arena_weight(self.l_obj, pc), self.l_obj.bias)
         out_obj = out_obj + torch.sum(arena_weight(self.l_y, pc).index_select(0, y) * f, dim=1, keepdim=True)
         return out_im, out_obj, out_app
@@ -129,29 +130,46 @@ class CombineDiscriminator128_app(nn.Module):
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()  # pending pass contexts stay: they are consumed by FlatAdam.step()
 
-    def _prepare(self, images, bbox, label):
-        """xywh in [0,1] -> (R,5) pixel ROIs with batch index, flat labels, validity, NHWC image padded to 8 channels
-        (reference :402-417 without the host-synchronising nonzero())."""
-        b, o = bbox.size(0), bbox.size(1)
-        size = images.size(2)
-        bb = bbox.to(images.device).float()
-        xyxy = torch.stack((bb[..., 0], bb[..., 1], bb[..., 0] + bb[..., 2], bb[..., 1] + bb[..., 3]), dim=-1) * size
-        idx = torch.arange(b, device=images.device, dtype=torch.float32).view(b, 1, 1).expand(b, o, 1)
-        rois = torch.cat((idx, xyxy), dim=2).view(-1, 5).contiguous()
-        y = label.reshape(-1)
-        valid = (y != 0).to(torch.int32).contiguous()
-        x = F.pad(images.permute(0, 2, 3, 1), (0, 8 - images.size(1))).contiguous()
-        return rois, y, valid, x
+    two_scale = True   # ROIs >= 64 px in width or height pool from the coarse map and come first (reference :131-146)
 
-    def forward_padded(self, images, bbox, label, need_wgrad=True, pc=None):
-        """pc: a pass context already prepared for this pass (GanTrainer prepares the fake pass's weights on the side
+    def prepare_layout(self, bbox, label, size, device):
+        """xywh in [0,1] -> (R,5) pixel ROIs with batch index, flat labels, validity and the device-side count, with the
+        R = b*o rows COMPACTED: real ROIs first, in the reference's output order (large ROIs, then small ones, original
+        order within each, :145-146), padding rows (label 0) behind them. Reference :402-417 without the
+        host-synchronising nonzero(): the count stays on the device, the ROI heads read it there (`nimg`).
+        The layout depends on (bbox, label) only: GanTrainer computes it once per iteration for the three D passes."""
+        b, o = bbox.size(0), bbox.size(1)
+        bb = bbox.to(device).float()
+        xyxy = torch.stack((bb[..., 0], bb[..., 1], bb[..., 0] + bb[..., 2], bb[..., 1] + bb[..., 3]), dim=-1) * size
+        idx = torch.arange(b, device=device, dtype=torch.float32).view(b, 1, 1).expand(b, o, 1)
+        rois = torch.cat((idx, xyxy), dim=2).view(-1, 5)
+        y = label.reshape(-1).to(device)
+        valid = y != 0
+        key = (~valid).to(torch.int64) * 2
+        if self.two_scale:
+            key = key + (((rois[:, 3] - rois[:, 1]) < 64) & ((rois[:, 4] - rois[:, 2]) < 64)).to(torch.int64)
+        order = torch.argsort(key, stable=True)
+        valid_c = valid[order].to(torch.int32).contiguous()
+        return rois[order].contiguous(), y[order].contiguous(), valid_c, valid_c.sum(dtype=torch.int32).view(1)
+
+    def _prepare(self, images, bbox, label, layout=None):
+        """-> (rois, y, valid, count) as prepare_layout gives them, and the NHWC image padded to 8 channels."""
+        if layout is None:
+            layout = self.prepare_layout(bbox, label, images.size(2), images.device)
+        x = F.pad(images.permute(0, 2, 3, 1), (0, 8 - images.size(1))).contiguous()
+        return (*layout, x)
+
+    def forward_padded(self, images, bbox, label, need_wgrad=True, pc=None, layout=None):
+        """The sync-free form: (d_img (b,1), d_obj (R,1), d_app (R,1), valid (R,), rois (R,5)) over the fixed R = b*o rows
+        in compacted order (prepare_layout); rows with valid == 0 are padding.
+        pc: a pass context already prepared for this pass (GanTrainer prepares the fake pass's weights on the side
         stream while the generator is still running), else one is prepared here."""
         if not images.is_cuda:
             raise RuntimeError("layout2img_amd discriminators run on the GPU HIP path only")
-        rois, y, valid, x = self._prepare(images, bbox, label)
+        rois, y, valid, count, x = self._prepare(images, bbox, label, layout)
         if pc is None:
             pc = self.arena.prepare(training=self.training, need_wgrad=need_wgrad)
-        d_img, d_obj, d_app = self.obD(x, y, rois, valid, pc)
+        d_img, d_obj, d_app = self.obD(x, y, rois, valid, pc, nimg=count)
         return d_img, d_obj, d_app, valid, rois
 
     def obD_arena(self):
@@ -159,10 +177,8 @@ class CombineDiscriminator128_app(nn.Module):
 
     def forward(self, images, bbox, label, mask=None):
         d_img, d_obj, d_app, valid, rois = self.forward_padded(images, bbox, label)
-        small = ((rois[:, 3] - rois[:, 1]) < 64) & ((rois[:, 4] - rois[:, 2]) < 64)
-        v = valid.bool()
-        order = torch.cat((torch.nonzero(v & ~small).view(-1), torch.nonzero(v & small).view(-1)))
-        return d_img, d_obj[order], d_app[order]
+        n = int(valid.sum())   # (host sync: the module boundary returns the reference's dynamic shape)
+        return d_img, d_obj[:n], d_app[:n]
 
 
 class ResnetDiscriminator64(nn.Module):
@@ -186,7 +202,7 @@ class ResnetDiscriminator64(nn.Module):
             if name[-4:] == "bias":
                 nn.init.constant_(p, 0)
 
-    def forward(self, x, y, rois, valid, pc):
+    def forward(self, x, y, rois, valid, pc, nimg=None):
         x = self.block1(x, pc)
         x = self.block2(x, pc)
         x1 = self.block3(x, pc)
@@ -194,7 +210,7 @@ class ResnetDiscriminator64(nn.Module):
         x = self.block5(x, pc)
         out_im = F.linear(F.relu(x).mean(dim=(1, 2)), arena_weight(self.l_im, pc), self.l_im.bias)
         obj = ops.roi_align(x1, None, rois, valid, 8, 1.0 / 2.0, 1.0, 1e30, 0)
-        f = F.relu(self.block_obj4(obj, pc)).sum(dim=(1, 2))
+        f = F.relu(self.block_obj4(obj, pc, nimg=nimg)).sum(dim=(1, 2))
         out_obj = F.linear(f, arena_weight(self.l_obj, pc), self.l_obj.bias)
         out_obj = out_obj + torch.sum(arena_weight(self.l_y, pc).index_select(0, y) * f, dim=1, keepdim=True)
         return out_im, out_obj
@@ -203,21 +219,23 @@ class ResnetDiscriminator64(nn.Module):
 class CombineDiscriminator64(CombineDiscriminator128_app):
     """reference model/rcnn_discriminator_orig.py:305-325; returns (d_img, d_obj). `bbox` is not modified."""
 
+    two_scale = False   # single-scale ROIAlign: valid rows keep their original order
+
     def __init__(self, num_classes=81):
         nn.Module.__init__(self)
         self.obD = ResnetDiscriminator64(num_classes=num_classes, input_dim=3)
 
-    def forward_padded(self, images, bbox, label, need_wgrad=True, pc=None):
+    def forward_padded(self, images, bbox, label, need_wgrad=True, pc=None, layout=None):
         """pc: a pass context already prepared for this pass (GanTrainer prepares the fake pass's weights on the side
         stream while the generator is still running), else one is prepared here."""
         if not images.is_cuda:
             raise RuntimeError("layout2img_amd discriminators run on the GPU HIP path only")
-        rois, y, valid, x = self._prepare(images, bbox, label)
+        rois, y, valid, count, x = self._prepare(images, bbox, label, layout)
         if pc is None:
             pc = self.arena.prepare(training=self.training, need_wgrad=need_wgrad)
-        d_img, d_obj = self.obD(x, y, rois, valid, pc)
+        d_img, d_obj = self.obD(x, y, rois, valid, pc, nimg=count)
         return d_img, d_obj, valid, rois
 
     def forward(self, images, bbox, label, mask=None):
         d_img, d_obj, valid, _ = self.forward_padded(images, bbox, label)
-        return d_img, d_obj[torch.nonzero(valid).view(-1)]
+        return d_img, d_obj[:int(valid.sum())]

@@ -27,6 +27,9 @@ def _code(dtype):
 def _chk(t, dtype=None):
     if not t.is_cuda:
         raise RuntimeError("layout2img_amd ops run on the GPU only (no CPU fallback)")
+    if t.device.index != _lib.current_device():
+        raise RuntimeError(f"tensor on cuda:{t.device.index} but the current device is cuda:{_lib.current_device()}: "
+                           "kernels are launched on the current device's stream (torch.cuda.set_device first)")
     if not t.is_contiguous():
         raise RuntimeError("layout2img_amd ops need contiguous tensors")
     if dtype is not None and t.dtype != dtype:
@@ -51,6 +54,21 @@ class ZeroPool:
 
     def end(self):
         self.active = False
+
+    def step(self, device, nfloats=8 << 20):
+        """Context manager form: `with POOL.step(dev): ...` -- the pool is deactivated even when the step raises, so a
+        failed iteration cannot leave later forwards / backwards taking never-re-zeroed slices."""
+        pool = self
+
+        class _Step:
+            def __enter__(self_):
+                pool.begin(device, nfloats)
+                return pool
+
+            def __exit__(self_, *exc):
+                pool.end()
+                return False
+        return _Step()
 
     def take(self, shape, device):
         n = 1
@@ -107,11 +125,14 @@ class KernelTimer:
 
 
 TIMER = None  # set to a KernelTimer by bench.py
+LIVE_IMAGE_FRACTION = 1.0   # bench.py: real ROIs / ROI slots of its batch, so that launches limited by a device-side image
+                            # count (`nimg`) are credited with the work on live rows only
 
 
 def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, up2=False, pool2=False, alpha=1.0,
-             want_f32=True, want_op=False, relu_op=False, want_raw=False, flops=None):
-    """out = alpha*pool?(conv(up?(x))) + bias, masked, + res.  x_op (B,Hi,Wi,Ci) operand dtype."""
+             want_f32=True, want_op=False, relu_op=False, want_raw=False, flops=None, nimg=None):
+    """out = alpha*pool?(conv(up?(x))) + bias, masked, + res.  x_op (B,Hi,Wi,Ci) operand dtype.
+    nimg: 1-element int32 device tensor = number of leading images that are live (the rest come out as zeros)."""
     _chk(x_op)
     B, Hi, Wi, Ci = x_op.shape
     Ho, Wo = (2 * Hi, 2 * Wi) if up2 else (Hi, Wi)
@@ -131,25 +152,27 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
         esz = x_op.element_size()   # algorithmic bytes: every operand and result once
         nbytes = (x_op.numel() + wpack.numel()) * esz + B * Hq * Wq * co * (
             4 * (want_f32 + (res is not None)) + esz * (want_op + want_raw + (relu_mask is not None)))
-        end = TIMER.time("conv_igemm", flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci, nbytes)
+        live = LIVE_IMAGE_FRACTION if nimg is not None else 1.0
+        end = TIMER.time("conv_igemm", live * (flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci), live * nbytes)
     _lib.call("l2i_conv2d_fwd", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
               _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
-              float(alpha), _stream())
+              float(alpha), _p(nimg), _stream())
     if end is not None:
         end.record()
     return out, out_op, out_raw
 
 
-def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None):
+def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None, nimg=None):
     _chk(x_op)
     _chk(dy_op, x_op.dtype)
     B, Hi, Wi, Ci = x_op.shape
     Ho, Wo = (2 * Hi, 2 * Wi) if up2 else (Hi, Wi)
     end = None
     if TIMER is not None:
-        end = TIMER.time("conv_wgrad", flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci)
+        live = LIVE_IMAGE_FRACTION if nimg is not None else 1.0
+        end = TIMER.time("conv_wgrad", live * (flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci))
     _lib.call("l2i_conv2d_wgrad", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
-              Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _stream())
+              Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _stream())
     if end is not None:
         end.record()
 
@@ -270,11 +293,12 @@ class FusedConvFn(Function):
     sides. The operand tensor produced by the prologue never becomes an autograd edge, so its
     gradient stays f32.
 
-    forward(x, res, bias, mask, wproj, bproj, holder, passctx, prologue, up2, pool2)
+    forward(x, res, bias, mask, wproj, bproj, holder, passctx, prologue, up2, pool2, nimg)
+    nimg: optional 1-element int32 device tensor, the number of leading images that are live (ROI heads).
     """
 
     @staticmethod
-    def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2):
+    def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None):
         _chk(x, torch.float32)
         opd = pc.arena.op_dtype
         B, H, W, C = x.shape
@@ -298,8 +322,8 @@ class FusedConvFn(Function):
         Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
         flops = 2.0 * B * Ho * Wo * holder.co * holder.ci * holder.kh * holder.kh  # algorithmic (unpadded) work
         out, _, _ = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p, res=res, up2=up2,
-                             pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops)
-        ctx.flops = flops
+                             pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops, nimg=nimg)
+        ctx.flops, ctx.nimg = flops, nimg
         ctx.holder, ctx.pc, ctx.pro, ctx.up2, ctx.pool2, ctx.stats = holder, pc, pro, up2, pool2, stats
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
         keep_x = x if pro.kind == "norm" else None
@@ -327,13 +351,13 @@ class FusedConvFn(Function):
             dy_op, _ = cast_op(dy, opd, raw=True, act=False)
         if pc.need_wgrad:
             wgrad_raw(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
-                      flops=ctx.flops)
+                      flops=ctx.flops, nimg=ctx.nimg)
         dx = d_mask = d_w = d_b = None
         if need_x or need_mod:
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
             relu_mask = x_op if pro.kind == "relu" else None
             dxo, _, _ = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
-                                 pool2=ctx.up2, alpha=alpha, flops=ctx.flops)
+                                 pool2=ctx.up2, alpha=alpha, flops=ctx.flops, nimg=ctx.nimg)
             if pro.kind == "norm":
                 sums, sq, count, sstride = ctx.stats
                 dx, d_w, d_b, d_mask = norm_bwd_raw(x, dxo, sums, sq, count, sstride, pro, mask, wproj, bproj,
@@ -341,7 +365,7 @@ class FusedConvFn(Function):
             else:
                 dx = dxo
         d_res = dy if ctx.has_res else None
-        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None
+        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None
 
 
 def _sibling(t, kind, dtype):
@@ -360,9 +384,9 @@ def precast(x, op_dtype):
     return x
 
 
-def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False):
+def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False, nimg=None):
     pro = prologue if prologue is not None else _CAST
-    return FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2)
+    return FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg)
 
 
 class _Simple(Prologue):

@@ -52,6 +52,15 @@ class GanTrainer:
             parallel.broadcast_flat_(netD.flat.data)
             parallel.broadcast_flat_(netG.arena.sn_flat.data)
             parallel.broadcast_flat_(netD.arena.sn_flat.data)
+            # every other buffer too (BN running statistics, num_batches_tracked): a checkpoint loaded on rank 0 only
+            # must give every rank the same eval-mode statistics. (The PSP stages' plain nn.BatchNorm2d are NOT
+            # synchronised in the reference either, resnet_generator_app_v2.py:745, so their running statistics drift
+            # per rank afterwards; checkpoints are saved from rank 0.)
+            sn_ptrs = {netG.arena.sn_flat.data.untyped_storage().data_ptr(), netD.arena.sn_flat.data.untyped_storage().data_ptr()}
+            for net in (netG, netD):
+                for buf in net.buffers():
+                    if buf.untyped_storage().data_ptr() not in sn_ptrs:
+                        parallel.broadcast_flat_(buf)
 
     def _counts(self, valid, b):
         if self.world == 1:
@@ -70,12 +79,18 @@ class GanTrainer:
     def step(self, real, label, bbox, z=None, z_im=None):
         """One iteration. real (b,3,H,W) in [-1,1]; label (b,o) int64; bbox (b,o,4). Returns loss tensors
         (device scalars, no host sync)."""
-        netG, netD = self.netG, self.netD
         b, o = label.shape[0], label.shape[1]
         y = label.view(b, o)
         if z is None:
             z = torch.randn(b, o, self.z_dim, device=real.device)
-        ops.POOL.begin(real.device)
+        with ops.POOL.step(real.device):
+            return self._step(real, y, bbox, z, z_im, b)
+
+    def _step(self, real, y, bbox, z, z_im, b):
+        netG, netD = self.netG, self.netD
+        # ROI rows compacted to the front in the reference's order + their device-side count: once for the three D passes
+        layout = netD.prepare_layout(bbox, y, real.size(2), real.device)
+        valid = layout[2]
         # ---- D step (reference :156-174)
         netD.zero_grad()
         if self.overlap:
@@ -85,13 +100,13 @@ class GanTrainer:
             # The loss terms of D(real) are formed on the side stream as well: the backward of that branch then hangs
             # off the very first node of the graph and starts at once (formed on the main stream it would queue behind
             # the whole backward of D(fake): measured 3 % slower than no overlap at all).
-            n_roi, n_img = self._counts((y.reshape(-1) != 0).to(torch.int32), b)   # (collective, if any, on the main stream)
+            n_roi, n_img = self._counts(valid, b)   # (collective, if any, on the main stream)
             cur = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream()
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
-                *outs_r, valid, _ = netD.forward_padded(real, bbox, y)
+                *outs_r, _, _ = netD.forward_padded(real, bbox, y, layout=layout)
                 d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
                 # the fake pass's power iteration + weight packs need only D's weights: done here, off the main stream
                 pc_fake = netD.arena.prepare(training=netD.training, need_wgrad=True)
@@ -99,24 +114,28 @@ class GanTrainer:
             cur.wait_stream(self._side)
         else:
             pc_fake = None
-            *outs_r, valid, _ = netD.forward_padded(real, bbox, y)
+            *outs_r, _, _ = netD.forward_padded(real, bbox, y, layout=layout)
             n_roi, n_img = self._counts(valid, b)
             d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
             fake = netG(z, bbox, z_im=z_im, y=y)
-        *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y, pc=pc_fake)
+        *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y, pc=pc_fake, layout=layout)
         d_loss_fake = self._d_terms(outs_f, valid, 1, n_roi, n_img)
         d_loss = d_loss_real + d_loss_fake
         d_loss.backward()
+        if self.overlap:
+            # D(real)'s backward ran on the side stream; what it wrote outside autograd's view (weight-gradient
+            # accumulators, direct bias-gradient atomics) and the pack buffers it read must be ordered before the
+            # optimizer step on this stream explicitly (capture-safe: one event).
+            torch.cuda.current_stream().wait_stream(self._side)
         self.d_opt.step()
         # ---- G step (reference :178-189)
         netG.zero_grad()
-        *outs_g, _, _ = netD.forward_padded(fake, bbox, y, need_wgrad=False)
+        *outs_g, _, _ = netD.forward_padded(fake, bbox, y, need_wgrad=False, layout=layout)
         g_adv = self._d_terms(outs_g, valid, 2, n_roi, n_img)
         pixel = ops.l1_loss(fake, real, 1.0 / self.world)
         g_loss = g_adv + pixel
         g_loss.backward()
         self.g_opt.step()
-        ops.POOL.end()
         return {"d_loss": d_loss.detach(), "g_loss": g_loss.detach(), "pixel": pixel.detach(), "fake": fake.detach()}
 
     # ---- whole-iteration HIP graph: the iteration is ~1700 launches and the Python / autograd side costs about as much
@@ -129,10 +148,17 @@ class GanTrainer:
         if ops.TIMER is not None:
             raise RuntimeError("capture with the kernel timer on")
         self._static = [None if t is None else t.detach().clone() for t in (real, label, bbox, z, z_im)]
+        from . import _lib
         cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
+        side = torch.cuda.Stream()   # the capture stream; also used for the warm-up, as torch.cuda.graphs asks
+        if self.overlap and self._side is None:
+            self._side = torch.cuda.Stream()
+        for s_ in (side, self._side):   # reduction workspaces of both streams exist BEFORE capture (never in the graph's pool)
+            if s_ is not None:
+                with torch.cuda.stream(s_):
+                    _lib.workspace(real.device)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):   # warm-up on a side stream (allocator / lazy-init state), as torch.cuda.graphs asks
+        with torch.cuda.stream(side):
             for _ in range(2):
                 self.step(*self._static)
         cur.wait_stream(side)
@@ -141,7 +167,7 @@ class GanTrainer:
             net.arena.free_packs = []
         graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):
                 self._graph_out = self.step(*self._static)
         except Exception:
             self._graph = None

@@ -555,3 +555,60 @@ def test_gram_head_matches_the_explicit_gram_matrices():
     assert float((out.detach().cpu().view(-1) - ref.detach()).abs().max()) < 1e-5 * s
     assert float((xg.grad.cpu() - xr.grad).abs().max()) < 1e-5 * float(xr.grad.abs().max())
     assert float((wg.grad.cpu() - wr.grad).abs().max()) < 1e-5 * float(wr.grad.abs().max())
+
+
+@pytest.mark.parametrize("n_live", [0, 3, 9, 20])
+@pytest.mark.parametrize("case", [(20, 8, 8, 64, 136, 3, False, False), (20, 8, 8, 128, 64, 3, False, True),
+                                  (20, 8, 8, 72, 128, 1, False, True), (20, 8, 8, 16, 40, 3, False, False)])
+def test_conv_device_side_image_count(case, n_live):
+    """`nimg`: the ROI heads run over the first *nimg images only (device-side count, fixed launch shape): live images
+    equal the full convolution, every row of a dead image is exactly zero -- forward/dgrad kernel (halo and generic
+    tiles, pooled and not) and weight gradient."""
+    from layout2img_amd import ops
+    B, H, W, Ci, Co, KH, up2, pool2 = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(17)
+    x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    w = _rt(torch.randn(Co, Ci, KH, KH, generator=g) / math.sqrt(Ci * KH * KH), dt)
+    bias = torch.randn(Co, generator=g)
+    ref = _ref_conv(x, w, bias, up2, pool2)
+    res = torch.randn(ref.shape, generator=g)
+    pack, kpad = _pack(w, 64)
+    nimg = torch.tensor([n_live], dtype=torch.int32, device=_dev())
+    out, out_op, _ = ops.conv_raw(x.to(_dev(), dt), pack.to(_dev(), dt), kpad, Co, KH, bias=bias.to(_dev()), res=res.to(_dev()),
+                                  up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, want_op=True, relu_op=True, nimg=nimg)
+    expect = ref + res
+    expect[n_live:] = 0
+    assert float((out.cpu() - expect).abs().max()) < 3e-5 * float(expect.abs().max()) + 1e-5
+    assert float(out[n_live:].abs().max() if n_live < B else 0.0) == 0.0
+    assert float(out_op[n_live:].float().abs().max() if n_live < B else 0.0) == 0.0
+    if Co % 8 == 0:
+        wz = torch.zeros(Co, Ci, KH, KH, requires_grad=True)
+        y = _ref_conv(x[:n_live], wz, None, up2, pool2) if n_live else None
+        dy = _rt(torch.randn(ref.shape, generator=g), dt)
+        K = KH * KH * Ci
+        refw = torch.zeros(Co, K)
+        if n_live:
+            y.backward(dy[:n_live])
+            refw = wz.grad.permute(0, 2, 3, 1).reshape(Co, -1)
+        dw = torch.zeros(Co, K, device=_dev())
+        # rows of dead images hold garbage on purpose: they must not be read
+        xg, dyg = x.clone(), dy.clone()
+        xg[n_live:] = float("nan")
+        dyg[n_live:] = float("nan")
+        ops.wgrad_raw(xg.to(_dev(), dt), dyg.to(_dev(), dt), dw, K, Co, KH, up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, nimg=nimg)
+        assert float((dw.cpu() - refw).abs().max()) < 5e-5 * float(refw.abs().max()) + 1e-5
+
+
+def test_roi_rows_are_compacted_in_reference_order():
+    """prepare_layout: valid rows first -- large ROIs, then small ones, original order within each
+    (model/rcnn_discriminator_app.py:131-146, 413-417) -- padding behind, count on the device."""
+    import layout2img_amd as L
+    d = L.CombineDiscriminator128_app(num_classes=10)
+    bbox = torch.tensor([[[0.1, 0.1, 0.2, 0.2], [-0.6, -0.6, 0.5, 0.5], [0.0, 0.0, 0.9, 0.9], [0.3, 0.3, 0.5, 0.1]],
+                         [[0.2, 0.2, 0.1, 0.6], [0.5, 0.5, 0.3, 0.3], [-0.6, -0.6, 0.5, 0.5], [-0.6, -0.6, 0.5, 0.5]]])
+    label = torch.tensor([[3, 0, 4, 5], [6, 7, 0, 0]])
+    rois, y, valid, count = d.prepare_layout(bbox.to(_dev()), label.to(_dev()), 128, _dev())
+    # large (w or h >= 64 px): (img0: 0.9x0.9), (img0: 0.5 wide = 64 px), (img1: 0.6 tall); small: img0 #0, img1 #1
+    assert y.tolist()[:5] == [4, 5, 6, 3, 7] and valid.tolist() == [1, 1, 1, 1, 1, 0, 0, 0] and int(count) == 5
+    assert rois[:5, 0].tolist() == [0.0, 0.0, 1.0, 0.0, 1.0]
