@@ -38,6 +38,7 @@ struct ConvArgs {
     int splits, ks_per;  // split-K: `out` pre-zeroed, partials combined with f32 atomics
     // halo kernel geometry (conv_halo_kernel): sub-patches of PHs x PW pixels, halo rows h = sp*SUBH + hy*P + hx
     int PHs, sub_shift, P, SUBH, HR, HWd, halo_pieces;
+    int compact;         // conv_halo3_kernel: sub-patches are whole images, no border rows are stored
     float alpha;
 };
 
@@ -430,8 +431,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
                  "s"(soff), "s"(ldsaddr)                                                                              \
                  : "memory")
 
-template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false>   // H1: ONE halo buffer, refilled at each chunk boundary
-__global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
+template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false, int ABL = 0>   // H1: ONE halo buffer, refilled at each chunk boundary
+__global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {   // ABL: ablations for tools/perf (results are wrong): 1 no weight DMA, 2 no DMA, 3 no DMA + no fragment reads, 4 no barrier
     typedef bf16_t T;
     constexpr int THREADS = WM * WN * 64, NW = WM * WN;
     constexpr int BK = 64, SZ = 2;
@@ -556,9 +557,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
         if (PIPE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSB == 3 ? BP : 0) : "memory");                                       \
         if (!PIPE) { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) asm volatile("" : "+v"(a_addr[i_][TAP])); }   /* keep the 72 XOR-ed copies out of registers */ \
-        __builtin_amdgcn_s_barrier();                                                                                  \
+        if (ABL != 4) __builtin_amdgcn_s_barrier();                                                                    \
         asm volatile("" ::: "memory");                                                                                 \
-        if (H1 && TAP == 0 && (DO_MFMA_PREV)) {   /* single halo buffer: everyone is past tap 8, refill and wait */      \
+        if (H1 && TAP == 0 && (DO_MFMA_PREV) && ABL < 2) {   /* single halo buffer: everyone is past tap 8, refill and wait */ \
             _Pragma("unroll") for (int q_ = 0; q_ < HPMAX; ++q_) if (q_ < nq) {                                        \
                 const unsigned vo_ = (cb_cur) < hlim[q_] ? hoff[q_] : OOB;                                             \
                 H2_DMA(rsrc_x, vo_, (unsigned)((cb_cur)*SZ), halo_w + (unsigned)(NW * q_) * 1024u);                     \
@@ -567,26 +568,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
             __builtin_amdgcn_s_barrier();                                                                              \
             asm volatile("" ::: "memory");                                                                             \
         }                                                                                                              \
-        H2_READS(SET, TAP, STG)                                                                                        \
+        if (ABL != 3) { H2_READS(SET, TAP, STG) }                                                                     \
+        else { _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { _Pragma("unroll") for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[SET][kk][i])); _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[SET][kk][j])); } } \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         const int cb2 = TAP + AHEAD >= 9 ? (cb_nxt) : (cb_cur);                                                        \
         const unsigned kadd = (unsigned)(TAP2 * ci2 + cb2 * SZ);                                                       \
         if (!PIPE || (DO_MFMA_PREV)) { H2_MFMA4(PSET, 0); }                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (!H1 && TAP < HPMAX && TAP < nq) {                                                                          \
+        if (!H1 && TAP < HPMAX && TAP < nq && (ABL < 2 || ABL == 4)) {                                                 \
             const unsigned vo = (cb_nxt) < hlim[TAP] ? hoff[TAP] : OOB;                                                \
             H2_DMA(rsrc_x, vo, (unsigned)((cb_nxt)*SZ), halo_w + (unsigned)(1 - HB) * halo_bytes + (unsigned)(NW * TAP) * 1024u); \
         }                                                                                                              \
-        H2_DMA(rsrc_w, b_off[0], kadd, ring_w + STG2 * BSTAGE);                                                        \
+        if (ABL == 0 || ABL == 4) H2_DMA(rsrc_w, b_off[0], kadd, ring_w + STG2 * BSTAGE);                               \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if (!PIPE || (DO_MFMA_PREV)) { H2_MFMA4(PSET, 1); }                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (BP > 1) H2_DMA(rsrc_w, b_off[BP > 1 ? 1 : 0], kadd, ring_w + STG2 * BSTAGE + 1u * RPP * 128u);              \
+        if (BP > 1 && (ABL == 0 || ABL == 4)) H2_DMA(rsrc_w, b_off[BP > 1 ? 1 : 0], kadd, ring_w + STG2 * BSTAGE + 1u * RPP * 128u); \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if (!PIPE || (DO_MFMA_PREV)) { H2_MFMA4(PSET, 2); }                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (BP > 2) H2_DMA(rsrc_w, b_off[BP > 2 ? 2 : 0], kadd, ring_w + STG2 * BSTAGE + 2u * RPP * 128u);              \
-        if (BP > 3) H2_DMA(rsrc_w, b_off[BP > 3 ? 3 : 0], kadd, ring_w + STG2 * BSTAGE + 3u * RPP * 128u);              \
+        if (BP > 2 && (ABL == 0 || ABL == 4)) H2_DMA(rsrc_w, b_off[BP > 2 ? 2 : 0], kadd, ring_w + STG2 * BSTAGE + 2u * RPP * 128u); \
+        if (BP > 3 && (ABL == 0 || ABL == 4)) H2_DMA(rsrc_w, b_off[BP > 3 ? 3 : 0], kadd, ring_w + STG2 * BSTAGE + 3u * RPP * 128u); \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if (!PIPE || (DO_MFMA_PREV)) { H2_MFMA4(PSET, 3); }                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -661,6 +663,223 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {
     else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
 }
 
+// ---------------------------------------------------------------- 256-pixel tiles: conv_halo3_kernel
+// Measured on the kernel above (tools/perf/conv_abl.py, 32x32x512->512, back to back): 1830 TFLOP/s with neither DMA nor
+// fragment reads, 1351 with the fragment reads, 1105 with everything -- the LDS fragment traffic and the weight stream,
+// not the MFMA issue, are what a 128x128 tile of four 64x64 waves pays for. This kernel doubles the work per byte on
+// both: a workgroup is still 4 waves (two workgroups per CU, one wave of each per SIMD), but its tile is 256 pixels x BN
+// channels and a wave owns 64 pixels x ALL BN channels (TM = 2, TN = BN/32): per k16 sub-step 2 A + TN B fragment reads
+// feed 2 TN MFMAs (0.75 reads per MFMA at BN = 128 instead of 1), the weight tile of a K-step is shared by 256 pixels
+// instead of 128 (half the L2 -> LDS bytes per MFMA), and a K-step between two barriers is 32 MFMAs per wave, not 16.
+//   * fragment reads are software-pipelined inside the K-step (two register sets, sub-step kk+2 is read under the MFMAs
+//     of kk): a quarter of the fragment registers of "read everything first", which is what lets 128 accumulators + two
+//     waves per SIMD fit;
+//   * ONE halo buffer (refilled at the chunk boundary) + a 2-stage weight ring: 41.5 + 32 KB = two workgroups per CU;
+//   * COMPACT halo when a sub-patch is a whole image (8x8 ROI maps, 16x16 maps, 8->16 upsampling): the one-pixel border
+//     is all padding, so only the image's own rows are staged (4 ROI maps: 32 KB instead of 50) and an out-of-image tap
+//     reads a 256-byte zero region at the bank slot the border row would have had (conflict-free by the same argument
+//     as the bordered layout: tools/perf/halo_check.py);
+//   * needs Ci % 64 == 0 (every layer this is used for); everything else as above (transposed accumulator, epilogue).
+template <int BN, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
+    typedef bf16_t T;
+    constexpr int NW = 4, TM = 2, TN = BN / 32, BP = BN / 32, SZ = 2;
+    constexpr int HPMAX = 11;                       // 18 x 18 halo rows = 41 KB-pieces over 4 waves
+    constexpr unsigned OOB = 0x80000000u, BSTAGE = BN * 128u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int split = blockIdx.x / nblk;
+    const int bid = xcd_remap(blockIdx.x - split * nblk, nblk);
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
+    const int n0 = tile_n * BN;
+    const int rows_total = p.B * p.Ho;
+    const int rows_live = p.nimg ? min(rows_total, *p.nimg * p.Ho) : rows_total;
+    const bool tile_dead = tile_r * p.PH >= rows_live;
+    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
+    const unsigned smem_addr = lds_addr_of(smem);
+    const unsigned halo_bytes = (unsigned)p.halo_pieces * 1024u;
+    const unsigned ring_off = halo_bytes, zero_off = halo_bytes + 2u * BSTAGE;   // [halo][ring x 2][256 zero bytes]
+    const int border = p.compact ? 0 : 1;          // rows of border stored around a sub-patch
+    const int Hh = (p.up2 ? p.PHs >> 1 : p.PHs), Wh = (p.up2 ? p.PW >> 1 : p.PW);   // sub-patch extent at input resolution
+
+    if (tid < 16) *reinterpret_cast<uint4*>(smem + zero_off + tid * 16) = make_uint4(0, 0, 0, 0);
+
+    // ---- halo pieces of this wave: piece = wv + 4 q, lane -> (row, 16-byte chunk). Stored row h = sp*SUBH + hy*P + hx;
+    // (hyp, hxp) are the coordinates in the bordered frame (border row / column = 0), which the swizzle is written in.
+    unsigned hoff[HPMAX];
+#pragma unroll
+    for (int q = 0; q < HPMAX; ++q) {
+        const int piece = wv + NW * q;
+        const int h = piece * 8 + (lane >> 3), pch = lane & 7;
+        const int sp = h / p.SUBH, rem = h - sp * p.SUBH;
+        const int hy = rem / p.P, hx = rem - hy * p.P;
+        const int hyp = hy + 1 - border, hxp = hx + 1 - border;
+        const int gr0 = tile_r * p.PH + sp * p.PHs;
+        const int b = gr0 / p.Ho, y0 = gr0 - b * p.Ho, x0 = tile_c * p.PW;
+        const int iy = (y0 >> p.up2) + hyp - 1, ix = (x0 >> p.up2) + hxp - 1;
+        const bool ok = h < p.HR && hx < p.HWd && gr0 < rows_total && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const int lch = pch ^ (((hxp >> 1) + 4 * hyp + 2 * sp) & 7);
+        hoff[q] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.Ci + lch * 8) * SZ : OOB;
+    }
+    const int nq = (p.halo_pieces - wv + NW - 1) / NW;
+    // ---- weight rows: 256 threads fill 32 rows x 128 bytes per pass
+    const int lrow = tid >> 3;
+    const int lchunk = (tid & 7) ^ ig2_swz(lrow);
+    unsigned b_off[BP];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) b_off[q] = (unsigned)((n0 + lrow + 32 * q) * p.Kpad + lchunk * 8) * SZ;
+    const unsigned ring_w = smem_addr + ring_off + (unsigned)wv * 1024u;
+    const unsigned halo_w = smem_addr + (unsigned)wv * 1024u;
+
+    // ---- fragment addresses. A: this lane's pixel of each 32-row MFMA tile, for each tap; B: row (lane & 31) of column
+    // tile 0 for each k16 sub-step (column tile j adds 4096 bytes, ring stage BSTAGE: immediates)
+    const int wrow = wave * 64;
+    const int hh = lane >> 5;
+    unsigned a_addr[TM][9];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int py, px;
+        idx2pix(wrow + i * 32 + (lane & 31), p.hw_shift, 0, py, px);
+        const int sp = py >> p.sub_shift, pyl = py & (p.PHs - 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            int hyp, hxp;   // bordered-frame coordinates of the input pixel this tap reads
+            if (p.up2) { hyp = ((pyl + ky - 1) >> 1) + 1; hxp = ((px + kx - 1) >> 1) + 1; }
+            else { hyp = pyl + ky; hxp = px + kx; }
+            const unsigned sl = (unsigned)((hh ^ (((hxp >> 1) + 4 * hyp + 2 * sp) & 7)) << 4);
+            const bool inside = hyp >= 1 && hyp <= Hh && hxp >= 1 && hxp <= Wh;
+            if (border || inside) a_addr[i][tap] = (unsigned)((sp * p.SUBH + (hyp - 1 + border) * p.P + (hxp - 1 + border)) * 128) + sl;
+            else a_addr[i][tap] = zero_off + (unsigned)(((hxp - 1) & 1) * 128) + sl;   // (parity of the row the border pixel would have had)
+        }
+    }
+    unsigned b_addr[4];
+    {
+        const int row = lane & 31;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b_addr[kk] = ring_off + (unsigned)(row * 128 + (((kk * 2 + hh) ^ ig2_swz(row)) << 4));
+    }
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nchunks_all = p.Ci >> 6, cper = p.ks_per / 9;
+    const int c_begin = split * cper, c_end = tile_dead ? c_begin : min(nchunks_all, c_begin + cper);
+    const int last_cb = (c_end - 1) * 64;
+    const int ci2 = p.Ci * SZ;
+
+    bf16x8_t fa[2][TM], fb[2][TN];   // two fragment register sets: sub-step kk lives in set kk & 1
+
+#define H3_RD(KK, TAP, STG)                                                                                            \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                              \
+            fa[(KK)&1][i_] = *reinterpret_cast<const bf16x8_t*>(smem + (a_addr[i_][TAP] ^ (unsigned)((KK) << 5)));     \
+        _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                                              \
+            fb[(KK)&1][j_] = *reinterpret_cast<const bf16x8_t*>(smem + b_addr[KK] + (STG) * BSTAGE + j_ * 4096u);      \
+    }
+#define H3_MM(KK)                                                                                                      \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)            \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                     \
+                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[(KK)&1][j_]),   /* weights first: transposed tile */ \
+                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[(KK)&1][i_]), acc[i_][j_], 0, 0, 0); \
+    }
+#define H3_HALO(cb)                                                                                                    \
+    _Pragma("unroll") for (int q_ = 0; q_ < HPMAX; ++q_) if (q_ < nq) {                                                \
+        H2_DMA(rsrc_x, hoff[q_], (unsigned)((cb)*SZ), halo_w + (unsigned)(NW * q_) * 1024u);                           \
+    }
+    // One K-step. S = step within the unrolled pair of chunks (0..17): tap = S % 9, ring stage = S & 1.
+#define H3_STEP(S, cb_cur, cb_nxt, REFILL)                                                                             \
+    {                                                                                                                  \
+        constexpr int TAP = (S) % 9, STG = (S)&1, TAP2 = (TAP + 1) % 9;                                                \
+        if (TAP == 0 && (REFILL)) {   /* every wave is past tap 8 of the previous chunk: refill the halo */              \
+            __builtin_amdgcn_s_barrier();                                                                              \
+            asm volatile("" ::: "memory");                                                                             \
+            if (ABL < 2) { H3_HALO(cb_cur) }                                                                           \
+        }                                                                                                              \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* this step's weight tile (issued a step ago) and the halo */ \
+        if (ABL != 4) __builtin_amdgcn_s_barrier();                                                                    \
+        asm volatile("" ::: "memory");                                                                                 \
+        const unsigned kadd = (unsigned)(TAP2 * ci2 + (TAP == 8 ? (cb_nxt) : (cb_cur)) * SZ);                          \
+        { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) asm volatile("" : "+v"(a_addr[i_][TAP])); }   /* keep the 72 XOR-ed copies out of registers */ \
+        if (ABL != 3) { H3_RD(0, TAP, STG) H3_RD(1, TAP, STG) }                                                        \
+        else { _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) asm volatile("" : "+v"(fa[s_][i_])); _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) asm volatile("" : "+v"(fb[s_][j_])); } } \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H3_MM(0)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (ABL == 0 || ABL == 4) {                                                                                    \
+            H2_DMA(rsrc_w, b_off[0], kadd, ring_w + (1 - STG) * BSTAGE);                                               \
+            if (BP > 1) H2_DMA(rsrc_w, b_off[BP > 1 ? 1 : 0], kadd, ring_w + (1 - STG) * BSTAGE + 4096u);              \
+        }                                                                                                              \
+        if (ABL != 3) { H3_RD(2, TAP, STG) }                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H3_MM(1)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (ABL == 0 || ABL == 4) {                                                                                    \
+            if (BP > 2) H2_DMA(rsrc_w, b_off[BP > 2 ? 2 : 0], kadd, ring_w + (1 - STG) * BSTAGE + 2 * 4096u);          \
+            if (BP > 3) H2_DMA(rsrc_w, b_off[BP > 3 ? 3 : 0], kadd, ring_w + (1 - STG) * BSTAGE + 3 * 4096u);          \
+        }                                                                                                              \
+        if (ABL != 3) { H3_RD(3, TAP, STG) }                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H3_MM(2)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H3_MM(3)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
+
+    if (c_begin < c_end) {
+        {   // prologue: the first halo and the weight tile of tap 0
+            const int cb0 = c_begin * 64;
+            H3_HALO(cb0)
+            const unsigned kadd0 = (unsigned)(cb0 * SZ);
+#pragma unroll
+            for (int q = 0; q < BP; ++q) H2_DMA(rsrc_w, b_off[q], kadd0, ring_w + (unsigned)q * 4096u);
+        }
+        bool first = true;
+        for (int c = c_begin; c < c_end; c += 2) {
+            const int cbA = c * 64;
+            const int cbB = min(cbA + 64, last_cb), cbC = min(cbA + 128, last_cb);
+            H3_STEP(0, cbA, cbB, !first)
+            H3_STEP(1, cbA, cbB, false)
+            H3_STEP(2, cbA, cbB, false)
+            H3_STEP(3, cbA, cbB, false)
+            H3_STEP(4, cbA, cbB, false)
+            H3_STEP(5, cbA, cbB, false)
+            H3_STEP(6, cbA, cbB, false)
+            H3_STEP(7, cbA, cbB, false)
+            H3_STEP(8, cbA, cbB, false)
+            first = false;
+            if (c + 1 < c_end) {
+                H3_STEP(9, cbB, cbC, true)
+                H3_STEP(10, cbB, cbC, false)
+                H3_STEP(11, cbB, cbC, false)
+                H3_STEP(12, cbB, cbC, false)
+                H3_STEP(13, cbB, cbC, false)
+                H3_STEP(14, cbB, cbC, false)
+                H3_STEP(15, cbB, cbC, false)
+                H3_STEP(16, cbB, cbC, false)
+                H3_STEP(17, cbB, cbC, false)
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped extra tile must not land after the LDS is reused / the wave ends
+    }
+#undef H3_STEP
+#undef H3_HALO
+#undef H3_MM
+#undef H3_RD
+    if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
+    else conv_epilogue<T, TM, TN>(p, acc, wrow, 0, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
+}
+
 static int ilog2(int v) {
     int s = 0;
     while ((1 << s) < v) ++s;
@@ -710,7 +929,7 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
 
 // Halo kernel launch (bf16, 3x3, Ci >= 64, Wo >= 8, no upsample into 8-wide maps). Returns -100 when the shape is
 // not covered so that the caller falls through to the generic kernel.
-template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false>
+template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false, int ABL = 0>
 static int launch_halo2(ConvArgs a, hipStream_t stream) {
     a.PH = BM / a.PW;
     a.PHs = a.PH < a.Ho ? a.PH : a.Ho;
@@ -746,10 +965,56 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     }
     static bool ready = false;
     if (!ready) {
-        (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ready = true;
     }
-    hipLaunchKernelGGL((conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL((conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+    return l2i_check_launch();
+}
+
+// conv_halo3_kernel launch (bf16, 3x3, Ci % 64 == 0, Wo >= 8). Returns -100 when the shape is not covered.
+template <int BN, int ABL = 0>
+static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
+    if (a.Ci % 64 || a.Wo < 8 || (a.up2 && a.Wo < 8)) return -100;
+    a.PH = 256 / a.PW;
+    a.PHs = a.PH < a.Ho ? a.PH : a.Ho;
+    a.sub_shift = ilog2(a.PHs);
+    const int nsp = a.PH / a.PHs;
+    const int Wh = a.up2 ? a.PW / 2 : a.PW, Hh = a.up2 ? a.PHs / 2 : a.PHs;
+    a.compact = (a.PW == a.Wo && a.PHs == a.Ho) ? 1 : 0;
+    if (a.compact) { a.HWd = Wh; a.P = Wh; a.SUBH = Hh * Wh; }
+    else { a.HWd = Wh + 2; a.P = (a.HWd + 1) & ~1; a.SUBH = (Hh + 2) * a.P; }
+    if ((a.P & 1) || (a.SUBH & 1)) return -100;
+    a.HR = nsp * a.SUBH;
+    a.halo_pieces = (a.HR + 7) / 8;
+    if (a.halo_pieces > 44) return -100;
+    const size_t lds = (size_t)a.halo_pieces * 1024 + (size_t)2 * BN * 128 + 256;
+    const int nchunks = a.Ci / 64;
+    a.nks = 9 * nchunks;
+    const int rows = a.B * a.Ho;
+    a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
+    a.tiles_n = (a.Co + BN - 1) / BN;
+    const int nblk = a.tiles_m * a.tiles_n;
+    int splits = 1;
+    if (a.out && !a.out_op && !a.out_op_raw && nblk < 128 && nchunks >= 4) {   // fill the 512 workgroup slots (two per CU)
+        splits = (g_split_target + nblk / 2) / nblk;
+        if (splits > nchunks / 2) splits = nchunks / 2;   // >= 18 K-steps per split
+        if (splits < 1) splits = 1;
+    }
+    if (force_splits > 0 && a.out && !a.out_op && !a.out_op_raw) splits = force_splits < nchunks ? force_splits : nchunks;
+    const int cper = (nchunks + splits - 1) / splits;
+    a.ks_per = 9 * cper;
+    a.splits = (nchunks + cper - 1) / cper;
+    if (a.splits > 1) {
+        const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
+        if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+    }
+    static bool ready = false;
+    if (!ready) {
+        (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<BN, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        ready = true;
+    }
+    hipLaunchKernelGGL((conv_halo3_kernel<BN, ABL>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
     return l2i_check_launch();
 }
 
@@ -809,6 +1074,11 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // 8x8 sub-patch halos only fit twice per CU single-buffered). Measured: tools/perf/conv_tune.py + in-iteration profile.
         int hc = 5;   // 128x64 tiles, single halo buffer: 48 KB, three workgroups per CU
         if (a.Co > 64 && t128h >= 512) hc = (a.Wo < 16 || a.Ci <= 256 || g_conv_cfg_override == -2) ? 4 : 0;
+        // 256-pixel tiles (conv_halo3_kernel; tools/perf/conv_sweep.py, profiles/r02_conv_sweep.txt): +4..11 % on the long
+        // reductions whose 256x128 grid still fills both workgroup slots of every CU (obj4 conv2 at 32x32, the
+        // 1024-channel ROI heads), and -- as 256x64 tiles -- on the upsampling layers from 32x32 outputs up.
+        if (a.Ci % 64 == 0 && a.Ci >= 512 && a.Co >= 512 && ((M + 255) / 256) * ((a.Co + 127) / 128) >= 512) hc = 7;
+        else if (a.Ci % 64 == 0 && a.up2 && a.Wo >= 32) hc = 8;
         // (256x128 / 8-wave tiles are ~10 % faster on the 1024-channel ROI-head layers in isolation but not inside the
         //  iteration -- rocprofv3: 1.90 vs 1.77 ms for those 9 launches -- so they stay a tuning option: cfg 12)
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
@@ -820,6 +1090,21 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
             case 4: rc = launch_halo2<128, 128, 2, 2, 3, false, true>(a, stream); break;   // single halo buffer: 72 KB, two per CU, 2 tiles ahead
             case 5: rc = launch_halo2<128, 64, 2, 2, 3, false, true>(a, stream); break;    // 48 KB: three per CU
             case 6: rc = launch_halo2<128, 64, 2, 2, 2, false, true>(a, stream); break;    // 40 KB: four per CU
+            case 7: rc = launch_halo3<128>(a, stream); break;    // 256 x 128 tiles, 4 waves of 64 x 128
+            case 8: rc = launch_halo3<64>(a, stream); break;     // 256 x 64 tiles
+#ifdef L2I_ABLATIONS
+            case 41: rc = launch_halo3<128, 1>(a, stream); break;
+            case 42: rc = launch_halo3<128, 2>(a, stream); break;
+            case 43: rc = launch_halo3<128, 3>(a, stream); break;
+            case 44: rc = launch_halo3<128, 4>(a, stream); break;
+            case 21: rc = launch_halo2<128, 128, 2, 2, 3, false, true, 1>(a, stream); break;
+            case 22: rc = launch_halo2<128, 128, 2, 2, 3, false, true, 2>(a, stream); break;
+            case 23: rc = launch_halo2<128, 128, 2, 2, 3, false, true, 3>(a, stream); break;
+            case 24: rc = launch_halo2<128, 128, 2, 2, 3, false, true, 4>(a, stream); break;
+            case 31: rc = launch_halo2<256, 128, 4, 2, 2, false, false, 1>(a, stream); break;
+            case 32: rc = launch_halo2<256, 128, 4, 2, 2, false, false, 2>(a, stream); break;
+            case 33: rc = launch_halo2<256, 128, 4, 2, 2, false, false, 3>(a, stream); break;
+#endif
             default: rc = launch_halo2<128, 128, 2, 2, 2, false>(a, stream); break;
         }
         if (rc != -100) return rc;
@@ -832,7 +1117,8 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     else if (!a.lin && a.Co % 256 == 0 && t256x256 >= 240 && a.nks >= 144) cfg = 4;   // 1024-channel 3x3 ROI heads
     else if (!a.lin && a.Co % 128 == 0 && t256x128 >= 384 && a.nks >= 72) cfg = 3;
     else if (t128 >= 192 && t128 <= 288) cfg = 2;
-    else cfg = t128 < 512 ? 1 : 0;   // small grids: 128x64 tiles (48 KB, three workgroups per CU)
+    else cfg = (t128 < 512 && !(t128 >= 64 && t128 < 192 && a.nks >= 16 && a.out && !a.out_op && !a.out_op_raw)) ? 1 : 0;   // small grids: 128x64 tiles (48 KB, three
+                                                          // workgroups per CU) -- unless split-K applies: 128x128 + split-K
     if (g_conv_cfg_override == 5 && a.Co <= 64) cfg = 6;
     if (g_conv_cfg_override >= 0 && a.Co > 64) {
         cfg = g_conv_cfg_override;

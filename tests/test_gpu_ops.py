@@ -115,13 +115,17 @@ def test_conv_split_k(case, dt):
     assert float((out.cpu() - expect).abs().max()) < 3e-5 * float(expect.abs().max()) + 1e-5
 
 
-@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 72, 3, False, False), (1, 32, 32, 128, 136, 3, False, True),
                                   (2, 16, 16, 64, 64, 3, True, False), (9, 16, 16, 192, 128, 3, False, False),
                                   (5, 8, 8, 64, 264, 3, False, True), (1, 64, 64, 64, 8, 3, True, False),
-                                  (3, 16, 16, 320, 136, 3, False, False), (2, 32, 32, 136, 72, 3, False, False)])
+                                  (3, 16, 16, 320, 136, 3, False, False), (2, 32, 32, 136, 72, 3, False, False),
+                                  (7, 8, 8, 128, 136, 3, False, False), (6, 4, 4, 64, 64, 3, True, False),
+                                  (1, 32, 32, 64, 200, 3, True, True), (2, 64, 64, 64, 64, 3, False, True),
+                                  (3, 8, 8, 128, 128, 3, True, False), (1, 128, 128, 64, 64, 3, False, False)])
 def test_conv_halo_tiles(case, cfg):
-    """every tile shape of the halo kernel (128x128, 128x64, 256x128) on every geometry, forced through the tuning hook"""
+    """every tile shape of the halo kernels (128x128, 128x64, 256x128; 17 / 18: the 256-pixel-tile kernel with its
+    bordered and compact halos) on every geometry, forced through the tuning hook"""
     from layout2img_amd import ops, _lib
     B, H, W, Ci, Co, KH, up2, pool2 = case
     dt = torch.bfloat16

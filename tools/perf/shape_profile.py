@@ -1,0 +1,84 @@
+"""In-situ per-layer kernel durations: run a few eager iterations (one stream) under
+    rocprofv3 --kernel-trace -d <dir> -o trace --output-format csv -- python tools/perf/shape_profile.py run <calls.json>
+then join the conv kernels of the trace with the logged calls, in launch order:
+    python tools/perf/shape_profile.py join <calls.json> <trace_kernel_trace.csv> [steps]
+Durations are the profiler's (kernel begin -> end), FLOPs are algorithmic (live ROI rows only)."""
+import collections, csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def run(path, steps=3):
+    import torch
+    os.environ["L2I_OVERLAP"] = "0"
+    import layout2img_amd as L
+    from layout2img_amd import ops, _lib
+    from layout2img_amd.synthetic import make_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1234)
+    netG = L.ResnetGenerator128_context(num_classes=184).finalize(dev, torch.bfloat16)
+    netD = L.CombineDiscriminator128_app(num_classes=184).finalize(dev, torch.bfloat16)
+    tr = L.GanTrainer(netG, netD)
+    real, label, bbox, z, z_im = make_batch(32, 128, "coco", seed=1234, device=dev)
+    live = float((label != 0).sum()) / label.numel()
+    for _ in range(2):
+        tr.step(real, label, bbox, z, None)
+    torch.cuda.synchronize()
+    calls = []
+    orig = _lib.call
+
+    def call(name, *a):
+        if name == "l2i_conv2d_fwd":
+            calls.append(("fwd",) + tuple(a[9:20]) + (a[22] is not None,))
+        elif name == "l2i_conv2d_wgrad":
+            calls.append(("wgr",) + tuple(a[4:14]) + (0, a[16] is not None))
+        orig(name, *a)
+    _lib.call = call
+    ops._lib.call = call
+    mark = torch.zeros(1, device=dev)
+    mark.fill_(1.0)   # (the join skips everything before the LAST `steps` iterations by counting conv kernels from the end)
+    for _ in range(steps):
+        tr.step(real, label, bbox, z, None)
+    torch.cuda.synchronize()
+    json.dump(dict(calls=calls, steps=steps, live=live), open(path, "w"))
+
+
+def join(path, trace, out=None):
+    meta = json.load(open(path))
+    calls, steps, live = meta["calls"], meta["steps"], meta["live"]
+    rows = list(csv.DictReader(open(trace)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    conv = [r for r in rows if r["Kernel_Name"].startswith(("void conv_", "conv_"))]
+    conv = conv[-len(calls):]
+    assert len(conv) == len(calls), (len(conv), len(calls))
+    agg = collections.OrderedDict()
+    for c, r in zip(calls, conv):
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        kind, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu, limited = c
+        kern = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        d = agg.setdefault((tuple(c), kern), [0, 0.0])
+        d[0] += 1
+        d[1] += us
+    lines = []
+    tot = {"fwd": [0.0, 0.0], "wgr": [0.0, 0.0]}
+    for (c, kern), (n, us) in agg.items():
+        kind, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu, limited = c
+        ci = 3 if Ci == 8 and Hi >= 64 and kind == "fwd" and Co == 64 else Ci   # (the image is padded 3 -> 8 channels)
+        fl = 2.0 * B * Ho * Wo * Co * ci * KH * KH * (live if limited else 1.0)
+        tot[kind][0] += fl * n / steps
+        tot[kind][1] += us / steps
+        lines.append((us / steps, n // steps, fl * n / us / 1e6, c, kern))
+    lines.sort(key=lambda t: -t[0])
+    o = open(out, "w") if out else sys.stdout
+    for k in ("fwd", "wgr"):
+        print(f"{k}: {tot[k][1] / 1e3:.3f} ms/iteration, {tot[k][0] / 1e9:.1f} GFLOP/iteration, {tot[k][0] / tot[k][1] / 1e6:.1f} TFLOP/s "
+              f"= {tot[k][0] / tot[k][1] / 1e6 / 2500:.3f} of the dense bf16 MFMA peak", file=o)
+    print("  us/iter  launches  TFLOP/s   (kind, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu, roi_limited)  kernel", file=o)
+    for us, n, tf, c, kern in lines:
+        print(f"{us:9.1f}  x{n:3d}  {tf:8.1f}   {c}  {kern}", file=o)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 3)
+    else:
+        join(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
