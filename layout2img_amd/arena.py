@@ -29,6 +29,11 @@ class FlatParams:
     def __init__(self, module: nn.Module, device):
         module.to(device)
         params = [(n, p) for n, p in module.named_parameters()]
+        # biases of grouped GEMM weights (GemmWeight.group: layers that run as ONE concatenated GEMM) are laid out
+        # back to back, in member order, so that the group sees one contiguous bias / bias-gradient vector
+        grouped = [m for m in module.modules() if isinstance(m, GemmWeight) and m.group is not None and m.bias is not None]
+        gid = {id(m.bias): i for i, m in enumerate(grouped)}
+        params = [t for t in params if id(t[1]) not in gid] + sorted((t for t in params if id(t[1]) in gid), key=lambda t: gid[id(t[1])])
         offs, total = {}, 0
         for n, p in params:
             offs[n] = total
@@ -114,6 +119,7 @@ class GemmWeight(nn.Module):
             self.bias = None
         self.layer_id = -1  # set by WeightArena
         self.use_rows = []   # LayerUse per application, set by WeightArena
+        self.group = None    # name of a GemmGroup (set by the owning network before finalize): see WeightArena
 
     def use(self, k):
         return self.use_rows[k] if k else self
@@ -156,6 +162,24 @@ class LayerUse:
 LSTRIDE = 20
 
 
+class GemmGroup:
+    """Linear layers that read the SAME input (the 40 ISLA projections of the generator all read the object latents,
+    model/norm_module.py:158-159,178) laid out as ONE GEMM: forward packs stacked along N, data-gradient packs side by side
+    along K (so dX = dYcat . Wcat is one launch instead of 40 launches + 39 additions), weight-gradient slices stacked,
+    biases contiguous. Spectral normalisation stays per layer (each row has its own sigma, u, v)."""
+
+    def __init__(self, name, members):
+        self.name, self.members = name, members
+        h0 = members[0]
+        assert all(m.kh == 1 and m.ci == h0.ci and m.uses == 1 and m.co == m.co_p and m.bias is not None for m in members)
+        self.ci, self.ci_p = h0.ci, h0.ci_p
+        self.offsets, n = [], 0
+        for m in members:
+            self.offsets.append(n)
+            n += m.co_p
+        self.n_total = n
+
+
 class WeightArena:
     def __init__(self, net: nn.Module, flat: FlatParams, device, op_dtype):
         self.flat = flat
@@ -180,6 +204,12 @@ class WeightArena:
                 k += 2
         rows = [(h, u) for h in holders for u in range(h.uses)]
         self.rounds = max(h.uses for h in holders)
+        self.groups = {}
+        for h in holders:
+            if h.group is not None:
+                self.groups.setdefault(h.group, []).append(h)
+        self.groups = {k: GemmGroup(k, v) for k, v in self.groups.items()}
+        member_of = {id(m): (g, i) for g in self.groups.values() for i, m in enumerate(g.members)}
         L = len(rows)
         tab = np.zeros((L, LSTRIDE), dtype=np.int64)
         packed_len = dw_len = uv_len = 0
@@ -204,12 +234,26 @@ class WeightArena:
             else:
                 row[1] = row[2] = -1
             row[3], row[4], row[5], row[6], row[7] = h.co, h.ci, h.kh, h.co_p, h.ci_p
-            row[8], row[9], row[10] = kpad, npad, packed_len
-            packed_len += npad * kpad
-            row[11], row[12], row[13] = kpad_d, npad_d, packed_len
-            packed_len += npad_d * kpad_d
-            row[14] = dw_len
-            dw_len += _round_up(h.co_p * kp, ALIGN)
+            if id(h) in member_of:
+                g, gi = member_of[id(h)]
+                if gi == 0:   # first member: reserve the group's regions
+                    g.kpad, g.kp, g.npad = kpad, kp, _round_up(g.n_total, 128)
+                    g.kpad_d, g.npad_d = _round_up(g.n_total, bk), npad_d
+                    g.fwd_off, packed_len = packed_len, packed_len + g.npad * kpad
+                    g.dg_off, packed_len = packed_len, packed_len + g.npad_d * g.kpad_d
+                    g.dw_off, dw_len = dw_len, dw_len + _round_up(g.n_total * kp, ALIGN)
+                off = g.offsets[gi]
+                row[8], row[9], row[10] = kpad, npad, g.fwd_off + off * kpad          # its rows of the stacked forward pack
+                row[11], row[12], row[13] = g.kpad_d, npad_d, g.dg_off + off          # its columns of the data-gradient pack (row stride = the group's K)
+                kpad_d = g.kpad_d
+                row[14] = g.dw_off + off * kp
+            else:
+                row[8], row[9], row[10] = kpad, npad, packed_len
+                packed_len += npad * kpad
+                row[11], row[12], row[13] = kpad_d, npad_d, packed_len
+                packed_len += npad_d * kpad_d
+                row[14] = dw_len
+                dw_len += _round_up(h.co_p * kp, ALIGN)
             row[15] = _f32_bits(h.eps)
             attrs = dict(layer_id=i, kpad=kpad, npad=npad, fwd_off=int(row[10]), kpad_d=kpad_d, npad_d=npad_d,
                          dg_off=int(row[13]), dw_off=int(row[14]), kp=kp)
@@ -321,3 +365,12 @@ class PassCtx:
 
     def sigma(self, h):
         return self.norms[4 * h.layer_id + 2]
+
+    def group_fwd_pack(self, g):
+        return self.packed[g.fwd_off:g.fwd_off + g.npad * g.kpad]
+
+    def group_dgrad_pack(self, g):
+        return self.packed[g.dg_off:g.dg_off + g.npad_d * g.kpad_d]
+
+    def group_dw_slice(self, g):
+        return self.dw()[g.dw_off:g.dw_off + g.n_total * g.kp]

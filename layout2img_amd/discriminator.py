@@ -28,13 +28,13 @@ class OptimizedBlock(nn.Module):
         self.conv1, self.conv2, self.c_sc = _conv(in_ch, out_ch, 3), _conv(out_ch, out_ch, 3), _conv(in_ch, out_ch, 1)
         self.downsample = downsample
 
-    def forward(self, x, pc):
-        h = fused_conv(x, self.conv1, pc)
+    def forward(self, x, pc, emit=()):
+        h = fused_conv(x, self.conv1, pc, emit=("relu",))     # conv2's ReLU'd operand comes out of conv1's epilogue
         xs = x
         if self.downsample:
             xs = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
         sc = fused_conv(xs, self.c_sc, pc)
-        return fused_conv(h, self.conv2, pc, prologue=RELU, res=sc, pool2=self.downsample)
+        return fused_conv(h, self.conv2, pc, prologue=RELU, res=sc, pool2=self.downsample, emit=emit, dx_raw=True)
 
 
 class ResBlock(nn.Module):
@@ -48,14 +48,18 @@ class ResBlock(nn.Module):
         if self.learnable_sc:
             self.c_sc = _conv(in_ch, out_ch, 1, uses)
 
-    def forward(self, x, pc, use=0, nimg=None):
+    def forward(self, x, pc, use=0, nimg=None, emit=()):
         """`use`: index of this application within the forward pass (each application of a spectral-normed
-        module runs its own power iteration in the reference). `nimg`: device count of live leading images (ROI heads)."""
+        module runs its own power iteration in the reference). `nimg`: device count of live leading images (ROI heads).
+        `emit`: operand copies of the block's result its consumers will read ("relu" / "raw"), written by conv2's
+        epilogue. Inside the block conv1's epilogue writes conv2's ReLU'd operand, and conv2's data-gradient launch
+        writes the operand copy of dh that conv1's backward reads."""
         if self.learnable_sc:
-            ops.precast(x, pc.arena.op_dtype)   # conv1 reads relu(x), the shortcut reads x: one cast launch for both
-        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg)
+            ops.precast(x, pc.arena.op_dtype)   # conv1 reads relu(x), the shortcut reads x: one cast launch for both (if not emitted upstream)
+        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, emit=("relu",))
         sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg) if self.learnable_sc else x
-        return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample, nimg=nimg)
+        return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample, nimg=nimg, emit=emit,
+                          dx_raw=True)
 
 
 class ResnetDiscriminator128_app(nn.Module):
@@ -81,16 +85,17 @@ class ResnetDiscriminator128_app(nn.Module):
     def forward(self, x, y, rois, valid, pc, nimg=None):
         """x (b,H,W,8) f32 NHWC (3 real channels); y (R,) labels; rois (R,5); valid (R,) int32; nimg: device int32 =
         number of valid rows when they are compacted to the front (the ROI heads then skip the rest)."""
-        x = self.block1(x, pc)
-        x1 = self.block2(x, pc)
-        x2 = self.block3(x1, pc)
-        x = self.block4(x2, pc)
-        x = self.block5(x, pc)
+        both = ("relu", "raw")   # what a following block with a learnable shortcut reads
+        x = self.block1(x, pc, emit=both)
+        x1 = self.block2(x, pc, emit=both)
+        x2 = self.block3(x1, pc, emit=both)
+        x = self.block4(x2, pc, emit=both)
+        x = self.block5(x, pc, emit=("relu",))
         x = self.block6(x, pc)
         feat = F.relu(x).sum(dim=(1, 2))
         out_im = F.linear(feat, arena_weight(self.l7, pc), self.l7.bias)
 
-        feat_s = self.block_obj4(self.block_obj3(x1, pc), pc, use=0)   # reference order :136-141
+        feat_s = self.block_obj4(self.block_obj3(x1, pc, emit=both), pc, use=0)   # reference order :136-141
         feat_l = self.block_obj4(x2, pc, use=1)
         obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0)  # (R,8,8,C)
 
@@ -203,10 +208,11 @@ class ResnetDiscriminator64(nn.Module):
                 nn.init.constant_(p, 0)
 
     def forward(self, x, y, rois, valid, pc, nimg=None):
-        x = self.block1(x, pc)
-        x = self.block2(x, pc)
-        x1 = self.block3(x, pc)
-        x = self.block4(x1, pc)
+        both = ("relu", "raw")
+        x = self.block1(x, pc, emit=both)
+        x = self.block2(x, pc, emit=both)
+        x1 = self.block3(x, pc, emit=both)
+        x = self.block4(x1, pc, emit=both)
         x = self.block5(x, pc)
         out_im = F.linear(F.relu(x).mean(dim=(1, 2)), arena_weight(self.l_im, pc), self.l_im.bias)
         obj = ops.roi_align(x1, None, rois, valid, 8, 1.0 / 2.0, 1.0, 1e30, 0)

@@ -74,7 +74,11 @@ class ISLANorm(nn.Module):
         self.bias_proj = GemmWeight("linear", c, num_w, sn=True, eps=1e-12)
         self.batch_norm2d = BNState(c, affine=False)
 
+    _proj = None   # (gw, gb) of the current forward pass when the network runs all projections as one grouped GEMM
+
     def project(self, w, pc, B, O):
+        if self._proj is not None:
+            return self._proj
         gw = fused_conv(w, self.weight_proj, pc).view(B, O, -1)
         gb = fused_conv(w, self.bias_proj, pc).view(B, O, -1)
         return gw, gb
@@ -187,7 +191,9 @@ class ResBlock(nn.Module):
         if predict_mask:
             self.conv_mask = ConvMaskHead(out_ch, psp_module)
 
-    def forward(self, x, w, mask, pc, sync):
+    def forward(self, x, w, mask, pc, sync, emit=()):
+        """emit: operand copies of the block's result written by conv2's epilogue ("raw": what the next block's shortcut
+        conv and this block's mask head read)."""
         B, H, W, C = x.shape
         O = mask.shape[1]
         up = self.upsample
@@ -198,7 +204,7 @@ class ResBlock(nn.Module):
         sc = fused_conv(x, self.c_sc, pc, up2=up) if self.learnable_sc else x
         gw2, gb2 = self.b2.project(w, pc, B, O)
         out = fused_conv(h, self.conv2, pc, prologue=self.b2.spec(self.training, sync),
-                         mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc)
+                         mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc, emit=emit)
         if self.training:
             self.b1.batch_norm2d.num_batches_tracked += 1
             self.b2.batch_norm2d.num_batches_tracked += 1
@@ -327,10 +333,29 @@ class _GeneratorBase(nn.Module):
 
     def finalize(self, device, op_dtype=torch.bfloat16):
         self.op_dtype = op_dtype
+        # the 2 x (number of ISLA layers) projections Linear(num_w -> C) (model/norm_module.py:158-159) all read the same
+        # object latents: they run as ONE grouped GEMM per pass (arena.GemmGroup / ops.GroupedLinearFn)
+        self._isla = [m for m in self.modules() if isinstance(m, ISLANorm)]
+        for n in self._isla:
+            n.weight_proj.group = n.bias_proj.group = "isla"
         self.flat = FlatParams(self, device)
         self.arena = WeightArena(self, self.flat, device, op_dtype)
         self.sync = None  # set by parallel.attach_sync_bn for world_size > 1
         return self
+
+    def _project_isla(self, wp, pc, b, o):
+        """One GEMM for every ISLA projection of the pass; each norm layer picks up its (b, o, C) slices."""
+        outs = ops.grouped_linear(wp.view(b * o, 1, 1, -1), self.arena.groups["isla"], pc)
+        for i, n in enumerate(self._isla):
+            gw, gb = outs[2 * i], outs[2 * i + 1]
+            sw, sb = gw._l2i_sink, gb._l2i_sink
+            gw, gb = gw.view(b, o, -1), gb.view(b, o, -1)
+            gw._l2i_sink, gb._l2i_sink = sw, sb
+            n._proj = (gw, gb)
+
+    def _release_isla(self):
+        for n in self._isla:
+            n._proj = None
 
     def init_parameter(self):
         """reference :501-506: orthogonal_ on every parameter with dim > 1, zeros on '*bias'."""
@@ -388,22 +413,24 @@ class ResnetGenerator128_context(_GeneratorBase):
         pc = self.arena.prepare(training=self.training)
         w = self.context(self._latent(z, y), bbox, y, pc)
         wp = _pad_last(w.reshape(b * o, -1), self.res1.b1.weight_proj.ci_p).reshape(b * o, 1, 1, -1).contiguous()
+        self._project_isla(wp, pc, b, o)
         bmask = self.mask_regress(wp, bbox, pc, self.sync)
         if z_im is None:
             z_im = torch.randn((b, 128), device=z.device)
         bbox_mask_ = bbox_mask(bbox, 64, 64)
         x = fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc).view(b, 16 * self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
-        x, m = self.res1(x, wp, bmask, pc, self.sync)
+        x, m = self.res1(x, wp, bmask, pc, self.sync, emit=("raw",))
         stage = bmask
         stages = []
         for blk, alpha in ((self.res2, self.alpha1), (self.res3, self.alpha2), (self.res4, self.alpha3), (self.res5, self.alpha4)):
             stage = self._stage_mask(m, bmask, bbox_mask_, alpha, y)
             stages.append(stage)
-            x, m = blk(x, wp, stage, pc, self.sync)
+            x, m = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",))
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
         pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
         bn.commit()
+        self._release_isla()
         img = torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()
         if taps is not None:
             taps.update(w=w, bmask=bmask, stages=stages, pre_tanh=pre[..., :self.output_dim])
@@ -436,16 +463,18 @@ class context_aware_generator(_GeneratorBase):
         pc = self.arena.prepare(training=self.training)
         w = self.context(self._latent(z, y), bbox, y, pc)
         wp = _pad_last(w.reshape(b * o, -1), self.res1.b1.weight_proj.ci_p).reshape(b * o, 1, 1, -1).contiguous()
+        self._project_isla(wp, pc, b, o)
         mask = self.mask_regress(wp, bbox, pc, self.sync)
         if z_im is None:
             z_im = torch.randn((b, 128), device=z.device)
         x = fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc).view(b, 16 * self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
         for i in range(1, 6):
-            x, _ = getattr(self, f"res{i}")(x, wp, mask, pc, self.sync)
+            x, _ = getattr(self, f"res{i}")(x, wp, mask, pc, self.sync, emit=("raw",) if i < 5 else ())
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
         pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
         bn.commit()
+        self._release_isla()
         return torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()
 
 
@@ -483,17 +512,19 @@ class ResnetGenerator64_context(ResnetGenerator128_context):
         pc = self.arena.prepare(training=self.training)
         w = self.context(self._latent(z, y), bbox, y, pc)
         wp = _pad_last(w.reshape(b * o, -1), self.res2.b1.weight_proj.ci_p).reshape(b * o, 1, 1, -1).contiguous()
+        self._project_isla(wp, pc, b, o)
         bmask = self.mask_regress(wp, bbox, pc, self.sync)
         if z_im is None:
             z_im = torch.randn((b, 128), device=z.device)
         bbox_mask_ = bbox_mask(bbox, 64, 64)
         x = fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc).view(b, 16 * self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
-        x, m = self.res2(x, wp, bmask, pc, self.sync)
+        x, m = self.res2(x, wp, bmask, pc, self.sync, emit=("raw",))
         for blk, alpha in ((self.res3, self.alpha1), (self.res4, self.alpha2), (self.res5, self.alpha3)):
             stage = self._stage_mask(m, bmask, bbox_mask_, alpha, y)
-            x, m = blk(x, wp, stage, pc, self.sync)
+            x, m = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",))
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
         pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
         bn.commit()
+        self._release_isla()
         return torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()

@@ -233,13 +233,24 @@ def _norm_stats(x, spec: NormSpec):
     return sums, sq, count, 0
 
 
+def _proj_strides(wproj, bproj, B, O, C):
+    """ISLA projections (B, O, C): contiguous, or slices of a wider (B*O, N) matrix (GroupedLinearFn) -- the kernels
+    address them as b*stride_b + o*stride_o + c."""
+    for t in (wproj, bproj):
+        if not t.is_cuda or t.dtype != torch.float32 or t.shape != (B, O, C) or t.stride(2) != 1:
+            raise RuntimeError("ISLA projections must be f32 (B, O, C) GPU tensors with unit channel stride")
+    if wproj.stride() != bproj.stride():
+        raise RuntimeError("weight / bias projections must share their strides")
+    return wproj.stride(0), wproj.stride(1)
+
+
 def norm_fwd_raw(x, sums, sq, count, stat_stride, spec, mask, wproj, bproj, op_dtype, want_f32=False, update_running=True):
     B, H, W, C = x.shape
     O = mask.shape[1] if mask is not None else 0
     if spec.mode == 0:
-        _chk(mask, torch.float32), _chk(wproj, torch.float32), _chk(bproj, torch.float32)
-        assert mask.shape == (B, O, H, W) and wproj.shape == (B, O, C) and bproj.shape == (B, O, C)
-        psb, pso = O * C, C
+        _chk(mask, torch.float32)
+        psb, pso = _proj_strides(wproj, bproj, B, O, C)
+        assert mask.shape == (B, O, H, W)
     else:
         psb = pso = 0
     out_op = torch.empty((B, H, W, C), dtype=op_dtype, device=x.device)
@@ -254,8 +265,10 @@ def norm_fwd_raw(x, sums, sq, count, stat_stride, spec, mask, wproj, bproj, op_d
     return out_op, out_f
 
 
-def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, add_to=None, need_mask_grad=True):
-    """Returns (dx, dwproj, dbproj, dmask). dy is overwritten with dxhat."""
+def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, add_to=None, need_mask_grad=True, sink=None):
+    """Returns (dx, dwproj, dbproj, dmask). dy is overwritten with dxhat.
+    sink: (GradSink, weight-projection column, bias-projection column) when wproj / bproj are slices of a grouped
+    projection: their gradients are accumulated straight into the group's dY matrix (same strides)."""
     B, H, W, C = x.shape
     O = mask.shape[1] if mask is not None else 0
     dev = x.device
@@ -265,9 +278,16 @@ def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, 
     dw = db = dm = None
     psb = pso = 0
     if spec.mode == 0:
-        dw, db = _zeros(wproj.shape, dev), _zeros(bproj.shape, dev)
+        psb, pso = _proj_strides(wproj, bproj, B, O, C)
+        if sink is not None:
+            dw, db = sink[0].slice(sink[1], C, B, O), sink[0].slice(sink[2], C, B, O)
+            assert dw.stride() == wproj.stride()
+        else:
+            if (psb, pso) != (O * C, C):
+                wproj, bproj = wproj.contiguous(), bproj.contiguous()
+                psb, pso = O * C, C
+            dw, db = _zeros(wproj.shape, dev), _zeros(bproj.shape, dev)
         dm = torch.zeros_like(mask) if need_mask_grad else None
-        psb, pso = O * C, C
     elif spec.mode == 1:
         dw, db = _zeros(wproj.shape, dev), _zeros(bproj.shape, dev)
     keep = None
@@ -298,7 +318,8 @@ class FusedConvFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None):
+    def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None,
+                emit=(), dx_raw=False):
         _chk(x, torch.float32)
         opd = pc.arena.op_dtype
         B, H, W, C = x.shape
@@ -321,9 +342,19 @@ class FusedConvFn(Function):
             bias_p = bias if bias.numel() == holder.co_p else torch.nn.functional.pad(bias, (0, holder.co_p - bias.numel()))
         Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
         flops = 2.0 * B * Ho * Wo * holder.co * holder.ci * holder.kh * holder.kh  # algorithmic (unpadded) work
-        out, _, _ = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p, res=res, up2=up2,
-                             pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops, nimg=nimg)
-        ctx.flops, ctx.nimg = flops, nimg
+        # `emit`: operand copies of the RESULT written by this launch's epilogue for the layers that read it next
+        # ("relu": ReLU'd copy for a pre-activation conv, "raw": plain copy for a shortcut conv) -- they ride on the
+        # result tensor (`_sibling`) and replace separate cast launches over the f32 stream.
+        if emit and ((B * Ho * Wo + 127) // 128) * ((holder.co_p + 127) // 128) < 192:
+            emit = ()   # small grids run split-K (partial sums combined by atomics): no epilogue copies there
+        out, o_relu, o_raw = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p, res=res,
+                                      up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops, nimg=nimg,
+                                      want_op="relu" in emit, relu_op=True, want_raw="raw" in emit)
+        if emit:
+            _attach(out, raw=o_raw, relu=o_relu)
+        ctx.flops, ctx.nimg, ctx.dx_raw = flops, nimg, dx_raw
+        sw, sb = getattr(wproj, "_l2i_sink", None), getattr(bproj, "_l2i_sink", None)
+        ctx.sink = (sw[0], sw[1], sb[1]) if sw is not None and sb is not None and sw[0] is sb[0] else None
         ctx.holder, ctx.pc, ctx.pro, ctx.up2, ctx.pool2, ctx.stats = holder, pc, pro, up2, pool2, stats
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
         keep_x = x if pro.kind == "norm" else None
@@ -340,15 +371,21 @@ class FusedConvFn(Function):
         need_mod = pro.kind == "norm" and pro.mode in (0, 1)
         alpha = 0.25 if ctx.pool2 else 1.0
         d_bias = None
-        if pc.need_wgrad and ctx.has_bias:  # bias gradient and the dY operand cast in one pass over dY
+        # the operand copy of dY: written by the data-gradient launch that produced dY (`dx_raw`), or by another layer
+        # that received the same dY (a block's conv2 and its shortcut), else cast here -- and left on dY for the others
+        dy_op = _sibling(dy, "raw", opd)
+        if pc.need_wgrad and ctx.has_bias:  # bias gradient (and the dY operand cast, if still needed) in one pass over dY
             bg = h.bias.grad
             direct = bg is not None and h.co == h.co_p and bg.is_contiguous() and bg.dtype == torch.float32
-            bsum, _, dy_op = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False, cast_to=opd,
-                                           accumulate_into=bg if direct else None)
-            dy_op = dy_op.view(dy.shape)
-            d_bias = None if direct else bsum[0][:h.co]   # direct: summed straight into the flat gradient buffer
-        else:
+            st = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False, cast_to=opd if dy_op is None else None,
+                               accumulate_into=bg if direct else None)
+            if dy_op is None:
+                dy_op = st[2].view(dy.shape)
+            d_bias = None if direct else st[0][0][:h.co]   # direct: summed straight into the flat gradient buffer
+        elif dy_op is None:
             dy_op, _ = cast_op(dy, opd, raw=True, act=False)
+        if _sibling(dy, "raw", opd) is None:
+            _attach(dy, raw=dy_op)
         if pc.need_wgrad:
             wgrad_raw(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
                       flops=ctx.flops, nimg=ctx.nimg)
@@ -356,37 +393,56 @@ class FusedConvFn(Function):
         if need_x or need_mod:
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
             relu_mask = x_op if pro.kind == "relu" else None
-            dxo, _, _ = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
-                                 pool2=ctx.up2, alpha=alpha, flops=ctx.flops, nimg=ctx.nimg)
+            Bq, Hq, Wq = dy.shape[0], dy.shape[1] << int(ctx.pool2), dy.shape[2] << int(ctx.pool2)
+            small = ((Bq * Hq * Wq + 127) // 128) * ((h.ci_p + 127) // 128) < 192   # split-K grid: no epilogue copies
+            emit_raw = ctx.dx_raw and pro.kind != "norm" and not small   # (the norm backward rewrites dxo: its copy would be stale)
+            dxo, _, dx_op = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
+                                     pool2=ctx.up2, alpha=alpha, flops=ctx.flops, nimg=ctx.nimg, want_raw=emit_raw)
+            if emit_raw:
+                _attach(dxo, raw=dx_op)
             if pro.kind == "norm":
                 sums, sq, count, sstride = ctx.stats
                 dx, d_w, d_b, d_mask = norm_bwd_raw(x, dxo, sums, sq, count, sstride, pro, mask, wproj, bproj,
-                                                    need_mask_grad=mask is not None and ctx.needs_input_grad[3])
+                                                    need_mask_grad=mask is not None and ctx.needs_input_grad[3], sink=ctx.sink)
             else:
                 dx = dxo
         d_res = dy if ctx.has_res else None
-        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None
+        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None
+
+
+def _attach(t, raw=None, relu=None):
+    """Let operand-dtype copies of stream `t` ride on the tensor object. The tensor's version counter is recorded:
+    autograd accumulates gradients IN PLACE when it can (a block input read by conv1 and by an identity shortcut), and a
+    copy made before such an accumulation must not be used after it."""
+    t._l2i_ops = {"raw": raw, "relu": relu, "ver": t._version}
 
 
 def _sibling(t, kind, dtype):
-    """Operand-dtype copy of stream `t` made by `precast` (it rides on the tensor object), or None."""
+    """Operand-dtype copy of stream `t` made by a producer's epilogue or by `precast`, or None."""
     d = getattr(t, "_l2i_ops", None)
-    v = d.get(kind) if d else None
+    if not d or d.get("ver") != t._version:
+        return None
+    v = d.get(kind)
     return v if v is not None and v.dtype == dtype and v.shape == t.shape else None
 
 
 def precast(x, op_dtype):
     """One launch producing BOTH operand copies of a stream (raw and ReLU'd) for a block whose two branches read it
     through different prologues (pre-activation conv + shortcut conv); the following fused_conv calls pick them up."""
-    if getattr(x, "_l2i_ops", None) is None:
-        raw, act = cast_op(x, op_dtype, raw=True, act=True)
-        x._l2i_ops = {"raw": raw, "relu": act}
+    have_raw, have_act = _sibling(x, "raw", op_dtype), _sibling(x, "relu", op_dtype)
+    if have_raw is None or have_act is None:
+        raw, act = cast_op(x, op_dtype, raw=have_raw is None, act=have_act is None)
+        _attach(x, raw=have_raw if have_raw is not None else raw, relu=have_act if have_act is not None else act)
     return x
 
 
-def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False, nimg=None):
+def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False, nimg=None,
+               emit=(), dx_raw=False):
+    """emit: operand copies of the result to write in the epilogue ("relu", "raw") for the layers that read it next.
+    dx_raw: x is read by this layer ONLY and was produced by another fused_conv -- the data-gradient launch then also
+    writes the operand copy of dx that the producer's backward needs (no separate cast pass over dx)."""
     pro = prologue if prologue is not None else _CAST
-    return FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg)
+    return FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg, tuple(emit), dx_raw)
 
 
 class _Simple(Prologue):
@@ -422,6 +478,79 @@ class NormActFn(Function):
 
 def norm_act(x, spec, wproj=None, bproj=None, mask=None):
     return NormActFn.apply(x, mask, wproj, bproj, spec)
+
+
+class GradSink:
+    """The dY matrix (rows, N) of one grouped projection, allocated (zero) when the first gradient slice is asked for."""
+
+    def __init__(self, rows, n, device):
+        self.rows, self.n, self.device, self.buf = rows, n, device, None
+        self.delivered = set()   # column offsets whose gradient was accumulated here directly
+
+    def slice(self, col, c, B, O):
+        if self.buf is None:
+            self.buf = torch.zeros((self.rows, self.n), dtype=torch.float32, device=self.device)
+        self.delivered.add(col)
+        return self.buf.view(B, O, self.n)[:, :, col:col + c]
+
+
+class GroupedLinearFn(Function):
+    """All layers of a GemmGroup (arena.py) applied to the same input in one GEMM: y = x Wcat^T + bcat, returned as one
+    (rows, C_i) slice per member. Backward: one bias-gradient / cast pass, one weight-gradient launch (stacked dW),
+    one data-gradient launch (K = sum C_i) -- instead of one of each per member and a chain of additions.
+    The members' output gradients are expected in the group's GradSink (ISLA backward accumulates them there)."""
+
+    @staticmethod
+    def forward(ctx, x, group, pc, sink):
+        _chk(x, torch.float32)
+        ctx.set_materialize_grads(False)
+        opd = pc.arena.op_dtype
+        rows = x.shape[0]
+        x_op, _ = cast_op(x, opd, raw=True, act=False)
+        flat = pc.arena.flat
+        b0 = flat.offset_of(group.members[0].bias)
+        bias = flat.data[b0:b0 + group.n_total]
+        flops = 2.0 * rows * group.n_total * group.ci
+        y, _, _ = conv_raw(x_op, pc.group_fwd_pack(group), group.kpad, group.n_total, 1, bias=bias, flops=flops)
+        ctx.group, ctx.pc, ctx.sink, ctx.flops, ctx.b0 = group, pc, sink, flops, b0
+        ctx.save_for_backward(x_op)
+        y2 = y.view(rows, group.n_total)
+        return tuple(y2[:, o:o + m.co_p] for o, m in zip(group.offsets, group.members))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g, pc, sink = ctx.group, ctx.pc, ctx.sink
+        (x_op,) = ctx.saved_tensors
+        opd = pc.arena.op_dtype
+        rows = x_op.shape[0]
+        if sink.buf is None:
+            sink.buf = torch.zeros((rows, g.n_total), dtype=torch.float32, device=x_op.device)
+        dy = sink.buf
+        for o, m, gr in zip(g.offsets, g.members, grads):   # anything that did not arrive through the sink
+            if gr is not None and o not in sink.delivered:
+                dy[:, o:o + m.co_p] += gr.reshape(rows, m.co_p)
+        dx = None
+        if pc.need_wgrad:
+            bg = pc.arena.flat.grad[ctx.b0:ctx.b0 + g.n_total]
+            _, _, dy_op = channel_stats(dy, want_sq=False, cast_to=opd, accumulate_into=bg)
+            dy4 = dy_op.view(rows, 1, 1, g.n_total)
+            wgrad_raw(x_op, dy4, pc.group_dw_slice(g), g.kp, g.n_total, 1, flops=ctx.flops)
+        else:
+            dy4, _ = cast_op(dy.view(rows, 1, 1, g.n_total), opd, raw=True, act=False)
+        if ctx.needs_input_grad[0]:
+            dx, _, _ = conv_raw(dy4, pc.group_dgrad_pack(g), g.kpad_d, g.ci_p, 1, flops=ctx.flops)
+        sink.buf = None
+        sink.delivered.clear()
+        return dx, None, None, None
+
+
+def grouped_linear(x, group, pc):
+    """-> list of (rows, C_i) outputs, one per group member, each carrying its gradient-sink coordinates."""
+    sink = GradSink(x.shape[0], group.n_total, x.device)
+    outs = GroupedLinearFn.apply(x, group, pc, sink)
+    for o, t in zip(group.offsets, outs):
+        t._l2i_sink = (sink, o)
+    return list(outs)
 
 
 class ArenaWeightFn(Function):

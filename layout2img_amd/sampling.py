@@ -9,6 +9,7 @@
 * `sample` -- the eval-mode generator call of test_context_app_v2.py:68-77.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -33,6 +34,47 @@ def load_reference_checkpoint(net, state, prefix="module."):
     return list(new), ignored
 
 
+def reference_state_dict(net, prefix="module."):
+    """`net.state_dict()` as the reference writes it (train_context_app_v2.py:215-217: the nets are wrapped in
+    nn.DataParallel there, hence the `module.` prefix): every entry cloned into its own CPU storage -- the parameters of
+    a finalized network are views into ONE flat buffer, which must not be what ends up in the file."""
+    return OrderedDict((prefix + k, v.detach().cpu().clone()) for k, v in net.state_dict().items())
+
+
+def save_checkpoint(out_path, epoch, netG, netD, g_opt=None, d_opt=None, prefix="module."):
+    """`out_path/model/G_<epoch>.pth`, `D_<epoch>.pth` in the reference's layout (loadable by the reference's resume code,
+    train_context_app_v2.py:71-105, and by its sampling script) plus -- which the reference omits -- the Adam state of
+    both optimizers in `opt_<epoch>.pth`. Under data parallelism call it on rank 0 only."""
+    d = os.path.join(out_path, "model")
+    os.makedirs(d, exist_ok=True)
+    paths = {}
+    for name, net in (("G", netG), ("D", netD)):
+        paths[name] = os.path.join(d, f"{name}_{epoch}.pth")
+        torch.save(reference_state_dict(net, prefix), paths[name])
+    if g_opt is not None and d_opt is not None:
+        paths["opt"] = os.path.join(d, f"opt_{epoch}.pth")
+        torch.save({k: dict(m=o.m.detach().cpu(), v=o.v.detach().cpu(), t=o.t, lr=o.lr, betas=o.betas, eps=o.eps)
+                    for k, o in (("G", g_opt), ("D", d_opt))}, paths["opt"])
+    return paths
+
+
+def load_checkpoint(out_path, epoch, netG, netD, g_opt=None, d_opt=None, prefix="module."):
+    """Resume (train_context_app_v2.py:71-105): strip the prefix, keep the keys the models have, load; restore the Adam
+    state when `opt_<epoch>.pth` exists. Returns the epoch to continue from."""
+    d = os.path.join(out_path, "model")
+    for name, net in (("G", netG), ("D", netD)):
+        load_reference_checkpoint(net, os.path.join(d, f"{name}_{epoch}.pth"), prefix)
+    p = os.path.join(d, f"opt_{epoch}.pth")
+    if g_opt is not None and d_opt is not None and os.path.exists(p):
+        st = torch.load(p, map_location="cpu")
+        for k, o in (("G", g_opt), ("D", d_opt)):
+            o.m.copy_(st[k]["m"])
+            o.v.copy_(st[k]["v"])
+            o.t = int(st[k]["t"])
+            o.t_dev.fill_(o.t)
+    return epoch
+
+
 def truncated_normal(shape, thres=1.0, device="cpu", generator=None, dtype=torch.float32):
     """N(0,1) conditioned on |z| <= thres, via z = sqrt(2) erfinv(u), u ~ U(-erf(t/sqrt2), erf(t/sqrt2))."""
     lim = math.erf(float(thres) / math.sqrt(2.0))
@@ -41,8 +83,9 @@ def truncated_normal(shape, thres=1.0, device="cpu", generator=None, dtype=torch
 
 
 @torch.no_grad()
-def sample(netG, label, bbox, thres=2.0, generator=None):
-    """Eval-mode images for layouts (label (b,o) int64, bbox (b,o,4)); truncated latents as the reference draws them."""
+def sample(netG, label, bbox, thres=2.0, generator=None, return_latents=False):
+    """Eval-mode images for layouts (label (b,o) int64, bbox (b,o,4)); truncated latents as the reference draws them
+    (test_context_app_v2.py:68-77: z_obj (b,o,128) and z_im (b,128), both truncated at `thres` = 2)."""
     was_training = netG.training
     netG.eval()
     try:
@@ -50,6 +93,7 @@ def sample(netG, label, bbox, thres=2.0, generator=None):
         dev = bbox.device if bbox.is_cuda else next(netG.parameters()).device
         z = truncated_normal((b, o, 128), thres, dev, generator)
         z_im = truncated_normal((b, 128), thres, dev, generator)
-        return netG(z, bbox.to(dev), z_im=z_im, y=label.to(dev).view(b, o))
+        img = netG(z, bbox.to(dev), z_im=z_im, y=label.to(dev).view(b, o))
+        return (img, z, z_im) if return_latents else img
     finally:
         netG.train(was_training)

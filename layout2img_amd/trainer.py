@@ -38,8 +38,10 @@ class FlatAdam:
 
 
 class GanTrainer:
-    def __init__(self, netG, netD, g_lr=1e-4, d_lr=1e-4, lamb_obj=1.0, lamb_app=1.0, lamb_img=0.1, z_dim=128):
-        self.netG, self.netD = netG, netD
+    def __init__(self, netG, netD, g_lr=1e-4, d_lr=1e-4, lamb_obj=1.0, lamb_app=1.0, lamb_img=0.1, z_dim=128, vgg=None):
+        """vgg: an optional layout2img_amd.VGGLoss (finalized) -- the perceptual term of the G loss
+        (train_context_app_v2.py:141,185); None leaves it out (the headline benchmark's configuration)."""
+        self.netG, self.netD, self.vgg = netG, netD, vgg
         self.g_opt, self.d_opt = FlatAdam(netG, g_lr), FlatAdam(netD, d_lr)
         self.l_obj, self.l_app, self.l_img, self.z_dim = lamb_obj, lamb_app, lamb_img, z_dim
         self.world = parallel.world_size()
@@ -134,6 +136,9 @@ class GanTrainer:
         g_adv = self._d_terms(outs_g, valid, 2, n_roi, n_img)
         pixel = ops.l1_loss(fake, real, 1.0 / self.world)
         g_loss = g_adv + pixel
+        if self.vgg is not None:
+            feat = self.vgg(fake, real)
+            g_loss = g_loss + (feat if self.world == 1 else feat / self.world)
         g_loss.backward()
         self.g_opt.step()
         return {"d_loss": d_loss.detach(), "g_loss": g_loss.detach(), "pixel": pixel.detach(), "fake": fake.detach()}

@@ -28,3 +28,16 @@ def maxdiff(a, b):
     a = a.detach().cpu().float() if torch.is_tensor(a) else torch.as_tensor(a).float()
     b = b.detach().cpu().float() if torch.is_tensor(b) else torch.as_tensor(b).float()
     return float((a - b).abs().max())
+
+
+def vgg_inputs():
+    """the (fake, real) pair tools/capture_goldens.py::capture_vgg fed to the reference's VGGLoss"""
+    g = torch.Generator().manual_seed(62)
+    x = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    y = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    return x, y
+
+
+def vgg_state(fx):
+    sd = fixture_state(fx, 61)
+    return {k: (v * (2.0 ** 0.5) if k.endswith("weight") else v) for k, v in sd.items()}

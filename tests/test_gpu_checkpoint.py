@@ -1,0 +1,98 @@
+"""SURVEY section 8 rows f1 / f2 on the GPU: checkpoint save -> resume (reference layout, train_context_app_v2.py:71-105,
+215-217) incl. the optimizer state, and the sampling path (test_context_app_v2.py:36-83) at batch 1 against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as O
+from tests.helpers import maxdiff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _nets(seed, dt=torch.float32, size=64):
+    import layout2img_amd as L
+    torch.manual_seed(seed)
+    if size == 64:
+        g, d = L.ResnetGenerator64_context(num_classes=184), L.CombineDiscriminator64(num_classes=184)
+    else:
+        g, d = L.ResnetGenerator128_context(num_classes=184), L.CombineDiscriminator128_app(num_classes=184)
+    for m in g.modules():
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = 0.0
+    return g.finalize(DEV, dt), d.finalize(DEV, dt)
+
+
+def test_save_resume_round_trip(tmp_path):
+    """train 2 steps -> save (G, D in the reference's `module.`-prefixed layout + Adam state) -> load into freshly
+    constructed, differently initialised networks -> identical eval output and an identical third step."""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_batch
+    g, d = _nets(1)
+    tr = L.GanTrainer(g, d)
+    tr.overlap = False
+    batch = make_batch(4, 64, "coco", seed=3, device=DEV)
+    for _ in range(2):
+        tr.step(*batch)
+    paths = L.save_checkpoint(str(tmp_path), 7, g, d, tr.g_opt, tr.d_opt)
+    sd = torch.load(paths["G"])
+    assert all(k.startswith("module.") for k in sd)                              # what nn.DataParallel leaves (:215-217)
+    assert len({v.untyped_storage().data_ptr() for v in sd.values()}) == len(sd)  # own storages, not views of the flat buffer
+    assert sd["module.fc.weight_orig"].shape == (16384, 128) and "module.res2.conv1.weight_u" in sd
+
+    g2, d2 = _nets(99)
+    assert maxdiff(g2.flat.data, g.flat.data) > 1e-3
+    tr2 = L.GanTrainer(g2, d2)
+    tr2.overlap = False
+    assert L.load_checkpoint(str(tmp_path), 7, g2, d2, tr2.g_opt, tr2.d_opt) == 7
+    assert torch.equal(g2.flat.data, g.flat.data) and torch.equal(d2.flat.data, d.flat.data)
+    assert torch.equal(g2.arena.sn_flat.data, g.arena.sn_flat.data)
+    assert tr2.g_opt.t == tr.g_opt.t == 2 and int(tr2.d_opt.t_dev) == 2
+    real, label, bbox, z, z_im = batch
+    g.eval(), g2.eval()
+    with torch.no_grad():
+        a, b = g(z, bbox, z_im, label), g2(z, bbox, z_im, label)
+    assert maxdiff(a, b) < 5e-5   # (split-K partial sums are combined by atomics: not order-deterministic)
+    g.train(), g2.train()
+    ra, rb = tr.step(*batch), tr2.step(*batch)
+    assert abs(float(ra["d_loss"]) - float(rb["d_loss"])) < 1e-4 * abs(float(ra["d_loss"])) + 1e-5
+    # (atomically reduced sums are not order-deterministic: identical up to f32 round-off amplified by one Adam step)
+    close = ((g.flat.data - g2.flat.data).abs() < 2.5e-4).float().mean()
+    assert float(close) > 0.98, float(close)
+
+
+def test_reference_checkpoint_loads_with_and_without_prefix(tmp_path):
+    import layout2img_amd as L
+    g, _ = _nets(2)
+    sd = L.reference_state_dict(g, prefix="module.")
+    sd["module.not_in_this_model"] = torch.zeros(3)
+    torch.save(sd, tmp_path / "G_200.pth")
+    g2, _ = _nets(5)
+    loaded, ignored = L.load_reference_checkpoint(g2, str(tmp_path / "G_200.pth"))
+    assert ignored == ["module.not_in_this_model"] and len(loaded) == len(g.state_dict())
+    assert torch.equal(g2.flat.data, g.flat.data)
+    g3, _ = _nets(6)
+    L.load_reference_checkpoint(g3, L.reference_state_dict(g, prefix=""))
+    assert torch.equal(g3.flat.data, g.flat.data)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_sample_batch1_matches_oracle(dt):
+    """test_context_app_v2.py:68-77: eval mode, batch 1, latents truncated at 2 -- the HIP path against the oracle's eval
+    forward on the very latents `sample` drew."""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_layouts
+    g, _ = _nets(3, dt, size=128)
+    real, label, bbox, z, z_im = __import__("layout2img_amd.synthetic", fromlist=["make_batch"]).make_batch(4, 128, "coco", seed=9, device=DEV)
+    g.train()
+    with torch.no_grad():
+        for _ in range(3):   # fill BN running statistics / advance the power iteration (a cold eval saturates tanh)
+            g(z, bbox, z_im, label)
+    lab1, box1 = make_layouts(1, "coco", seed=21, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    img, zs, zi = L.sample(g, lab1, box1, thres=2.0, generator=gen, return_latents=True)
+    assert img.shape == (1, 3, 128, 128) and float(zs.abs().max()) <= 2.0 and float(zi.abs().max()) <= 2.0 and g.training
+    sd = {k: v.detach().cpu().clone() for k, v in g.state_dict().items()}
+    ref = O.generator_forward(sd, zs.cpu(), box1.cpu(), zi.cpu(), lab1.cpu(), training=False)
+    assert maxdiff(img, ref) < (1e-3 if dt == torch.float32 else 1e-1)

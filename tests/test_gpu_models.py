@@ -323,3 +323,31 @@ def test_full_size_vg_step_properties():
             bbox2[i, int(n_real[i])] = torch.tensor([-0.6, -0.6, 0.5, 0.5], device=DEV)   # image slot -> plain padding
         b = g(z, bbox2, z_im, label)
     assert maxdiff(a, b) > 1e-3   # its full-canvas mask contributes to ISLA
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_vgg_loss_vs_reference(dt):
+    """VGG19 perceptual loss (reference utils/util.py:49-94, train_context_app_v2.py:141,185) on the MFMA conv path
+    against the reference's own VGGLoss run on recipe weights (tests/golden/vgg.npz): loss value, the gradient with
+    respect to the fake image, and state_dict keys = the reference's."""
+    import layout2img_amd as L
+    from tests.helpers import vgg_inputs, vgg_state
+    fx = load_fixture("vgg.npz")
+    m = L.VGGLoss()
+    sd = vgg_state(fx)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd)
+    m.finalize(DEV, dt)
+    x, y = vgg_inputs()
+    x = x.to(DEV).requires_grad_(True)
+    loss = m(x, y.to(DEV))
+    loss.backward()
+    f32 = dt == torch.float32
+    ref = float(fx["loss"])
+    assert abs(float(loss) - ref) < (1e-4 if f32 else 2e-2) * abs(ref), (float(loss), ref)
+    g = torch.from_numpy(fx["grad_x_sub"])
+    err = float((x.grad[:, :, ::2, ::2].cpu() - g).norm() / g.norm())
+    # bf16 operands: 13 layers of operand rounding in front of ReLU gates of a RANDOM-weight network -- the image
+    # gradient is only loosely reproduced (0.35 measured); the loss value itself is within 2 %
+    assert err < (1e-3 if f32 else 5e-1), err
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in m.parameters())   # frozen

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import model as O
-from tests.helpers import fixture_inputs, fixture_state, load_fixture, maxdiff
+from tests.helpers import fixture_inputs, fixture_state, load_fixture, maxdiff, vgg_inputs, vgg_state
 
 TOL = 2e-5
 
@@ -166,3 +166,19 @@ def test_vg_models_with_image_slot_match_reference():
         assert abs(float(r["d_loss"]) - float(fx[f"d_loss{it}"])) < rel * max(1.0, abs(float(fx[f"d_loss{it}"])))
         assert abs(float(r["g_loss"]) - float(fx[f"g_loss{it}"])) < rel * max(1.0, abs(float(fx[f"g_loss{it}"])))
         assert maxdiff(r["fake"][:, :, ::4, ::4], fx[f"fake_sub{it}"]) < tol_img
+
+
+def test_vgg_loss_matches_reference():
+    """utils/util.py:49-94 (VGGLoss over the torchvision VGG19 stack), recipe weights: the pretrained ones need network."""
+    fx = load_fixture("vgg.npz")
+    x, y = vgg_inputs()
+    assert abs(float(x.double().sum()) - float(fx["x_sum"])) < 1e-6
+    sd = vgg_state(fx)
+    x = x.requires_grad_(True)
+    loss = O.vgg_loss(sd, x, y)
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
+    loss.backward()
+    assert maxdiff(x.grad[:, :, ::2, ::2], fx["grad_x_sub"]) < 1e-4 * float(np.abs(fx["grad_x_sub"]).max())
+    feats = O.vgg_features(sd, x.detach())
+    assert np.abs(np.array([float(f.mean()) for f in feats]) - fx["tap_means"]).max() < 1e-5
+    assert maxdiff(feats[4], fx["tap5"]) < 1e-4 * float(np.abs(fx["tap5"]).max())

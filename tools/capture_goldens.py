@@ -39,6 +39,21 @@ def patch_env():
     tv.ops.RoIAlign = RoIAlign
     tv.ops.RoIPool = RoIAlign
     tv.models = types.ModuleType("torchvision.models")
+
+    def vgg19(pretrained=True):
+        """torchvision.models.vgg19's `features` stack (configuration "E", no batch norm), random-initialised: the
+        reference's utils/util.py::Vgg19 only slices `.features[0:30]`. (The pretrained weights cannot be fetched here.)"""
+        layers, c = [], 3
+        for v in [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(c, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                c = v
+        m = nn.Module()
+        m.features = nn.Sequential(*layers)
+        return m
+    tv.models.vgg19 = vgg19
     sys.modules.update({"torchvision": tv, "torchvision.ops": tv.ops, "torchvision.models": tv.models})
     torch.Tensor.cuda = lambda self, *a, **k: self
     sys.path.insert(0, REF)
@@ -296,6 +311,31 @@ def capture_vg():
     print("VG loop captured", {k: v for k, v in rec.items() if isinstance(v, float)})
 
 
+def capture_vgg():
+    """The reference's own VGGLoss (utils/util.py:49-94) on the stubbed torchvision stack with recipe weights."""
+    from utils.util import VGGLoss
+    torch.manual_seed(0)
+    m = VGGLoss()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = recipe.make_state_dict(shapes, 61)
+    for k in sd:   # He-style scale so that activations neither vanish nor explode through 13 ReLU convs
+        if k.endswith("weight"):
+            sd[k] = sd[k] * (2.0 ** 0.5)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(62)
+    x = (torch.rand(2, 3, 128, 128, generator=g) * 2 - 1).requires_grad_(True)
+    y = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    loss = m(x, y)
+    loss.backward()
+    feats = m.vgg(x.detach())
+    ks, shp = keys_blob(shapes)
+    # (inputs are regenerated by the tests from the same seed: tests/helpers.py::vgg_inputs)
+    np.savez_compressed(os.path.join(OUT, "vgg.npz"), keys=ks, shapes=shp, x_sum=float(x.detach().double().sum()), loss=float(loss.detach()),
+                        grad_x_sub=x.grad.numpy()[:, :, ::2, ::2].copy(),
+                        tap_means=np.array([float(f.mean()) for f in feats]), tap5=feats[4].detach().numpy())
+    print("vgg captured: loss", float(loss), [float(f.mean()) for f in feats])
+
+
 def capture_small_ops():
     """Known answers the survey lists for masks_to_layout / bbox_mask."""
     from model.resnet_generator_app_v2 import bbox_mask
@@ -313,7 +353,7 @@ def capture_small_ops():
 if __name__ == "__main__":
     patch_env()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["small", "g_coco", "g_vg", "d", "d64", "loop", "vg"]
+    which = sys.argv[1:] or ["small", "g_coco", "g_vg", "d", "d64", "loop", "vg", "vgg"]
     with torch.random.fork_rng():
         if "small" in which:
             capture_small_ops()
@@ -329,3 +369,5 @@ if __name__ == "__main__":
             capture_train_loop()
         if "vg" in which:
             capture_vg()
+        if "vggloss" in which or "vgg" in which:
+            capture_vgg()
