@@ -50,9 +50,11 @@ int l2i_set_conv_config(int cfg);
 
 /* Weight gradient of the same convolution: dw[Co][ldw] += alpha * dYfull^T . im2col(x)
  * (autograd of the layers above). dy [B,Ho>>pool2,Wo>>pool2,Co] T; k order (ky,kx,ci).
- * nimg (optional DEVICE int, needs Ho*Wo % 64 == 0): the reduction covers the first *nimg images only. */
+ * nimg (optional DEVICE int, needs Ho*Wo % 64 == 0): the reduction covers the first *nimg images only.
+ * dbias (optional, [Co] f32, +=): the bias gradient alpha * sum_m dYfull[m, co], summed from the dY tiles the kernel
+ * stages anyway (no separate pass over dY). */
 int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
-                     int Co, int KH, int up2, int pool2, int ldw, float alpha, const int* nimg, void* stream);
+                     int Co, int KH, int up2, int pool2, int ldw, float alpha, const int* nimg, float* dbias, void* stream);
 /* Tuning hook: co-resident workgroups a weight-gradient launch is sized for (0 = derive from the tile: default). */
 int l2i_set_wgrad_blocks(int n);
 /* Debug aid: co-resident workgroups per CU for conv instantiation `which` with lds_bytes of dynamic LDS. */

@@ -25,6 +25,7 @@ struct WgradArgs {
     float alpha;
     unsigned x_bytes, dy_bytes;   // buffer-descriptor ranges of x and dy
     const int* nimg;              // device int (optional): reduce over the first *nimg images only
+    float* dbias;                 // optional [Co]: += alpha * sum_m dYfull[m, co] (the bias gradient), by the tile_k == 0 workgroups
 };
 
 // The reduction range [m_begin, m_end) of one split. With a device-side image count the live pixels are divided over
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float bsum = 0.f;
 
     const int wrow = (wave >> 1) * (BMO / 2), wcol = (wave & 1) * 64;
     if (m_begin < m_end) {
@@ -177,9 +179,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             store_step();
             __syncthreads();
             if (ms + BK < m_end) load_step(ms + BK);
+            if (p.dbias && tile_k == 0 && tid < 2 * BMO) {   // bias gradient: row (= channel) sums of the dY tile
+                const T* rowp = reinterpret_cast<const T*>(As + (tid >> 1) * IG_ROWB) + (tid & 1) * (BK / 2);
+#pragma unroll 8
+                for (int j = 0; j < BK / 2; ++j) bsum += OpT<T>::to(rowp[j]);
+            }
             Mma<T>::template step<TM, TN>(As, Bs, wrow, wcol, lane, acc);
             __syncthreads();
         }
+    }
+    if (p.dbias && tile_k == 0 && tid < 2 * BMO) {
+        bsum += __shfl_xor(bsum, 1, 64);
+        const int co = co0 + (tid >> 1);
+        if (!(tid & 1) && co < p.Co && bsum != 0.f) atomicAdd(p.dbias + co, p.alpha * bsum);
     }
 
     const int c = lane & 31, h = lane >> 5;
@@ -382,6 +394,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
             fb_addr[j] = (unsigned)(BK * RSA + prow0 * RSB + (((ch >> 3) ^ wg_swz<RSB>(prow0)) << 4) + ((ch >> 2) & 1) * 8);
         }
     }
+    // bias gradient: the tiles_k workgroups that share a (channel tile, split) stage the same dY steps; workgroup tile_k
+    // sums the steps with index % tiles_k == tile_k (every pixel once, the extra work spread evenly -- giving it all to
+    // the tile_k == 0 workgroups made them the tail of the launch: measured +25 % on the whole weight-gradient time).
+    // Per such step every thread adds up one 8-channel chunk of the dY stage over 64 / (256 / A_CH) pixel rows; the
+    // 256 / A_CH partial sums per channel are combined at the end.
+    // (Shared by only min(tiles_k, 4) of them, and combined across the four waves in LDS: every atomic on a bias
+    // address costs ~0.09 us of serialised tail, and 500+ workgroups adding to the same 128 addresses tripled the launch.)
+    const int nb_bias = p.tiles_k >= 4 ? 4 : (p.tiles_k >= 2 ? 2 : 1);   // (a power of two)
+    const bool do_bias = p.dbias != nullptr && tile_k < nb_bias;
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int BS_PG = 256 / A_CH, BS_PP = BK / BS_PG;   // pixel groups, pixels per thread per step
+#define WG_BIAS(STG, MS)                                                                                              \
+    if (do_bias && ((((MS) - m_begin) >> 6) & (nb_bias - 1)) == tile_k) {                                               \
+        const int c_ = tid % A_CH, pg_ = tid / A_CH;                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < BS_PP; ++i_) {                                                        \
+            const int pr_ = pg_ + BS_PG * i_;                                                                         \
+            const uint4 v_ = *reinterpret_cast<const uint4*>(smem + (STG) * STAGE + pr_ * RSA + ((c_ ^ wg_swz<RSA>(pr_)) << 4)); \
+            bs[0] += __uint_as_float(v_.x << 16); bs[1] += __uint_as_float(v_.x & 0xffff0000u);                       \
+            bs[2] += __uint_as_float(v_.y << 16); bs[3] += __uint_as_float(v_.y & 0xffff0000u);                       \
+            bs[4] += __uint_as_float(v_.z << 16); bs[5] += __uint_as_float(v_.z & 0xffff0000u);                       \
+            bs[6] += __uint_as_float(v_.w << 16); bs[7] += __uint_as_float(v_.w & 0xffff0000u);                       \
+        }                                                                                                             \
+    }
 #define WG_TR(ADDR) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)((__attribute__((address_space(3))) char*)smem + (ADDR)))
 #define WG_STEP(STG)                                                                                                  \
     {                                                                                                                 \
@@ -416,22 +451,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
             __builtin_amdgcn_s_barrier();                       // ... everyone's did, and the other stage is free
             asm volatile("" ::: "memory");
             issue(ms + BK, smem_addr + STAGE);                  // in flight under the MFMAs below
+            WG_BIAS(0, ms)
             WG_STEP(0)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (ms + 2 * BK < m_end) issue(ms + 2 * BK, smem_addr);
+            WG_BIAS(1, ms + BK)
             WG_STEP(1)
         }
         if (ms < m_end) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            WG_BIAS(0, ms)
             WG_STEP(0)
         }
     }
 #undef WG_STEP
 #undef WG_TR
+#undef WG_BIAS
+    if (do_bias) {   // lanes that share a chunk within a wave are A_CH apart; waves combine through LDS: one atomic per channel
+        float* red = reinterpret_cast<float*>(smem);   // [4 waves][BMO]
+        __syncthreads();                                // every wave is done with the stages
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = bs[e];
+            for (int o = A_CH; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (lane < A_CH) red[wave * BMO + lane * 8 + e] = v;
+        }
+        __syncthreads();
+        if (tid < BMO) {
+            const float v = red[tid] + red[BMO + tid] + red[2 * BMO + tid] + red[3 * BMO + tid];
+            if (co0 + tid < p.Co && v != 0.f) atomicAdd(p.dbias + co0 + tid, p.alpha * v);
+        }
+    }
 
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -524,11 +578,12 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
 
 extern "C" int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
                                 int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
-                                const int* nimg, void* stream) {
+                                const int* nimg, float* dbias, void* stream) {
     if (!x || !dy || !dw) return L2I_ERR_ARG;
     if (nimg && (Ho * Wo) % 64) return L2I_ERR_ARG;
     WgradArgs a;
     a.nimg = nimg;
+    a.dbias = dbias;
     a.x = x; a.dy = dy; a.dw = dw;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.ldw = ldw; a.alpha = alpha;

@@ -56,10 +56,11 @@ class ResBlock(nn.Module):
         writes the operand copy of dh that conv1's backward reads."""
         if self.learnable_sc:
             ops.precast(x, pc.arena.op_dtype)   # conv1 reads relu(x), the shortcut reads x: one cast launch for both (if not emitted upstream)
-        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, emit=("relu",))
-        sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg) if self.learnable_sc else x
+        j = ops.GradJoin()   # dx of the shortcut branch enters conv1's data-gradient epilogue instead of a separate add
+        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, emit=("relu",), join=(j, "take"))
+        sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg, join=(j, "give")) if self.learnable_sc else x
         return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample, nimg=nimg, emit=emit,
-                          dx_raw=True)
+                          dx_raw=True, join=None if self.learnable_sc else (j, "give_res"))
 
 
 class ResnetDiscriminator128_app(nn.Module):

@@ -198,10 +198,11 @@ class ResBlock(nn.Module):
         O = mask.shape[1]
         up = self.upsample
         gw1, gb1 = self.b1.project(w, pc, B, O)
+        j = ops.GradJoin()   # the shortcut's dx is accumulated by the second pass of b1's backward instead of a separate add
         h = fused_conv(x, self.conv1, pc, prologue=self.b1.spec(self.training, sync), mask=_resize_mask(mask, H, W).contiguous(),
-                       wproj=gw1, bproj=gb1, up2=up)
+                       wproj=gw1, bproj=gb1, up2=up, join=(j, "take"))
         H2, W2 = h.shape[1], h.shape[2]
-        sc = fused_conv(x, self.c_sc, pc, up2=up) if self.learnable_sc else x
+        sc = fused_conv(x, self.c_sc, pc, up2=up, join=(j, "give")) if self.learnable_sc else x
         gw2, gb2 = self.b2.project(w, pc, B, O)
         out = fused_conv(h, self.conv2, pc, prologue=self.b2.spec(self.training, sync),
                          mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc, emit=emit)

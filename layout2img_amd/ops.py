@@ -162,7 +162,8 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
     return out, out_op, out_raw
 
 
-def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None, nimg=None):
+def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None, nimg=None, dbias=None):
+    """dbias: optional (co,) f32 tensor the bias gradient is atomically added to (summed from the staged dY tiles)."""
     _chk(x_op)
     _chk(dy_op, x_op.dtype)
     B, Hi, Wi, Ci = x_op.shape
@@ -172,7 +173,7 @@ def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0
         live = LIVE_IMAGE_FRACTION if nimg is not None else 1.0
         end = TIMER.time("conv_wgrad", live * (flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci))
     _lib.call("l2i_conv2d_wgrad", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
-              Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _stream())
+              Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), _stream())
     if end is not None:
         end.record()
 
@@ -308,6 +309,30 @@ def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, 
 
 
 # ----------------------------------------------------------------------------- fused conv Function
+class GradJoin:
+    """Joins the two gradient branches of a residual block's input inside the data-gradient launch: the shortcut
+    branch (whose backward runs first: autograd orders ready nodes by creation, latest first) GIVES its dx, the conv1
+    branch TAKES it as the residual input of its own data-gradient epilogue (or of the norm backward's second pass) --
+    instead of autograd materialising both and adding them with one more pass. If the order ever differs, both
+    branches simply return their gradients the ordinary way."""
+
+    def __init__(self):
+        self.t, self.state = None, "open"
+
+    def give(self, dx):
+        if self.state == "open" and dx is not None:
+            self.t, self.state = dx, "filled"
+            return None
+        return dx
+
+    def take(self):
+        if self.state == "filled":
+            t, self.t, self.state = self.t, None, "done"
+            return t
+        self.state = "closed"
+        return None
+
+
 class FusedConvFn(Function):
     """[prologue] -> implicit-GEMM conv/linear (+bias, +res, up2 / pool2) with f32 streams on both
     sides. The operand tensor produced by the prologue never becomes an autograd edge, so its
@@ -319,7 +344,7 @@ class FusedConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None,
-                emit=(), dx_raw=False):
+                emit=(), dx_raw=False, join=None):
         _chk(x, torch.float32)
         opd = pc.arena.op_dtype
         B, H, W, C = x.shape
@@ -352,7 +377,7 @@ class FusedConvFn(Function):
                                       want_op="relu" in emit, relu_op=True, want_raw="raw" in emit)
         if emit:
             _attach(out, raw=o_raw, relu=o_relu)
-        ctx.flops, ctx.nimg, ctx.dx_raw = flops, nimg, dx_raw
+        ctx.flops, ctx.nimg, ctx.dx_raw, ctx.join = flops, nimg, dx_raw, join
         sw, sb = getattr(wproj, "_l2i_sink", None), getattr(bproj, "_l2i_sink", None)
         ctx.sink = (sw[0], sw[1], sb[1]) if sw is not None and sb is not None and sw[0] is sb[0] else None
         ctx.holder, ctx.pc, ctx.pro, ctx.up2, ctx.pool2, ctx.stats = holder, pc, pro, up2, pool2, stats
@@ -374,21 +399,24 @@ class FusedConvFn(Function):
         # the operand copy of dY: written by the data-gradient launch that produced dY (`dx_raw`), or by another layer
         # that received the same dY (a block's conv2 and its shortcut), else cast here -- and left on dY for the others
         dy_op = _sibling(dy, "raw", opd)
-        if pc.need_wgrad and ctx.has_bias:  # bias gradient (and the dY operand cast, if still needed) in one pass over dY
+        dbias = None
+        if pc.need_wgrad and ctx.has_bias:
             bg = h.bias.grad
             direct = bg is not None and h.co == h.co_p and bg.is_contiguous() and bg.dtype == torch.float32
-            st = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False, cast_to=opd if dy_op is None else None,
-                               accumulate_into=bg if direct else None)
-            if dy_op is None:
-                dy_op = st[2].view(dy.shape)
-            d_bias = None if direct else st[0][0][:h.co]   # direct: summed straight into the flat gradient buffer
-        elif dy_op is None:
+            if direct:   # the weight-gradient launch sums the bias gradient from the dY tiles it stages, straight into the
+                dbias = bg   # flat gradient buffer: no pass over dY at all when its operand copy already exists
+            else:        # (padded channel counts: bias gradient and the dY operand cast in one pass over dY)
+                st = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False, cast_to=opd if dy_op is None else None)
+                if dy_op is None:
+                    dy_op = st[2].view(dy.shape)
+                d_bias = st[0][0][:h.co]
+        if dy_op is None:
             dy_op, _ = cast_op(dy, opd, raw=True, act=False)
         if _sibling(dy, "raw", opd) is None:
             _attach(dy, raw=dy_op)
         if pc.need_wgrad:
             wgrad_raw(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
-                      flops=ctx.flops, nimg=ctx.nimg)
+                      flops=ctx.flops, nimg=ctx.nimg, dbias=dbias)
         dx = d_mask = d_w = d_b = None
         if need_x or need_mod:
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
@@ -396,18 +424,24 @@ class FusedConvFn(Function):
             Bq, Hq, Wq = dy.shape[0], dy.shape[1] << int(ctx.pool2), dy.shape[2] << int(ctx.pool2)
             small = ((Bq * Hq * Wq + 127) // 128) * ((h.ci_p + 127) // 128) < 192   # split-K grid: no epilogue copies
             emit_raw = ctx.dx_raw and pro.kind != "norm" and not small   # (the norm backward rewrites dxo: its copy would be stale)
+            joined = ctx.join[0].take() if ctx.join is not None and ctx.join[1] == "take" and need_x else None
             dxo, _, dx_op = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
-                                     pool2=ctx.up2, alpha=alpha, flops=ctx.flops, nimg=ctx.nimg, want_raw=emit_raw)
+                                     pool2=ctx.up2, alpha=alpha, flops=ctx.flops, nimg=ctx.nimg, want_raw=emit_raw,
+                                     res=joined if pro.kind != "norm" else None)
             if emit_raw:
                 _attach(dxo, raw=dx_op)
             if pro.kind == "norm":
                 sums, sq, count, sstride = ctx.stats
-                dx, d_w, d_b, d_mask = norm_bwd_raw(x, dxo, sums, sq, count, sstride, pro, mask, wproj, bproj,
+                dx, d_w, d_b, d_mask = norm_bwd_raw(x, dxo, sums, sq, count, sstride, pro, mask, wproj, bproj, add_to=joined,
                                                     need_mask_grad=mask is not None and ctx.needs_input_grad[3], sink=ctx.sink)
             else:
                 dx = dxo
+            if ctx.join is not None and ctx.join[1] == "give":
+                dx = ctx.join[0].give(dx)
         d_res = dy if ctx.has_res else None
-        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None
+        if d_res is not None and ctx.join is not None and ctx.join[1] == "give_res":
+            d_res = ctx.join[0].give(d_res)
+        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None
 
 
 def _attach(t, raw=None, relu=None):
@@ -437,12 +471,13 @@ def precast(x, op_dtype):
 
 
 def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False, nimg=None,
-               emit=(), dx_raw=False):
+               emit=(), dx_raw=False, join=None):
     """emit: operand copies of the result to write in the epilogue ("relu", "raw") for the layers that read it next.
     dx_raw: x is read by this layer ONLY and was produced by another fused_conv -- the data-gradient launch then also
-    writes the operand copy of dx that the producer's backward needs (no separate cast pass over dx)."""
+    writes the operand copy of dx that the producer's backward needs (no separate cast pass over dx).
+    join: (GradJoin, "give" | "take" | "give_res") -- see GradJoin."""
     pro = prologue if prologue is not None else _CAST
-    return FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg, tuple(emit), dx_raw)
+    return FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg, tuple(emit), dx_raw, join)
 
 
 class _Simple(Prologue):

@@ -1,0 +1,85 @@
+"""End-to-end training entry (the loop of reference train_context_app_v2.py:38-217 on the HIP path):
+
+    python -m layout2img_amd.train --dataset coco --batch_size 32 --total_epoch 200 --out_path ./outputs/
+    python -m torch.distributed.run --nproc-per-node 8 -m layout2img_amd.train ...      (one process per GPU, RCCL)
+
+Same flags as the reference (:220-237). `--synthetic N` trains on N synthetic batches instead of a dataset on disk.
+Checkpoints are written every 5 epochs in the reference's layout (G_<e>.pth / D_<e>.pth, `module.` prefix) plus the
+optimizer state; `--checkpoint_epoch E` resumes from them (the reference's default of 55 would make a fresh run
+return at once, :74-75 -- here 0 means "start fresh").
+"""
+import argparse
+import os
+import time
+
+import torch
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset", type=str, default="coco")
+    ap.add_argument("--batch_size", type=int, default=16, help="per GPU")
+    ap.add_argument("--total_epoch", type=int, default=200)
+    ap.add_argument("--d_lr", type=float, default=0.0001)
+    ap.add_argument("--g_lr", type=float, default=0.0001)
+    ap.add_argument("--out_path", type=str, default="./outputs/")
+    ap.add_argument("--checkpoint_epoch", type=int, default=0)
+    ap.add_argument("--data_root", type=str, default=".")
+    ap.add_argument("--synthetic", type=int, default=0, help="iterations per epoch on synthetic layouts (no dataset on disk)")
+    ap.add_argument("--vgg_weights", type=str, default="", help="torchvision vgg19 state_dict (.pth) for the perceptual loss; empty = term omitted")
+    ap.add_argument("--img_size", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    args = ap.parse_args(argv)
+
+    import layout2img_amd as L
+    from layout2img_amd import data, generator, parallel
+    from layout2img_amd.synthetic import make_batch
+    rank, world, local = parallel.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    opd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    num_classes = 184 if args.dataset == "coco" else 179                      # :44-45
+    out_path = os.path.join(args.out_path, args.dataset, str(args.img_size))  # :48
+    if args.dataset == "coco":
+        netG = (L.ResnetGenerator128_context if args.img_size == 128 else L.ResnetGenerator64_context)(num_classes=num_classes)
+    else:
+        netG = generator.context_aware_generator(num_classes=num_classes)
+    netD = (L.CombineDiscriminator128_app if args.img_size == 128 else L.CombineDiscriminator64)(num_classes=num_classes)
+    netG.finalize(dev, opd), netD.finalize(dev, opd)
+    vgg = None
+    if args.vgg_weights:
+        vgg = L.VGGLoss().finalize(dev, opd)
+        vgg.load_torchvision_state_dict(torch.load(args.vgg_weights, map_location="cpu"))
+    trainer = L.GanTrainer(netG, netD, g_lr=args.g_lr, d_lr=args.d_lr, vgg=vgg)
+    start = 0
+    if args.checkpoint_epoch > 0:
+        start = L.load_checkpoint(out_path, args.checkpoint_epoch, netG, netD, trainer.g_opt, trainer.d_opt)
+    if args.synthetic:
+        batches = lambda epoch: (make_batch(args.batch_size, args.img_size, args.dataset, seed=epoch * 100003 + i * world + rank, device=dev)[:3]
+                                 for i in range(args.synthetic))
+    else:
+        ds = data.get_dataset(args.dataset, args.img_size, args.data_root)
+        loader = data.make_loader(ds, args.batch_size, num_workers=2, shuffle=True, rank=rank, world=world)
+        to_dev = data.DeviceBatcher(dev, (args.img_size, args.img_size))
+
+        def batches(epoch):
+            if hasattr(loader.sampler, "set_epoch"):
+                loader.sampler.set_epoch(epoch)
+            return (to_dev(b) for b in loader)
+    netG.train(), netD.train()
+    t0 = time.time()
+    for epoch in range(start, args.total_epoch):
+        for idx, (real, label, bbox) in enumerate(batches(epoch)):
+            r = trainer.step(real, label, bbox)
+            if rank == 0 and (idx + 1) % 500 == 0:   # (the only host synchronisation: logging, as :191-209)
+                print(f"Time Elapsed: {time.time() - t0:.0f}s  Epoch[{epoch + 1}/{args.total_epoch}], Step[{idx + 1}], "
+                      f"d_loss: {float(r['d_loss']):.4f}, g_loss: {float(r['g_loss']):.4f}, pixel: {float(r['pixel']):.4f}", flush=True)
+        if rank == 0 and (epoch + 1) % 5 == 0:       # :215-217
+            L.save_checkpoint(out_path, epoch + 1, netG, netD, trainer.g_opt, trainer.d_opt)
+    if rank == 0:
+        L.save_checkpoint(out_path, args.total_epoch, netG, netD, trainer.g_opt, trainer.d_opt)
+    return trainer
+
+
+if __name__ == "__main__":
+    main()

@@ -96,3 +96,13 @@ def test_sample_batch1_matches_oracle(dt):
     sd = {k: v.detach().cpu().clone() for k, v in g.state_dict().items()}
     ref = O.generator_forward(sd, zs.cpu(), box1.cpu(), zi.cpu(), lab1.cpu(), training=False)
     assert maxdiff(img, ref) < (1e-3 if dt == torch.float32 else 1e-1)
+
+
+def test_training_entry_runs_and_resumes(tmp_path):
+    """python -m layout2img_amd.train on synthetic layouts: 2 epochs, checkpoint, resume for a third."""
+    from layout2img_amd import train
+    common = ["--dataset", "coco", "--batch_size", "4", "--out_path", str(tmp_path), "--synthetic", "2", "--img_size", "64", "--dtype", "f32"]
+    tr = train.main(common + ["--total_epoch", "2"])
+    assert tr.g_opt.t == 4 and (tmp_path / "coco" / "64" / "model" / "G_2.pth").exists()
+    tr2 = train.main(common + ["--total_epoch", "3", "--checkpoint_epoch", "2"])
+    assert tr2.g_opt.t == 6 and (tmp_path / "coco" / "64" / "model" / "D_3.pth").exists()

@@ -336,6 +336,79 @@ def capture_vgg():
     print("vgg captured: loss", float(loss), [float(f.mean()) for f in feats])
 
 
+def capture_datasets():
+    """The reference's dataset classes (data/cocostuff_loader.py, data/vg.py) on the miniature datasets of
+    tests/golden/tiny_datasets.py. Stubs for what is not installed: torchvision.transforms (Compose / ToTensor /
+    Normalize -- scale to [0,1], CHW, (x - mean) / std), skimage, pycocotools (imported, never called), h5py (a
+    read-only File over the .npz holding the same arrays)."""
+    import random
+    import tempfile
+    from tests.golden import tiny_datasets
+    T = types.ModuleType("torchvision.transforms")
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToTensor:
+        def __call__(self, im):
+            return torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1).contiguous()
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.m, self.s = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.m) / self.s
+    T.Compose, T.ToTensor, T.Normalize = Compose, ToTensor, Normalize
+    sys.modules["torchvision"].transforms = T
+    sys.modules["torchvision.transforms"] = T
+    sk, skt = types.ModuleType("skimage"), types.ModuleType("skimage.transform")
+    skt.resize = None
+    sys.modules.update({"skimage": sk, "skimage.transform": skt})
+    pc, pcm = types.ModuleType("pycocotools"), types.ModuleType("pycocotools.mask")
+    sys.modules.update({"pycocotools": pc, "pycocotools.mask": pcm})
+    h5 = types.ModuleType("h5py")
+
+    class File:
+        def __init__(self, path, mode):
+            self.z = np.load(path, allow_pickle=False)
+
+        def __enter__(self):
+            return {k: self.z[k] for k in self.z.files}
+
+        def __exit__(self, *a):
+            self.z.close()
+    h5.File = File
+    sys.modules["h5py"] = h5
+    import PIL.ImageOps  # noqa: F401  (the reference calls PIL.ImageOps.mirror without importing the submodule)
+    from data.cocostuff_loader import CocoSceneGraphDataset
+    from data.vg import VgSceneGraphDataset
+    rec = {}
+    with tempfile.TemporaryDirectory() as root:
+        tiny_datasets.write(root)
+        ds = CocoSceneGraphDataset(os.path.join(root, "images"), os.path.join(root, "instances.json"), os.path.join(root, "stuff.json"),
+                                   stuff_only=True, image_size=(32, 32), left_right_flip=True)
+        rec["coco_len"], rec["coco_ids"] = len(ds), np.array(ds.image_ids)
+        for i in range(len(ds)):
+            im, objs, boxes = ds[i]
+            rec[f"coco_img{i}"], rec[f"coco_objs{i}"], rec[f"coco_boxes{i}"] = im.numpy(), objs.numpy(), np.asarray(boxes, np.float64)
+        vg = VgSceneGraphDataset(os.path.join(root, "vocab.json"), os.path.join(root, "vg.npz"), os.path.join(root, "images"),
+                                 image_size=(32, 32), max_objects=10, left_right_flip=True)
+        rec["vg_len"] = len(vg)
+        for i in range(len(vg)):
+            random.seed(1000 + i)
+            im, objs, boxes = vg[i]
+            rec[f"vg_img{i}"], rec[f"vg_objs{i}"], rec[f"vg_boxes{i}"] = im.numpy(), objs.numpy(), boxes.numpy()
+    np.savez_compressed(os.path.join(OUT, "datasets.npz"), **rec)
+    print("datasets captured: coco", rec["coco_len"], rec["coco_ids"], "vg", rec["vg_len"])
+
+
 def capture_small_ops():
     """Known answers the survey lists for masks_to_layout / bbox_mask."""
     from model.resnet_generator_app_v2 import bbox_mask
@@ -353,7 +426,7 @@ def capture_small_ops():
 if __name__ == "__main__":
     patch_env()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["small", "g_coco", "g_vg", "d", "d64", "loop", "vg", "vgg"]
+    which = sys.argv[1:] or ["small", "g_coco", "g_vg", "d", "d64", "loop", "vg", "vgg", "data"]
     with torch.random.fork_rng():
         if "small" in which:
             capture_small_ops()
@@ -371,3 +444,5 @@ if __name__ == "__main__":
             capture_vg()
         if "vggloss" in which or "vgg" in which:
             capture_vgg()
+        if "data" in which:
+            capture_datasets()
