@@ -314,6 +314,8 @@ class WeightArena:
 
     def flush_grads(self):
         """Apply the spectral-norm backward of every pending pass into the flat gradient buffer."""
+        from .ops import WgradSide
+        WgradSide.join()   # weight-gradient launches run on side streams (ops.WgradSide)
         for p in self.pending:
             if p.dwbar is None:
                 continue

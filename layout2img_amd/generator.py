@@ -423,10 +423,12 @@ class ResnetGenerator128_context(_GeneratorBase):
         x, m = self.res1(x, wp, bmask, pc, self.sync, emit=("raw",))
         stage = bmask
         stages = []
+        res_out = [x]
         for blk, alpha in ((self.res2, self.alpha1), (self.res3, self.alpha2), (self.res4, self.alpha3), (self.res5, self.alpha4)):
             stage = self._stage_mask(m, bmask, bbox_mask_, alpha, y)
             stages.append(stage)
             x, m = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",))
+            res_out.append(x)
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
         pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
@@ -434,7 +436,7 @@ class ResnetGenerator128_context(_GeneratorBase):
         self._release_isla()
         img = torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()
         if taps is not None:
-            taps.update(w=w, bmask=bmask, stages=stages, pre_tanh=pre[..., :self.output_dim])
+            taps.update(w=w, bmask=bmask, stages=stages, pre_tanh=pre[..., :self.output_dim], res=res_out)
         return img
 
 
