@@ -680,7 +680,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {  
 //     reads a 256-byte zero region at the bank slot the border row would have had (conflict-free by the same argument
 //     as the bordered layout: tools/perf/halo_check.py);
 //   * needs Ci % 64 == 0 (every layer this is used for); everything else as above (transposed accumulator, epilogue).
-template <int BN, int ABL = 0>
+template <int BN, int ABL = 0, bool PF = false>
 __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
     typedef bf16_t T;
     constexpr int NW = 4, TM = 2, TN = BN / 32, BP = BN / 32, SZ = 2;
@@ -836,6 +836,92 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
 
+    // ---- PF: the K-step's barrier sits BETWEEN its third and fourth k16 sub-step, and the first sub-step's fragments of
+    // the NEXT K-step are read right behind it (under the last 8 MFMAs): a wave comes out of the barrier with MFMAs to
+    // issue and its next fragments already in flight, instead of "barrier -> reads -> wait ~200 cycles -> first MFMA".
+    // Invariant at the top of a step: set 0 holds (or is receiving) sub-step 0's fragments, this step's weight tile is
+    // visible, the next one is in flight. Mid-step: this wave's reads of the current stage are complete (lgkmcnt(0)),
+    // its pieces of the next tile landed (vmcnt(0)), barrier -> the current stage is free for the tile after next.
+    // A chunk boundary (tap 8 -> tap 0) refills the halo behind the mid-step barrier of tap 8 and pays one ordinary
+    // "wait, barrier, read" at tap 0.
+#define H3P_STEP(S, cb_cur, cb_nxt, cb_nn, HEAD)                                                                       \
+    {                                                                                                                  \
+        constexpr int TAP = (S) % 9, STG = (S)&1, TAP1 = (TAP + 1) % 9, TAP2 = (TAP + 2) % 9;                          \
+        if (HEAD) {   /* first step of a chunk: the halo (and this step's tile) must have landed; no prefetched set */ \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+            __builtin_amdgcn_s_barrier();                                                                              \
+            asm volatile("" ::: "memory");                                                                             \
+            { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) asm volatile("" : "+v"(a_addr[i_][TAP])); }          \
+            H3_RD(0, TAP, STG)                                                                                         \
+        }                                                                                                              \
+        { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) asm volatile("" : "+v"(a_addr[i_][TAP])); }              \
+        H3_RD(1, TAP, STG)                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H3_MM(0)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H3_RD(2, TAP, STG)                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H3_MM(1)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H3_RD(3, TAP, STG)                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H3_MM(2)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        {   /* the tile after next -> the stage this step has just finished reading */                                 \
+            const unsigned kadd2 = (unsigned)(TAP2 * ci2 + (TAP >= 7 ? (TAP == 7 ? (cb_nxt) : (cb_nxt)) : (cb_cur)) * SZ); \
+            _Pragma("unroll") for (int q_ = 0; q_ < BP; ++q_) H2_DMA(rsrc_w, b_off[q_], kadd2, ring_w + STG * BSTAGE + (unsigned)q_ * 4096u); \
+        }                                                                                                              \
+        if (TAP == 8) { H3_HALO(cb_nxt) }   /* nobody reads the halo any more: refill it for the next chunk */           \
+        else {                                                                                                         \
+            { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) asm volatile("" : "+v"(a_addr[i_][TAP1])); }         \
+            H3_RD(0, TAP1, 1 - STG)                                                                                    \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H3_MM(3)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
+    if (PF) {
+        if (c_begin < c_end) {
+            {   // prologue: the first halo and the weight tiles of taps 0 and 1
+                const int cb0 = c_begin * 64;
+                H3_HALO(cb0)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned kadd0 = (unsigned)(t * ci2 + cb0 * SZ);
+#pragma unroll
+                    for (int q = 0; q < BP; ++q) H2_DMA(rsrc_w, b_off[q], kadd0, ring_w + (unsigned)t * BSTAGE + (unsigned)q * 4096u);
+                }
+            }
+            for (int c = c_begin; c < c_end; c += 2) {
+                const int cbA = c * 64;
+                const int cbB = min(cbA + 64, last_cb), cbC = min(cbA + 128, last_cb);
+                H3P_STEP(0, cbA, cbB, cbC, true)
+                H3P_STEP(1, cbA, cbB, cbC, false)
+                H3P_STEP(2, cbA, cbB, cbC, false)
+                H3P_STEP(3, cbA, cbB, cbC, false)
+                H3P_STEP(4, cbA, cbB, cbC, false)
+                H3P_STEP(5, cbA, cbB, cbC, false)
+                H3P_STEP(6, cbA, cbB, cbC, false)
+                H3P_STEP(7, cbA, cbB, cbC, false)
+                H3P_STEP(8, cbA, cbB, cbC, false)
+                if (c + 1 < c_end) {
+                    H3P_STEP(9, cbB, cbC, cbC, true)
+                    H3P_STEP(10, cbB, cbC, cbC, false)
+                    H3P_STEP(11, cbB, cbC, cbC, false)
+                    H3P_STEP(12, cbB, cbC, cbC, false)
+                    H3P_STEP(13, cbB, cbC, cbC, false)
+                    H3P_STEP(14, cbB, cbC, cbC, false)
+                    H3P_STEP(15, cbB, cbC, cbC, false)
+                    H3P_STEP(16, cbB, cbC, cbC, false)
+                    H3P_STEP(17, cbB, cbC, cbC, false)
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else
     if (c_begin < c_end) {
         {   // prologue: the first halo and the weight tile of tap 0
             const int cb0 = c_begin * 64;
@@ -873,6 +959,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped extra tile must not land after the LDS is reused / the wave ends
     }
 #undef H3_STEP
+#undef H3P_STEP
 #undef H3_HALO
 #undef H3_MM
 #undef H3_RD
@@ -973,7 +1060,7 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
 }
 
 // conv_halo3_kernel launch (bf16, 3x3, Ci % 64 == 0, Wo >= 8). Returns -100 when the shape is not covered.
-template <int BN, int ABL = 0>
+template <int BN, int ABL = 0, bool PF = false>
 static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     if (a.Ci % 64 || a.Wo < 8 || (a.up2 && a.Wo < 8)) return -100;
     a.PH = 256 / a.PW;
@@ -1011,10 +1098,10 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     }
     static bool ready = false;
     if (!ready) {
-        (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<BN, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<BN, ABL, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ready = true;
     }
-    hipLaunchKernelGGL((conv_halo3_kernel<BN, ABL>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_halo3_kernel<BN, ABL, PF>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
     return l2i_check_launch();
 }
 
@@ -1077,8 +1164,9 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // 256-pixel tiles (conv_halo3_kernel; tools/perf/conv_sweep.py, profiles/r02_conv_sweep.txt): +4..11 % on the long
         // reductions whose 256x128 grid still fills both workgroup slots of every CU (obj4 conv2 at 32x32, the
         // 1024-channel ROI heads), and -- as 256x64 tiles -- on the upsampling layers from 32x32 outputs up.
-        if (a.Ci % 64 == 0 && a.Ci >= 512 && a.Co >= 512 && ((M + 255) / 256) * ((a.Co + 127) / 128) >= 512) hc = 7;
-        else if (a.Ci % 64 == 0 && a.up2 && a.Wo >= 32) hc = 8;
+        // (9 / 19: their variants with the barrier inside the K-step, +2..4 % on these shapes)
+        if (a.Ci % 64 == 0 && a.Ci >= 512 && a.Co >= 512 && ((M + 255) / 256) * ((a.Co + 127) / 128) >= 512) hc = 9;
+        else if (a.Ci % 64 == 0 && a.up2 && a.Wo >= 32) hc = 19;
         // (256x128 / 8-wave tiles are ~10 % faster on the 1024-channel ROI-head layers in isolation but not inside the
         //  iteration -- rocprofv3: 1.90 vs 1.77 ms for those 9 launches -- so they stay a tuning option: cfg 12)
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
@@ -1092,6 +1180,8 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
             case 6: rc = launch_halo2<128, 64, 2, 2, 2, false, true>(a, stream); break;    // 40 KB: four per CU
             case 7: rc = launch_halo3<128>(a, stream); break;    // 256 x 128 tiles, 4 waves of 64 x 128
             case 8: rc = launch_halo3<64>(a, stream); break;     // 256 x 64 tiles
+            case 9: rc = launch_halo3<128, 0, true>(a, stream); break;   // the same with the barrier moved inside the K-step (PF)
+            case 19: rc = launch_halo3<64, 0, true>(a, stream); break;
 #ifdef L2I_ABLATIONS
             case 41: rc = launch_halo3<128, 1>(a, stream); break;
             case 42: rc = launch_halo3<128, 2>(a, stream); break;

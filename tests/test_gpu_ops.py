@@ -115,7 +115,7 @@ def test_conv_split_k(case, dt):
     assert float((out.cpu() - expect).abs().max()) < 3e-5 * float(expect.abs().max()) + 1e-5
 
 
-@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 29])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 72, 3, False, False), (1, 32, 32, 128, 136, 3, False, True),
                                   (2, 16, 16, 64, 64, 3, True, False), (9, 16, 16, 192, 128, 3, False, False),
                                   (5, 8, 8, 64, 264, 3, False, True), (1, 64, 64, 64, 8, 3, True, False),
