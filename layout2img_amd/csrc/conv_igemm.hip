@@ -16,6 +16,7 @@
 // a tile are a PHxPW patch enumerated quad-major (4 consecutive rows of the
 // GEMM = one 2x2 pixel quad), so a 32x32 accumulator's registers 4g..4g+3 are
 // one quad and the 2x2 pool is an in-register sum.
+#include <stdlib.h>
 #include "igemm.h"
 
 struct ConvArgs {
@@ -974,6 +975,7 @@ static int ilog2(int v) {
 }
 
 static int g_split_target = 512;   // tuning hook: workgroups a split-K launch aims for
+static int g_force_splits = 0;     // tuning hook (l2i_set_conv_config(2000 + n)): split count of the 256-pixel-tile kernel
 // Launch one instantiation; LDS rings above 64 KB need the opt-in attribute (set once per instantiation).
 template <typename T, int BM, int BN, int WM, int WN, int NS, int HK = 0>
 static int launch_cfg(ConvArgs a, hipStream_t stream) {
@@ -1062,7 +1064,8 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
 // conv_halo3_kernel launch (bf16, 3x3, Ci % 64 == 0, Wo >= 8). Returns -100 when the shape is not covered.
 template <int BN, int ABL = 0, bool PF = false>
 static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
-    if (a.Ci % 64 || a.Wo < 8 || (a.up2 && a.Wo < 8)) return -100;
+    if (a.Ci % 64 || a.Wo < 4 || (a.up2 && a.Wo < 8)) return -100;
+    if (force_splits == 0) force_splits = g_force_splits;
     a.PH = 256 / a.PW;
     a.PHs = a.PH < a.Ho ? a.PH : a.Ho;
     a.sub_shift = ilog2(a.PHs);
@@ -1083,9 +1086,10 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     a.tiles_n = (a.Co + BN - 1) / BN;
     const int nblk = a.tiles_m * a.tiles_n;
     int splits = 1;
-    if (a.out && !a.out_op && !a.out_op_raw && nblk < 128 && nchunks >= 4) {   // fill the 512 workgroup slots (two per CU)
-        splits = (g_split_target + nblk / 2) / nblk;
+    if (a.out && !a.out_op && !a.out_op_raw && nblk < 256 && nchunks >= 4) {   // fill the 512 workgroup slots (two per CU); more than 8
+        splits = (g_split_target + nblk / 2) / nblk;                           // splits lose to their atomics (tools/perf/conv_small.py)
         if (splits > nchunks / 2) splits = nchunks / 2;   // >= 18 K-steps per split
+        if (splits > 8) splits = 8;
         if (splits < 1) splits = 1;
     }
     if (force_splits > 0 && a.out && !a.out_op && !a.out_op_raw) splits = force_splits < nchunks ? force_splits : nchunks;
@@ -1107,6 +1111,7 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
 
 static int g_conv_cfg_override = -1;  // tuning hook (l2i_set_conv_config): -1 = heuristic
 extern "C" int l2i_set_conv_config(int cfg) {
+    if (cfg >= 2000) { g_force_splits = cfg - 2000; return L2I_OK; }   // 2000 + n: forced split count, conv_halo3 (tuning only)
     if (cfg >= 1000) { g_split_target = cfg - 1000; return L2I_OK; }   // 1000 + n: split-K target (tuning only)
     g_conv_cfg_override = cfg;
     return L2I_OK;
@@ -1151,7 +1156,13 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     // Heuristic from tools/perf/conv_tune.py on MI355X (TFLOP/s, bf16): big-tile configs pay only when their grid still
     // fills the 256 CUs; a single wave of 128x128 tiles (one workgroup per CU) prefers the 8-wave deep ring.
     const long long M = (long long)a.B * a.Ho * a.Wo;
-    if (sizeof(T) == 2 && a.KH == 3 && a.Ci >= 64 && !a.lin && a.Wo >= 8 && !(a.up2 && a.Wo < 16) && a.Ho >= 2 &&
+    // tuning: bit 0 = 4-wide maps, bit 1 = 4 -> 8 upsampling stay on the generic kernel. Same-box A/B inside the iteration
+    // (profiles/r02_small_map_ab.txt): 4 -> 8 layers 870 -> 657 us and 240 -> 193 us on conv_halo3; the 4x4 maps of D
+    // block6 are FASTER on the generic split-K kernel there (570 vs 666 us) although slower back to back -> default 1.
+    static const int no_small = getenv("L2I_NO_SMALL_HALO") ? atoi(getenv("L2I_NO_SMALL_HALO")) : 1;
+    const bool small_map = a.Wo < 8 || (a.up2 && a.Wo < 16);   // 4-wide maps, 4 -> 8 upsampling: only conv_halo3's compact halo covers them
+    if (sizeof(T) == 2 && a.KH == 3 && a.Ci >= 64 && !a.lin && a.Wo >= 4 && !(a.up2 && a.Wo < 8) && a.Ho >= 2 &&
+        (!small_map || (a.Ci % 64 == 0 && a.Ci >= 256 && !((no_small & 1) && a.Wo < 8) && !((no_small & 2) && a.up2))) &&
         (g_conv_cfg_override < 0 || g_conv_cfg_override >= 10)) {   // (-2: tuning, single halo buffer for every 128x128 launch)
         // 128x128 tiles (two workgroups per CU, 2-stage weight ring) when they make at least one full wave of
         // workgroups; otherwise 128x64 tiles (twice the workgroups, 3-stage ring). Measured: tools/perf/conv_tune.py.
@@ -1170,6 +1181,8 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // (256x128 / 8-wave tiles are ~10 % faster on the 1024-channel ROI-head layers in isolation but not inside the
         //  iteration -- rocprofv3: 1.90 vs 1.77 ms for those 9 launches -- so they stay a tuning option: cfg 12)
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
+        if (small_map && hc != 7 && hc != 8 && hc != 9 && hc != 19)   // 256x128 tiles when they still make a full grid, else 256x64 + split-K
+            hc = ((M + 255) / 256) * ((a.Co + 127) / 128) >= 256 ? 9 : 19;
         int rc;
         switch (hc) {
             case 1: rc = launch_halo2<128, 64, 2, 2, 3, false>(a, stream); break;
