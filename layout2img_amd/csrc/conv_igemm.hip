@@ -1171,13 +1171,16 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // ring wins on long reductions, the single halo buffer + 3-stage ring on short ones and on 8-wide maps (whose two
         // 8x8 sub-patch halos only fit twice per CU single-buffered). Measured: tools/perf/conv_tune.py + in-iteration profile.
         int hc = 5;   // 128x64 tiles, single halo buffer: 48 KB, three workgroups per CU
-        if (a.Co > 64 && t128h >= 512) hc = (a.Wo < 16 || a.Ci <= 256 || g_conv_cfg_override == -2) ? 4 : 0;
+        // (in-situ sweep, profiles/r02_insitu_cfg_sweep.txt: the single-halo 128x128 tile also beats the double-buffered one
+        //  on the long reductions now -- 210 vs 270 us on 32x32x512->256 -- so 0 is only a tuning option)
+        if (a.Co > 64 && t128h >= 512) hc = 4;
         // 256-pixel tiles (conv_halo3_kernel; tools/perf/conv_sweep.py, profiles/r02_conv_sweep.txt): +4..11 % on the long
         // reductions whose 256x128 grid still fills both workgroup slots of every CU (obj4 conv2 at 32x32, the
         // 1024-channel ROI heads), and -- as 256x64 tiles -- on the upsampling layers from 32x32 outputs up.
         // (9 / 19: their variants with the barrier inside the K-step, +2..4 % on these shapes)
+        // (256x64 tiles looked 5-7 % better on the upsampling layers back to back, but lose 15-25 % to the 128x64 tiles
+        //  inside the iteration: not used there)
         if (a.Ci % 64 == 0 && a.Ci >= 512 && a.Co >= 512 && ((M + 255) / 256) * ((a.Co + 127) / 128) >= 512) hc = 9;
-        else if (a.Ci % 64 == 0 && a.up2 && a.Wo >= 32) hc = 19;
         // (256x128 / 8-wave tiles are ~10 % faster on the 1024-channel ROI-head layers in isolation but not inside the
         //  iteration -- rocprofv3: 1.90 vs 1.77 ms for those 9 launches -- so they stay a tuning option: cfg 12)
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;

@@ -14,6 +14,8 @@ def run(path, steps=3):
     from layout2img_amd import ops, _lib
     from layout2img_amd.synthetic import make_batch
     dev = torch.device("cuda:0")
+    if "L2I_CONV_CFG" in os.environ:   # force one tile configuration on every halo-eligible layer (tuning)
+        _lib.call("l2i_set_conv_config", int(os.environ["L2I_CONV_CFG"]))
     torch.manual_seed(1234)
     netG = L.ResnetGenerator128_context(num_classes=184).finalize(dev, torch.bfloat16)
     netD = L.CombineDiscriminator128_app(num_classes=184).finalize(dev, torch.bfloat16)
