@@ -47,6 +47,17 @@ def cpu_baseline(netG, netD, size, seconds_budget=20.0):
                 sample=f"{n} training iterations at batch {b}, {size}x{size}, fp32, oracle/model.py OracleTrainer (VGG term omitted)")
 
 
+def hbm_kernels():
+    """HBM-bound kernels against the 6.3 TB/s achievable HBM3E bandwidth: PMC bytes / profiler durations of this same
+    command, collected by tools/perf/traffic2.sh on the GPU box and committed under profiles/ (null if absent)."""
+    p = os.path.join(ROOT, "profiles", "r02_hbm_kernels.json")
+    if not os.path.exists(p):
+        return None
+    d = json.load(open(p))
+    return {k: {"gb_per_s": v["gb_per_s"], "frac_of_6300": v["frac_of_6300"], "avg_launch_us": v["avg_launch_us"]}
+            for k, v in d.items() if isinstance(v, dict)}
+
+
 def g_forward_figures(netG, args, z, bbox, z_im, label, op_dtype):
     import torch
     from layout2img_amd.sampling import sample
@@ -204,11 +215,12 @@ def main():
             peak = 2500.0 if op_dtype == torch.bfloat16 else 157.3
             ach = s["work"] / (s["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")   # PMC pass of this same command (tools/perf/traffic.sh)
+            tpath = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")   # PMC passes of this same command (tools/perf/traffic2.sh)
             if op_dtype == torch.bfloat16 and args.size == 128 and os.path.exists(tpath):
                 traffic = round(json.load(open(tpath))["conv(fwd+dgrad)"]["traffic_bytes_per_launch"])
-                traffic_src = "profiles/r01_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE; separate passes)"
-            roof = dict(bound="mfma", kernel="l2i_conv2d_fwd launches (conv_halo2_kernel + conv_igemm_kernel), forward and data-gradient",
+                traffic_src = "profiles/r02_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE; separate passes)"
+            roof = dict(bound="mfma", kernel="l2i_conv2d_fwd launches (conv_halo2/3_kernel + conv_igemm_kernel), forward and data-gradient",
+                        timing="HIP events attached to each dispatch (hipExtLaunchKernelGGL) on the launching stream, inside the timed region",
                         achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
                         traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=round(s["bytes"] / s["launches"]),
@@ -216,8 +228,10 @@ def main():
                         avg_launch_us=round(1e3 * s["ms"] / s["launches"], 2),
                         gflop_per_launch=round(s["work"] / s["launches"] / 1e9, 3))
             w = ops.TIMER.summary().get("conv_wgrad")
-            if w:
+            if w and w["launches"]:
                 roof["wgrad_tflops"] = round(w["work"] / (w["ms"] * 1e-3) / 1e12, 2)
+                roof["wgrad_frac"] = round(w["work"] / (w["ms"] * 1e-3) / 1e12 / peak, 4)
+            ops.TIMER.close()
             ops.TIMER = None
         # secondary figures of SURVEY section 8d: the generator forward alone (train-mode statistics, no autograd tape),
         # replayed as its own HIP graph, against the MFMA roofline (26.35 GFLOP per image), and the batch-1
@@ -245,7 +259,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": ("HIP graph replay, D(real) on a side stream (last timed step eager on one stream, with HIP events)"
                                   if graphed else "eager")},
-            "roofline": roof, "cpu_baseline": cpu, "g_forward": g_fwd,
+            "roofline": roof, "hbm_kernels": hbm_kernels(), "cpu_baseline": cpu, "g_forward": g_fwd,
             "g_forward_images_per_sec": None if g_fwd is None else g_fwd["images_per_sec"],
         }
         print(json.dumps(out), flush=True)

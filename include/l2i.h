@@ -45,6 +45,14 @@ int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float*
                    float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                    int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, void* stream);
 
+/* Per-launch timing of the two MFMA entry points (bench.py's roofline leg). l2i_timing(1): from now on every kernel
+ * launched by l2i_conv2d_fwd (class 0) / l2i_conv2d_wgrad (class 1) carries a start / stop HIP event pair attached to
+ * its dispatch (hipExtLaunchKernelGGL: the kernel's own begin / end on the stream it runs on); l2i_timing_read
+ * synchronises on them and returns the summed duration and the launch count of a class; l2i_timing(0) stops and frees.
+ * Not for use under graph capture. */
+int l2i_timing(int on);
+int l2i_timing_read(int cls, double* total_ms, int* launches);
+
 /* Tuning hook: force one of the forward-kernel tile configurations (see conv_igemm.hip), -1 = built-in heuristic. */
 int l2i_set_conv_config(int cfg);
 

@@ -91,6 +91,33 @@ static inline void ws_fold(float* ws, int L, int C, float* d0, float* d1, float*
     hipLaunchKernelGGL(ws_fold_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, a);
 }
 
+// ---------------------------------------------------------------- optional per-launch timing (l2i_timing / l2i_timing_read)
+// bench.py's roofline leg needs the duration of every conv / weight-gradient launch inside a timed iteration. A pair of
+// hipEventRecord calls around a launch also brackets the launch latency (~4 us per launch, 1.2 ms per iteration over the
+// ~250 conv launches: measured 550 TFLOP/s where rocprofv3's kernel durations give 596). hipExtLaunchKernelGGL attaches the
+// start / stop events to the DISPATCH itself, so their timestamps are the kernel's own begin and end -- what rocprofv3
+// reports -- on the stream the kernel is launched on.
+#include <hip/hip_ext.h>
+#include <vector>
+struct L2iTimer {
+    bool on = false;
+    std::vector<hipEvent_t> start[2], stop[2];   // class 0: l2i_conv2d_fwd launches, 1: l2i_conv2d_wgrad launches
+};
+inline L2iTimer g_l2i_timer;
+#define L2I_LAUNCH(CLS, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                                         \
+    do {                                                                                                               \
+        if (g_l2i_timer.on) {                                                                                          \
+            hipEvent_t e0_, e1_;                                                                                       \
+            (void)hipEventCreate(&e0_);                                                                                \
+            (void)hipEventCreate(&e1_);                                                                                \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, e0_, e1_, 0, __VA_ARGS__);                         \
+            g_l2i_timer.start[CLS].push_back(e0_);                                                                     \
+            g_l2i_timer.stop[CLS].push_back(e1_);                                                                      \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                                         \
+        }                                                                                                              \
+    } while (0)
+
 static inline int l2i_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? L2I_OK : L2I_ERR_LAUNCH;

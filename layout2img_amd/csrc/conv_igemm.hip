@@ -1012,7 +1012,7 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
         ready = true;
     }
     (void)BK;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, NS, HK>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+    L2I_LAUNCH(0, (conv_igemm_kernel<T, BM, BN, WM, WN, NS, HK>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
     return l2i_check_launch();
 }
 
@@ -1057,7 +1057,7 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ready = true;
     }
-    hipLaunchKernelGGL((conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+    L2I_LAUNCH(0, (conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
     return l2i_check_launch();
 }
 
@@ -1105,7 +1105,7 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
         (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<BN, ABL, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ready = true;
     }
-    hipLaunchKernelGGL((conv_halo3_kernel<BN, ABL, PF>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
+    L2I_LAUNCH(0, (conv_halo3_kernel<BN, ABL, PF>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
     return l2i_check_launch();
 }
 
@@ -1242,6 +1242,31 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
 }
 
 // C ABI -- see include/l2i.h
+extern "C" int l2i_timing(int on) {
+    for (int c = 0; c < 2; ++c) {
+        for (hipEvent_t e : g_l2i_timer.start[c]) (void)hipEventDestroy(e);
+        for (hipEvent_t e : g_l2i_timer.stop[c]) (void)hipEventDestroy(e);
+        g_l2i_timer.start[c].clear();
+        g_l2i_timer.stop[c].clear();
+    }
+    g_l2i_timer.on = on != 0;
+    return L2I_OK;
+}
+extern "C" int l2i_timing_read(int cls, double* total_ms, int* launches) {
+    if (cls < 0 || cls > 1 || !total_ms || !launches) return L2I_ERR_ARG;
+    double t = 0.0;
+    const size_t n = g_l2i_timer.start[cls].size();
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_l2i_timer.stop[cls][i]) != hipSuccess) return L2I_ERR_LAUNCH;
+        if (hipEventElapsedTime(&ms, g_l2i_timer.start[cls][i], g_l2i_timer.stop[cls][i]) != hipSuccess) return L2I_ERR_LAUNCH;
+        t += ms;
+    }
+    *total_ms = t;
+    *launches = (int)n;
+    return L2I_OK;
+}
+
 extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float* res,
                               const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                               int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, void* stream) {

@@ -558,21 +558,21 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
         const bool whole = a.M % 64 == 0;
         const int mode = !whole ? 0 : (!a.pool2 && !a.up2) ? 1 : ((a.Ho * a.Wo) % 64 == 0 ? 2 : 0);
         if (BMO == 64) {
-            if (mode == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 1>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
-            else if (mode == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
-            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 1>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
         } else {
-            if (mode == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 1>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
-            else if (mode == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
-            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 1>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
         }
         return l2i_check_launch();
     }
     const size_t lds = (size_t)(BMO + 128) * IG_ROWB;
     if (BMO == 64)
-        hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), dim3(nblk), dim3(256), lds, stream, a);
+        L2I_LAUNCH(1, (conv_wgrad_kernel<T, 64>), dim3(nblk), dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), dim3(nblk), dim3(256), lds, stream, a);
+        L2I_LAUNCH(1, (conv_wgrad_kernel<T, 128>), dim3(nblk), dim3(256), lds, stream, a);
     return l2i_check_launch();
 }
 

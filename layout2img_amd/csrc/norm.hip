@@ -12,6 +12,7 @@
 //    735-746, model/mask_regression.py:66-80): same kernels, mode 1 (per-channel affine) / 2 (none),
 //    statistics grouped per image for the instance norm.
 //  * their backward passes (autograd of the above in the reference).
+#include <stdlib.h>
 #include "common.h"
 
 #define NM_PT 64    // pixels per block
@@ -581,6 +582,196 @@ __global__ __launch_bounds__(256) void norm_bwd_a_kernel(NormArgs p, int nseg, i
     }
 }
 
+// ---------------------------------------------------------------- ISLA backward pass A, up to 8 objects: registers, not LDS
+// Measured on the kernel above (tools/perf/norm_micro.py, 32 x 128^2 x 64 channels, 8 objects): 564 us against 153 us for
+// the same tensor without the modulation, i.e. 4x the HBM time, spent on LDS traffic -- phase 1 re-reads W, B of every
+// object for every pixel, phase 2 parks g, g*xhat in LDS and reads them back once per object -- and on half-idle lanes
+// when C = 64 (a 128-channel chunk is hard-wired). Here a thread owns (pixel row, 4 channels) for both jobs:
+//   * W, B of the 8 objects for its 4 channels live in registers (loaded once per workgroup run);
+//   * gamma / beta, the ReLU gate, dxhat and s1, s2 as before;
+//   * dW[o] += mn_o g xhat, dB[o] += mn_o g for all 8 objects from its OWN g, g*xhat registers (no parking), reduced over
+//     the pixel rows of the workgroup through LDS once at the end of the run;
+//   * dmask: part[o,p] = sum_c (g xhat W_o + g B_o) reduced over the channel lanes with DPP, combined as above.
+// CV = float4 lanes across channels: 32 (128-channel chunks) or 16 (C = 64: every lane busy).
+template <int CV>
+__device__ __forceinline__ float sum_cv(float v) {   // sum over the CV channel lanes that share a pixel row
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    if (CV == 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+template <int CV>
+__global__ __launch_bounds__(256, 2) void norm_bwd_a8_kernel(NormArgs p, int nseg, int seg_pixels) {
+    constexpr int CC = 4 * CV, PR = 256 / CV, NPI = NB_PX / PR;   // channels per chunk, pixel rows per pass, passes per sub-tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* mn4 = reinterpret_cast<float4*>(smem);         // [NB_PX][2]: mn of objects 0-3 / 4-7 of a pixel
+    float* sinv = reinterpret_cast<float*>(mn4 + 2 * NB_PX);   // [NB_PX]
+    float* partl = sinv + NB_PX;                           // [8][NB_PX]
+    float4* red = reinterpret_cast<float4*>(partl + 8 * NB_PX);   // [PR][8][CV] end-of-run reductions (32 KB)
+
+    const int tiles_c = (p.C + CC - 1) / CC;
+    int bid = blockIdx.x;
+    const int tc = bid % tiles_c; bid /= tiles_c;
+    const int seg = bid % nseg;
+    const int b = bid / nseg;
+    const int c0 = tc * CC;
+    const int cc = min(CC, p.C - c0);
+    const int tid = threadIdx.x;
+    const int px_begin = seg * seg_pixels, px_end = min(p.HW, px_begin + seg_pixels);
+    const int O = p.O;
+    const int cv = tid % CV, prow = tid / CV;
+    const int c = c0 + 4 * cv;
+    const bool con = 4 * cv < cc;
+    const float4 z4 = make_float4(0, 0, 0, 0);
+
+    float4 Wr[8], Br[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        Wr[o] = z4; Br[o] = z4;
+        if (con && o < O) {
+            const size_t off = (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + c;
+            Wr[o] = *reinterpret_cast<const float4*>(p.wproj + off);
+            Br[o] = *reinterpret_cast<const float4*>(p.bproj + off);
+        }
+    }
+    float4 mean = z4, istd = make_float4(1, 1, 1, 1);
+    if (con) {
+        const size_t so = (size_t)b * p.stat_stride + c;
+        const float4 s = *reinterpret_cast<const float4*>(p.sums + so);
+        const float4 q = *reinterpret_cast<const float4*>(p.sqsums + so);
+        const float ic = 1.f / p.count;
+        mean = make_float4(s.x * ic, s.y * ic, s.z * ic, s.w * ic);
+        istd.x = rsqrtf(fmaxf(q.x * ic - mean.x * mean.x, 0.f) + p.eps);
+        istd.y = rsqrtf(fmaxf(q.y * ic - mean.y * mean.y, 0.f) + p.eps);
+        istd.z = rsqrtf(fmaxf(q.z * ic - mean.z * mean.z, 0.f) + p.eps);
+        istd.w = rsqrtf(fmaxf(q.w * ic - mean.w * mean.w, 0.f) + p.eps);
+    }
+    float4 acc_s1 = z4, acc_s2 = z4, adw[8], adb[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { adw[o] = z4; adb[o] = z4; }
+
+    for (int p0 = px_begin; p0 < px_end; p0 += NB_PX) {
+        __syncthreads();   // previous sub-tile's mn / partl consumed
+        if (tid < NB_PX) {
+            const int px = p0 + tid;
+            float m[8];
+            float S = 1e-6f;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                m[o] = (o < O && px < px_end) ? p.mask[((size_t)b * O + o) * p.HW + px] : 0.f;
+                S += m[o];
+            }
+            const float inv = 1.f / S;
+            sinv[tid] = inv;
+            mn4[2 * tid] = make_float4(m[0] * inv, m[1] * inv, m[2] * inv, m[3] * inv);
+            mn4[2 * tid + 1] = make_float4(m[4] * inv, m[5] * inv, m[6] * inv, m[7] * inv);
+        }
+        float4 xv[NPI], dv[NPI];   // (the loads do not depend on the mask: issued before the barrier)
+#pragma unroll
+        for (int pi = 0; pi < NPI; ++pi) {
+            const int px = p0 + prow + PR * pi;
+            xv[pi] = z4; dv[pi] = z4;
+            if (con && px < px_end) {
+                const size_t off = ((size_t)b * p.HW + px) * p.C + c;
+                xv[pi] = *reinterpret_cast<const float4*>(p.x + off);
+                dv[pi] = *reinterpret_cast<const float4*>(p.dy + off);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pi = 0; pi < NPI; ++pi) {
+            const int pl = prow + PR * pi, px = p0 + pl;
+            const bool on = con && px < px_end;
+            const float4 ma = mn4[2 * pl], mb = mn4[2 * pl + 1];
+            const float m[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+            float4 gg = z4, gxv = z4;
+            if (on) {
+                const float4 xh = make_float4((xv[pi].x - mean.x) * istd.x, (xv[pi].y - mean.y) * istd.y,
+                                              (xv[pi].z - mean.z) * istd.z, (xv[pi].w - mean.w) * istd.w);
+                float4 ga = make_float4(1, 1, 1, 1), be = z4;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) { ga = f4mad(m[o], Wr[o], ga); be = f4mad(m[o], Br[o], be); }
+                const float4 d = dv[pi];
+                gg.x = (!p.relu || fmaf(ga.x, xh.x, be.x) > 0.f) ? d.x : 0.f;
+                gg.y = (!p.relu || fmaf(ga.y, xh.y, be.y) > 0.f) ? d.y : 0.f;
+                gg.z = (!p.relu || fmaf(ga.z, xh.z, be.z) > 0.f) ? d.z : 0.f;
+                gg.w = (!p.relu || fmaf(ga.w, xh.w, be.w) > 0.f) ? d.w : 0.f;
+                gxv = make_float4(gg.x * xh.x, gg.y * xh.y, gg.z * xh.z, gg.w * xh.w);
+                const float4 dxh = make_float4(gg.x * ga.x, gg.y * ga.y, gg.z * ga.z, gg.w * ga.w);
+                *reinterpret_cast<float4*>(p.out_f32 + ((size_t)b * p.HW + px) * p.C + c) = dxh;
+                acc_s1.x += dxh.x; acc_s1.y += dxh.y; acc_s1.z += dxh.z; acc_s1.w += dxh.w;
+                acc_s2.x += dxh.x * xh.x; acc_s2.y += dxh.y * xh.y; acc_s2.z += dxh.z * xh.z; acc_s2.w += dxh.w * xh.w;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) { adw[o] = f4mad(m[o], gxv, adw[o]); adb[o] = f4mad(m[o], gg, adb[o]); }
+            }
+            if (p.dmask) {   // (every lane of the row takes part in the DPP reduction; idle lanes carry zeros)
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    float part = gxv.x * Wr[o].x + gxv.y * Wr[o].y + gxv.z * Wr[o].z + gxv.w * Wr[o].w +
+                                 gg.x * Br[o].x + gg.y * Br[o].y + gg.z * Br[o].z + gg.w * Br[o].w;
+                    part = sum_cv<CV>(part);
+                    if (cv == 0) partl[o * NB_PX + pl] = part;
+                }
+            }
+        }
+        if (p.dmask) {
+            __syncthreads();
+            for (int i = tid; i < O * NB_PX; i += 256) {
+                const int o = i / NB_PX, pl = i - o * NB_PX;
+                const int px = p0 + pl;
+                if (px >= px_end) continue;
+                const float4 ma = mn4[2 * pl], mb = mn4[2 * pl + 1];
+                const float t0 = ma.x * partl[0 * NB_PX + pl] + ma.y * partl[1 * NB_PX + pl] + ma.z * partl[2 * NB_PX + pl] +
+                                 ma.w * partl[3 * NB_PX + pl] + mb.x * partl[4 * NB_PX + pl] + mb.y * partl[5 * NB_PX + pl] +
+                                 mb.z * partl[6 * NB_PX + pl] + mb.w * partl[7 * NB_PX + pl];
+                atomicAdd(p.dmask + ((size_t)b * O + o) * p.HW + px, (partl[i] - t0) * sinv[pl]);
+            }
+        }
+    }
+
+    // ---- per-object gradients: sum the PR pixel-row partials through LDS (dW, then dB), one atomic per value per workgroup
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 8; ++o) red[(prow * 8 + o) * CV + cv] = pass == 0 ? adw[o] : adb[o];
+        __syncthreads();
+        for (int i = tid; i < 8 * CV; i += 256) {
+            const int o = i / CV, lc = i - o * CV;
+            if (o >= O || 4 * lc >= cc) continue;
+            float4 a = red[o * CV + lc];
+            for (int r = 1; r < PR; ++r) {
+                const float4 t = red[(r * 8 + o) * CV + lc];
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            float* dst = (pass == 0 ? p.dwproj : p.dbproj) + (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + c0 + 4 * lc;
+            atomicAdd(dst + 0, a.x); atomicAdd(dst + 1, a.y); atomicAdd(dst + 2, a.z); atomicAdd(dst + 3, a.w);
+        }
+    }
+    // ---- per-channel sums s1, s2
+    __syncthreads();
+    red[(0 * PR + prow) * CV + cv] = acc_s1;
+    red[(1 * PR + prow) * CV + cv] = acc_s2;
+    __syncthreads();
+    for (int i = tid; i < 2 * CV; i += 256) {
+        const int k = i / CV, lc = i - k * CV;
+        if (4 * lc >= cc) continue;
+        float4 a = red[(k * PR) * CV + lc];
+        for (int r = 1; r < PR; ++r) {
+            const float4 t = red[(k * PR + r) * CV + lc];
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        const int cch = c0 + 4 * lc;
+        float* dst;
+        if (p.ws) dst = ws_replica(p.ws, (blockIdx.x / tiles_c) % L2I_WS_R, 2 * p.C) + k * p.C + cch;
+        else dst = (k == 0 ? p.s1 : p.s2) + (size_t)b * p.stat_stride + cch;
+        atomicAdd(dst + 0, a.x); atomicAdd(dst + 1, a.y); atomicAdd(dst + 2, a.z); atomicAdd(dst + 3, a.w);
+    }
+}
+
 static size_t norm_bwd_lds(const NormArgs& a) {
     const int O = a.mode == 0 ? a.O : 0;
     const size_t tile = a.mode == 0 ? (size_t)2 * NB_PX * NM_CC : (size_t)4 * 4 * 8 * 32;   // g, gx | reduction buffer (float4 x 4 x 8 x 32)
@@ -647,6 +838,22 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
         (void)hipFuncSetAttribute((const void*)norm_bwd_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         ready = true;
     }
+    static const bool no_a8 = getenv("L2I_NORM_A8") && atoi(getenv("L2I_NORM_A8")) == 0;   // tuning: the LDS version for every layer
+    if (mode == 0 && O <= 8 && !no_a8) {   // COCO layouts: the register-resident version
+        const size_t lds8 = sizeof(float) * (8 * NB_PX + NB_PX + 8 * NB_PX) + 32 * 1024 + 16;
+        if (C <= 64) {
+            const int t64 = (C + 63) / 64;
+            int ns = 2048 / (B * t64);
+            if (ns > subtiles) ns = subtiles;
+            if (ns < 1) ns = 1;
+            const int sp = ((subtiles + ns - 1) / ns) * NB_PX;
+            ns = (HW + sp - 1) / sp;
+            a.ws = (stat_stride == 0 && B * ns > 32) ? ws : nullptr;
+            hipLaunchKernelGGL(norm_bwd_a8_kernel<16>, dim3(B * ns * t64), dim3(256), lds8, (hipStream_t)stream, a, ns, sp);
+        } else {
+            hipLaunchKernelGGL(norm_bwd_a8_kernel<32>, dim3(B * nseg * tiles_c), dim3(256), lds8, (hipStream_t)stream, a, nseg, seg_pixels);
+        }
+    } else
     hipLaunchKernelGGL(norm_bwd_a_kernel, dim3(B * nseg * tiles_c), dim3(256), norm_bwd_lds(a), (hipStream_t)stream, a, nseg,
                        seg_pixels);
     if (a.ws) ws_fold(a.ws, (mode == 1 ? 4 : 2) * C, C, s1, s2, dwproj, dbproj, (hipStream_t)stream);

@@ -103,25 +103,38 @@ def cast_op(x, op_dtype, raw=True, act=False):
 
 
 class KernelTimer:
-    """Optional HIP-event timing of individual launches (bench.py's roofline leg). Events are recorded on
-    the stream the kernels are launched on (torch's current stream)."""
+    """Timing of the individual conv / weight-gradient launches of an eager iteration (bench.py's roofline leg): the
+    algorithmic work of every launch is accumulated here, the durations come from HIP events the library attaches to
+    each DISPATCH (l2i_timing: hipExtLaunchKernelGGL start / stop events = the kernel's own begin / end on its stream,
+    which is what rocprofv3's kernel trace reports)."""
+    CLASSES = {"conv_igemm": 0, "conv_wgrad": 1}
 
     def __init__(self):
-        self.records = {}
+        self.acc = {k: [0, 0.0, 0.0] for k in self.CLASSES}   # launches, work, bytes
+        _lib.call("l2i_timing", 1)
 
     def time(self, name, work, nbytes=0.0):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.setdefault(name, []).append((a, b, work, nbytes))
-        a.record()
-        return b
+        a = self.acc[name]
+        a[0] += 1
+        a[1] += work
+        a[2] += nbytes
+        return None
 
     def summary(self):
+        import ctypes
         torch.cuda.synchronize()
         out = {}
-        for name, recs in self.records.items():
-            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
-            out[name] = dict(launches=len(recs), ms=ms, work=float(sum(r[2] for r in recs)), bytes=float(sum(r[3] for r in recs)))
+        for name, cls in self.CLASSES.items():
+            ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+            _lib.call("l2i_timing_read", cls, ctypes.byref(ms), ctypes.byref(n))
+            a = self.acc[name]
+            if n.value != a[0]:
+                raise RuntimeError(f"{name}: {a[0]} launches accounted, {n.value} timed")
+            out[name] = dict(launches=a[0], ms=ms.value, work=a[1], bytes=a[2])
         return out
+
+    def close(self):
+        _lib.call("l2i_timing", 0)
 
 
 TIMER = None  # set to a KernelTimer by bench.py

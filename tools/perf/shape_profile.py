@@ -16,6 +16,9 @@ def run(path, steps=3):
     dev = torch.device("cuda:0")
     if "L2I_CONV_CFG" in os.environ:   # force one tile configuration on every halo-eligible layer (tuning)
         _lib.call("l2i_set_conv_config", int(os.environ["L2I_CONV_CFG"]))
+    if "L2I_WGRAD_BLOCKS" in os.environ:
+        for v in os.environ["L2I_WGRAD_BLOCKS"].split(","):
+            _lib.call("l2i_set_wgrad_blocks", int(v))
     torch.manual_seed(1234)
     netG = L.ResnetGenerator128_context(num_classes=184).finalize(dev, torch.bfloat16)
     netD = L.CombineDiscriminator128_app(num_classes=184).finalize(dev, torch.bfloat16)
