@@ -976,6 +976,7 @@ static int ilog2(int v) {
 
 static int g_split_target = 512;   // tuning hook: workgroups a split-K launch aims for
 static int g_force_splits = 0;     // tuning hook (l2i_set_conv_config(2000 + n)): split count of the 256-pixel-tile kernel
+static int g_generic_cfg = -1;     // tuning hook (l2i_set_conv_config(3000 + n)): tile configuration of the generic kernel only
 // Launch one instantiation; LDS rings above 64 KB need the opt-in attribute (set once per instantiation).
 template <typename T, int BM, int BN, int WM, int WN, int NS, int HK = 0>
 static int launch_cfg(ConvArgs a, hipStream_t stream) {
@@ -1111,6 +1112,7 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
 
 static int g_conv_cfg_override = -1;  // tuning hook (l2i_set_conv_config): -1 = heuristic
 extern "C" int l2i_set_conv_config(int cfg) {
+    if (cfg >= 3000) { g_generic_cfg = cfg - 3000 - 1; return L2I_OK; }   // 3000 = heuristic, 3001 + n = configuration n
     if (cfg >= 2000) { g_force_splits = cfg - 2000; return L2I_OK; }   // 2000 + n: forced split count, conv_halo3 (tuning only)
     if (cfg >= 1000) { g_split_target = cfg - 1000; return L2I_OK; }   // 1000 + n: split-K target (tuning only)
     g_conv_cfg_override = cfg;
@@ -1225,6 +1227,10 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     else if (t128 >= 192 && t128 <= 288) cfg = 2;
     else cfg = (t128 < 512 && !(t128 >= 64 && t128 < 192 && a.nks >= 16 && a.out && !a.out_op && !a.out_op_raw)) ? 1 : 0;   // small grids: 128x64 tiles (48 KB, three
                                                           // workgroups per CU) -- unless split-K applies: 128x128 + split-K
+    if (g_generic_cfg >= 0 && a.Co > 64 && !a.lin) {
+        cfg = g_generic_cfg;
+        if ((cfg == 3 || cfg == 4) && t256x128 < 128) cfg = 0;
+    }
     if (g_conv_cfg_override == 5 && a.Co <= 64) cfg = 6;
     if (g_conv_cfg_override >= 0 && a.Co > 64) {
         cfg = g_conv_cfg_override;

@@ -15,7 +15,8 @@ def run(path, steps=3):
     from layout2img_amd.synthetic import make_batch
     dev = torch.device("cuda:0")
     if "L2I_CONV_CFG" in os.environ:   # force one tile configuration on every halo-eligible layer (tuning)
-        _lib.call("l2i_set_conv_config", int(os.environ["L2I_CONV_CFG"]))
+        for v in os.environ["L2I_CONV_CFG"].split(","):
+            _lib.call("l2i_set_conv_config", int(v))
     if "L2I_WGRAD_BLOCKS" in os.environ:
         for v in os.environ["L2I_WGRAD_BLOCKS"].split(","):
             _lib.call("l2i_set_wgrad_blocks", int(v))
