@@ -216,7 +216,7 @@ def main():
             ach = s["work"] / (s["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")   # PMC passes of this same command (tools/perf/traffic2.sh)
-            if op_dtype == torch.bfloat16 and args.size == 128 and os.path.exists(tpath):
+            if op_dtype == torch.bfloat16 and args.size == 128 and args.layout == "coco" and not args.vgg and os.path.exists(tpath):
                 traffic = round(json.load(open(tpath))["conv(fwd+dgrad)"]["traffic_bytes_per_launch"])
                 traffic_src = "profiles/r02_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE; separate passes)"
             roof = dict(bound="mfma", kernel="l2i_conv2d_fwd launches (conv_halo2/3_kernel + conv_igemm_kernel), forward and data-gradient",
@@ -259,7 +259,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": ("HIP graph replay, D(real) on a side stream (last timed step eager on one stream, with HIP events)"
                                   if graphed else "eager")},
-            "roofline": roof, "hbm_kernels": hbm_kernels(), "cpu_baseline": cpu, "g_forward": g_fwd,
+            "roofline": roof, "hbm_kernels": hbm_kernels() if (args.size == 128 and args.layout == "coco" and args.dtype == "bf16") else None,
+            "cpu_baseline": cpu, "g_forward": g_fwd,
             "g_forward_images_per_sec": None if g_fwd is None else g_fwd["images_per_sec"],
         }
         print(json.dumps(out), flush=True)

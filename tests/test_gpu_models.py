@@ -85,7 +85,8 @@ def test_generator_coco_vs_reference(dt):
     chk(taps["stages"][0], fx["tap_stage_in2"], "stage2")
     chk(taps["stages"][3][:, :, ::4, ::4], fx["tap_stage_in5"], "stage5")
     chk(taps["pre_tanh"].permute(0, 3, 1, 2), fx["tap_pre_tanh"], "pre_tanh")
-    assert maxdiff(out1, fx["out_train1"]) < (1e-3 if f32 else 1e-1)
+    # bf16 operands: 6.3e-2 measured (2^-9 per operand pair, a random walk over ~25 layers)
+    assert maxdiff(out1, fx["out_train1"]) < (1e-3 if f32 else 8e-2)
     proj = torch.randn(out1.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
     g.zero_grad()
     (out1 * proj).sum().backward()
