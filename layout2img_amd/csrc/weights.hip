@@ -174,36 +174,52 @@ __device__ __forceinline__ void store8t(T* dst, const T (&v)[8]) {   // 8 alread
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
-                                                      const float* __restrict__ params, const float* __restrict__ norms,
-                                                      T* __restrict__ packed, int training) {
-    extern __shared__ __attribute__((aligned(16))) char tile_raw[];
-    T* tile = reinterpret_cast<T*>(tile_raw);   // [64][RUN + 2] in the OPERAND type: 37 KB for bf16 -> four workgroups per CU in flight
-    const int* e = table + 3 * blockIdx.x;
-    const int layer = e[0];
-    const long long* L = layers + L2I_LSTRIDE * layer;
-    const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Co_p = (int)LF(6), Ci_p = (int)LF(7);
-    const int taps = KH * KH;
-    const int TCI = taps == 1 ? 256 : 32;
-    const int RUN = TCI * taps, RUNP = RUN + 2;
+// (TAPS is a template parameter: with the tap count a run-time value every index computation of the tile loops was an
+//  emulated integer division -- the kernel ran at 35 % of the HBM rate, profiles/r02_hbm_kernels.json)
+template <typename T, int TAPS>
+__device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, const int* __restrict__ e, int layer,
+                                             const float* __restrict__ params, const float* __restrict__ norms,
+                                             T* __restrict__ packed, int training, T* tile) {
+    const int Co = (int)LF(3), Ci = (int)LF(4), Co_p = (int)LF(6), Ci_p = (int)LF(7);
+    constexpr int taps = TAPS;
+    constexpr int TCI = TAPS == 1 ? 256 : 32;
+    constexpr int RUN = TCI * TAPS, RUNP = RUN + 2;
     const int co0 = e[1] * PK_TCO, ci0 = e[2] * TCI;
     const int nco = min(PK_TCO, Co - co0), nrun = min(TCI, Ci - ci0) * taps;   // valid rows / valid floats per row (may be <= 0)
     const float inv = 1.f / layer_sigma(L, norms, layer, training);
     const float* W = params + LF(0);
-#pragma unroll 12
-    for (int idx = threadIdx.x; idx < PK_TCO * RUN; idx += 256) {
-        const int row = idx / RUN, j = idx - row * RUN;
-        float v = 0.f;
-        if (row < nco && j < nrun) v = W[((size_t)(co0 + row) * Ci + ci0) * taps + j] * inv;
-        tile[row * RUNP + j] = OpT<T>::from(v);
+    // The tile is kept TAP-major in LDS ([row][tap][ci], row pitch RUNP): the forward pack's 8 consecutive input
+    // channels of one tap are then one 16-byte LDS read instead of eight 2-byte gathers (the kernel was bound by its
+    // instruction count, not by HBM). W is read in its own order, four floats per lane where the run allows it.
+    const bool vec = ((Ci * taps) & 3) == 0 && ((ci0 * taps) & 3) == 0 && (nrun & 3) == 0;
+    if (vec) {
+        for (int idx = threadIdx.x; idx < PK_TCO * (RUN / 4); idx += 256) {
+            const int row = idx / (RUN / 4), j = 4 * (idx - row * (RUN / 4));
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nco && j < nrun) v = *reinterpret_cast<const float4*>(W + ((size_t)(co0 + row) * Ci + ci0) * taps + j);
+            const float vv[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jj = j + q, cil = jj / taps, tap = jj - cil * taps;
+                tile[row * RUNP + tap * TCI + cil] = OpT<T>::from(vv[q]);
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int idx = threadIdx.x; idx < PK_TCO * RUN; idx += 256) {
+            const int row = idx / RUN, j = idx - row * RUN;
+            float v = 0.f;
+            if (row < nco && j < nrun) v = W[((size_t)(co0 + row) * Ci + ci0) * taps + j] * inv;
+            const int cil = j / taps, tap = j - cil * taps;
+            tile[row * RUNP + tap * TCI + cil] = OpT<T>::from(v);
+        }
     }
     __syncthreads();
     // forward pack
     {
         const int Kpad = (int)LF(8);
         T* dst = packed + LF(10);
-        const int c8n = TCI / 8;
+        constexpr int c8n = TCI / 8;
         for (int u = threadIdx.x; u < PK_TCO * taps * c8n; u += 256) {
             const int c8 = u % c8n, rest = u / c8n;
             const int tap = rest % taps, row = rest / taps;
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restric
             if (co >= Co || ci >= Ci_p) continue;
             T v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = tile[row * RUNP + (8 * c8 + j) * taps + tap];
+            for (int j = 0; j < 8; ++j) v[j] = tile[row * RUNP + tap * TCI + 8 * c8 + j];
             store8t<T>(dst + (size_t)co * Kpad + tap * Ci_p + ci, v);
         }
     }
@@ -226,10 +242,23 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restric
             if (ci >= Ci || co >= Co_p) continue;
             T v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = tile[(8 * co8 + j) * RUNP + cil * taps + tap];
+            for (int j = 0; j < 8; ++j) v[j] = tile[(8 * co8 + j) * RUNP + tap * TCI + cil];
             store8t<T>(dst + (size_t)ci * Kpad_d + (taps - 1 - tap) * Co_p + co, v);
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
+                                                      const float* __restrict__ params, const float* __restrict__ norms,
+                                                      T* __restrict__ packed, int training) {
+    extern __shared__ __attribute__((aligned(16))) char tile_raw[];
+    T* tile = reinterpret_cast<T*>(tile_raw);   // [64][RUN + 2] in the OPERAND type: 37 KB for bf16 -> four workgroups per CU in flight
+    const int* e = table + 3 * blockIdx.x;
+    const int layer = e[0];
+    const long long* L = layers + L2I_LSTRIDE * layer;
+    if ((int)LF(5) == 3) sn_pack_body<T, 9>(L, e, layer, params, norms, packed, training, tile);
+    else sn_pack_body<T, 1>(L, e, layer, params, norms, packed, training, tile);
 }
 
 // ---------------------------------------------------------------- phase 3b: sigma, normalised u / v
