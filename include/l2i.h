@@ -176,6 +176,17 @@ int l2i_gram_head_fwd(const float* x, const float* w, float* out, float* s_keep,
 int l2i_gram_head_bwd(const float* x, const float* w, const float* s_keep, const float* t_keep, const float* g, float* dx,
                       float* dw, float* ws, int R, int HW, int C, void* stream);
 
+/* Stage-mask blend of the generator (model/resnet_generator_app_v2.py:465-470): per object
+ *   out = bilinear(bmask, H) * (1 - a) + sigmoid(logits[..., y]) * nearest(boxm, H) * a,  a = sigmoid(alpha[y]).
+ * logits [B][H][H][Cp] f32 NHWC (Cp % 4 == 0); bmask, boxm [B][O][S][S] planar f32 with S = f*H, f = 1 or even;
+ * y [B][O] int64 class ids < Cp; alpha [Cp]; out [B][O][H][H]; keep [2][B][O][H][H] (sigmoid and resized bmask, for bwd).
+ * bwd: g [B][O][H][H] -> dlogits [B][H][H][Cp] and dbmask [B][O][S][S] (both fully written), dalpha [Cp] += ;
+ * gl [B][O][H][H] is scratch. */
+int l2i_stage_mask_fwd(const float* logits, const float* bmask, const float* boxm, const float* alpha, const long long* y,
+                       float* out, float* keep, int B, int O, int H, int Cp, int S, void* stream);
+int l2i_stage_mask_bwd(const float* g, const float* keep, const float* boxm, const float* alpha, const long long* y, float* gl,
+                       float* dlogits, float* dbmask, float* dalpha, int B, int O, int H, int Cp, int S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,8 @@ SIGNATURES = {
     "l2i_resize_bilinear": [_p, _p, _ll, _i, _i, _i, _i, _p],
     "l2i_gram_head_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "l2i_gram_head_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "l2i_stage_mask_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "l2i_stage_mask_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "l2i_relu_bwd": [_p, _p, _p, _p, _ll, _p],
 }
 

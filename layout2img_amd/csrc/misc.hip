@@ -301,4 +301,133 @@ extern "C" int l2i_resize_bilinear(const float* in, float* out, long long N, int
     return l2i_check_launch();
 }
 
+// ---------------------------------------------------------------- stage-mask blend of the generator
+// reference model/resnet_generator_app_v2.py:465-470, per block with a mask head:
+//   seman = sigmoid(gather(logits, y)) * nearest(bbox_mask, H);  a = sigmoid(alpha[y]);
+//   stage = bilinear(bmask, H) * (1 - a) + seman * a
+// as ONE forward and two backward launches instead of ~35 elementwise / gather / scatter_add / resize launches per
+// stage. logits [B][H][H][Cp] f32 NHWC; bmask, boxm [B][O][S][S] planar f32 (S = 64); y [B][O] int64; alpha [Cp];
+// out [B][O][H][H]. S = f * H with f = 1 or even: nearest reads (f*h, f*w); bilinear(align_corners=False) at an even
+// integer factor is the lerp (weights 1/2) of the 2 x 2 pixels at f*h + f/2 - 1 + {0,1} -- written in the order
+// resize_bilinear_kernel evaluates it so both give the same bits.
+__device__ __forceinline__ float sm_sigmoid(float v) { return 1.f / (1.f + __expf(-v)); }
+
+__global__ __launch_bounds__(256) void stage_mask_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ bmask,
+                                                             const float* __restrict__ boxm, const float* __restrict__ alpha,
+                                                             const long long* __restrict__ y, float* __restrict__ out,
+                                                             float* __restrict__ keep, int O, int H, int Cp, int S) {
+    const int bo = blockIdx.x, b = bo / O;
+    const int f = S / H, off = f / 2 - 1;
+    const int cls = (int)y[bo];
+    const float a = sm_sigmoid(alpha[cls]);
+    const float* bm = bmask + (size_t)bo * S * S;
+    const float* xm = boxm + (size_t)bo * S * S;
+    const size_t plane = (size_t)gridDim.x * H * H;
+    for (int p = blockIdx.y * 256 + threadIdx.x; p < H * H; p += gridDim.y * 256) {
+        const int h = p / H, w = p - h * H;
+        float rb;
+        if (f == 1) {
+            rb = bm[p];
+        } else {
+            const float* q = bm + (size_t)(f * h + off) * S + f * w + off;
+            const float top = q[0] * 0.5f + q[1] * 0.5f, bot = q[S] * 0.5f + q[S + 1] * 0.5f;
+            rb = top * 0.5f + bot * 0.5f;
+        }
+        const float sg = sm_sigmoid(logits[((size_t)b * H * H + p) * Cp + cls]);
+        const float m = xm[(size_t)(f * h) * S + f * w];
+        out[(size_t)bo * H * H + p] = rb * (1.f - a) + (sg * m) * a;
+        keep[(size_t)bo * H * H + p] = sg;
+        keep[plane + (size_t)bo * H * H + p] = rb;
+    }
+}
+
+// backward, planar part: gl[b,o,p] = g a m s(1-s) (the logit gradient before the per-class scatter),
+// dbmask (every pixel of the S x S plane written), dalpha[y] += a(1-a) sum_p g (s m - rb).
+__global__ __launch_bounds__(256) void stage_mask_bwd_planar_kernel(const float* __restrict__ g, const float* __restrict__ keep,
+                                                                    const float* __restrict__ boxm, const float* __restrict__ alpha,
+                                                                    const long long* __restrict__ y, float* __restrict__ gl,
+                                                                    float* __restrict__ dbmask, float* __restrict__ dalpha,
+                                                                    int O, int H, int S) {
+    __shared__ float red[8];
+    const int bo = blockIdx.x;
+    const int f = S / H, off = f / 2 - 1;
+    const int cls = (int)y[bo];
+    const float a = sm_sigmoid(alpha[cls]);
+    const float* xm = boxm + (size_t)bo * S * S;
+    const float* gp = g + (size_t)bo * H * H;
+    const size_t plane = (size_t)gridDim.x * H * H;
+    float acc = 0.f;
+    for (int p = threadIdx.x; p < H * H; p += 256) {
+        const int h = p / H, w = p - h * H;
+        const float gv = gp[p], sg = keep[(size_t)bo * H * H + p], rb = keep[plane + (size_t)bo * H * H + p];
+        const float m = xm[(size_t)(f * h) * S + f * w];
+        gl[(size_t)bo * H * H + p] = gv * a * m * sg * (1.f - sg);
+        acc += gv * (sg * m - rb);
+    }
+    float* db = dbmask + (size_t)bo * S * S;
+    for (int q = threadIdx.x; q < S * S; q += 256) {
+        const int Y = q / S, X = q - Y * S;
+        float v;
+        if (f == 1) {
+            v = gp[q] * (1.f - a);
+        } else {
+            const int ry = Y % f - off, rx = X % f - off;
+            v = (ry == 0 || ry == 1) && (rx == 0 || rx == 1) ? 0.25f * (1.f - a) * gp[(Y / f) * H + X / f] : 0.f;
+        }
+        db[q] = v;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(dalpha + cls, acc * a * (1.f - a));
+}
+
+// backward, logits: dlogits[b,p,c] = sum_o [y[b,o] == c] gl[b,o,p] -- every element written (no zero fill + scatter_add).
+__global__ __launch_bounds__(256) void stage_mask_bwd_logits_kernel(const float* __restrict__ gl, const long long* __restrict__ y,
+                                                                    float* __restrict__ dlogits, int O, int HH, int Cp, long long total4) {
+    const int c4n = Cp / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c = 4 * (int)(i % c4n);
+        const long long bp = i / c4n;
+        const int b = (int)(bp / HH), p = (int)(bp - (long long)b * HH);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int o = 0; o < O; ++o) {
+            const int d = (int)y[b * O + o] - c;
+            if (d >= 0 && d < 4) {
+                const float t = gl[((size_t)b * O + o) * HH + p];
+                v.x += d == 0 ? t : 0.f; v.y += d == 1 ? t : 0.f; v.z += d == 2 ? t : 0.f; v.w += d == 3 ? t : 0.f;
+            }
+        }
+        *reinterpret_cast<float4*>(dlogits + 4 * i) = v;
+    }
+}
+
+static bool stage_mask_geom_ok(int B, int O, int H, int Cp, int S) {
+    if (B <= 0 || O <= 0 || H <= 0 || S <= 0 || Cp <= 0 || Cp % 4 || S % H) return false;
+    const int f = S / H;
+    return f == 1 || f % 2 == 0;
+}
+
+extern "C" int l2i_stage_mask_fwd(const float* logits, const float* bmask, const float* boxm, const float* alpha,
+                                  const long long* y, float* out, float* keep, int B, int O, int H, int Cp, int S, void* stream) {
+    if (!logits || !bmask || !boxm || !alpha || !y || !out || !keep || !stage_mask_geom_ok(B, O, H, Cp, S)) return L2I_ERR_ARG;
+    int parts = (H * H + 1023) / 1024;
+    hipLaunchKernelGGL(stage_mask_fwd_kernel, dim3(B * O, parts), dim3(256), 0, (hipStream_t)stream, logits, bmask, boxm, alpha, y,
+                       out, keep, O, H, Cp, S);
+    return l2i_check_launch();
+}
+
+extern "C" int l2i_stage_mask_bwd(const float* g, const float* keep, const float* boxm, const float* alpha, const long long* y,
+                                  float* gl, float* dlogits, float* dbmask, float* dalpha, int B, int O, int H, int Cp, int S,
+                                  void* stream) {
+    if (!g || !keep || !boxm || !alpha || !y || !gl || !dlogits || !dbmask || !dalpha || !stage_mask_geom_ok(B, O, H, Cp, S))
+        return L2I_ERR_ARG;
+    hipLaunchKernelGGL(stage_mask_bwd_planar_kernel, dim3(B * O), dim3(256), 0, (hipStream_t)stream, g, keep, boxm, alpha, y, gl,
+                       dbmask, dalpha, O, H, S);
+    const long long total4 = (long long)B * H * H * (Cp / 4);
+    long long nblk = (total4 + 255) / 256;
+    if (nblk > 16384) nblk = 16384;
+    hipLaunchKernelGGL(stage_mask_bwd_logits_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, gl, y, dlogits, O,
+                       H * H, Cp, total4);
+    return l2i_check_launch();
+}
+
 extern "C" int l2i_version(void) { return 1; }

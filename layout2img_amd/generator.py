@@ -398,8 +398,11 @@ class ResnetGenerator128_context(_GeneratorBase):
 
     def _stage_mask(self, stage_logits, bmask, bbox_mask_, alpha, y):
         """reference :465-470: blend the regressed mask with the predicted semantic mask."""
-        B, H, W, _ = stage_logits.shape
+        B, H, W, Cp = stage_logits.shape
         b, o = y.shape
+        S = bmask.shape[-1]
+        if H == W and Cp % 4 == 0 and alpha.numel() == Cp and S % H == 0 and (S == H or (S // H) % 2 == 0):
+            return ops.stage_mask(stage_logits, bmask, bbox_mask_, alpha, y)   # the fused form of the lines below
         idx = y.view(b, 1, 1, o).expand(b, H, W, o)
         seman = torch.sigmoid(torch.gather(stage_logits, 3, idx)).permute(0, 3, 1, 2)
         seman = seman * F.interpolate(bbox_mask_, size=(H, W), mode="nearest")

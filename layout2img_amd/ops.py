@@ -787,6 +787,45 @@ def gram_head(x, w):
     return GramHeadFn.apply(x, w)
 
 
+class StageMaskFn(Function):
+    """The generator's stage-mask blend (reference model/resnet_generator_app_v2.py:465-470) as one launch forward and two
+    backward (csrc/misc.hip): out = bilinear(bmask, H) * (1 - a) + sigmoid(logits[..., y]) * nearest(boxm, H) * a with
+    a = sigmoid(alpha[y])."""
+
+    @staticmethod
+    def forward(ctx, logits, bmask, boxm, alpha, y):
+        for t in (logits, bmask, boxm, alpha):
+            _chk(t, torch.float32)
+        B, H, W, Cp = logits.shape
+        b, o, S, _ = bmask.shape
+        assert H == W and b == B and boxm.shape == bmask.shape and y.dtype == torch.int64 and alpha.numel() == Cp
+        out = torch.empty((B, o, H, H), dtype=torch.float32, device=logits.device)
+        keep = torch.empty((2, B, o, H, H), dtype=torch.float32, device=logits.device)
+        _lib.call("l2i_stage_mask_fwd", logits.data_ptr(), bmask.data_ptr(), boxm.data_ptr(), alpha.data_ptr(), y.data_ptr(),
+                  out.data_ptr(), keep.data_ptr(), B, o, H, Cp, S, _stream())
+        ctx.save_for_backward(keep, boxm, alpha, y)
+        ctx.geom = (B, o, H, Cp, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        keep, boxm, alpha, y = ctx.saved_tensors
+        B, o, H, Cp, S = ctx.geom
+        g = g.contiguous()
+        dev = g.device
+        gl = torch.empty((B, o, H, H), dtype=torch.float32, device=dev)
+        dlogits = torch.empty((B, H, H, Cp), dtype=torch.float32, device=dev)
+        dbmask = torch.empty((B, o, S, S), dtype=torch.float32, device=dev)
+        dalpha = _zeros(tuple(alpha.shape), dev)
+        _lib.call("l2i_stage_mask_bwd", g.data_ptr(), keep.data_ptr(), boxm.data_ptr(), alpha.data_ptr(), y.data_ptr(),
+                  gl.data_ptr(), dlogits.data_ptr(), dbmask.data_ptr(), dalpha.data_ptr(), B, o, H, Cp, S, _stream())
+        return dlogits, dbmask, None, dalpha, None
+
+
+def stage_mask(logits, bmask, boxm, alpha, y):
+    return StageMaskFn.apply(logits.contiguous(), bmask.contiguous(), boxm.contiguous(), alpha.contiguous(), y.contiguous())
+
+
 class ResizeBilinearFn(Function):
     """F.interpolate(x, size=(H, W), mode="bilinear") for planar (b, o, h, w) f32 maps; the (cheap) backward is
     torch's own adjoint kernel."""

@@ -561,6 +561,42 @@ def test_gram_head_matches_the_explicit_gram_matrices():
     assert float((wg.grad.cpu() - wr.grad).abs().max()) < 1e-5 * float(wr.grad.abs().max())
 
 
+@pytest.mark.parametrize("case", [(3, 8, 8), (2, 8, 16), (2, 5, 32), (1, 8, 64), (2, 31, 16)])
+def test_stage_mask_matches_the_composed_torch_ops(case):
+    """ops.stage_mask == reference model/resnet_generator_app_v2.py:465-470 written with torch ops on the CPU (gather,
+    sigmoid, nearest / bilinear F.interpolate, blend), forward and the three gradients; repeated classes inside one image
+    (their logit gradients add up) and label-0 padding objects included."""
+    from layout2img_amd import ops
+    B, O, H = case
+    g = torch.Generator().manual_seed(31 + H + O)
+    Cp, S = 184, 64
+    logits = torch.randn(B, H, H, Cp, generator=g)
+    bmask = torch.rand(B, O, S, S, generator=g)
+    boxm = (torch.rand(B, O, S, S, generator=g) > 0.4).float()
+    alpha = torch.randn(1, Cp, 1, generator=g)
+    y = torch.randint(0, Cp, (B, O), generator=g)
+    y[:, -1] = 0
+    if O > 2:
+        y[:, 1] = y[:, 0]
+    dy = torch.randn(B, O, H, H, generator=g)
+
+    lr, br, ar = (t.clone().requires_grad_(True) for t in (logits, bmask, alpha))
+    idx = y.view(B, 1, 1, O).expand(B, H, H, O)
+    seman = torch.sigmoid(torch.gather(lr, 3, idx)).permute(0, 3, 1, 2) * F.interpolate(boxm, size=(H, H), mode="nearest")
+    a = torch.gather(torch.sigmoid(ar).expand(B, -1, -1), dim=1, index=y.view(B, O, 1)).unsqueeze(-1)
+    rb = br if H == S else F.interpolate(br, size=(H, H), mode="bilinear")
+    ref = rb * (1 - a) + seman * a
+    ref.backward(dy)
+
+    dev = _dev()
+    lg, bg, ag = (t.to(dev).requires_grad_(True) for t in (logits, bmask, alpha))
+    out = ops.stage_mask(lg, bg, boxm.to(dev), ag, y.to(dev))
+    out.backward(dy.to(dev))
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 2e-6
+    for got, want in ((lg.grad, lr.grad), (bg.grad, br.grad), (ag.grad, ar.grad)):
+        assert float((got.cpu() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
 @pytest.mark.parametrize("n_live", [0, 3, 9, 20])
 @pytest.mark.parametrize("case", [(20, 8, 8, 64, 136, 3, False, False), (20, 8, 8, 128, 64, 3, False, True),
                                   (20, 8, 8, 72, 128, 1, False, True), (20, 8, 8, 16, 40, 3, False, False)])
