@@ -187,6 +187,24 @@ int l2i_stage_mask_fwd(const float* logits, const float* bmask, const float* box
 int l2i_stage_mask_bwd(const float* g, const float* keep, const float* boxm, const float* alpha, const long long* y, float* gl,
                        float* dlogits, float* dbmask, float* dalpha, int B, int O, int H, int Cp, int S, void* stream);
 
+/* Projection heads of the discriminator (model/rcnn_discriminator_app.py:127-129 image head, :160-166 object head):
+ *   f[r,c] = scale * sum_p relu(x[r,p,c]);  out[r] = sum_c f[r,c] (wl[c] + emb[y[r]][c]) + bias[0]
+ * x [R][HW][C] f32 pre-ReLU; wl [C] and emb rows (emb_stride elements apart) of `dtype` (the pass's packed operands);
+ * emb / y / bias may be NULL. feat [R][C] is kept for bwd. bwd: dx [R][HW][C] written; dwl [C] +=, demb[y[r]] += (f32 rows
+ * demb_stride apart), dbias[0] += -- each may be NULL. */
+int l2i_proj_head_fwd(const float* x, const void* wl, const void* emb, int emb_stride, const long long* y, const float* bias,
+                      float scale, float* out, float* feat, int R, int HW, int C, int dtype, void* stream);
+int l2i_proj_head_bwd(const float* x, const void* wl, const void* emb, int emb_stride, const long long* y, const float* g,
+                      const float* feat, float scale, float* dx, float* dwl, float* demb, int demb_stride, float* dbias, int R,
+                      int HW, int C, int dtype, void* stream);
+
+/* Class-embedding term of the appearance head (model/rcnn_discriminator_app.py:154-157):
+ * out[r] = sum_c emb[y[r]][c] w2[c] + bias[0]; bwd: demb[y[r]][c] += g[r] w2[c], dw2[c] += sum_r g[r] emb[y[r]][c], dbias += sum g. */
+int l2i_emb_dot_fwd(const void* emb, int emb_stride, const long long* y, const void* w2, const float* bias, float* out, int R,
+                    int C, int dtype, void* stream);
+int l2i_emb_dot_bwd(const void* emb, int emb_stride, const long long* y, const void* w2, const float* g, float* demb,
+                    int demb_stride, float* dw2, float* dbias, int R, int C, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

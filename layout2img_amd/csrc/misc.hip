@@ -430,4 +430,180 @@ extern "C" int l2i_stage_mask_bwd(const float* g, const float* keep, const float
     return l2i_check_launch();
 }
 
+// ---------------------------------------------------------------- projection heads of the discriminator
+// reference model/rcnn_discriminator_app.py:127-129 (image head) and :160-166 (object head):
+//   f[r,c] = scale * sum_p relu(x[r,p,c]);  out[r] = sum_c f[r,c] (wl[c] + E[y[r],c]) + bias      (E, y optional)
+// one launch each way instead of relu / sum / linear / index_select / mul / sum / add and their ~20 backward launches.
+// wl and E are read straight from the pass's packed operand copies (T = bf16 or f32; E rows emb_stride apart) and the
+// weight gradients are added straight into the pass's f32 dW accumulators (demb rows demb_stride apart).
+template <typename T>
+__global__ __launch_bounds__(256) void proj_head_fwd_kernel(const float* __restrict__ x, const T* __restrict__ wl,
+                                                            const T* __restrict__ emb, int emb_stride, const long long* __restrict__ y,
+                                                            const float* __restrict__ bias, float scale, float* __restrict__ out,
+                                                            float* __restrict__ feat, int HW, int C) {
+    __shared__ float red[8];
+    const int r = blockIdx.x;
+    const T* e = emb ? emb + (size_t)y[r] * emb_stride : nullptr;
+    float acc = 0.f;
+    for (int c = 4 * threadIdx.x; c < C; c += 1024) {
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* col = x + (size_t)r * HW * C + c;
+        for (int p = 0; p < HW; ++p) {
+            const float4 v = *reinterpret_cast<const float4*>(col + (size_t)p * C);
+            f.x += fmaxf(v.x, 0.f); f.y += fmaxf(v.y, 0.f); f.z += fmaxf(v.z, 0.f); f.w += fmaxf(v.w, 0.f);
+        }
+        f.x *= scale; f.y *= scale; f.z *= scale; f.w *= scale;
+        *reinterpret_cast<float4*>(feat + (size_t)r * C + c) = f;
+        float w0 = OpT<T>::to(wl[c]), w1 = OpT<T>::to(wl[c + 1]), w2 = OpT<T>::to(wl[c + 2]), w3 = OpT<T>::to(wl[c + 3]);
+        if (e) { w0 += OpT<T>::to(e[c]); w1 += OpT<T>::to(e[c + 1]); w2 += OpT<T>::to(e[c + 2]); w3 += OpT<T>::to(e[c + 3]); }
+        acc += f.x * w0 + f.y * w1 + f.z * w2 + f.w * w3;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) out[r] = acc + (bias ? bias[0] : 0.f);
+}
+
+// blocks [0, R): dx of row r and dE[y[r]] += g[r] f[r];  blocks [R, R + ceil(C/256)): dwl[c] += sum_r g[r] f[r,c], and the
+// first of them dbias += sum_r g[r]. (A transposed pass over the saved f instead of R-way atomics per channel.)
+template <typename T>
+__global__ __launch_bounds__(256) void proj_head_bwd_kernel(const float* __restrict__ x, const T* __restrict__ wl,
+                                                            const T* __restrict__ emb, int emb_stride, const long long* __restrict__ y,
+                                                            const float* __restrict__ g, const float* __restrict__ feat, float scale,
+                                                            float* __restrict__ dx, float* __restrict__ dwl, float* __restrict__ demb,
+                                                            int demb_stride, float* __restrict__ dbias, int R, int HW, int C) {
+    __shared__ float red[8];
+    if ((int)blockIdx.x >= R) {
+        const int c = ((int)blockIdx.x - R) * 256 + threadIdx.x;
+        if (dwl && c < C) {
+            float t = 0.f;
+            for (int r = 0; r < R; ++r) t = fmaf(g[r], feat[(size_t)r * C + c], t);
+            atomicAdd(dwl + c, t);
+        }
+        if ((int)blockIdx.x == R && dbias) {
+            float t = 0.f;
+            for (int r = threadIdx.x; r < R; r += 256) t += g[r];
+            t = block_sum(t, red);
+            if (threadIdx.x == 0) atomicAdd(dbias, t);
+        }
+        return;
+    }
+    const int r = blockIdx.x;
+    const float gr = g[r], gs = gr * scale;
+    const long long cls = emb ? y[r] : 0;
+    const T* e = emb ? emb + (size_t)cls * emb_stride : nullptr;
+    for (int c = 4 * threadIdx.x; c < C; c += 1024) {
+        float w0 = OpT<T>::to(wl[c]), w1 = OpT<T>::to(wl[c + 1]), w2 = OpT<T>::to(wl[c + 2]), w3 = OpT<T>::to(wl[c + 3]);
+        if (e) { w0 += OpT<T>::to(e[c]); w1 += OpT<T>::to(e[c + 1]); w2 += OpT<T>::to(e[c + 2]); w3 += OpT<T>::to(e[c + 3]); }
+        w0 *= gs; w1 *= gs; w2 *= gs; w3 *= gs;
+        const size_t base = (size_t)r * HW * C + c;
+        for (int p = 0; p < HW; ++p) {
+            const float4 v = *reinterpret_cast<const float4*>(x + base + (size_t)p * C);
+            float4 d;
+            d.x = v.x > 0.f ? w0 : 0.f; d.y = v.y > 0.f ? w1 : 0.f; d.z = v.z > 0.f ? w2 : 0.f; d.w = v.w > 0.f ? w3 : 0.f;
+            *reinterpret_cast<float4*>(dx + base + (size_t)p * C) = d;
+        }
+        if (demb && gr != 0.f) {
+            const float4 f = *reinterpret_cast<const float4*>(feat + (size_t)r * C + c);
+            float* d = demb + (size_t)cls * demb_stride + c;
+            atomicAdd(d, gr * f.x); atomicAdd(d + 1, gr * f.y); atomicAdd(d + 2, gr * f.z); atomicAdd(d + 3, gr * f.w);
+        }
+    }
+}
+
+extern "C" int l2i_proj_head_fwd(const float* x, const void* wl, const void* emb, int emb_stride, const long long* y,
+                                 const float* bias, float scale, float* out, float* feat, int R, int HW, int C, int dtype,
+                                 void* stream) {
+    if (!x || !wl || !out || !feat || (emb && !y) || C % 4 || R < 0 || HW <= 0) return L2I_ERR_ARG;
+    if (R == 0) return L2I_OK;
+    if (dtype == 1)
+        hipLaunchKernelGGL(proj_head_fwd_kernel<bf16_t>, dim3(R), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)wl,
+                           (const bf16_t*)emb, emb_stride, y, bias, scale, out, feat, HW, C);
+    else
+        hipLaunchKernelGGL(proj_head_fwd_kernel<float>, dim3(R), dim3(256), 0, (hipStream_t)stream, x, (const float*)wl,
+                           (const float*)emb, emb_stride, y, bias, scale, out, feat, HW, C);
+    return l2i_check_launch();
+}
+
+extern "C" int l2i_proj_head_bwd(const float* x, const void* wl, const void* emb, int emb_stride, const long long* y,
+                                 const float* g, const float* feat, float scale, float* dx, float* dwl, float* demb,
+                                 int demb_stride, float* dbias, int R, int HW, int C, int dtype, void* stream) {
+    if (!x || !wl || !g || !feat || !dx || (emb && !y) || (demb && !emb) || C % 4 || R < 0 || HW <= 0) return L2I_ERR_ARG;
+    if (R == 0) return L2I_OK;
+    const int extra = (dwl || dbias) ? (C + 255) / 256 : 0;
+    if (dtype == 1)
+        hipLaunchKernelGGL(proj_head_bwd_kernel<bf16_t>, dim3(R + extra), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)wl,
+                           (const bf16_t*)emb, emb_stride, y, g, feat, scale, dx, dwl, demb, demb_stride, dbias, R, HW, C);
+    else
+        hipLaunchKernelGGL(proj_head_bwd_kernel<float>, dim3(R + extra), dim3(256), 0, (hipStream_t)stream, x, (const float*)wl,
+                           (const float*)emb, emb_stride, y, g, feat, scale, dx, dwl, demb, demb_stride, dbias, R, HW, C);
+    return l2i_check_launch();
+}
+
+// The class-embedding term of the appearance head (reference model/rcnn_discriminator_app.py:154-157):
+//   out[r] = sum_c E[y[r],c] w2[c] + bias;  bwd: dE[y[r],c] += g[r] w2[c], dw2[c] += sum_r g[r] E[y[r],c], dbias += sum_r g[r].
+template <typename T>
+__global__ __launch_bounds__(256) void emb_dot_fwd_kernel(const T* __restrict__ emb, int emb_stride, const long long* __restrict__ y,
+                                                          const T* __restrict__ w2, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int R, int C) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const T* e = emb + (size_t)y[r] * emb_stride;
+    float t = 0.f;
+    for (int c = lane; c < C; c += 64) t = fmaf(OpT<T>::to(e[c]), OpT<T>::to(w2[c]), t);
+    t = wave_sum(t);
+    if (lane == 0) out[r] = t + (bias ? bias[0] : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void emb_dot_bwd_kernel(const T* __restrict__ emb, int emb_stride, const long long* __restrict__ y,
+                                                          const T* __restrict__ w2, const float* __restrict__ g,
+                                                          float* __restrict__ demb, int demb_stride, float* __restrict__ dw2,
+                                                          float* __restrict__ dbias, int R, int C) {
+    __shared__ float red[8];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float t = 0.f;
+    if (c < C) {
+        const float w = OpT<T>::to(w2[c]);
+        for (int r = 0; r < R; ++r) {
+            const float gr = g[r];
+            const long long cls = y[r];
+            t = fmaf(gr, OpT<T>::to(emb[(size_t)cls * emb_stride + c]), t);
+            if (gr != 0.f) atomicAdd(demb + (size_t)cls * demb_stride + c, gr * w);
+        }
+        atomicAdd(dw2 + c, t);
+    }
+    if (blockIdx.x == 0 && dbias) {
+        float s = 0.f;
+        for (int r = threadIdx.x; r < R; r += 256) s += g[r];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) atomicAdd(dbias, s);
+    }
+}
+
+extern "C" int l2i_emb_dot_fwd(const void* emb, int emb_stride, const long long* y, const void* w2, const float* bias, float* out,
+                               int R, int C, int dtype, void* stream) {
+    if (!emb || !y || !w2 || !out || R < 0 || C <= 0) return L2I_ERR_ARG;
+    if (R == 0) return L2I_OK;
+    if (dtype == 1)
+        hipLaunchKernelGGL(emb_dot_fwd_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)emb,
+                           emb_stride, y, (const bf16_t*)w2, bias, out, R, C);
+    else
+        hipLaunchKernelGGL(emb_dot_fwd_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)emb,
+                           emb_stride, y, (const float*)w2, bias, out, R, C);
+    return l2i_check_launch();
+}
+
+extern "C" int l2i_emb_dot_bwd(const void* emb, int emb_stride, const long long* y, const void* w2, const float* g, float* demb,
+                               int demb_stride, float* dw2, float* dbias, int R, int C, int dtype, void* stream) {
+    if (!emb || !y || !w2 || !g || !demb || !dw2 || R < 0 || C <= 0) return L2I_ERR_ARG;
+    if (R == 0) return L2I_OK;
+    if (dtype == 1)
+        hipLaunchKernelGGL(emb_dot_bwd_kernel<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)emb,
+                           emb_stride, y, (const bf16_t*)w2, g, demb, demb_stride, dw2, dbias, R, C);
+    else
+        hipLaunchKernelGGL(emb_dot_bwd_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)emb,
+                           emb_stride, y, (const float*)w2, g, demb, demb_stride, dw2, dbias, R, C);
+    return l2i_check_launch();
+}
+
 extern "C" int l2i_version(void) { return 1; }

@@ -93,8 +93,7 @@ class ResnetDiscriminator128_app(nn.Module):
         x = self.block4(x2, pc, emit=both)
         x = self.block5(x, pc, emit=("relu",))
         x = self.block6(x, pc)
-        feat = F.relu(x).sum(dim=(1, 2))
-        out_im = F.linear(feat, arena_weight(self.l7, pc), self.l7.bias)
+        out_im = ops.proj_head(x, self.l7, pc)                               # l7(sum_hw relu(x))
 
         feat_s = self.block_obj4(self.block_obj3(x1, pc, emit=both), pc, use=0)   # reference order :136-141
         feat_l = self.block_obj4(x2, pc, use=1)
@@ -104,16 +103,14 @@ class ResnetDiscriminator128_app(nn.Module):
         a = self.app_conv(obj, pc, nimg=nimg)                             # (R, 8, 8, C) pre-ReLU
         s2 = a.shape[3]
         wa = arena_weight(self.app, pc)                                   # (1, 2C)
-        emb_app = arena_weight(self.l_y_app, pc).index_select(0, y)                     # (R, C)
         # w1 . sum_rows(Gram) / C with Gram = F F^T / C, F = relu(a): only this contraction of the (R,C,C) Gram
-        # matrices reaches the output, so they are never formed (ops.GramHeadFn / csrc/misc.hip)
+        # matrices reaches the output, so they are never formed (ops.GramHeadFn / csrc/misc.hip); the class-embedding
+        # half of the head, l_y_app(y) . w2 + bias, is ops.emb_dot
         gram_term = ops.gram_head(a, wa[0, :s2].contiguous())
-        out_app = gram_term + emb_app @ wa[0, s2:].unsqueeze(1) + self.app.bias
+        out_app = gram_term + ops.emb_dot(self.l_y_app, y, self.app, s2, pc)
 
-        # projection head (reference :160-166)
-        f = F.relu(self.block_obj5(obj, pc, nimg=nimg)).sum(dim=(1, 2))   # (R, 16ch)
-        out_obj = F.linear(f, arena_weight(self.l_obj, pc), self.l_obj.bias)
-        out_obj = out_obj + torch.sum(arena_weight(self.l_y, pc).index_select(0, y) * f, dim=1, keepdim=True)
+        # projection head (reference :160-166): l_obj(f) + sum(l_y(y) * f), f = sum_hw relu(block_obj5(obj))
+        out_obj = ops.proj_head(self.block_obj5(obj, pc, nimg=nimg), self.l_obj, pc, emb=self.l_y, y=y)
         return out_im, out_obj, out_app
 
 
@@ -215,11 +212,9 @@ class ResnetDiscriminator64(nn.Module):
         x1 = self.block3(x, pc, emit=both)
         x = self.block4(x1, pc, emit=both)
         x = self.block5(x, pc)
-        out_im = F.linear(F.relu(x).mean(dim=(1, 2)), arena_weight(self.l_im, pc), self.l_im.bias)
+        out_im = ops.proj_head(x, self.l_im, pc, scale=1.0 / (x.shape[1] * x.shape[2]))    # MEAN pooling (:117)
         obj = ops.roi_align(x1, None, rois, valid, 8, 1.0 / 2.0, 1.0, 1e30, 0)
-        f = F.relu(self.block_obj4(obj, pc, nimg=nimg)).sum(dim=(1, 2))
-        out_obj = F.linear(f, arena_weight(self.l_obj, pc), self.l_obj.bias)
-        out_obj = out_obj + torch.sum(arena_weight(self.l_y, pc).index_select(0, y) * f, dim=1, keepdim=True)
+        out_obj = ops.proj_head(self.block_obj4(obj, pc, nimg=nimg), self.l_obj, pc, emb=self.l_y, y=y)
         return out_im, out_obj
 
 

@@ -826,6 +826,84 @@ def stage_mask(logits, bmask, boxm, alpha, y):
     return StageMaskFn.apply(logits.contiguous(), bmask.contiguous(), boxm.contiguous(), alpha.contiguous(), y.contiguous())
 
 
+class ProjHeadFn(Function):
+    """Projection head of the discriminator in one launch each way (reference model/rcnn_discriminator_app.py:127-129,
+    160-166): out[r] = sum_c f[r,c] (wl[c] + E[y[r],c]) + bias, f = scale * sum_hw relu(x). The normalised weights are
+    read from the pass's packed operands and their gradients are added straight to the pass's dW accumulators."""
+
+    @staticmethod
+    def forward(ctx, x, bias, y, hl, he, pc, scale):
+        _chk(x, torch.float32)
+        R, H, W, C = x.shape
+        assert hl.kh == 1 and hl.ci == C and (he is None or he.ci == C)
+        wl = pc.fwd_pack(hl)
+        emb = pc.fwd_pack(he) if he is not None else None
+        out = torch.empty((R, 1), dtype=torch.float32, device=x.device)
+        feat = torch.empty((R, C), dtype=torch.float32, device=x.device)
+        _lib.call("l2i_proj_head_fwd", x.data_ptr(), wl.data_ptr(), _p(emb), he.kpad if he is not None else 0, _p(y), _p(bias),
+                  float(scale), out.data_ptr(), feat.data_ptr(), R, H * W, C, _code(wl.dtype), _stream())
+        ctx.save_for_backward(x, feat, y, bias)
+        ctx.meta = (hl, he, pc, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, feat, y, bias = ctx.saved_tensors
+        hl, he, pc, scale = ctx.meta
+        R, H, W, C = x.shape
+        g = g.contiguous()
+        wl = pc.fwd_pack(hl)
+        emb = pc.fwd_pack(he) if he is not None else None
+        dx = torch.empty_like(x)
+        wg = pc.need_wgrad
+        dbias = _zeros((1,), x.device) if (wg and bias is not None) else None
+        dwl = pc.dw_slice(hl) if wg else None
+        demb = pc.dw_slice(he) if (wg and he is not None) else None
+        _lib.call("l2i_proj_head_bwd", x.data_ptr(), wl.data_ptr(), _p(emb), he.kpad if he is not None else 0, _p(y), g.data_ptr(),
+                  feat.data_ptr(), scale, dx.data_ptr(), _p(dwl), _p(demb), he.kp if he is not None else 0, _p(dbias),
+                  R, H * W, C, _code(wl.dtype), _stream())
+        return dx, dbias, None, None, None, None, None
+
+
+def proj_head(x, linear, pc, emb=None, y=None, scale=1.0):
+    """x (R,H,W,C) pre-ReLU block output; linear: GemmWeight Linear(C -> 1) (+ bias); emb: GemmWeight embedding (K, C), y (R,)."""
+    return ProjHeadFn.apply(x.contiguous(), linear.bias, y, linear, emb, pc, scale)
+
+
+class EmbDotFn(Function):
+    """out[r] = E[y[r]] . w2 + bias: the class-embedding term of the appearance head (reference
+    model/rcnn_discriminator_app.py:154-157), w2 = columns [off, off + C) of the head's Linear(2C -> 1) weight."""
+
+    @staticmethod
+    def forward(ctx, bias, y, he, hl, off, pc):
+        emb, wl = pc.fwd_pack(he), pc.fwd_pack(hl)
+        R, C = y.numel(), he.ci
+        out = torch.empty((R, 1), dtype=torch.float32, device=y.device)
+        _lib.call("l2i_emb_dot_fwd", emb.data_ptr(), he.kpad, y.data_ptr(), wl.data_ptr() + off * wl.element_size(), _p(bias),
+                  out.data_ptr(), R, C, _code(wl.dtype), _stream())
+        ctx.save_for_backward(y, bias)
+        ctx.meta = (he, hl, off, pc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, bias = ctx.saved_tensors
+        he, hl, off, pc = ctx.meta
+        if not pc.need_wgrad:
+            return None, None, None, None, None, None
+        g = g.contiguous()
+        emb, wl = pc.fwd_pack(he), pc.fwd_pack(hl)
+        dbias = _zeros((1,), g.device) if bias is not None else None
+        _lib.call("l2i_emb_dot_bwd", emb.data_ptr(), he.kpad, y.data_ptr(), wl.data_ptr() + off * wl.element_size(), g.data_ptr(),
+                  pc.dw_slice(he).data_ptr(), he.kp, pc.dw_slice(hl).data_ptr() + 4 * off, _p(dbias), y.numel(), he.ci,
+                  _code(wl.dtype), _stream())
+        return dbias, None, None, None, None, None
+
+
+def emb_dot(emb, y, linear, off, pc):
+    return EmbDotFn.apply(linear.bias, y, emb, linear, off, pc)
+
+
 class ResizeBilinearFn(Function):
     """F.interpolate(x, size=(H, W), mode="bilinear") for planar (b, o, h, w) f32 maps; the (cheap) backward is
     torch's own adjoint kernel."""

@@ -561,6 +561,68 @@ def test_gram_head_matches_the_explicit_gram_matrices():
     assert float((wg.grad.cpu() - wr.grad).abs().max()) < 1e-5 * float(wr.grad.abs().max())
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_discriminator_heads_fused(dt):
+    """ops.proj_head / ops.emb_dot against the reference's head arithmetic written with torch ops
+    (model/rcnn_discriminator_app.py:127-129, 154-157, 160-166): outputs, dx and every weight / bias gradient
+    (through the spectral-norm backward of the arena); repeated classes and an all-negative (dead) row included."""
+    from layout2img_amd import ops
+    from layout2img_amd.arena import GemmWeight
+    torch.manual_seed(4)
+    C, K, R, H = 72, 11, 9, 4
+    lin, emb, app, emba = GemmWeight("linear", 1, C, sn=True), GemmWeight("embedding", K, C, bias=False, sn=True), \
+        GemmWeight("linear", 1, 2 * C, sn=True), GemmWeight("embedding", K, C, bias=False, sn=True)
+    sds = [_sd_of(lin, "l."), _sd_of(emb, "e."), _sd_of(app, "a."), _sd_of(emba, "f.")]
+    net, flat, arena = _mk([lin, emb, app, emba], dt)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(R, H, H, C, generator=g)
+    x[3] = -x[3].abs()
+    y = torch.randint(0, K, (R,), generator=g)
+    y[5] = y[1]
+    gy, ga, gi = (torch.randn(R, 1, generator=g) for _ in range(3))
+
+    class _STE(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return _rt(t, dt)
+
+        @staticmethod
+        def backward(ctx, gg):
+            return gg
+    xr = x.clone().requires_grad_(True)
+    wl, we, wa, wf = (_STE.apply(O._w(sd, p, 1e-12, True)) for sd, p in zip(sds, ("l.", "e.", "a.", "f.")))
+    f = F.relu(xr).sum(dim=(1, 2))
+    obj_r = F.linear(f, wl, sds[0]["l.bias"]) + torch.sum(we.index_select(0, y) * f, dim=1, keepdim=True)
+    img_r = F.linear(F.relu(xr).mean(dim=(1, 2)), wl, sds[0]["l.bias"])
+    app_r = wf.index_select(0, y) @ wa[0, C:].unsqueeze(1) + sds[2]["a.bias"]
+    ((obj_r * gy).sum() + (img_r * gi).sum() + (app_r * ga).sum()).backward()
+
+    dev = _dev()
+    xg = x.to(dev).requires_grad_(True)
+    yd = y.to(dev)
+    pc = arena.prepare(training=True)
+    obj = ops.proj_head(xg, lin, pc, emb=emb, y=yd)
+    img = ops.proj_head(xg, lin, pc, scale=1.0 / (H * H))
+    apph = ops.emb_dot(emba, yd, app, C, pc)
+    ((obj * gy.to(dev)).sum() + (img * gi.to(dev)).sum() + (apph * ga.to(dev)).sum()).backward()
+    arena.flush_grads()
+    bf = dt == torch.bfloat16
+    tol = 2e-2 if bf else 2e-4
+
+    def close(a_, b_, name, t=tol):
+        sc = float(b_.abs().max()) + 1e-6
+        d = float((a_.detach().cpu() - b_).abs().max())
+        assert d < t * sc, (name, d, sc)
+    close(obj, obj_r, "obj", 2e-3 if bf else 2e-5)
+    close(img, img_r, "img", 2e-3 if bf else 2e-5)
+    close(apph, app_r, "app", 2e-3 if bf else 2e-5)
+    close(xg.grad, xr.grad, "dx")
+    for hh, sd, p in ((lin, sds[0], "l."), (emb, sds[1], "e."), (app, sds[2], "a."), (emba, sds[3], "f.")):
+        close(hh.weight_orig.grad, sd[p + "weight_orig"].grad, p + "dW")
+        if hh.bias is not None:
+            close(hh.bias.grad, sd[p + "bias"].grad, p + "db", 2e-3 if bf else 2e-5)
+
+
 @pytest.mark.parametrize("case", [(3, 8, 8), (2, 8, 16), (2, 5, 32), (1, 8, 64), (2, 31, 16)])
 def test_stage_mask_matches_the_composed_torch_ops(case):
     """ops.stage_mask == reference model/resnet_generator_app_v2.py:465-470 written with torch ops on the CPU (gather,
