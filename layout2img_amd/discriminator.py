@@ -29,7 +29,7 @@ class OptimizedBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x, pc, emit=()):
-        h = fused_conv(x, self.conv1, pc, emit=("relu",))     # conv2's ReLU'd operand comes out of conv1's epilogue
+        h = fused_conv(x, self.conv1, pc, relu_op_out=True)   # conv2's ReLU'd operand comes out of conv1's epilogue
         xs = x
         if self.downsample:
             xs = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
@@ -52,12 +52,13 @@ class ResBlock(nn.Module):
         """`use`: index of this application within the forward pass (each application of a spectral-normed
         module runs its own power iteration in the reference). `nimg`: device count of live leading images (ROI heads).
         `emit`: operand copies of the block's result its consumers will read ("relu" / "raw"), written by conv2's
-        epilogue. Inside the block conv1's epilogue writes conv2's ReLU'd operand, and conv2's data-gradient launch
-        writes the operand copy of dh that conv1's backward reads."""
+        epilogue. Inside the block conv1's epilogue writes conv2's ReLU'd operand and conv2's data-gradient launch
+        writes dh in the operand dtype -- on all but the smallest maps that operand tensor IS the autograd edge between
+        the two convs, so neither h nor dh exists as an f32 stream (ops.fused_conv relu_op_out)."""
         if self.learnable_sc:
             ops.precast(x, pc.arena.op_dtype)   # conv1 reads relu(x), the shortcut reads x: one cast launch for both (if not emitted upstream)
         j = ops.GradJoin()   # dx of the shortcut branch enters conv1's data-gradient epilogue instead of a separate add
-        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, emit=("relu",), join=(j, "take"))
+        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, relu_op_out=True, join=(j, "take"))
         sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg, join=(j, "give")) if self.learnable_sc else x
         return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample, nimg=nimg, emit=emit,
                           dx_raw=True, join=None if self.learnable_sc else (j, "give_res"))

@@ -396,13 +396,15 @@ class FusedConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None,
-                emit=(), dx_raw=False, join=None):
-        _chk(x, torch.float32)
+                emit=(), dx_raw=False, join=None, op_out=False):
         opd = pc.arena.op_dtype
+        _chk(x, opd if pro.kind == "op" else torch.float32)
         B, H, W, C = x.shape
         assert C == holder.ci_p, (C, holder.ci_p, holder.kind)
         stats = None
-        if pro.kind == "norm":
+        if pro.kind == "op":     # x IS the ReLU'd operand written by the producing conv's epilogue (`op_out`): no f32 stream
+            x_op = x
+        elif pro.kind == "norm":
             sums, sq, count, sstride = _norm_stats(x, pro)
             x_op, _ = norm_fwd_raw(x, sums, sq, count, sstride, pro, mask, wproj, bproj, opd)
             stats = (sums, sq, count, sstride)
@@ -424,11 +426,17 @@ class FusedConvFn(Function):
         # result tensor (`_sibling`) and replace separate cast launches over the f32 stream.
         if emit and ((B * Ho * Wo + 127) // 128) * ((holder.co_p + 127) // 128) < 192:
             emit = ()   # small grids run split-K (partial sums combined by atomics): no epilogue copies there
+        # `op_out`: the ONLY reader of the result is a pre-activation conv -- the epilogue writes relu(result) in the operand
+        # dtype and nothing else; that tensor is the autograd edge (its gradient arrives, and is used, in the operand dtype)
         out, o_relu, o_raw = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p, res=res,
                                       up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops, nimg=nimg,
-                                      want_op="relu" in emit, relu_op=True, want_raw="raw" in emit)
-        if emit:
+                                      want_f32=not op_out, want_op=op_out or "relu" in emit, relu_op=True,
+                                      want_raw="raw" in emit)
+        if op_out:
+            out = o_relu
+        elif emit:
             _attach(out, raw=o_raw, relu=o_relu)
+        ctx.op_out = op_out
         ctx.flops, ctx.nimg, ctx.dx_raw, ctx.join = flops, nimg, dx_raw, join
         sw, sb = getattr(wproj, "_l2i_sink", None), getattr(bproj, "_l2i_sink", None)
         ctx.sink = (sw[0], sw[1], sb[1]) if sw is not None and sb is not None and sw[0] is sb[0] else None
@@ -450,13 +458,15 @@ class FusedConvFn(Function):
         d_bias = None
         # the operand copy of dY: written by the data-gradient launch that produced dY (`dx_raw`), or by another layer
         # that received the same dY (a block's conv2 and its shortcut), else cast here -- and left on dY for the others
-        dy_op = _sibling(dy, "raw", opd)
+        dy_op = dy if ctx.op_out else _sibling(dy, "raw", opd)
         dbias = None
         if pc.need_wgrad and ctx.has_bias:
             bg = h.bias.grad
             direct = bg is not None and h.co == h.co_p and bg.is_contiguous() and bg.dtype == torch.float32
             if direct:   # the weight-gradient launch sums the bias gradient from the dY tiles it stages, straight into the
                 dbias = bg   # flat gradient buffer: no pass over dY at all when its operand copy already exists
+            elif ctx.op_out:
+                d_bias = dy.float().sum(dim=(0, 1, 2))[:h.co]
             else:        # (padded channel counts: bias gradient and the dY operand cast in one pass over dY)
                 st = channel_stats(dy.view(-1, dy.shape[-1]), want_sq=False, cast_to=opd if dy_op is None else None)
                 if dy_op is None:
@@ -464,7 +474,7 @@ class FusedConvFn(Function):
                 d_bias = st[0][0][:h.co]
         if dy_op is None:
             dy_op, _ = cast_op(dy, opd, raw=True, act=False)
-        if _sibling(dy, "raw", opd) is None:
+        if not ctx.op_out and _sibling(dy, "raw", opd) is None:
             _attach(dy, raw=dy_op)
         if pc.need_wgrad:
             wgrad_side(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
@@ -472,15 +482,18 @@ class FusedConvFn(Function):
         dx = d_mask = d_w = d_b = None
         if need_x or need_mod:
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
-            relu_mask = x_op if pro.kind == "relu" else None
+            relu_mask = x_op if pro.kind in ("relu", "op") else None
             Bq, Hq, Wq = dy.shape[0], dy.shape[1] << int(ctx.pool2), dy.shape[2] << int(ctx.pool2)
             small = ((Bq * Hq * Wq + 127) // 128) * ((h.ci_p + 127) // 128) < 192   # split-K grid: no epilogue copies
-            emit_raw = ctx.dx_raw and pro.kind != "norm" and not small   # (the norm backward rewrites dxo: its copy would be stale)
+            op_in = pro.kind == "op"    # the input edge is an operand tensor: its gradient is the operand copy alone
+            emit_raw = op_in or (ctx.dx_raw and pro.kind != "norm" and not small)   # (the norm backward rewrites dxo: its copy would be stale)
             joined = ctx.join[0].take() if ctx.join is not None and ctx.join[1] == "take" and need_x else None
             dxo, _, dx_op = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
                                      pool2=ctx.up2, alpha=alpha, flops=ctx.flops, nimg=ctx.nimg, want_raw=emit_raw,
-                                     res=joined if pro.kind != "norm" else None)
-            if emit_raw:
+                                     want_f32=not op_in, res=joined if pro.kind != "norm" else None)
+            if op_in:
+                dxo = dx_op
+            elif emit_raw:
                 _attach(dxo, raw=dx_op)
             if pro.kind == "norm":
                 sums, sq, count, sstride = ctx.stats
@@ -493,7 +506,7 @@ class FusedConvFn(Function):
         d_res = dy if ctx.has_res else None
         if d_res is not None and ctx.join is not None and ctx.join[1] == "give_res":
             d_res = ctx.join[0].give(d_res)
-        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None
+        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None, None
 
 
 def _attach(t, raw=None, relu=None):
@@ -523,13 +536,29 @@ def precast(x, op_dtype):
 
 
 def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False, nimg=None,
-               emit=(), dx_raw=False, join=None):
+               emit=(), dx_raw=False, join=None, relu_op_out=False):
     """emit: operand copies of the result to write in the epilogue ("relu", "raw") for the layers that read it next.
     dx_raw: x is read by this layer ONLY and was produced by another fused_conv -- the data-gradient launch then also
     writes the operand copy of dx that the producer's backward needs (no separate cast pass over dx).
-    join: (GradJoin, "give" | "take" | "give_res") -- see GradJoin."""
+    join: (GradJoin, "give" | "take" | "give_res") -- see GradJoin.
+    relu_op_out: the result is read by ONE pre-activation (ReLU-prologue) fused_conv and by nothing else: where the grid
+    allows epilogue copies the launch then writes only relu(result) in the operand dtype and returns that tensor (the f32
+    stream of the result and of its gradient are never written); otherwise this is emit=("relu",)."""
     pro = prologue if prologue is not None else _CAST
-    return FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg, tuple(emit), dx_raw, join)
+    if getattr(x, "_l2i_relu_op", False):
+        if pro is not RELU:
+            raise RuntimeError("a relu_op_out result can only feed a ReLU-prologue fused_conv")
+        pro = _OP
+    if relu_op_out:
+        B, H, W, _ = x.shape
+        Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+        if res is not None or pool2 or ((B * Ho * Wo + 127) // 128) * ((holder.co_p + 127) // 128) < 192 or not OP_EDGES:
+            relu_op_out, emit = False, tuple(emit) + ("relu",)
+    out = FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg, tuple(emit), dx_raw, join,
+                            relu_op_out)
+    if relu_op_out:
+        out._l2i_relu_op = True
+    return out
 
 
 class _Simple(Prologue):
@@ -537,7 +566,8 @@ class _Simple(Prologue):
         self.kind = kind
 
 
-_CAST, RELU = _Simple("cast"), _Simple("relu")
+_CAST, RELU, _OP = _Simple("cast"), _Simple("relu"), _Simple("op")
+OP_EDGES = __import__("os").environ.get("L2I_OP_EDGES", "1") != "0"   # operand-dtype autograd edges inside D blocks (A/B switch)
 
 
 class NormActFn(Function):
