@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import _lib
 
-ALIGN = 4  # elements (16 bytes)
+ALIGN = 8  # elements: every parameter owns a zero-padded slot of a multiple of 8 floats (ops.pad_param reads the pad)
 
 
 def _round_up(v, m):
@@ -49,6 +49,7 @@ class FlatParams:
                 self.data[o:o + k].copy_(p.detach().reshape(-1))
                 p.data = self.data[o:o + k].view(p.shape)
                 p.grad = self.grad[o:o + k].view(p.shape)
+                p._l2i_slot = _round_up(k, ALIGN)   # floats of flat storage this parameter owns (pad stays zero: its gradient is never written)
         self._params = params
         self._by_id = {id(p): offs[n] for n, p in params}
 

@@ -462,7 +462,32 @@ __global__ __launch_bounds__(256) void proj_head_fwd_kernel(const float* __restr
     if (threadIdx.x == 0) out[r] = acc + (bias ? bias[0] : 0.f);
 }
 
-// blocks [0, R): dx of row r and dE[y[r]] += g[r] f[r];  blocks [R, R + ceil(C/256)): dwl[c] += sum_r g[r] f[r,c], and the
+// dst[c] += sum_r g[r] M[row(r)][c] for the 16 columns c0..c0+15, by one 256-thread block: 16 row slices x 16 columns
+// (64-byte row segments), the loads of a slice independent of each other; the slices are combined in LDS.
+// rows: optional row indirection (class ids), else row(r) = r.
+template <typename T>
+__device__ __forceinline__ void colsum16(const T* __restrict__ M, int ld, const long long* __restrict__ rows,
+                                         const float* __restrict__ g, int R, int C, int c0, float* __restrict__ dst, float* red) {
+    const int cl = threadIdx.x & 15, rs = threadIdx.x >> 4, c = c0 + cl;
+    float t = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int r = rs; r < R; r += 16) {
+            const size_t row = rows ? (size_t)rows[r] : (size_t)r;
+            t = fmaf(g[r], OpT<T>::to(M[row * ld + c]), t);
+        }
+    }
+    red[rs * 16 + cl] = t;
+    __syncthreads();
+    if (rs == 0 && c < C) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k * 16 + cl];
+        atomicAdd(dst + c, a);
+    }
+}
+
+// blocks [0, R): dx of row r and dE[y[r]] += g[r] f[r];  blocks [R, R + ceil(C/16)): dwl[c] += sum_r g[r] f[r,c], and the
 // first of them dbias += sum_r g[r]. (A transposed pass over the saved f instead of R-way atomics per channel.)
 template <typename T>
 __global__ __launch_bounds__(256) void proj_head_bwd_kernel(const float* __restrict__ x, const T* __restrict__ wl,
@@ -470,15 +495,11 @@ __global__ __launch_bounds__(256) void proj_head_bwd_kernel(const float* __restr
                                                             const float* __restrict__ g, const float* __restrict__ feat, float scale,
                                                             float* __restrict__ dx, float* __restrict__ dwl, float* __restrict__ demb,
                                                             int demb_stride, float* __restrict__ dbias, int R, int HW, int C) {
-    __shared__ float red[8];
+    __shared__ float red[256];
     if ((int)blockIdx.x >= R) {
-        const int c = ((int)blockIdx.x - R) * 256 + threadIdx.x;
-        if (dwl && c < C) {
-            float t = 0.f;
-            for (int r = 0; r < R; ++r) t = fmaf(g[r], feat[(size_t)r * C + c], t);
-            atomicAdd(dwl + c, t);
-        }
+        if (dwl) colsum16<float>(feat, C, nullptr, g, R, C, ((int)blockIdx.x - R) * 16, dwl, red);
         if ((int)blockIdx.x == R && dbias) {
+            __syncthreads();
             float t = 0.f;
             for (int r = threadIdx.x; r < R; r += 256) t += g[r];
             t = block_sum(t, red);
@@ -528,7 +549,7 @@ extern "C" int l2i_proj_head_bwd(const float* x, const void* wl, const void* emb
                                  int demb_stride, float* dbias, int R, int HW, int C, int dtype, void* stream) {
     if (!x || !wl || !g || !feat || !dx || (emb && !y) || (demb && !emb) || C % 4 || R < 0 || HW <= 0) return L2I_ERR_ARG;
     if (R == 0) return L2I_OK;
-    const int extra = (dwl || dbias) ? (C + 255) / 256 : 0;
+    const int extra = (dwl || dbias) ? (C + 15) / 16 : 0;
     if (dtype == 1)
         hipLaunchKernelGGL(proj_head_bwd_kernel<bf16_t>, dim3(R + extra), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)wl,
                            (const bf16_t*)emb, emb_stride, y, g, feat, scale, dx, dwl, demb, demb_stride, dbias, R, HW, C);
@@ -554,25 +575,24 @@ __global__ __launch_bounds__(256) void emb_dot_fwd_kernel(const T* __restrict__ 
     if (lane == 0) out[r] = t + (bias ? bias[0] : 0.f);
 }
 
+// blocks [0, R): dE[y[r]][c] += g[r] w2[c];  blocks [R, R + ceil(C/16)): dw2[c] += sum_r g[r] E[y[r]][c]; the first of them dbias.
 template <typename T>
 __global__ __launch_bounds__(256) void emb_dot_bwd_kernel(const T* __restrict__ emb, int emb_stride, const long long* __restrict__ y,
                                                           const T* __restrict__ w2, const float* __restrict__ g,
                                                           float* __restrict__ demb, int demb_stride, float* __restrict__ dw2,
                                                           float* __restrict__ dbias, int R, int C) {
-    __shared__ float red[8];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    float t = 0.f;
-    if (c < C) {
-        const float w = OpT<T>::to(w2[c]);
-        for (int r = 0; r < R; ++r) {
-            const float gr = g[r];
-            const long long cls = y[r];
-            t = fmaf(gr, OpT<T>::to(emb[(size_t)cls * emb_stride + c]), t);
-            if (gr != 0.f) atomicAdd(demb + (size_t)cls * demb_stride + c, gr * w);
-        }
-        atomicAdd(dw2 + c, t);
+    __shared__ float red[256];
+    if ((int)blockIdx.x < R) {
+        const int r = blockIdx.x;
+        const float gr = g[r];
+        if (gr == 0.f) return;
+        float* d = demb + (size_t)y[r] * demb_stride;
+        for (int c = threadIdx.x; c < C; c += 256) atomicAdd(d + c, gr * OpT<T>::to(w2[c]));
+        return;
     }
-    if (blockIdx.x == 0 && dbias) {
+    colsum16<T>(emb, emb_stride, y, g, R, C, ((int)blockIdx.x - R) * 16, dw2, red);
+    if ((int)blockIdx.x == R && dbias) {
+        __syncthreads();
         float s = 0.f;
         for (int r = threadIdx.x; r < R; r += 256) s += g[r];
         s = block_sum(s, red);
@@ -598,10 +618,10 @@ extern "C" int l2i_emb_dot_bwd(const void* emb, int emb_stride, const long long*
     if (!emb || !y || !w2 || !g || !demb || !dw2 || R < 0 || C <= 0) return L2I_ERR_ARG;
     if (R == 0) return L2I_OK;
     if (dtype == 1)
-        hipLaunchKernelGGL(emb_dot_bwd_kernel<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)emb,
+        hipLaunchKernelGGL(emb_dot_bwd_kernel<bf16_t>, dim3(R + (C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)emb,
                            emb_stride, y, (const bf16_t*)w2, g, demb, demb_stride, dw2, dbias, R, C);
     else
-        hipLaunchKernelGGL(emb_dot_bwd_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)emb,
+        hipLaunchKernelGGL(emb_dot_bwd_kernel<float>, dim3(R + (C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)emb,
                            emb_stride, y, (const float*)w2, g, demb, demb_stride, dw2, dbias, R, C);
     return l2i_check_launch();
 }

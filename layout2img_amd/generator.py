@@ -36,30 +36,39 @@ class BNState(nn.Module):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
+    def _padded_running(self, cp):
+        """running_mean / running_var as the first c entries of PADDED storage (cp channels: mean 0, var 1 behind them),
+        so that a layer with a padded channel count reads and updates them in place -- no pad / copy-back launches per
+        forward. Re-linked if the buffers were moved or replaced (.to(), a fresh load)."""
+        rm, rv = self.running_mean, self.running_var
+        st = getattr(self, "_store", None)
+        if (st is None or st.shape[1] != cp or st.device != rm.device or rm.data_ptr() != st[0].data_ptr()
+                or rv.data_ptr() != st[1].data_ptr()):
+            with torch.no_grad():
+                st = torch.zeros(2, cp, dtype=torch.float32, device=rm.device)
+                st[1].fill_(1.0)
+                st[0, :self.c].copy_(rm)
+                st[1, :self.c].copy_(rv)
+                rm.data, rv.data = st[0, :self.c], st[1, :self.c]
+            self._store = st
+        return st[0], st[1]
+
     def spec(self, training, sync, cp=None):
         """NormSpec + (weight, bias) padded to cp channels."""
         cp = cp or self.c
-        rm, rv = self.running_mean, self.running_var
-        if cp != self.c:  # padded channels: keep private padded running stats
-            if not hasattr(self, "_rm_p") or self._rm_p.device != rm.device:
-                self._rm_p, self._rv_p = _pad_last(rm.detach().clone(), cp), F.pad(rv.detach().clone(), (0, cp - self.c), value=1.0)
-            else:
-                self._rm_p[:self.c].copy_(rm), self._rv_p[:self.c].copy_(rv)
-            running = (self._rm_p, self._rv_p)
-        else:
-            running = (rm, rv)
+        running = self._padded_running(cp) if cp != self.c else (self.running_mean, self.running_var)
         s = NormSpec(1 if self.affine else 2, eps=self.eps, relu=True, sync=sync, running=running, momentum=self.momentum,
                      training=training)
         w = b = None
         if self.affine:
-            w, b = _pad_last(self.weight, cp), _pad_last(self.bias, cp)
+            w, b = ops.pad_param(self.weight, cp), ops.pad_param(self.bias, cp)
         return s, w, b
 
+    _nbt_shared = False   # True once the network keeps every num_batches_tracked in one tensor and bumps them together
+
     def commit(self, cp=None):
-        """Copy padded running stats back after a train-mode forward."""
-        if cp and cp != self.c and hasattr(self, "_rm_p"):
-            self.running_mean.copy_(self._rm_p[:self.c]), self.running_var.copy_(self._rv_p[:self.c])
-        if self.training:
+        """After a train-mode forward (the running statistics were updated in place by the normalisation launch)."""
+        if self.training and not self._nbt_shared:
             self.num_batches_tracked += 1
 
 
@@ -130,7 +139,7 @@ class PSPModule(nn.Module):
         pooled = torch.matmul(resample_matrix("adaptive_avg", H, s, flat.device), flat)        # (B, s*s, C)
         y = pooled.reshape(B * s * s, -1) @ conv.weight.view(conv.weight.shape[0], -1).t()       # (B*s*s, 100)
         y = F.relu(F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps))
-        if bn.training:
+        if bn.training and not getattr(bn, "_nbt_shared", False):
             bn.num_batches_tracked += 1
         return torch.matmul(resample_matrix("bilinear_ac", s, H, flat.device), y.view(B, s * s, -1)).view(B, H, W, -1)
 
@@ -206,9 +215,8 @@ class ResBlock(nn.Module):
         gw2, gb2 = self.b2.project(w, pc, B, O)
         out = fused_conv(h, self.conv2, pc, prologue=self.b2.spec(self.training, sync),
                          mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc, emit=emit)
-        if self.training:
-            self.b1.batch_norm2d.num_batches_tracked += 1
-            self.b2.batch_norm2d.num_batches_tracked += 1
+        self.b1.batch_norm2d.commit()
+        self.b2.batch_norm2d.commit()
         m = self.conv_mask(out, pc, sync) if self.predict_mask else None
         return out, m
 
@@ -342,7 +350,20 @@ class _GeneratorBase(nn.Module):
         self.flat = FlatParams(self, device)
         self.arena = WeightArena(self, self.flat, device, op_dtype)
         self.sync = None  # set by parallel.attach_sync_bn for world_size > 1
+        # every batch-norm layer of the network runs in every forward: their num_batches_tracked counters live in one
+        # tensor (each buffer a 0-dim view of it) and a training forward bumps them with ONE launch (_bump_nbt)
+        bns = [m for m in self.modules() if isinstance(m, (BNState, nn.BatchNorm2d))]
+        self._nbt = torch.zeros(len(bns), dtype=torch.long, device=device)
+        with torch.no_grad():
+            for i, m in enumerate(bns):
+                self._nbt[i] = m.num_batches_tracked
+                m.num_batches_tracked.data = self._nbt[i]
+                m._nbt_shared = True
         return self
+
+    def _bump_nbt(self):
+        if self.training:
+            self._nbt += 1
 
     def _project_isla(self, wp, pc, b, o):
         """One GEMM for every ISLA projection of the pass; each norm layer picks up its (b, o, C) slices."""
@@ -437,6 +458,7 @@ class ResnetGenerator128_context(_GeneratorBase):
         pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
         bn.commit()
         self._release_isla()
+        self._bump_nbt()
         img = torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()
         if taps is not None:
             taps.update(w=w, bmask=bmask, stages=stages, pre_tanh=pre[..., :self.output_dim], res=res_out)
@@ -481,6 +503,7 @@ class context_aware_generator(_GeneratorBase):
         pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
         bn.commit()
         self._release_isla()
+        self._bump_nbt()
         return torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()
 
 
@@ -533,4 +556,5 @@ class ResnetGenerator64_context(ResnetGenerator128_context):
         pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
         bn.commit()
         self._release_isla()
+        self._bump_nbt()
         return torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()

@@ -786,6 +786,60 @@ def hinge(x, valid, mode, weight=1.0, count=None):
     return HingeFn.apply(x, valid, mode, weight, count)
 
 
+class PadParamFn(Function):
+    """A 1-D parameter seen with its channel count padded to n: a VIEW of the parameter's slot in the flat buffer
+    (arena.FlatParams keeps the pad behind every parameter at zero), not a copy -- no pad launch forward, a slice view
+    backward."""
+
+    @staticmethod
+    def forward(ctx, p, n):
+        ctx.c = p.numel()
+        return torch.as_strided(p.detach(), (n,), (1,), p.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.c], None
+
+
+def pad_param(p, n):
+    if p.numel() == n:
+        return p
+    if p.dim() == 1 and p.is_contiguous() and getattr(p, "_l2i_slot", 0) >= n:
+        return PadParamFn.apply(p, n)
+    return torch.nn.functional.pad(p, (0, n - p.numel()))
+
+
+class HingeSumFn(Function):
+    """Sum of hinge terms over several discriminator outputs (ops.hinge semantics per term) accumulated into ONE scalar:
+    no per-term zero fills, additions or gradient scalings."""
+
+    @staticmethod
+    def forward(ctx, mode, n, *args):
+        xs, valids, weights, counts = args[:n], args[n:2 * n], args[2 * n:3 * n], args[3 * n:4 * n]
+        loss = _zeros((1,), xs[0].device)
+        grads = []
+        for x, valid, wgt, cnt in zip(xs, valids, weights, counts):
+            xc = _chk(x.contiguous().view(-1), torch.float32)
+            g = torch.empty_like(xc)
+            _lib.call("l2i_hinge_fwd_bwd", xc.data_ptr(), _p(valid), xc.numel(), mode, float(wgt), _p(cnt), loss.data_ptr(),
+                      g.data_ptr(), _stream())
+            grads.append(g.view(x.shape))
+        ctx.save_for_backward(*grads)
+        ctx.n = n
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = torch._foreach_mul(list(ctx.saved_tensors), g)
+        return (None, None, *grads, *([None] * (3 * ctx.n)))
+
+
+def hinge_sum(terms, mode):
+    """terms: [(x, valid | None, weight, count | None), ...] -> scalar sum of the hinge terms."""
+    n = len(terms)
+    return HingeSumFn.apply(mode, n, *[t[0] for t in terms], *[t[1] for t in terms], *[t[2] for t in terms], *[t[3] for t in terms])
+
+
 class GramHeadFn(Function):
     """gram_term[r] = w1 . (Gram_r 1) / C with Gram_r = F F^T / C, F = relu(x_r) -- the only part of the Gram matrix the
     appearance head reads (reference model/rcnn_discriminator_app.py:148-157) -- in one pass over x, both ways."""

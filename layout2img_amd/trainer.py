@@ -73,10 +73,10 @@ class GanTrainer:
 
     def _d_terms(self, outs, valid, mode, n_roi, n_img):
         """outs = (d_img, d_obj[, d_app]) -- the 64x64 discriminator has no appearance head."""
-        loss = ops.hinge(outs[1], valid, mode, self.l_obj, n_roi) + ops.hinge(outs[0], None, mode, self.l_img, n_img)
+        terms = [(outs[1], valid, self.l_obj, n_roi), (outs[0], None, self.l_img, n_img)]
         if len(outs) > 2:
-            loss = loss + ops.hinge(outs[2], valid, mode, self.l_app, n_roi)
-        return loss
+            terms.append((outs[2], valid, self.l_app, n_roi))
+        return ops.hinge_sum(terms, mode)
 
     def step(self, real, label, bbox, z=None, z_im=None):
         """One iteration. real (b,3,H,W) in [-1,1]; label (b,o) int64; bbox (b,o,4). Returns loss tensors
