@@ -205,6 +205,30 @@ int l2i_emb_dot_fwd(const void* emb, int emb_stride, const long long* y, const v
 int l2i_emb_dot_bwd(const void* emb, int emb_stride, const long long* y, const void* w2, const float* g, float* demb,
                     int demb_stride, float* dw2, float* dbias, int R, int C, int dtype, void* stream);
 
+/* Pyramid-pooling stages of the PSP mask head (model/resnet_generator_app_v2.py:724-752) as fixed sparse linear maps over
+ * the H x H pixels of one image (H*H % 128 == 0, H even, <= 128); bins (NB <= 64 in all) are numbered stage after stage,
+ * row-major inside a stage. Pixel -> bins direction as per-pixel tap tables, bins -> ... reductions in separable form:
+ *   aidx, aw [HW][TA]     (TA = 12 | 16, zero-padded): the AdaptiveAvgPool2d bins a pixel belongs to
+ *   uidx, uw [HW][NS][4]  (zero-padded): the bins of stage s a pixel's bilinear (align_corners=True) sample reads
+ *   wx [NQ][H], wy [NB][H], xq [NB]: weight of x-bin q (numbered stage after stage, NQ <= 16) at column x; weight of bin k
+ *   at row y; the x-bin of bin k -- of the pooling (pool_fwd) resp. the bilinear map (expand_bwd); qoff [NS+1] = first
+ *   x-bin of each stage (device array)
+ *  pool_fwd:   pooled[b,k,c] = sum_{y,x} wy[k,y] wx[xq[k],x] feats[b,y,x,c]     feats [B][H][H][C] f32, pooled [B][NB][C];
+ *              rows: scratch [B][H][NQ][C] f32
+ *  pool_bwd:   dfeats[b,p,c] = add[b,p,c] + sum_t aw[p,t] dpooled[b,aidx[p,t],c]            (add may be NULL)
+ *  expand_fwd: cat[b,p,:] = [sum_t uw[p,s,t] y[b,uidx[p,s,t],:] for s] ++ feats[b,p,:]     y [B][NB][F], cat [B][HW][NS*F+C]
+ *              of `dtype`
+ *  expand_bwd: g = d cat (dtype) -> dy[b,k,j] = sum_{y,x} wy[k,y] wx[xq[k],x] g[b,y,x,s(k)*F+j], dfeats [B][HW][C] =
+ *              g[..., NS*F:]; rows: scratch [B][H][NQ][F] f32 */
+int l2i_psp_pool_fwd(const float* feats, const float* wx, const float* wy, const int* xq, float* pooled, float* rows, int B, int H,
+                     int C, int NB, int NQ, void* stream);
+int l2i_psp_pool_bwd(const float* dpooled, const int* aidx, const float* aw, int TA, const float* add, float* dfeats, int B,
+                     int HW, int C, int NB, void* stream);
+int l2i_psp_expand_fwd(const float* feats, const float* y, const int* uidx, const float* uw, void* cat, int B, int HW, int C,
+                       int F, int NB, int n_stages, int dtype, void* stream);
+int l2i_psp_expand_bwd(const void* g, const float* wx, const float* wy, const int* xq, const int* qoff, float* dy, float* dfeats,
+                       float* rows, int B, int H, int C, int F, int NB, int NQ, int n_stages, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,10 @@ SIGNATURES = {
     "l2i_proj_head_bwd": [_p, _p, _p, _i, _p, _p, _p, _f, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p],
     "l2i_emb_dot_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "l2i_emb_dot_bwd": [_p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p],
+    "l2i_psp_pool_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "l2i_psp_pool_bwd": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p],
+    "l2i_psp_expand_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "l2i_psp_expand_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "l2i_stage_mask_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "l2i_stage_mask_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "l2i_relu_bwd": [_p, _p, _p, _p, _ll, _p],

@@ -52,6 +52,14 @@ class FlatParams:
                 p._l2i_slot = _round_up(k, ALIGN)   # floats of flat storage this parameter owns (pad stays zero: its gradient is never written)
         self._params = params
         self._by_id = {id(p): offs[n] for n, p in params}
+        # "loose" parameters: everything that is not a GemmWeight's weight / bias (norm affines, layer norms, alphas, the
+        # label embedding, PSP stage convs ...). Their gradients come through autograd's AccumulateGrad, one small add_
+        # launch each (~45 per generator backward). With .grad detached (None) while the backward runs, AccumulateGrad
+        # keeps the incoming tensor instead, and flush_loose() moves all of them into the flat buffer in one
+        # multi-tensor launch before the optimizer / the gradient all-reduce read it.
+        owned = {id(q) for m in module.modules() if isinstance(m, GemmWeight) for q in m.parameters(recurse=False)}
+        self._loose = [(p, offs[n]) for n, p in params if id(p) not in owned]
+        self.defer_loose = True
 
     def offset_of(self, param):
         return self._by_id[id(param)]
@@ -63,6 +71,23 @@ class FlatParams:
             o = self._by_id[id(p)]
             if p.grad is None or p.grad.data_ptr() != base + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        if self.defer_loose:
+            for p, _ in self._loose:
+                p.grad = None
+
+    def flush_loose(self):
+        """Gradients autograd left on detached loose parameters -> the flat buffer (one multi-tensor add), views re-attached."""
+        src, dst = [], []
+        base = self.grad.data_ptr()
+        for p, o in self._loose:
+            g = p.grad
+            view = self.grad[o:o + p.numel()].view(p.shape)
+            if g is not None and g.data_ptr() != base + 4 * o:
+                src.append(g.to(torch.float32).reshape(p.shape))
+                dst.append(view)
+            p.grad = view
+        if src:
+            torch._foreach_add_(dst, src)
 
 
 class FlatBuffers:
@@ -317,6 +342,7 @@ class WeightArena:
         """Apply the spectral-norm backward of every pending pass into the flat gradient buffer."""
         from .ops import WgradSide
         WgradSide.join()   # weight-gradient launches run on side streams (ops.WgradSide)
+        self.flat.flush_loose()
         for p in self.pending:
             if p.dwbar is None:
                 continue

@@ -34,6 +34,31 @@ template <> struct OpT<float> {
     __device__ static __forceinline__ float to(float v) { return v; }
 };
 
+// four consecutive operand elements <-> four floats (8- / 16-byte accesses)
+template <typename T> struct Op4;
+template <> struct Op4<bf16_t> {
+    __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+    __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+        uint2 u;
+        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+};
+template <> struct Op4<float> {
+    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 u = *reinterpret_cast<const float4*>(p);
+        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+    }
+    __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

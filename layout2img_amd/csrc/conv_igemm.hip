@@ -64,30 +64,6 @@ __device__ __forceinline__ float quad_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
     return v;
 }
-template <typename T> struct Op4;
-template <> struct Op4<bf16_t> {
-    __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
-        const uint2 u = *reinterpret_cast<const uint2*>(p);
-        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-    }
-    __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
-        uint2 u;
-        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        *reinterpret_cast<uint2*>(p) = u;
-    }
-};
-template <> struct Op4<float> {
-    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
-        const float4 u = *reinterpret_cast<const float4*>(p);
-        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
-    }
-    __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-};
-
 // Split-K partial tiles are combined with f32 atomics, which only run at speed when a wave's 64 addresses are
 // contiguous runs; the transposed accumulator would scatter them over 32 rows. Each wave therefore turns its 32x32
 // tiles back through a private 32 x 36-float LDS patch (the ring is idle by then) and adds 128-byte row segments.

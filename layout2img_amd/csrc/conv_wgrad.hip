@@ -244,15 +244,20 @@ __device__ __forceinline__ bf16x8_t wg_frag(const char* tile, int pixbase, int c
 // MODE 2 (SEMI): pool and/or upsample, M % 64 == 0 and Ho*Wo % 64 == 0: a 64-pixel step lies inside one image and starts
 //   on a row (or half-row) boundary, so image / row / column of the step are SCALARS and a lane adds its constant (dx, dy).
 // MODE 0: general (any size), per-lane decode of the pixel index.
-template <int BMO, int MODE>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lgW, int lgH) {
+// NW = 4: four waves as 2 x 2, each a (BMO/2) x 64 piece of the tile, 64-pixel steps.
+// NW = 2: two waves side by side, each BMO x 64 (a wave then reads 12 KB of LDS per 16 MFMAs instead of 16 KB: the
+//   transposing reads, not the MFMAs, bound the 2 x 2 form), 32-pixel steps so that twice as many workgroups fit a CU
+//   and the waves per SIMD stay the same. Either way a wave stages 16 pixel rows per step.
+template <int BMO, int MODE, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_dma_kernel(WgradArgs p, int lgW, int lgH) {
     constexpr bool FAST = MODE == 1, SEMI = MODE == 2;
-    constexpr int BNK = 128, BK = 64;
+    constexpr int BNK = 128, BK = 16 * NW, NT = 64 * NW, LGBK = NW == 4 ? 6 : 5;
     constexpr int RSA = BMO * 2, RSB = BNK * 2;
-    constexpr int TM = BMO / 64, TN = 2;
+    constexpr int WM = NW == 4 ? 2 : 1;          // waves along the channel (row) dimension of the tile
+    constexpr int TM = BMO / (32 * WM), TN = 2;
     constexpr int STAGE = BK * (RSA + RSB);
     constexpr int A_ROWS = 1024 / RSA;           // pixel rows per wave-instruction (4 | 8)
-    constexpr int A_Q = BK / (4 * A_ROWS);       // A instructions per wave per step (4 | 2)
+    constexpr int A_Q = 16 / A_ROWS;             // A instructions per wave per step (4 | 2)
     constexpr int A_CH = RSA / 16;               // 16-byte chunks per A row (16 | 8)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int wrow = (wave >> 1) * (BMO / 2), wcol = (wave & 1) * 64;
+    const int wrow = NW == 4 ? (wave >> 1) * (BMO / 2) : 0, wcol = (NW == 4 ? (wave & 1) : wave) * 64;
     // fragment read addresses (stage-relative): piece (row 8h + (t>>2), 4-channel block) of the k16 sub-step 0, r = 0;
     // sub-step kk adds 16 rows and r adds 4 rows -- neither changes the row's swizzle, so they are immediates
     unsigned fa_addr[TM], fb_addr[TN];
@@ -404,9 +409,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
     const int nb_bias = p.tiles_k >= 4 ? 4 : (p.tiles_k >= 2 ? 2 : 1);   // (a power of two)
     const bool do_bias = p.dbias != nullptr && tile_k < nb_bias;
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    constexpr int BS_PG = 256 / A_CH, BS_PP = BK / BS_PG;   // pixel groups, pixels per thread per step
+    constexpr int BS_PG = NT / A_CH, BS_PP = BK / BS_PG;   // pixel groups, pixels per thread per step
 #define WG_BIAS(STG, MS)                                                                                              \
-    if (do_bias && ((((MS) - m_begin) >> 6) & (nb_bias - 1)) == tile_k) {                                               \
+    if (do_bias && ((((MS) - m_begin) >> LGBK) & (nb_bias - 1)) == tile_k) {                                               \
         const int c_ = tid % A_CH, pg_ = tid / A_CH;                                                                  \
         _Pragma("unroll") for (int i_ = 0; i_ < BS_PP; ++i_) {                                                        \
             const int pr_ = pg_ + BS_PG * i_;                                                                         \
@@ -420,15 +425,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
 #define WG_TR(ADDR) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)((__attribute__((address_space(3))) char*)smem + (ADDR)))
 #define WG_STEP(STG)                                                                                                  \
     {                                                                                                                 \
-        s16x4_t ra[4][TM][2], rb[4][TN][2];                                                                           \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                            \
+        s16x4_t ra[BK / 16][TM][2], rb[BK / 16][TN][2];                                                               \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 16; ++kk) {                                                            \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int r = 0; r < 2; ++r)              \
                 ra[kk][i][r] = WG_TR(fa_addr[i] + (STG) * STAGE + (kk * 16 + 4 * r) * RSA);                           \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int r = 0; r < 2; ++r)              \
                 rb[kk][j][r] = WG_TR(fb_addr[j] + (STG) * STAGE + (kk * 16 + 4 * r) * RSB);                           \
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 16; ++kk)                                                        \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {           \
                 bf16x8_t fa, fb;                                                                                      \
                 fa[0] = ra[kk][i][0][0]; fa[1] = ra[kk][i][0][1]; fa[2] = ra[kk][i][0][2]; fa[3] = ra[kk][i][0][3];   \
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
 #undef WG_TR
 #undef WG_BIAS
     if (do_bias) {   // lanes that share a chunk within a wave are A_CH apart; waves combine through LDS: one atomic per channel
-        float* red = reinterpret_cast<float*>(smem);   // [4 waves][BMO]
+        float* red = reinterpret_cast<float*>(smem);   // [NW waves][BMO]
         __syncthreads();                                // every wave is done with the stages
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -482,7 +487,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
         }
         __syncthreads();
         if (tid < BMO) {
-            const float v = red[tid] + red[BMO + tid] + red[2 * BMO + tid] + red[3 * BMO + tid];
+            float v = red[tid] + red[BMO + tid];
+            if (NW == 4) v += red[2 * BMO + tid] + red[3 * BMO + tid];
             if (co0 + tid < p.Co && v != 0.f) atomicAdd(p.dbias + co0 + tid, p.alpha * v);
         }
     }
@@ -504,9 +510,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs p, int lg
 
 static int g_wgrad_blocks = 0;   // tuning hook l2i_set_wgrad_blocks: workgroups per wave of the grid (0 = from the tile's occupancy)
 static int g_wgrad_force64 = 0;   // tuning: 64-row tiles for every layer (n = -64), back to the default (n = -128)
+static int g_wgrad_nw2 = -1;      // tuning: two-wave 128-row kernel on (n = -2) / off (n = -4) / by the heuristic (n = -3)
 extern "C" int l2i_set_wgrad_blocks(int n) {
     if (n == -64) { g_wgrad_force64 = 1; return L2I_OK; }
     if (n == -128) { g_wgrad_force64 = 0; return L2I_OK; }
+    if (n == -2) { g_wgrad_nw2 = 1; return L2I_OK; }
+    if (n == -4) { g_wgrad_nw2 = 0; return L2I_OK; }
+    if (n == -3) { g_wgrad_nw2 = -1; return L2I_OK; }
     g_wgrad_blocks = n > 0 ? n : 0;
     return L2I_OK;
 }
@@ -531,7 +541,9 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     // Split the pixel (reduction) dimension so that the grid is ONE full wave of co-resident workgroups (2 per CU for
     // the 128-row tile, 3 for the 64-row one: LDS-limited) -- every extra split costs Co*K atomics, and a grid of 1.1-1.9
     // waves leaves half the chip idle in its second round. Tile counts too large for that go to >= 3 waves instead.
-    const int cap = g_wgrad_blocks > 0 ? g_wgrad_blocks : (BMO == 64 ? 768 : 512);
+    const bool pow2 = !(a.Ho & (a.Ho - 1)) && !(a.Wo & (a.Wo - 1));
+    const bool nw2 = BMO == 128 && sizeof(T) == 2 && pow2 && (g_wgrad_nw2 < 0 ? false : g_wgrad_nw2 == 1);
+    const int cap = g_wgrad_blocks > 0 ? g_wgrad_blocks : (BMO == 64 ? 768 : (nw2 ? 1024 : 512));
     int splits = cap / tiles;
     if (splits < 1 || (long long)splits * tiles * 5 < (long long)cap * 4) {
         splits = (3 * cap + tiles - 1) / tiles;
@@ -543,7 +555,6 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.Mper = per * BK;
     a.splits = (a.M + a.Mper - 1) / a.Mper;
     const int nblk = tiles * a.splits;
-    const bool pow2 = !(a.Ho & (a.Ho - 1)) && !(a.Wo & (a.Wo - 1));
     {
         const size_t xb = (size_t)a.B * a.Hi * a.Wi * a.Ci * sizeof(T);
         const size_t yb = (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co * sizeof(T);
@@ -561,6 +572,11 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
             if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 1>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
             else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
             else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+        } else if (nw2) {
+            const size_t lds1 = (size_t)2 * 32 * (BMO * 2 + 256);
+            if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 1, 2>), dim3(nblk), dim3(128), lds1, stream, a, lgW, lgH);
+            else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 2, 2>), dim3(nblk), dim3(128), lds1, stream, a, lgW, lgH);
+            else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 0, 2>), dim3(nblk), dim3(128), lds1, stream, a, lgW, lgH);
         } else {
             if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 1>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
             else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);

@@ -99,6 +99,7 @@ class ISLANorm(nn.Module):
 
 
 _RESAMPLE = {}
+_PSP_TAPS = {}
 
 
 def resample_matrix(kind, n_in, n_out, device):
@@ -114,6 +115,50 @@ def resample_matrix(kind, n_in, n_out, device):
             out = F.interpolate(eye, size=(n_out, n_out), mode="bilinear", align_corners=(kind == "bilinear_ac"))
         _RESAMPLE[key] = out.reshape(n_in * n_in, n_out * n_out).t().contiguous().to(device)
     return _RESAMPLE[key]
+
+
+def psp_taps(H, sizes, device):
+    """Per-pixel tap tables of the PSP resamplings (csrc/psp.hip), extracted from the dense maps torch's own ops give for
+    the identity basis (resample_matrix: nn.AdaptiveAvgPool2d, reference :743; bilinear align_corners=True, :750):
+    dict(aidx, aw (HW, 12): bins a pixel is pooled into; uidx, uw (HW, n_stages, 4): bins a pixel's bilinear sample reads;
+    nb = total number of bins; pwx / uwx (nq, H), pwy / uwy (nb, H), xq (nb), qoff: the separable form, see below).
+    Bins are numbered stage after stage, row-major inside a stage."""
+    key = (H, tuple(sizes), str(device))
+    if key not in _PSP_TAPS:
+        At = torch.cat([resample_matrix("adaptive_avg", H, s, "cpu") for s in sizes], dim=0).t().contiguous()   # (HW, NB)
+        assert int((At != 0).sum(dim=1).max()) <= 12
+        _, ai = torch.topk(At.abs(), 12, dim=1)
+        aw = torch.gather(At, 1, ai)
+        ai = torch.where(aw != 0, ai, torch.zeros_like(ai))
+        uis, uws, off = [], [], 0
+        for s in sizes:
+            Us = resample_matrix("bilinear_ac", s, H, "cpu")                                                       # (HW, s*s)
+            assert int((Us != 0).sum(dim=1).max()) <= 4
+            k = min(4, s * s)
+            _, ui = torch.topk(Us.abs(), k, dim=1)
+            uw = torch.gather(Us, 1, ui)
+            ui, uw = F.pad(ui, (0, 4 - k)), F.pad(uw, (0, 4 - k))
+            uis.append(ui + off), uws.append(uw)
+            off += s * s
+        # the same two maps factored along x and y (both are separable) for the reductions over pixels: x-bins q are
+        # numbered stage after stage (qoff), bin k = (stage, ky, kx) reads x-bin xq[k] with the y-weights wy[k]
+        eye = torch.eye(H).view(H, 1, 1, H)
+        pwx, uwx, pwy, uwy, xq, qoff = [], [], [], [], [], [0]
+        for s in sizes:
+            p1 = F.adaptive_avg_pool2d(eye, (1, s)).view(H, s).t()                                               # (s, H): bin <- position
+            u1 = F.interpolate(torch.eye(s).view(s, 1, 1, s), size=(1, H), mode="bilinear", align_corners=True).view(s, H)
+            pwx.append(p1), uwx.append(u1)
+            for ky in range(s):
+                for kx in range(s):
+                    pwy.append(p1[ky]), uwy.append(u1[ky]), xq.append(qoff[-1] + kx)
+            qoff.append(qoff[-1] + s)
+        dv = lambda t: t.contiguous().to(device)
+        _PSP_TAPS[key] = dict(aidx=dv(ai.to(torch.int32)), aw=dv(aw), uidx=dv(torch.stack(uis, 1).to(torch.int32)),
+                              uw=dv(torch.stack(uws, 1)), nb=off, sizes=tuple(sizes), nq=qoff[-1],
+                              pwx=dv(torch.cat(pwx, 0)), pwy=dv(torch.stack(pwy, 0)), uwx=dv(torch.cat(uwx, 0)),
+                              uwy=dv(torch.stack(uwy, 0)), xq=dv(torch.tensor(xq, dtype=torch.int32)),
+                              qoff=dv(torch.tensor(qoff, dtype=torch.int32)))
+    return _PSP_TAPS[key]
 
 
 def _resize_mask(mask, H, W):
@@ -132,23 +177,25 @@ class PSPModule(nn.Module):
                                          BNState(out_features)])
         self.dropout_p = 0.1
 
-    def _stage(self, st, s, flat, B, H, W):
-        """AdaptiveAvgPool(s) -> 1x1 conv -> BatchNorm2d -> ReLU -> bilinear(align_corners=True) back to HxW, with
-        both resamplings expressed as (tiny) matrices so forward and backward are plain GEMMs in NHWC."""
-        conv, bn = st[1], st[2]
-        pooled = torch.matmul(resample_matrix("adaptive_avg", H, s, flat.device), flat)        # (B, s*s, C)
-        y = pooled.reshape(B * s * s, -1) @ conv.weight.view(conv.weight.shape[0], -1).t()       # (B*s*s, 100)
-        y = F.relu(F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps))
-        if bn.training and not getattr(bn, "_nbt_shared", False):
-            bn.num_batches_tracked += 1
-        return torch.matmul(resample_matrix("bilinear_ac", s, H, flat.device), y.view(B, s * s, -1)).view(B, H, W, -1)
+    SIZES = (1, 2, 3, 6)
 
     def forward(self, feats, pc, sync):
-        # feats: (B,H,W,C) f32
+        """feats (B,H,W,C) f32. Each stage is AdaptiveAvgPool(s) -> 1x1 conv -> BatchNorm2d -> ReLU -> bilinear
+        (align_corners=True) back to HxW; the two resamplings are fixed sparse linear maps over the pixels (psp_taps) applied
+        by csrc/psp.hip for all stages at once, the tiny per-stage conv / BN / ReLU between them stay torch ops."""
         B, H, W, C = feats.shape
-        flat = feats.view(B, H * W, C)
-        priors = [self._stage(st, s, flat, B, H, W) for st, s in zip(self.stages, (1, 2, 3, 6))]
-        cat = torch.cat(priors + [feats], dim=3).contiguous()
+        taps = psp_taps(H, self.SIZES, feats.device)
+        j = ops.GradJoin()   # d feats: the concat branch's part enters the pooling branch's backward launch
+        pooled = ops.psp_pool(feats, taps, j)                                                  # (B, 50, C)
+        ys = []
+        for st, part in zip(self.stages, pooled.split([s * s for s in self.SIZES], dim=1)):
+            conv, bn = st[1], st[2]
+            y = part.reshape(-1, C) @ conv.weight.view(conv.weight.shape[0], -1).t()         # (B*s*s, 100)
+            y = F.relu(F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps))
+            if bn.training and not getattr(bn, "_nbt_shared", False):
+                bn.num_batches_tracked += 1
+            ys.append(y.view(B, -1, y.shape[-1]))
+        cat = ops.psp_expand(feats, torch.cat(ys, dim=1), taps, pc.arena.op_dtype, j)          # (B,H,W,4*100+C), operand dtype
         conv, bn = self.bottleneck
         h = fused_conv(cat, conv, pc)
         spec, w, b = bn.spec(self.training, sync, conv.co_p)

@@ -5,6 +5,8 @@ layers are (rows, 1, 1, C); "streams" are f32, MFMA "operands" are `op_dtype` (b
 are planar (B, O, H, W) f32. Everything here requires a GPU and the built library: there is no
 fallback of any kind.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -398,12 +400,12 @@ class FusedConvFn(Function):
     def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None,
                 emit=(), dx_raw=False, join=None, op_out=False):
         opd = pc.arena.op_dtype
-        _chk(x, opd if pro.kind == "op" else torch.float32)
+        _chk(x, opd if pro.kind in ("op", "opraw") else torch.float32)
         B, H, W, C = x.shape
         assert C == holder.ci_p, (C, holder.ci_p, holder.kind)
         stats = None
-        if pro.kind == "op":     # x IS the ReLU'd operand written by the producing conv's epilogue (`op_out`): no f32 stream
-            x_op = x
+        if pro.kind in ("op", "opraw"):   # x IS the operand: the ReLU'd result of the producing conv's epilogue (`op_out`),
+            x_op = x                      # or a tensor produced in the operand dtype (ops.psp_expand) -- no f32 stream
         elif pro.kind == "norm":
             sums, sq, count, sstride = _norm_stats(x, pro)
             x_op, _ = norm_fwd_raw(x, sums, sq, count, sstride, pro, mask, wproj, bproj, opd)
@@ -485,7 +487,7 @@ class FusedConvFn(Function):
             relu_mask = x_op if pro.kind in ("relu", "op") else None
             Bq, Hq, Wq = dy.shape[0], dy.shape[1] << int(ctx.pool2), dy.shape[2] << int(ctx.pool2)
             small = ((Bq * Hq * Wq + 127) // 128) * ((h.ci_p + 127) // 128) < 192   # split-K grid: no epilogue copies
-            op_in = pro.kind == "op"    # the input edge is an operand tensor: its gradient is the operand copy alone
+            op_in = pro.kind in ("op", "opraw")   # the input edge is an operand tensor: its gradient is the operand copy alone
             emit_raw = op_in or (ctx.dx_raw and pro.kind != "norm" and not small)   # (the norm backward rewrites dxo: its copy would be stale)
             joined = ctx.join[0].take() if ctx.join is not None and ctx.join[1] == "take" and need_x else None
             dxo, _, dx_op = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
@@ -549,6 +551,10 @@ def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None,
         if pro is not RELU:
             raise RuntimeError("a relu_op_out result can only feed a ReLU-prologue fused_conv")
         pro = _OP
+    elif getattr(x, "_l2i_raw_op", False):
+        if pro is not _CAST:
+            raise RuntimeError("an operand-dtype tensor can only feed a plain (cast-prologue) fused_conv")
+        pro = _OPRAW
     if relu_op_out:
         B, H, W, _ = x.shape
         Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
@@ -566,7 +572,7 @@ class _Simple(Prologue):
         self.kind = kind
 
 
-_CAST, RELU, _OP = _Simple("cast"), _Simple("relu"), _Simple("op")
+_CAST, RELU, _OP, _OPRAW = _Simple("cast"), _Simple("relu"), _Simple("op"), _Simple("opraw")
 OP_EDGES = __import__("os").environ.get("L2I_OP_EDGES", "1") != "0"   # operand-dtype autograd edges inside D blocks (A/B switch)
 
 
@@ -986,6 +992,78 @@ class EmbDotFn(Function):
 
 def emb_dot(emb, y, linear, off, pc):
     return EmbDotFn.apply(linear.bias, y, emb, linear, off, pc)
+
+
+class PspPoolFn(Function):
+    """pooled[b,k,:] = sum_p A[k,p] feats[b,p,:]: every adaptive-average-pool stage of the PSP head in one pass over the
+    feature map (csrc/psp.hip; taps = generator.psp_taps). Backward adds the gradient the concat branch left in `join`."""
+
+    @staticmethod
+    def forward(ctx, feats, taps, join):
+        _chk(feats, torch.float32)
+        B, H, W, C = feats.shape
+        NB, NQ = taps["nb"], taps["nq"]
+        assert H == W
+        pooled = torch.empty((B, NB, C), dtype=torch.float32, device=feats.device)
+        rows = torch.empty((B, H, NQ, C), dtype=torch.float32, device=feats.device)
+        _lib.call("l2i_psp_pool_fwd", feats.data_ptr(), taps["pwx"].data_ptr(), taps["pwy"].data_ptr(), taps["xq"].data_ptr(),
+                  pooled.data_ptr(), rows.data_ptr(), B, H, C, NB, NQ, _stream())
+        ctx.shape, ctx.join, ctx.taps = (B, H, W, C), join, taps
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        taps = ctx.taps
+        B, H, W, C = ctx.shape
+        g = g.contiguous()
+        add = ctx.join.take() if ctx.join is not None else None
+        dfeats = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
+        _lib.call("l2i_psp_pool_bwd", g.data_ptr(), taps["aidx"].data_ptr(), taps["aw"].data_ptr(), taps["aidx"].shape[1], _p(add),
+                  dfeats.data_ptr(), B, H * W, C, taps["nb"], _stream())
+        return dfeats, None, None
+
+
+def psp_pool(feats, taps, join=None):
+    return PspPoolFn.apply(feats.contiguous(), taps, join)
+
+
+class PspExpandFn(Function):
+    """cat = [bilinear(align_corners) upsample of each stage's y] ++ feats, written once in the operand dtype of the 3x3
+    bottleneck that reads it (its gradient arrives in that dtype too): no per-stage bmm, no f32 concat, no cast pass."""
+
+    @staticmethod
+    def forward(ctx, feats, y, taps, op_dtype, join):
+        _chk(feats, torch.float32), _chk(y, torch.float32)
+        B, H, W, C = feats.shape
+        NB, F_ = y.shape[1], y.shape[2]
+        ns = taps["uidx"].shape[1]
+        assert NB == taps["nb"]
+        cat = torch.empty((B, H, W, ns * F_ + C), dtype=op_dtype, device=feats.device)
+        _lib.call("l2i_psp_expand_fwd", feats.data_ptr(), y.data_ptr(), taps["uidx"].data_ptr(), taps["uw"].data_ptr(),
+                  cat.data_ptr(), B, H * W, C, F_, NB, ns, _code(op_dtype), _stream())
+        ctx.meta = (B, H, W, C, NB, F_, ns, op_dtype, join, taps)
+        return cat
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, C, NB, F_, ns, op_dtype, join, taps = ctx.meta
+        g = _chk(g.contiguous(), op_dtype)
+        dy = torch.empty((B, NB, F_), dtype=torch.float32, device=g.device)
+        dfeats = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
+        rows = torch.empty((B, H, taps["nq"], F_), dtype=torch.float32, device=g.device)
+        _lib.call("l2i_psp_expand_bwd", g.data_ptr(), taps["uwx"].data_ptr(), taps["uwy"].data_ptr(), taps["xq"].data_ptr(),
+                  taps["qoff"].data_ptr(), dy.data_ptr(), dfeats.data_ptr(), rows.data_ptr(), B, H, C, F_, NB, taps["nq"], ns,
+                  _code(op_dtype), _stream())
+        if join is not None:
+            dfeats = join.give(dfeats)
+        return dfeats, dy, None, None, None
+
+
+def psp_expand(feats, y, taps, op_dtype, join=None):
+    """-> (B, H, W, n_stages * F + C) tensor of op_dtype that a following plain fused_conv consumes as its operand."""
+    out = PspExpandFn.apply(feats.contiguous(), y.contiguous(), taps, op_dtype, join)
+    out._l2i_raw_op = True
+    return out
 
 
 class ResizeBilinearFn(Function):

@@ -53,7 +53,15 @@ def test_flat_params_and_arena_tables_on_cpu():
     (net.s * 2).sum().backward()
     assert float(flat.grad.sum()) == 10.0          # autograd accumulated into the flat gradient view
     flat.zero_grad()
-    assert float(flat.grad.abs().sum()) == 0.0 and net.s.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.offset_of(net.s)
+    # a parameter that is not a GemmWeight's ("loose") has its .grad detached while backward runs: autograd keeps the
+    # incoming tensor (no add_ launch per parameter) and flush_loose() moves them all into the flat buffer at once
+    assert float(flat.grad.abs().sum()) == 0.0 and net.s.grad is None
+    assert net.a.weight_orig.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.offset_of(net.a.weight_orig)
+    (net.s * 3).sum().backward()
+    assert float(flat.grad.abs().sum()) == 0.0 and float(net.s.grad.sum()) == 15.0
+    flat.flush_loose()
+    assert float(flat.grad.sum()) == 15.0 and net.s.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.offset_of(net.s)
+    flat.zero_grad()
     arena = WeightArena(net, flat, "cpu", torch.bfloat16)
     assert arena.n_layers == 4 and arena.rounds == 2          # b is applied twice -> two rows, two rounds
     tab = arena.layers.view(-1, 20).numpy()

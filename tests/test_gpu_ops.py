@@ -623,6 +623,46 @@ def test_discriminator_heads_fused(dt):
             close(hh.bias.grad, sd[p + "bias"].grad, p + "db", 2e-3 if bf else 2e-5)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", [(2, 16, 8, 12), (1, 32, 128, 100)])
+def test_psp_pool_and_expand(case, dt):
+    """ops.psp_pool / ops.psp_expand == the pyramid stages of reference model/resnet_generator_app_v2.py:741-751 written
+    with nn.AdaptiveAvgPool2d and F.interpolate(bilinear, align_corners=True) on the CPU: pooled features, the concat
+    [priors..., feats] and the gradients w.r.t. feats and the stage outputs (the two feats branches joined in one launch)."""
+    from layout2img_amd import ops
+    from layout2img_amd.generator import psp_taps
+    B, H, C, Fo = case
+    sizes = (1, 2, 3, 6)
+    g = torch.Generator().manual_seed(H + C)
+    feats = torch.randn(B, H, H, C, generator=g)
+    mix = [torch.randn(C, Fo, generator=g) / C ** 0.5 for _ in sizes]   # stands in for the per-stage conv / BN / ReLU
+    gcat = torch.randn(B, H, H, len(sizes) * Fo + C, generator=g)
+
+    fr = feats.clone().requires_grad_(True)
+    fn = fr.permute(0, 3, 1, 2)
+    priors, ys_ref = [], []
+    for s, m in zip(sizes, mix):
+        pooled = F.adaptive_avg_pool2d(fn, (s, s))                                    # (B,C,s,s)
+        y = torch.relu(torch.einsum("bcij,cf->bfij", pooled, m))
+        ys_ref.append(y)
+        priors.append(F.interpolate(y, size=(H, H), mode="bilinear", align_corners=True))
+    ref = torch.cat(priors + [fn], dim=1).permute(0, 2, 3, 1)
+    (ref * _rt(gcat, dt)).sum().backward()
+
+    dev = _dev()
+    taps = psp_taps(H, sizes, dev)
+    fg = feats.to(dev).requires_grad_(True)
+    j = ops.GradJoin()
+    pooled = ops.psp_pool(fg, taps, j)
+    ys = [torch.relu(part @ m.to(dev)) for part, m in zip(pooled.split([s * s for s in sizes], dim=1), mix)]
+    cat = ops.psp_expand(fg, torch.cat(ys, dim=1), taps, dt, j)
+    assert cat.dtype == dt and cat.shape == ref.shape
+    cat.backward(gcat.to(dev).to(dt))
+    bf = dt == torch.bfloat16
+    assert float((cat.detach().float().cpu() - ref.detach()).abs().max()) < (3e-2 if bf else 1e-5) * float(ref.abs().max())
+    assert float((fg.grad.cpu() - fr.grad).abs().max()) < (1e-4 if bf else 2e-5) * float(fr.grad.abs().max())
+
+
 @pytest.mark.parametrize("case", [(3, 8, 8), (2, 8, 16), (2, 5, 32), (1, 8, 64), (2, 31, 16)])
 def test_stage_mask_matches_the_composed_torch_ops(case):
     """ops.stage_mask == reference model/resnet_generator_app_v2.py:465-470 written with torch ops on the CPU (gather,
