@@ -53,12 +53,14 @@ __global__ __launch_bounds__(256) void psp_pool_rows_kernel(const float* __restr
             for (int x0 = half * hw; x0 < (half + 1) * hw; x0 += 16) {
                 float v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = x0 + u < (half + 1) * hw ? row[(size_t)(x0 + u) * C + c] : 0.f;
+                for (int u = 0; u < 16; ++u) v[u] = row[(size_t)min(x0 + u, W - 1) * C + c];   // (unconditional loads: all 16 in flight)
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < 16; ++u) {
+                    const bool in = x0 + u < (half + 1) * hw;
 #pragma unroll
                     for (int q = 0; q < PSP_MAXQ; ++q)
-                        if (q < NQ) acc[q] = fmaf(wl[q * W + min(x0 + u, W - 1)], v[u], acc[q]);
+                        if (q < NQ) acc[q] = fmaf(in ? wl[q * W + min(x0 + u, W - 1)] : 0.f, v[u], acc[q]);
+                }
             }
         }
         if (half == 1)
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void psp_expand_rows_kernel(const T_* __restri
         const int s = col / F, j = col - s * F;
         float v[WMAX];
 #pragma unroll
-        for (int x = 0; x < WMAX; ++x) v[x] = x < W ? OpT<T_>::to(row[(size_t)x * Wd + col]) : 0.f;
+        for (int x = 0; x < WMAX; ++x) v[x] = OpT<T_>::to(row[(size_t)min(x, W - 1) * Wd + col]);   // (unconditional: a guarded load is waited for at once; columns past W get weight 0 below)
         const int q0 = qo[s], nq = qo[s + 1] - q0;
         for (int q = 0; q < nq; ++q) {
             const float* w = wl + (q0 + q) * W;
