@@ -46,13 +46,14 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
         const int tx = threadIdx.x % ncol, ty = threadIdx.x / ncol;
         float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
         if (ty < TY) {
-#pragma unroll 8
-            for (long long r = r0 + ty; r < r1; r += TY) {
-                const size_t off = (size_t)r * C + 4 * (cbase + tx);
-                const float4 v = *reinterpret_cast<const float4*>(x + off);
+            // eight rows per batch, the eight loads issued back to back (an `unroll 8` of the plain loop kept its per-row
+            // bound checks between the loads and waited for each: 1.1 TB/s), then single rows
+            const float* xc = x + 4 * (cbase + tx);
+            auto acc1 = [&](const float4 v, long long r) {
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
                 if (raw) {
+                    const size_t off = (size_t)r * C + 4 * (cbase + tx);
                     if constexpr (sizeof(T) == 2) {
                         uint2 pk;
                         pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
@@ -62,7 +63,16 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(raw) + off) = v;
                     }
                 }
+            };
+            long long r = r0 + ty;
+            for (; r + 7LL * TY < r1; r += 8LL * TY) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(xc + (size_t)(r + (long long)u * TY) * C);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc1(v[u], r + (long long)u * TY);
             }
+            for (; r < r1; r += TY) acc1(*reinterpret_cast<const float4*>(xc + (size_t)r * C), r);
         }
         __syncthreads();
         red[0][threadIdx.x] = s;

@@ -192,16 +192,31 @@ __device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, co
     // channels of one tap are then one 16-byte LDS read instead of eight 2-byte gathers (the kernel was bound by its
     // instruction count, not by HBM). W is read in its own order, four floats per lane where the run allows it.
     const bool vec = ((Ci * taps) & 3) == 0 && ((ci0 * taps) & 3) == 0 && (nrun & 3) == 0;
-    if (vec) {
-        for (int idx = threadIdx.x; idx < PK_TCO * (RUN / 4); idx += 256) {
-            const int row = idx / (RUN / 4), j = 4 * (idx - row * (RUN / 4));
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nco && j < nrun) v = *reinterpret_cast<const float4*>(W + ((size_t)(co0 + row) * Ci + ci0) * taps + j);
-            const float vv[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+    if (vec && nco > 0 && nrun > 0) {
+        // Loads in batches, every one unconditional (clamped address, value dropped afterwards): a load under a condition
+        // is waited for before the next one is issued, which made this loop 18 serial round trips to HBM.
+        constexpr int NIT = PK_TCO * (RUN / 4) / 256, BATCH = NIT / 2;
+        static_assert(PK_TCO * (RUN / 4) % 256 == 0 && NIT % 2 == 0, "tile / thread mapping");
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int jj = j + q, cil = jj / taps, tap = jj - cil * taps;
-                tile[row * RUNP + tap * TCI + cil] = OpT<T>::from(vv[q]);
+        for (int b0 = 0; b0 < NIT; b0 += BATCH) {
+            float4 v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = threadIdx.x + (b0 + u) * 256;
+                const int row = idx / (RUN / 4), j = 4 * (idx - row * (RUN / 4));
+                v[u] = *reinterpret_cast<const float4*>(W + ((size_t)(co0 + min(row, nco - 1)) * Ci + ci0) * taps + min(j, nrun - 4));
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = threadIdx.x + (b0 + u) * 256;
+                const int row = idx / (RUN / 4), j = 4 * (idx - row * (RUN / 4));
+                const float sc = (row < nco && j < nrun) ? inv : 0.f;
+                const float vv[4] = {v[u].x * sc, v[u].y * sc, v[u].z * sc, v[u].w * sc};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int jj = j + q, cil = jj / taps, tap = jj - cil * taps;
+                    tile[row * RUNP + tap * TCI + cil] = OpT<T>::from(vv[q]);
+                }
             }
         }
     } else {
