@@ -60,9 +60,15 @@ int l2i_set_conv_config(int cfg);
  * (autograd of the layers above). dy [B,Ho>>pool2,Wo>>pool2,Co] T; k order (ky,kx,ci).
  * nimg (optional DEVICE int, needs Ho*Wo % 64 == 0): the reduction covers the first *nimg images only.
  * dbias (optional, [Co] f32, +=): the bias gradient alpha * sum_m dYfull[m, co], summed from the dY tiles the kernel
- * stages anyway (no separate pass over dY). */
+ * stages anyway (no separate pass over dY).
+ * scratch (optional, caller-owned, scratch_floats f32 on the device, not shared between streams): when the pixel
+ * reduction is split over several workgroups per tile, each STORES its partial tile there and a second kernel adds the
+ * splits into dw (plain stores run at 4.5x the rate of f32 atomics); L2I_WGRAD_SCRATCH_FLOATS always suffices. Without
+ * it (or when it is too small) the partial tiles are combined by f32 atomics on dw. */
+#define L2I_WGRAD_SCRATCH_FLOATS (32LL << 20)
 int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
-                     int Co, int KH, int up2, int pool2, int ldw, float alpha, const int* nimg, float* dbias, void* stream);
+                     int Co, int KH, int up2, int pool2, int ldw, float alpha, const int* nimg, float* dbias,
+                     float* scratch, long long scratch_floats, void* stream);
 /* Tuning hook: co-resident workgroups a weight-gradient launch is sized for (0 = derive from the tile: default). */
 int l2i_set_wgrad_blocks(int n);
 /* Debug aid: co-resident workgroups per CU for conv instantiation `which` with lds_bytes of dynamic LDS. */
@@ -120,10 +126,12 @@ int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW, int C, co
                        float* s1, float* s2, float* dwproj, float* dbproj, float* dmask, float* dy_keep, float* ws,
                        void* stream);
 
-/* Backward, second pass: dx (+)= invstd * (dxhat - s1/count - xhat*s2/count). */
+/* Backward, second pass: dx (+)= invstd * (dxhat - s1/count - xhat*s2/count).
+ * dx_op_bf16 (optional, [rows][C] bf16): also receives the bf16 operand copy of the final dx -- what the backward of the
+ * convolution that produced x reads as its dY operand (saves a cast pass over dx). */
 int l2i_norm_bwd_b(const float* x, const float* dxhat, const float* sums, const float* sqsums, const float* s1,
                    const float* s2, float* dx, long long rows, int C, long long rows_per_group, float count, float eps,
-                   int accumulate, void* stream);
+                   int accumulate, void* dx_op_bf16, void* stream);
 
 /* ROIAlign (torchvision.ops.RoIAlign semantics, aligned=False) with the two-scale routing of
  * model/rcnn_discriminator_app.py:98-99,131-145; rows with valid == 0 give zeros. */

@@ -18,13 +18,13 @@ SIGNATURES = {
     "l2i_set_conv_config": [_i],
     "l2i_timing": [_i],
     "l2i_timing_read": [_i, _p, _p],
-    "l2i_conv2d_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p],
+    "l2i_conv2d_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _ll, _p],
     "l2i_weights_prepare": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p],
     "l2i_weights_backward": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "l2i_channel_stats": [_p, _ll, _i, _ll, _p, _p, _p, _i, _p, _p],
     "l2i_norm_mod_fwd": [_p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _i, _p, _p, _f, _p],
     "l2i_norm_mod_bwd_a": [_p, _p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    "l2i_norm_bwd_b": [_p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _f, _f, _i, _p],
+    "l2i_norm_bwd_b": [_p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _f, _f, _i, _p, _p],
     "l2i_roi_align_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f, _i, _p],
     "l2i_roi_align_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f, _i, _p],
     "l2i_box_attention_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
@@ -107,3 +107,19 @@ def workspace(device):
     if w is None:
         w = _WS[key] = torch.zeros(WS_FLOATS, dtype=torch.float32, device=device)
     return w.data_ptr()
+
+
+WGRAD_SCRATCH_FLOATS = 32 << 20   # L2I_WGRAD_SCRATCH_FLOATS of include/l2i.h
+_WGS = {}
+
+
+def wgrad_scratch(device):
+    """(pointer, floats) of the (device, current stream)'s scratch for the partial tiles of split weight-gradient
+    launches (l2i_conv2d_wgrad). Created on first use; GanTrainer.capture creates the ones of its streams before capturing."""
+    import torch
+    idx = torch.device(device).index
+    key = (current_device() if idx is None else idx, raw_stream())
+    w = _WGS.get(key)
+    if w is None:
+        w = _WGS[key] = torch.empty(WGRAD_SCRATCH_FLOATS, dtype=torch.float32, device=device)
+    return w.data_ptr(), WGRAD_SCRATCH_FLOATS

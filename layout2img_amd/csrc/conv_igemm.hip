@@ -41,6 +41,8 @@ struct ConvArgs {
     int PHs, sub_shift, P, SUBH, HR, HWd, halo_pieces;
     int compact;         // conv_halo3_kernel: sub-patches are whole images, no border rows are stored
     float alpha;
+    int no_epi;          // tuning (L2I_CONV_NOEPI=1, results are wrong): skip the epilogue to measure what it costs
+    int epi_lds;         // 1: coalesced epilogue through LDS (conv_epilogue_lds; default), 0: direct stores from the accumulator layout (L2I_EPI=0, A/B)
 };
 
 __device__ __forceinline__ void idx2pix(int idx, int hw_shift, int lin, int& py, int& px) {
@@ -122,6 +124,17 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvArgs& p, f32x16_t
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane,
                                               int tile_r, int tile_c, int n0, int split, int rows_total, int rows_live) {
+    if (p.no_epi) {   // (keeps the accumulators live)
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s_ += acc[i][j][e];
+        if (s_ == 1.2345e30f && p.out) p.out[0] = s_;
+        return;
+    }
     const int m = lane & 31, h = lane >> 5;
     T* __restrict__ OutOp = reinterpret_cast<T*>(p.out_op);
     T* __restrict__ OutRaw = reinterpret_cast<T*>(p.out_op_raw);
@@ -194,6 +207,126 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)
                     }
                     Op4<T>::store(OutOp + off, v);
                 }
+            }
+        }
+    }
+}
+
+// The same epilogue with COALESCED global accesses. In conv_epilogue a wave's store instruction touches 32 pixel rows
+// with 32 bytes each (the transposed accumulator gives a lane 4 consecutive channels of ONE pixel, and the 32 lanes of a
+// half-wave are 32 different pixels): in-situ ablation (L2I_CONV_NOEPI) put that epilogue at 29 % of all conv time, a
+// third of the HBM rate. Here each wave turns its 32-pixel x (32 TN)-channel slab through a private LDS patch (the ring
+// and the halo are idle by then) and reads it back pixel-major: one instruction then covers 64 / (8 TN) pixels with
+// 128 TN contiguous bytes each (f32; half of that for the bf16 copies / the ReLU mask), i.e. whole cache lines.
+// The 2x2 average pool sums the 4 LDS rows of a quad (quad-major pixel order) instead of DPP permutes.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane, int wave,
+                                                  int tile_r, int tile_c, int n0, int rows_total, int rows_live, char* smem) {
+    if (p.no_epi) {   // (keeps the accumulators live)
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s_ += acc[i][j][e];
+        if (s_ == 1.2345e30f && p.out) p.out[0] = s_;
+        return;
+    }
+    constexpr int NCH = TN * 32, LD = NCH + 4;   // floats per LDS row: +4 keeps 16-byte alignment and spreads the banks
+    constexpr int L4 = NCH / 4, PPI = 64 / L4;   // float4 groups per pixel; pixels (or quads) per wave-instruction
+    float* patch = reinterpret_cast<float*>(smem) + wave * 32 * LD;
+    T* __restrict__ OutOp = reinterpret_cast<T*>(p.out_op);
+    T* __restrict__ OutRaw = reinterpret_cast<T*>(p.out_op_raw);
+    const T* __restrict__ Mask = reinterpret_cast<const T*>(p.relu_mask);
+    const int m = lane & 31, h = lane >> 5;
+    const int cq = lane % L4, pp0 = lane / L4;
+    const int n = n0 + wcol + cq * 4;
+    const bool nv = n < p.Co;
+    float bb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && nv) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+        bb[0] = b4.x; bb[1] = b4.y; bb[2] = b4.z; bb[3] = b4.w;
+    }
+    const int wrow_s = __builtin_amdgcn_readfirstlane(wrow);
+    const size_t tile_base = ((size_t)tile_r * p.PH * p.Wo + (size_t)tile_c * p.PW) * p.Co;
+    __syncthreads();   // every wave is done reading the ring / the halo
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(patch + m * LD + j * 32 + 8 * g + 4 * h) =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        // (same wave wrote and reads: LDS operations of a wave complete in order)
+        constexpr int NIT = (32 / PPI);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (p.pool2 && it >= NIT / 4) break;   // 8 quads per 32-pixel slab
+            float v[4];
+            size_t rowoff;
+            bool live, dead;
+            if (p.pool2) {
+                const int ql = it * PPI + pp0;             // quad within the slab
+                const float* r0 = patch + (4 * ql) * LD + cq * 4;
+                const float4 a0 = *reinterpret_cast<const float4*>(r0), a1 = *reinterpret_cast<const float4*>(r0 + LD);
+                const float4 a2 = *reinterpret_cast<const float4*>(r0 + 2 * LD), a3 = *reinterpret_cast<const float4*>(r0 + 3 * LD);
+                v[0] = (a0.x + a1.x) + (a2.x + a3.x); v[1] = (a0.y + a1.y) + (a2.y + a3.y);
+                v[2] = (a0.z + a1.z) + (a2.z + a3.z); v[3] = (a0.w + a1.w) + (a2.w + a3.w);
+                const int q = (wrow + i * 32) / 4 + ql;
+                const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
+                const int r2 = tile_r * (p.PH >> 1) + qy;
+                const int Hq = p.Ho >> 1, Wq = p.Wo >> 1;
+                const int b = r2 / Hq, y2 = r2 - b * Hq, x2 = tile_c * (p.PW >> 1) + qx;
+                rowoff = ((size_t)(b * Hq + y2) * Wq + x2) * p.Co;
+                live = r2 < p.B * Hq;
+                dead = 2 * r2 >= rows_live;
+            } else {
+                const int pix = it * PPI + pp0;
+                const float4 a0 = *reinterpret_cast<const float4*>(patch + pix * LD + cq * 4);
+                v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w;
+                // pixel index = (wave-uniform base, a multiple of PPI) + pp0: the quad-major decode splits into a SCALAR part
+                // and lane constants (the per-instruction address arithmetic of this loop is what the direct form avoids)
+                const int pbase = wrow_s + i * 32 + it * PPI;
+                int py, px;
+                if (p.lin) { py = pbase + pp0; px = 0; }
+                else {
+                    const int q = (pbase >> 2) + (PPI >= 4 ? (pp0 >> 2) : 0);
+                    const int sq = PPI >= 4 ? (pp0 & 3) : ((pbase & 3) + pp0);
+                    const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
+                    py = 2 * qy + (sq >> 1);
+                    px = 2 * qx + (sq & 1);
+                }
+                const int r = tile_r * p.PH + py;
+                rowoff = tile_base + (size_t)(unsigned)((py * p.Wo + px) * p.Co);
+                live = r < rows_total;
+                dead = r >= rows_live;
+            }
+            if (!live || !nv) continue;
+            const size_t off = rowoff + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * p.alpha + bb[e];
+            if (Mask) {
+                float mk[4];
+                Op4<T>::load(Mask + off, mk);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (!(mk[e] > 0.f)) v[e] = 0.f;
+            }
+            if (p.res) {
+                const float4 rr = *reinterpret_cast<const float4*>(p.res + off);
+                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
+            if (dead) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+            if (p.out) *reinterpret_cast<float4*>(p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+            if (OutRaw) Op4<T>::store(OutRaw + off, v);
+            if (OutOp) {
+                if (p.relu_op) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                Op4<T>::store(OutOp + off, v);
             }
         }
     }
@@ -370,6 +503,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
     }
 
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
+    else if (p.epi_lds) conv_epilogue_lds<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
     else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
 }
 
@@ -637,6 +771,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {  
 #undef H2_MFMA
 #undef H2_READS
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
+    else if (p.epi_lds) conv_epilogue_lds<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
     else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
 }
 
@@ -941,6 +1076,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
 #undef H3_MM
 #undef H3_RD
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
+    else if (p.epi_lds) conv_epilogue_lds<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
     else conv_epilogue<T, TM, TN>(p, acc, wrow, 0, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
 }
 
@@ -957,7 +1093,9 @@ static int g_generic_cfg = -1;     // tuning hook (l2i_set_conv_config(3000 + n)
 template <typename T, int BM, int BN, int WM, int WN, int NS, int HK = 0>
 static int launch_cfg(ConvArgs a, hipStream_t stream) {
     constexpr int BK = Mma<T>::BK >> HK;
-    constexpr size_t lds = (size_t)NS * (BM + BN) * (HK ? 64 : 128);
+    constexpr size_t ring = (size_t)NS * (BM + BN) * (HK ? 64 : 128);
+    constexpr size_t epi = (size_t)WM * WN * 32 * (BN / WN + 4) * 4;   // conv_epilogue_lds: a 32-pixel slab per wave
+    constexpr size_t lds = ring > epi ? ring : epi;
     a.chunk_major = (a.KH == 3 && a.Ci >= BK) ? 1 : 0;
     a.nks = a.chunk_major ? 9 * ((a.Ci + BK - 1) / BK) : a.Kpad / BK;
     a.PH = BM / a.PW;
@@ -1008,8 +1146,10 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     a.HR = nsp * a.SUBH;
     a.halo_pieces = (a.HR + 7) / 8;
     if (a.halo_pieces > 7 * WM * WN) return -100;
-    const size_t lds = (size_t)(H1 ? 1 : 2) * a.halo_pieces * 1024 + (size_t)NSB * BN * 128;
+    size_t lds = (size_t)(H1 ? 1 : 2) * a.halo_pieces * 1024 + (size_t)NSB * BN * 128;
     if (lds > 160 * 1024) return -100;
+    constexpr size_t epi = (size_t)WM * WN * 32 * (BN / WN + 4) * 4;   // conv_epilogue_lds: a 32-pixel slab per wave
+    if (lds < epi) lds = epi;
     const int nchunks = (a.Ci + 63) / 64;
     a.nks = 9 * nchunks;
     const int rows = a.B * a.Ho;
@@ -1055,7 +1195,9 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     a.HR = nsp * a.SUBH;
     a.halo_pieces = (a.HR + 7) / 8;
     if (a.halo_pieces > 44) return -100;
-    const size_t lds = (size_t)a.halo_pieces * 1024 + (size_t)2 * BN * 128 + 256;
+    size_t lds = (size_t)a.halo_pieces * 1024 + (size_t)2 * BN * 128 + 256;
+    constexpr size_t epi = (size_t)4 * 32 * (BN + 4) * 4;   // conv_epilogue_lds: a 32-pixel slab of all BN channels per wave
+    if (lds < epi) lds = epi;
     const int nchunks = a.Ci / 64;
     a.nks = 9 * nchunks;
     const int rows = a.B * a.Ho;
@@ -1087,7 +1229,9 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
 }
 
 static int g_conv_cfg_override = -1;  // tuning hook (l2i_set_conv_config): -1 = heuristic
+static int g_epi_mode = -1;           // forced epilogue form (tests / tuning), -1 = default
 extern "C" int l2i_set_conv_config(int cfg) {
+    if (cfg >= 4000) { g_epi_mode = cfg == 4009 ? -1 : cfg - 4000; return L2I_OK; }   // 4000 + m: epilogue form m (see l2i_conv2d_fwd); 4009: default
     if (cfg >= 3000) { g_generic_cfg = cfg - 3000 - 1; return L2I_OK; }   // 3000 = heuristic, 3001 + n = configuration n
     if (cfg >= 2000) { g_force_splits = cfg - 2000; return L2I_OK; }   // 2000 + n: forced split count, conv_halo3 (tuning only)
     if (cfg >= 1000) { g_split_target = cfg - 1000; return L2I_OK; }   // 1000 + n: split-K target (tuning only)
@@ -1144,7 +1288,11 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         (g_conv_cfg_override < 0 || g_conv_cfg_override >= 10)) {   // (-2: tuning, single halo buffer for every 128x128 launch)
         // 128x128 tiles (two workgroups per CU, 2-stage weight ring) when they make at least one full wave of
         // workgroups; otherwise 128x64 tiles (twice the workgroups, 3-stage ring). Measured: tools/perf/conv_tune.py.
-        const long long t128h = ((M + 127) / 128) * ((a.Co + 127) / 128);
+        // ROI-head launches (device-side live-image count): only the live rows make workgroups that do work; the grid-size
+        // thresholds below are applied to an ESTIMATE of the live pixels (L2I_ROI_LIVE percent of the rows; tuning, 100 = off)
+        static const int roi_live = getenv("L2I_ROI_LIVE") ? atoi(getenv("L2I_ROI_LIVE")) : 100;
+        const long long Ml = a.nimg ? M * roi_live / 100 : M;
+        const long long t128h = ((Ml + 127) / 128) * ((a.Co + 127) / 128);
         // 128x128 tiles need >= 512 workgroups (one full wave at two per CU); with them, the double-buffered halo + 2-stage
         // ring wins on long reductions, the single halo buffer + 3-stage ring on short ones and on 8-wide maps (whose two
         // 8x8 sub-patch halos only fit twice per CU single-buffered). Measured: tools/perf/conv_tune.py + in-iteration profile.
@@ -1158,7 +1306,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // (9 / 19: their variants with the barrier inside the K-step, +2..4 % on these shapes)
         // (256x64 tiles looked 5-7 % better on the upsampling layers back to back, but lose 15-25 % to the 128x64 tiles
         //  inside the iteration: not used there)
-        if (a.Ci % 64 == 0 && a.Ci >= 512 && a.Co >= 512 && ((M + 255) / 256) * ((a.Co + 127) / 128) >= 512) hc = 9;
+        if (a.Ci % 64 == 0 && a.Ci >= 512 && a.Co >= 512 && ((Ml + 255) / 256) * ((a.Co + 127) / 128) >= 512) hc = 9;
         // (256x128 / 8-wave tiles are ~10 % faster on the 1024-channel ROI-head layers in isolation but not inside the
         //  iteration -- rocprofv3: 1.90 vs 1.77 ms for those 9 launches -- so they stay a tuning option: cfg 12)
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
@@ -1254,6 +1402,15 @@ extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, c
                               int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, void* stream) {
     if (!x || !w || (!out && !out_op && !out_op_raw)) return L2I_ERR_ARG;
     ConvArgs a;
+    static const int no_epi = getenv("L2I_CONV_NOEPI") ? atoi(getenv("L2I_CONV_NOEPI")) : 0;
+    a.no_epi = no_epi;
+    // Epilogue form. 2 (default): conv_epilogue_lds for every launch; 1: only when the epilogue touches operand-dtype
+    // tensors (ReLU mask, operand copies); 0: direct stores from the accumulator layout. Same-box A/B of the training
+    // iteration: 25.4 ms (0), 25.0-25.2 (1), 24.3-24.9 (2). (Delaying every second workgroup of a CU so that one stores while
+    // the other multiplies was tried as well, with s_sleep at kernel start: it only adds the delay to the launch.)
+    static const int epi_env = getenv("L2I_EPI") ? atoi(getenv("L2I_EPI")) : 2;
+    const int epi_mode = g_epi_mode >= 0 ? g_epi_mode : epi_env;
+    a.epi_lds = epi_mode == 2 || (epi_mode == 1 && (relu_mask != nullptr || out_op != nullptr || out_op_raw != nullptr));
     a.nimg = nimg;
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out; a.out_op = out_op; a.out_op_raw = out_op_raw; a.relu_mask = relu_mask;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;

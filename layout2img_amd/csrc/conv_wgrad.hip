@@ -14,6 +14,7 @@
 // EPG 16-byte rows [channel][pixel0..] into LDS; after that the LDS image and
 // the MFMA loop are the same as the forward kernel's. The pixel reduction is
 // split over `splits` workgroups per output tile, combined by f32 atomics.
+#include <stdlib.h>
 #include "igemm.h"
 
 struct WgradArgs {
@@ -26,6 +27,9 @@ struct WgradArgs {
     unsigned x_bytes, dy_bytes;   // buffer-descriptor ranges of x and dy
     const int* nimg;              // device int (optional): reduce over the first *nimg images only
     float* dbias;                 // optional [Co]: += alpha * sum_m dYfull[m, co] (the bias gradient), by the tile_k == 0 workgroups
+    int no_epi;                   // tuning (L2I_WGRAD_NOEPI=1, results are wrong): skip the atomic epilogue to measure what it costs
+    float* part;                  // optional scratch: every workgroup STORES its partial tile there ([tile][split][BMO][128] f32) and
+                                  // wgrad_reduce_kernel adds the splits into dw -- instead of one f32 atomic per element and split
 };
 
 // The reduction range [m_begin, m_end) of one split. With a device-side image count the live pixels are divided over
@@ -493,7 +497,30 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_dma_kernel(WgradArgs p,
         }
     }
 
+    if (p.no_epi) {   // (keeps the accumulators live)
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s_ += acc[i][j][e];
+        if (s_ == 1.2345e30f) p.dw[0] = s_;
+        return;
+    }
     const int c = lane & 31, h = lane >> 5;
+    if (p.part) {   // plain stores of the whole tile (128-byte runs; dead splits store their zeros): measured 5.8 TB/s against
+                    // 1.3 TB/s for the same pattern of f32 atomics (tools/perf/t_atomic.hip)
+        float* t = p.part + ((size_t)(tile_co * p.tiles_k + tile_k) * p.splits + split) * (size_t)(BMO * BNK);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    t[(wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BNK + wcol + j * 32 + c] = acc[i][j][e];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -506,6 +533,41 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_dma_kernel(WgradArgs p,
                 if (row < p.Co) atomicAdd(p.dw + (size_t)row * p.ldw + col, p.alpha * acc[i][j][e]);
             }
         }
+}
+
+// dw[row][col] += alpha * sum over splits of the partial tiles stored by conv_wgrad_dma_kernel (WgradArgs::part).
+// One thread per float4 of a tile row; a layer's dw slice is written by one launch at a time (same stream), so the
+// read-modify-write needs no atomics.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int BMO, int tiles_k,
+                                                           int ntiles, int splits, int Co, int K, int ldw, float alpha) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = (int)(gid & 31);
+    const long long rr = gid >> 5;
+    const int r = (int)(rr % BMO), tile = (int)(rr / BMO);
+    if (tile >= ntiles) return;
+    const int tile_k = tile % tiles_k, tile_co = tile / tiles_k;
+    const int row = tile_co * BMO + r, col = tile_k * 128 + c4 * 4;
+    if (row >= Co || col >= K) return;
+    const size_t tsz = (size_t)BMO * 128;
+    const float* src = part + (size_t)tile * splits * tsz + (size_t)r * 128 + c4 * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)s * tsz);
+        const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(s + 1) * tsz);
+        const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(s + 2) * tsz);
+        const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(s + 3) * tsz);
+        a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+        a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < splits; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)s * tsz);
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    }
+    float4* d = reinterpret_cast<float4*>(dw + (size_t)row * ldw + col);
+    float4 o = *d;
+    o.x += alpha * a.x; o.y += alpha * a.y; o.z += alpha * a.z; o.w += alpha * a.w;
+    *d = o;
 }
 
 static int g_wgrad_blocks = 0;   // tuning hook l2i_set_wgrad_blocks: workgroups per wave of the grid (0 = from the tile's occupancy)
@@ -522,7 +584,7 @@ extern "C" int l2i_set_wgrad_blocks(int n) {
 }
 
 template <typename T>
-static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
+static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long long scratch_floats) {
     constexpr int BK = Mma<T>::BK;
     constexpr int EPG = OpT<T>::EPG;
     if (a.KH != 1 && a.KH != 3) return L2I_ERR_ARG;
@@ -561,7 +623,10 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
         if (xb >= 0x80000000ull || yb >= 0x80000000ull) return L2I_ERR_ARG;   // 32-bit buffer offsets
         a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     }
+    a.part = nullptr;
     if (sizeof(T) == 2 && pow2) {  // bf16: LDS-DMA + transposing-read kernel
+        static const int use_part = getenv("L2I_WGRAD_PART") ? atoi(getenv("L2I_WGRAD_PART")) : 1;   // (0: atomics, A/B)
+        if (use_part && scratch && a.splits > 1 && (long long)nblk * BMO * 128 <= scratch_floats) a.part = scratch;
         int lgW = 0, lgH = 0;
         while ((1 << lgW) < a.Wo) ++lgW;
         while ((1 << lgH) < a.Ho) ++lgH;
@@ -582,6 +647,11 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
             else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
             else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
         }
+        if (a.part) {
+            const long long nthr = (long long)tiles * BMO * 32;
+            L2I_LAUNCH(1, wgrad_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
+                       a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha);
+        }
         return l2i_check_launch();
     }
     const size_t lds = (size_t)(BMO + 128) * IG_ROWB;
@@ -594,16 +664,18 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream) {
 
 extern "C" int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
                                 int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
-                                const int* nimg, float* dbias, void* stream) {
+                                const int* nimg, float* dbias, float* scratch, long long scratch_floats, void* stream) {
     if (!x || !dy || !dw) return L2I_ERR_ARG;
     if (nimg && (Ho * Wo) % 64) return L2I_ERR_ARG;
     WgradArgs a;
+    static const int no_epi = getenv("L2I_WGRAD_NOEPI") ? atoi(getenv("L2I_WGRAD_NOEPI")) : 0;
+    a.no_epi = no_epi;
     a.nimg = nimg;
     a.dbias = dbias;
     a.x = x; a.dy = dy; a.dw = dw;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.ldw = ldw; a.alpha = alpha;
-    if (dtype == 0) return launch_wgrad<float>(a, (hipStream_t)stream);
-    if (dtype == 1) return launch_wgrad<bf16_t>(a, (hipStream_t)stream);
+    if (dtype == 0) return launch_wgrad<float>(a, (hipStream_t)stream, scratch, scratch_floats);
+    if (dtype == 1) return launch_wgrad<bf16_t>(a, (hipStream_t)stream, scratch, scratch_floats);
     return L2I_ERR_ARG;
 }

@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void norm_bwd_b_kernel(const float* __restrict
                                                          const float* __restrict__ sums, const float* __restrict__ sqsums,
                                                          const float* __restrict__ s1, const float* __restrict__ s2,
                                                          float* __restrict__ dx, long long rows, int C, long long rows_per_group,
-                                                         float count, float eps, int accumulate) {
+                                                         float count, float eps, int accumulate, bf16_t* __restrict__ dx_op) {
     const int cols4 = C >> 2;
     const long long total = rows * cols4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -906,17 +906,21 @@ __global__ __launch_bounds__(256) void norm_bwd_b_kernel(const float* __restrict
             o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
         }
         *dst = o;
+        if (dx_op) {   // the bf16 operand copy of dx the producing convolution's backward reads (instead of a cast pass over dx)
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+            Op4<bf16_t>::store(dx_op + r * C + c, ov);
+        }
     }
 }
 
 extern "C" int l2i_norm_bwd_b(const float* x, const float* dxhat, const float* sums, const float* sqsums, const float* s1,
                               const float* s2, float* dx, long long rows, int C, long long rows_per_group, float count,
-                              float eps, int accumulate, void* stream) {
+                              float eps, int accumulate, void* dx_op_bf16, void* stream) {
     if (!x || !dxhat || !sums || !sqsums || !s1 || !s2 || !dx || C % 4 || rows_per_group <= 0) return L2I_ERR_ARG;
     const long long total = rows * (C / 4);
     long long nblk = (total + 255) / 256;
     if (nblk > 4096) nblk = 4096;
     hipLaunchKernelGGL(norm_bwd_b_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, dxhat, sums, sqsums, s1,
-                       s2, dx, rows, C, rows_per_group, count, eps, accumulate);
+                       s2, dx, rows, C, rows_per_group, count, eps, accumulate, reinterpret_cast<bf16_t*>(dx_op_bf16));
     return l2i_check_launch();
 }

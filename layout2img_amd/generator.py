@@ -225,7 +225,7 @@ class ConvMaskHead(nn.ModuleList):
         conv, bn, _, out = self
         h = fused_conv(x, conv, pc)
         spec, w, b = bn.spec(self.training, sync, conv.co_p)
-        m = fused_conv(h, out, pc, prologue=spec, wproj=w, bproj=b)
+        m = fused_conv(h, out, pc, prologue=spec, wproj=w, bproj=b, dx_raw=True)   # (h has this one reader: its gradient's operand copy comes out of the norm backward)
         bn.commit(conv.co_p)
         return m
 
@@ -261,7 +261,7 @@ class ResBlock(nn.Module):
         sc = fused_conv(x, self.c_sc, pc, up2=up, join=(j, "give")) if self.learnable_sc else x
         gw2, gb2 = self.b2.project(w, pc, B, O)
         out = fused_conv(h, self.conv2, pc, prologue=self.b2.spec(self.training, sync),
-                         mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc, emit=emit)
+                         mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc, emit=emit, dx_raw=True)
         self.b1.batch_norm2d.commit()
         self.b2.batch_norm2d.commit()
         m = self.conv_mask(out, pc, sync) if self.predict_mask else None
@@ -377,7 +377,7 @@ class MaskRegressNetv2(nn.Module):
             a = torch.matmul(resample_matrix("bilinear", size // 2, size, a.device), a.view(N, -1, self.ch)).view(N, size, size, self.ch)
             h = fused_conv(a, blk[0], pc)
         spec, wa, ba = self._spec(self.conv3, sync)
-        m = fused_conv(h, self.conv3[3], pc, prologue=spec, wproj=wa, bproj=ba)[..., 0]
+        m = fused_conv(h, self.conv3[3], pc, prologue=spec, wproj=wa, bproj=ba, dx_raw=True)[..., 0]
         if not self.instance:
             self.conv3[1].commit()
         m = torch.sigmoid(m).view(b, o, self.mask_size, self.mask_size)

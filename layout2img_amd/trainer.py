@@ -162,6 +162,7 @@ class GanTrainer:
             if s_ is not None:
                 with torch.cuda.stream(s_):
                     _lib.workspace(real.device)
+                    _lib.wgrad_scratch(real.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(2):

@@ -62,6 +62,16 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=[0, 2], ids=["epi_direct", "epi_lds"])
+def epi(request):
+    """Both forms of the convolution epilogue (tuning hook 4000 + m: 0 direct stores from the accumulator layout, 2 the
+    coalesced form through LDS, the default)."""
+    from layout2img_amd import _lib
+    _lib.call("l2i_set_conv_config", 4000 + request.param)
+    yield request.param
+    _lib.call("l2i_set_conv_config", 4009)
+
+
 def _ref_conv(x_nhwc, w, bias, up2, pool2):
     x = x_nhwc.permute(0, 3, 1, 2)
     if up2:
@@ -74,7 +84,7 @@ def _ref_conv(x_nhwc, w, bias, up2, pool2):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_forward(case, dt):
+def test_conv_forward(case, dt, epi):
     from layout2img_amd import ops
     B, H, W, Ci, Co, KH, up2, pool2 = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
@@ -123,9 +133,10 @@ def test_conv_split_k(case, dt):
                                   (7, 8, 8, 128, 136, 3, False, False), (6, 4, 4, 64, 64, 3, True, False),
                                   (1, 32, 32, 64, 200, 3, True, True), (2, 64, 64, 64, 64, 3, False, True),
                                   (3, 8, 8, 128, 128, 3, True, False), (1, 128, 128, 64, 64, 3, False, False)])
-def test_conv_halo_tiles(case, cfg):
+def test_conv_halo_tiles(case, cfg, epi):
     """every tile shape of the halo kernels (128x128, 128x64, 256x128; 17 / 18: the 256-pixel-tile kernel with its
-    bordered and compact halos) on every geometry, forced through the tuning hook"""
+    bordered and compact halos) on every geometry, forced through the tuning hook -- with both forms of the epilogue
+    (epi 0: direct stores from the accumulator layout, 2: the coalesced form through LDS; hook 4000 + epi)"""
     from layout2img_amd import ops, _lib
     B, H, W, Ci, Co, KH, up2, pool2 = case
     dt = torch.bfloat16
@@ -146,7 +157,7 @@ def test_conv_halo_tiles(case, cfg):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_conv_relu_mask(dt):
+def test_conv_relu_mask(dt, epi):
     from layout2img_amd import ops
     g = torch.Generator().manual_seed(3)
     x = _rt(torch.randn(2, 8, 8, 16, generator=g), dt)
@@ -159,10 +170,15 @@ def test_conv_relu_mask(dt):
     assert float((out.cpu() - expect).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("combine", ["scratch", "atomics"])
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_wgrad(case, dt):
-    from layout2img_amd import ops
+def test_conv_wgrad(case, dt, combine, monkeypatch):
+    """combine: how the partial tiles of a split pixel reduction reach dw -- stored to the caller's scratch and added by
+    a second kernel (the default), or f32 atomics on dw (no scratch given); dw starts non-zero (it is accumulated into)"""
+    from layout2img_amd import ops, _lib
+    if combine == "atomics":
+        monkeypatch.setattr(_lib, "wgrad_scratch", lambda device: (None, 0))
     B, H, W, Ci, Co, KH, up2, pool2 = case
     if Co % 8:
         pytest.skip("operand channels are padded to 8 by the caller")
@@ -174,10 +190,11 @@ def test_conv_wgrad(case, dt):
     y.backward(dy)
     ref = w.grad.permute(0, 2, 3, 1).reshape(Co, -1)
     K = KH * KH * Ci
-    dw = torch.zeros(Co, K, device=_dev())
+    dw0 = torch.randn(Co, K, generator=g)
+    dw = dw0.to(_dev())
     ops.wgrad_raw(x.to(_dev(), dt), dy.to(_dev(), dt), dw, K, Co, KH, up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0)
     scale = float(ref.abs().max())
-    assert float((dw.cpu() - ref).abs().max()) < 5e-5 * scale + 1e-5
+    assert float((dw.cpu() - dw0 - ref).abs().max()) < 5e-5 * scale + 1e-5
 
 
 class _Net(nn.Module):
@@ -702,7 +719,7 @@ def test_stage_mask_matches_the_composed_torch_ops(case):
 @pytest.mark.parametrize("n_live", [0, 3, 9, 20])
 @pytest.mark.parametrize("case", [(20, 8, 8, 64, 136, 3, False, False), (20, 8, 8, 128, 64, 3, False, True),
                                   (20, 8, 8, 72, 128, 1, False, True), (20, 8, 8, 16, 40, 3, False, False)])
-def test_conv_device_side_image_count(case, n_live):
+def test_conv_device_side_image_count(case, n_live, epi):
     """`nimg`: the ROI heads run over the first *nimg images only (device-side count, fixed launch shape): live images
     equal the full convolution, every row of a dead image is exactly zero -- forward/dgrad kernel (halo and generic
     tiles, pooled and not) and weight gradient."""
