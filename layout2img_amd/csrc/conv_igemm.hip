@@ -41,6 +41,7 @@ struct ConvArgs {
     int PHs, sub_shift, P, SUBH, HR, HWd, halo_pieces;
     int compact;         // conv_halo3_kernel: sub-patches are whole images, no border rows are stored
     float alpha;
+    int roi_remap;       // tuning (L2I_ROI_REMAP=1): keep the XCD remap on launches with a live-image count (A/B)
     int no_epi;          // tuning (L2I_CONV_NOEPI=1, results are wrong): skip the epilogue to measure what it costs
     int epi_lds;         // 1: coalesced epilogue through LDS (conv_epilogue_lds; default), 0: direct stores from the accumulator layout (L2I_EPI=0, A/B)
 };
@@ -359,7 +360,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = p.tiles_m * p.tiles_n;
     const int split = blockIdx.x / nblk;
-    const int bid = xcd_remap(blockIdx.x - split * nblk, nblk);
+    // (ROI heads: the live rows are compacted to the FRONT, so the contiguous-run-per-XCD remap would give all live tiles
+    //  to the first XCDs and leave the others idle; the dispatcher's own round robin spreads them evenly)
+    const int bid = (p.nimg && !p.roi_remap) ? (int)blockIdx.x - split * nblk : xcd_remap(blockIdx.x - split * nblk, nblk);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
     const int n0 = tile_n * BN;
@@ -559,7 +562,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {  
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int nblk = p.tiles_m * p.tiles_n;
     const int split = blockIdx.x / nblk;
-    const int bid = xcd_remap(blockIdx.x - split * nblk, nblk);
+    // (ROI heads: the live rows are compacted to the FRONT, so the contiguous-run-per-XCD remap would give all live tiles
+    //  to the first XCDs and leave the others idle; the dispatcher's own round robin spreads them evenly)
+    const int bid = (p.nimg && !p.roi_remap) ? (int)blockIdx.x - split * nblk : xcd_remap(blockIdx.x - split * nblk, nblk);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
     const int n0 = tile_n * BN;
@@ -804,7 +809,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int nblk = p.tiles_m * p.tiles_n;
     const int split = blockIdx.x / nblk;
-    const int bid = xcd_remap(blockIdx.x - split * nblk, nblk);
+    // (ROI heads: the live rows are compacted to the FRONT, so the contiguous-run-per-XCD remap would give all live tiles
+    //  to the first XCDs and leave the others idle; the dispatcher's own round robin spreads them evenly)
+    const int bid = (p.nimg && !p.roi_remap) ? (int)blockIdx.x - split * nblk : xcd_remap(blockIdx.x - split * nblk, nblk);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
     const int n0 = tile_n * BN;
@@ -1404,6 +1411,8 @@ extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, c
     ConvArgs a;
     static const int no_epi = getenv("L2I_CONV_NOEPI") ? atoi(getenv("L2I_CONV_NOEPI")) : 0;
     a.no_epi = no_epi;
+    static const int roi_remap = getenv("L2I_ROI_REMAP") ? atoi(getenv("L2I_ROI_REMAP")) : 0;
+    a.roi_remap = roi_remap;
     // Epilogue form. 2 (default): conv_epilogue_lds for every launch; 1: only when the epilogue touches operand-dtype
     // tensors (ReLU mask, operand copies); 0: direct stores from the accumulator layout. Same-box A/B of the training
     // iteration: 25.4 ms (0), 25.0-25.2 (1), 24.3-24.9 (2). (Delaying every second workgroup of a CU so that one stores while

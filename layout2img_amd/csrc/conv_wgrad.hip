@@ -28,6 +28,7 @@ struct WgradArgs {
     const int* nimg;              // device int (optional): reduce over the first *nimg images only
     float* dbias;                 // optional [Co]: += alpha * sum_m dYfull[m, co] (the bias gradient), by the tile_k == 0 workgroups
     int no_epi;                   // tuning (L2I_WGRAD_NOEPI=1, results are wrong): skip the atomic epilogue to measure what it costs
+    int lgbk;                     // log2 of the kernel's pixel step (6; 7 for the eight-wave kernel)
     float* part;                  // optional scratch: every workgroup STORES its partial tile there ([tile][split][BMO][128] f32) and
                                   // wgrad_reduce_kernel adds the splits into dw -- instead of one f32 atomic per element and split
 };
@@ -38,8 +39,8 @@ __device__ __forceinline__ void wgrad_range(const WgradArgs& p, int split, int& 
     int M = p.M, Mper = p.Mper;
     if (p.nimg) {
         M = min(M, *p.nimg * p.Ho * p.Wo);
-        const int steps = (M + 63) >> 6;
-        Mper = ((steps + p.splits - 1) / p.splits) << 6;
+        const int steps = (M + (1 << p.lgbk) - 1) >> p.lgbk;
+        Mper = ((steps + p.splits - 1) / p.splits) << p.lgbk;
     }
     m_begin = split * Mper;
     m_end = min(M, m_begin + Mper);
@@ -252,14 +253,19 @@ __device__ __forceinline__ bf16x8_t wg_frag(const char* tile, int pixbase, int c
 // NW = 2: two waves side by side, each BMO x 64 (a wave then reads 12 KB of LDS per 16 MFMAs instead of 16 KB: the
 //   transposing reads, not the MFMAs, bound the 2 x 2 form), 32-pixel steps so that twice as many workgroups fit a CU
 //   and the waves per SIMD stay the same. Either way a wave stages 16 pixel rows per step.
+// NW = 8: TWO groups of four waves in one workgroup (one workgroup per CU, the same two waves per SIMD). A step is 128
+//   pixels; group g multiplies pixels [64 g, 64 g + 64) of it into its own accumulators, and at the end group 1 hands its
+//   tile to group 0 through LDS. Half as many partial tiles leave the chip for the same occupancy: combining the
+//   splits (stores + wgrad_reduce_kernel, or atomics) is what a weight-gradient launch pays per resident wave.
 template <int BMO, int MODE, int NW = 4>
-__global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_dma_kernel(WgradArgs p, int lgW, int lgH) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kernel(WgradArgs p, int lgW, int lgH) {
     constexpr bool FAST = MODE == 1, SEMI = MODE == 2;
-    constexpr int BNK = 128, BK = 16 * NW, NT = 64 * NW, LGBK = NW == 4 ? 6 : 5;
+    constexpr int BNK = 128, BK = 16 * NW, NT = 64 * NW, LGBK = NW == 8 ? 7 : (NW == 4 ? 6 : 5);
     constexpr int RSA = BMO * 2, RSB = BNK * 2;
-    constexpr int WM = NW == 4 ? 2 : 1;          // waves along the channel (row) dimension of the tile
+    constexpr int WM = NW >= 4 ? 2 : 1;          // waves along the channel (row) dimension of the tile (of a group)
     constexpr int TM = BMO / (32 * WM), TN = 2;
     constexpr int STAGE = BK * (RSA + RSB);
+    constexpr int KS16 = (NW == 8 ? 64 : BK) / 16;   // k16 sub-steps a wave multiplies per step (its group's 64 pixels)
     constexpr int A_ROWS = 1024 / RSA;           // pixel rows per wave-instruction (4 | 8)
     constexpr int A_Q = 16 / A_ROWS;             // A instructions per wave per step (4 | 2)
     constexpr int A_CH = RSA / 16;               // 16-byte chunks per A row (16 | 8)
@@ -385,13 +391,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_dma_kernel(WgradArgs p,
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int wrow = NW == 4 ? (wave >> 1) * (BMO / 2) : 0, wcol = (NW == 4 ? (wave & 1) : wave) * 64;
+    const int grp = NW == 8 ? (wave >> 2) : 0, wq = NW == 8 ? (wave & 3) : wave;   // pixel group, position within the group
+    const int wrow = NW >= 4 ? (wq >> 1) * (BMO / 2) : 0, wcol = (NW >= 4 ? (wq & 1) : wq) * 64;
     // fragment read addresses (stage-relative): piece (row 8h + (t>>2), 4-channel block) of the k16 sub-step 0, r = 0;
     // sub-step kk adds 16 rows and r adds 4 rows -- neither changes the row's swizzle, so they are immediates
     unsigned fa_addr[TM], fb_addr[TN];
     {
         const int t = lane & 15, cb = ((lane >> 4) & 1) * 16, h = lane >> 5;
-        const int prow0 = 8 * h + (t >> 2);
+        const int prow0 = 64 * grp + 8 * h + (t >> 2);   // (64 rows: the swizzle of a row is unchanged)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int ch = wrow + i * 32 + cb + (t & 3) * 4;
@@ -429,15 +436,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_dma_kernel(WgradArgs p,
 #define WG_TR(ADDR) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)((__attribute__((address_space(3))) char*)smem + (ADDR)))
 #define WG_STEP(STG)                                                                                                  \
     {                                                                                                                 \
-        s16x4_t ra[BK / 16][TM][2], rb[BK / 16][TN][2];                                                               \
-        _Pragma("unroll") for (int kk = 0; kk < BK / 16; ++kk) {                                                            \
+        s16x4_t ra[KS16][TM][2], rb[KS16][TN][2];                                                               \
+        _Pragma("unroll") for (int kk = 0; kk < KS16; ++kk) {                                                            \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int r = 0; r < 2; ++r)              \
                 ra[kk][i][r] = WG_TR(fa_addr[i] + (STG) * STAGE + (kk * 16 + 4 * r) * RSA);                           \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int r = 0; r < 2; ++r)              \
                 rb[kk][j][r] = WG_TR(fb_addr[j] + (STG) * STAGE + (kk * 16 + 4 * r) * RSB);                           \
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
-        _Pragma("unroll") for (int kk = 0; kk < BK / 16; ++kk)                                                        \
+        _Pragma("unroll") for (int kk = 0; kk < KS16; ++kk)                                                        \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {           \
                 bf16x8_t fa, fb;                                                                                      \
                 fa[0] = ra[kk][i][0][0]; fa[1] = ra[kk][i][0][1]; fa[2] = ra[kk][i][0][2]; fa[3] = ra[kk][i][0][3];   \
@@ -491,10 +498,31 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_dma_kernel(WgradArgs p,
         }
         __syncthreads();
         if (tid < BMO) {
-            float v = red[tid] + red[BMO + tid];
-            if (NW == 4) v += red[2 * BMO + tid] + red[3 * BMO + tid];
+            float v = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < NW; ++w_) v += red[w_ * BMO + tid];
             if (co0 + tid < p.Co && v != 0.f) atomicAdd(p.dbias + co0 + tid, p.alpha * v);
         }
+    }
+    if (NW == 8) {   // group 1 hands its tile to group 0: [wave of the group][register][lane] f32, 64 KB
+        float* xch = reinterpret_cast<float*>(smem);
+        __syncthreads();   // every wave is done with the stages (and with the bias scratch)
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) xch[((wq * TM * TN + i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += xch[((wq * TM * TN + i * TN + j) * 16 + e) * 64 + lane];
     }
 
     if (p.no_epi) {   // (keeps the accumulators live)
@@ -599,13 +627,21 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
     a.tiles_co = (a.Co + BMO - 1) / BMO;
     a.tiles_k = (a.K + 127) / 128;
     const int tiles = a.tiles_co * a.tiles_k;
-    const int steps = (a.M + BK - 1) / BK;
+    const bool pow2 = !(a.Ho & (a.Ho - 1)) && !(a.Wo & (a.Wo - 1));
+    // eight-wave / two-group kernel (128-pixel steps): bf16, 128-row tiles, whole steps, and -- with pool / upsample -- steps
+    // that stay inside one image
+    static const int nw8_env = getenv("L2I_WGRAD_NW8") ? atoi(getenv("L2I_WGRAD_NW8")) : 0;   // measured: 25.04 vs 24.86 ms per iteration with it ON (the reduce
+    // kernels gain 0.15 ms, the eight-wave main loops lose 0.55 ms): a tuning option, off by default
+    const bool nw8 = nw8_env && g_wgrad_nw2 != 1 && BMO == 128 && sizeof(T) == 2 && pow2 && a.M % 128 == 0 &&
+                     ((!a.pool2 && !a.up2) || (a.Ho * a.Wo) % 128 == 0) && (!a.nimg || (a.Ho * a.Wo) % 128 == 0);   // (live pixels: whole steps)
+    const int SBK = nw8 ? 128 : BK;   // pixels per step of the kernel that will run
+    a.lgbk = nw8 ? 7 : 6;
+    const int steps = (a.M + SBK - 1) / SBK;
     // Split the pixel (reduction) dimension so that the grid is ONE full wave of co-resident workgroups (2 per CU for
     // the 128-row tile, 3 for the 64-row one: LDS-limited) -- every extra split costs Co*K atomics, and a grid of 1.1-1.9
     // waves leaves half the chip idle in its second round. Tile counts too large for that go to >= 3 waves instead.
-    const bool pow2 = !(a.Ho & (a.Ho - 1)) && !(a.Wo & (a.Wo - 1));
     const bool nw2 = BMO == 128 && sizeof(T) == 2 && pow2 && (g_wgrad_nw2 < 0 ? false : g_wgrad_nw2 == 1);
-    const int cap = g_wgrad_blocks > 0 ? g_wgrad_blocks : (BMO == 64 ? 768 : (nw2 ? 1024 : 512));
+    const int cap = g_wgrad_blocks > 0 ? g_wgrad_blocks : (BMO == 64 ? 768 : (nw2 ? 1024 : (nw8 ? 256 : 512)));
     int splits = cap / tiles;
     if (splits < 1 || (long long)splits * tiles * 5 < (long long)cap * 4) {
         splits = (3 * cap + tiles - 1) / tiles;
@@ -614,7 +650,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
     if (splits > steps / 4) splits = steps / 4;
     if (splits < 1) splits = 1;
     int per = (steps + splits - 1) / splits;
-    a.Mper = per * BK;
+    a.Mper = per * SBK;
     a.splits = (a.M + a.Mper - 1) / a.Mper;
     const int nblk = tiles * a.splits;
     {
@@ -637,6 +673,16 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 1>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
             else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
             else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+        } else if (nw8) {
+            const size_t lds8 = (size_t)2 * 128 * (BMO * 2 + 256);   // 128 KB: one workgroup per CU
+            static bool ready8 = false;
+            if (!ready8) {
+                (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<128, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+                (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<128, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+                ready8 = true;
+            }
+            if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 1, 8>), dim3(nblk), dim3(512), lds8, stream, a, lgW, lgH);
+            else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 2, 8>), dim3(nblk), dim3(512), lds8, stream, a, lgW, lgH);
         } else if (nw2) {
             const size_t lds1 = (size_t)2 * 32 * (BMO * 2 + 256);
             if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 1, 2>), dim3(nblk), dim3(128), lds1, stream, a, lgW, lgH);

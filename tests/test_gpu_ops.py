@@ -170,9 +170,15 @@ def test_conv_relu_mask(dt, epi):
     assert float((out.cpu() - expect).abs().max()) < 1e-4
 
 
+# shapes of the eight-wave / two-group weight-gradient kernel (128-pixel steps): 8x8 images inside a step, upsample, pool,
+# an odd number of steps per split, a 1x1 layer
+WGRAD_EXTRA = [(4, 8, 8, 64, 128, 3, False, False), (2, 16, 16, 64, 136, 3, True, False), (2, 16, 16, 64, 128, 3, False, True),
+               (6, 16, 16, 72, 264, 3, False, False), (3, 32, 32, 64, 128, 1, False, False), (2, 64, 64, 16, 136, 3, False, True)]
+
+
 @pytest.mark.parametrize("combine", ["scratch", "atomics"])
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("case", CONV_CASES + WGRAD_EXTRA)
 def test_conv_wgrad(case, dt, combine, monkeypatch):
     """combine: how the partial tiles of a split pixel reduction reach dw -- stored to the caller's scratch and added by
     a second kernel (the default), or f32 atomics on dw (no scratch given); dw starts non-zero (it is accumulated into)"""
