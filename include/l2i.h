@@ -40,10 +40,15 @@ int l2i_version(void);
  * nimg (optional DEVICE int): only the first *nimg of the B images are live -- workgroups whose rows all belong to
  * later images skip the reduction, and every row of a later image is written as zeros. This is how the ROI heads of the
  * discriminator (model/rcnn_discriminator_app.py:148-166) run over the batch's real ROIs only while the launch keeps
- * the fixed, host-sync-free shape R = b*o: ROIs are compacted to the front (reference order, :145-146, 413-417). */
+ * the fixed, host-sync-free shape R = b*o: ROIs are compacted to the front (reference order, :145-146, 413-417).
+ * stats (optional, [2][Co] f32, ZEROED by the caller, needs `out`, Co % 4 == 0 and ws = the stream's all-zero workspace of
+ * L2I_WS_FLOATS floats, see l2i_channel_stats): += per-channel sum and sum of squares of `out` over all pixels -- the
+ * batch statistics of a following normalisation (model/norm_module.py:163, sync_batchnorm/batchnorm.py:77-88), gathered by
+ * the epilogue instead of a separate pass over `out`. */
 int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float* res, const void* relu_mask,
                    float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
-                   int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, void* stream);
+                   int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats,
+                   float* ws, void* stream);
 
 /* Per-launch timing of the two MFMA entry points (bench.py's roofline leg). l2i_timing(1): from now on every kernel
  * launched by l2i_conv2d_fwd (class 0) / l2i_conv2d_wgrad (class 1) carries a start / stop HIP event pair attached to

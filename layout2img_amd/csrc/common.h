@@ -92,6 +92,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // again. (An in-kernel "last workgroup folds" needs an agent-scope release per workgroup, which writes the dirty L2
 // back each time: measured 2x slower than the plain atomics.) Layout: ws[r*L + i] = replica r of value i.
 #define L2I_WS_R 32
+#ifndef L2I_WS_FLOATS
+#define L2I_WS_FLOATS (32 * 4 * 1024)   // include/l2i.h
+#endif
 __device__ __forceinline__ float* ws_replica(float* ws, int r, int L) { return ws + (size_t)r * L; }
 
 // value i = row k (= i / C) x channel: added to dst[k][i % C]

@@ -41,6 +41,8 @@ struct ConvArgs {
     int PHs, sub_shift, P, SUBH, HR, HWd, halo_pieces;
     int compact;         // conv_halo3_kernel: sub-patches are whole images, no border rows are stored
     float alpha;
+    float* stat_ws;      // optional: the stream's replicated workspace (common.h) -- the epilogue adds every channel's sum and sum of squares
+                         // of the f32 result there (what the batch-norm layer reading this result needs: no separate pass over it)
     int roi_remap;       // tuning (L2I_ROI_REMAP=1): keep the XCD remap on launches with a live-image count (A/B)
     int no_epi;          // tuning (L2I_CONV_NOEPI=1, results are wrong): skip the epilogue to measure what it costs
     int epi_lds;         // 1: coalesced epilogue through LDS (conv_epilogue_lds; default), 0: direct stores from the accumulator layout (L2I_EPI=0, A/B)
@@ -249,6 +251,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
         const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
         bb[0] = b4.x; bb[1] = b4.y; bb[2] = b4.z; bb[3] = b4.w;
     }
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};   // per-channel statistics of this lane's pixels (stat_ws)
     const int wrow_s = __builtin_amdgcn_readfirstlane(wrow);
     const size_t tile_base = ((size_t)tile_r * p.PH * p.Wo + (size_t)tile_c * p.PW) * p.Co;
     __syncthreads();   // every wave is done reading the ring / the halo
@@ -320,6 +323,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
                 v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
             }
             if (dead) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+            if (p.stat_ws) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] = fmaf(v[e], v[e], ssq[e]); }
+            }
             if (p.out) *reinterpret_cast<float4*>(p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
             if (OutRaw) Op4<T>::store(OutRaw + off, v);
             if (OutOp) {
@@ -329,6 +336,17 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
                 }
                 Op4<T>::store(OutOp + off, v);
             }
+        }
+    }
+    if (p.stat_ws) {   // lanes that share a channel group are L4 apart: combine them, one atomic per channel and wave into a replica
+#pragma unroll
+        for (int o = L4; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ssum[e] += __shfl_xor(ssum[e], o, 64); ssq[e] += __shfl_xor(ssq[e], o, 64); }
+        if (lane < L4 && nv) {
+            float* d = ws_replica(p.stat_ws, blockIdx.x % L2I_WS_R, 2 * p.Co) + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { atomicAdd(d + e, ssum[e]); atomicAdd(d + p.Co + e, ssq[e]); }
         }
     }
 }
@@ -1114,7 +1132,7 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     const int nks = a.nks;
     // split-K for small grids with a long reduction (D block5/6, G res1/res2, ROI heads): fill the 256 CUs
     int splits = 1;
-    if (a.out && !a.out_op && !a.out_op_raw && nblk < 192 && nks >= 16) {
+    if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 192 && nks >= 16) {
         splits = (g_split_target + nblk - 1) / nblk;
         const int min_steps = nblk < 32 ? 4 : 16;   // >= 16 K-steps per split (shorter ones are all prologue + atomic epilogue), except for the
         if (splits > nks / min_steps) splits = nks / min_steps;   // handful-of-tiles Linear layers, which otherwise run on 6 CUs
@@ -1164,7 +1182,7 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     a.tiles_n = (a.Co + BN - 1) / BN;
     const int nblk = a.tiles_m * a.tiles_n;
     int splits = 1;
-    if (a.out && !a.out_op && !a.out_op_raw && nblk < 192 && nchunks >= 4) {
+    if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 192 && nchunks >= 4) {
         splits = (g_split_target + nblk - 1) / nblk;
         if (splits > nchunks / 2) splits = nchunks / 2;   // >= 18 K-steps per split
         if (splits < 1) splits = 1;
@@ -1212,13 +1230,13 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     a.tiles_n = (a.Co + BN - 1) / BN;
     const int nblk = a.tiles_m * a.tiles_n;
     int splits = 1;
-    if (a.out && !a.out_op && !a.out_op_raw && nblk < 256 && nchunks >= 4) {   // fill the 512 workgroup slots (two per CU); more than 8
+    if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 256 && nchunks >= 4) {   // fill the 512 workgroup slots (two per CU); more than 8
         splits = (g_split_target + nblk / 2) / nblk;                           // splits lose to their atomics (tools/perf/conv_small.py)
         if (splits > nchunks / 2) splits = nchunks / 2;   // >= 18 K-steps per split
         if (splits > 8) splits = 8;
         if (splits < 1) splits = 1;
     }
-    if (force_splits > 0 && a.out && !a.out_op && !a.out_op_raw) splits = force_splits < nchunks ? force_splits : nchunks;
+    if (force_splits > 0 && a.out && !a.out_op && !a.out_op_raw && !a.stat_ws) splits = force_splits < nchunks ? force_splits : nchunks;
     const int cper = (nchunks + splits - 1) / splits;
     a.ks_per = 9 * cper;
     a.splits = (nchunks + cper - 1) / cper;
@@ -1406,8 +1424,10 @@ extern "C" int l2i_timing_read(int cls, double* total_ms, int* launches) {
 
 extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float* res,
                               const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
-                              int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, void* stream) {
+                              int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
+                              void* stream) {
     if (!x || !w || (!out && !out_op && !out_op_raw)) return L2I_ERR_ARG;
+    if (stats && (!ws || !out || Co % 4 || 2LL * Co * L2I_WS_R > L2I_WS_FLOATS)) return L2I_ERR_ARG;
     ConvArgs a;
     static const int no_epi = getenv("L2I_CONV_NOEPI") ? atoi(getenv("L2I_CONV_NOEPI")) : 0;
     a.no_epi = no_epi;
@@ -1425,9 +1445,17 @@ extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, c
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.relu_op = relu_op ? 1 : 0;
     a.Kpad = Kpad; a.alpha = alpha;
-    if (dtype == 0) return launch_conv<float>(a, (hipStream_t)stream);
-    if (dtype == 1) return launch_conv<bf16_t>(a, (hipStream_t)stream);
-    return L2I_ERR_ARG;
+    a.stat_ws = stats ? ws : nullptr;
+    if (stats) a.epi_lds = 1;   // (the statistics are gathered by the LDS form of the epilogue; no split-K on such a launch)
+    int rc;
+    if (dtype == 0) rc = launch_conv<float>(a, (hipStream_t)stream);
+    else if (dtype == 1) rc = launch_conv<bf16_t>(a, (hipStream_t)stream);
+    else return L2I_ERR_ARG;
+    if (rc == L2I_OK && stats) {
+        ws_fold(ws, 2 * Co, Co, stats, stats + Co, nullptr, nullptr, (hipStream_t)stream);
+        rc = l2i_check_launch();
+    }
+    return rc;
 }
 
 // Debug aid: co-resident workgroups per CU the runtime computes for a few instantiations (tools/perf/occupancy.py).

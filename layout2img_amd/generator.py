@@ -197,7 +197,7 @@ class PSPModule(nn.Module):
             ys.append(y.view(B, -1, y.shape[-1]))
         cat = ops.psp_expand(feats, torch.cat(ys, dim=1), taps, pc.arena.op_dtype, j)          # (B,H,W,4*100+C), operand dtype
         conv, bn = self.bottleneck
-        h = fused_conv(cat, conv, pc)
+        h = fused_conv(cat, conv, pc, emit=("stats",) if self.training else ())
         spec, w, b = bn.spec(self.training, sync, conv.co_p)
         y = ops.norm_act(h, spec, w, b)
         bn.commit(conv.co_p)
@@ -223,7 +223,7 @@ class ConvMaskHead(nn.ModuleList):
             y = self[0](x, pc, sync)
             return fused_conv(y, self[1], pc)
         conv, bn, _, out = self
-        h = fused_conv(x, conv, pc)
+        h = fused_conv(x, conv, pc, emit=("stats",) if self.training else ())
         spec, w, b = bn.spec(self.training, sync, conv.co_p)
         m = fused_conv(h, out, pc, prologue=spec, wproj=w, bproj=b, dx_raw=True)   # (h has this one reader: its gradient's operand copy comes out of the norm backward)
         bn.commit(conv.co_p)
@@ -256,12 +256,14 @@ class ResBlock(nn.Module):
         gw1, gb1 = self.b1.project(w, pc, B, O)
         j = ops.GradJoin()   # the shortcut's dx is accumulated by the second pass of b1's backward instead of a separate add
         h = fused_conv(x, self.conv1, pc, prologue=self.b1.spec(self.training, sync), mask=_resize_mask(mask, H, W).contiguous(),
-                       wproj=gw1, bproj=gb1, up2=up, join=(j, "take"))
+                       wproj=gw1, bproj=gb1, up2=up, join=(j, "take"),
+                       emit=("stats",) if self.training else ())   # b2's batch statistics come out of this epilogue
         H2, W2 = h.shape[1], h.shape[2]
         sc = fused_conv(x, self.c_sc, pc, up2=up, join=(j, "give")) if self.learnable_sc else x
         gw2, gb2 = self.b2.project(w, pc, B, O)
         out = fused_conv(h, self.conv2, pc, prologue=self.b2.spec(self.training, sync),
-                         mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc, emit=emit, dx_raw=True)
+                         mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc, emit=tuple(emit) + (("stats",) if self.training else ()),
+                         dx_raw=True)   # (the block's result is normalised next: by the following block's b1 or by the final BN)
         self.b1.batch_norm2d.commit()
         self.b2.batch_norm2d.commit()
         m = self.conv_mask(out, pc, sync) if self.predict_mask else None

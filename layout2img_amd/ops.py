@@ -145,9 +145,11 @@ LIVE_IMAGE_FRACTION = 1.0   # bench.py: real ROIs / ROI slots of its batch, so t
 
 
 def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, up2=False, pool2=False, alpha=1.0,
-             want_f32=True, want_op=False, relu_op=False, want_raw=False, flops=None, nimg=None):
+             want_f32=True, want_op=False, relu_op=False, want_raw=False, flops=None, nimg=None, stats=False):
     """out = alpha*pool?(conv(up?(x))) + bias, masked, + res.  x_op (B,Hi,Wi,Ci) operand dtype.
-    nimg: 1-element int32 device tensor = number of leading images that are live (the rest come out as zeros)."""
+    nimg: 1-element int32 device tensor = number of leading images that are live (the rest come out as zeros).
+    stats: the epilogue also gathers the per-channel sum / sum of squares of `out` (the batch statistics of a following
+    normalisation); they ride on `out` (`_l2i_stats`) for ops._norm_stats."""
     _chk(x_op)
     B, Hi, Wi, Ci = x_op.shape
     Ho, Wo = (2 * Hi, 2 * Wi) if up2 else (Hi, Wi)
@@ -169,9 +171,12 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
             4 * (want_f32 + (res is not None)) + esz * (want_op + want_raw + (relu_mask is not None)))
         live = LIVE_IMAGE_FRACTION if nimg is not None else 1.0
         end = TIMER.time("conv_igemm", live * (flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci), live * nbytes)
+    st = _zeros((2, 1, co), dev) if (stats and out is not None and co <= 1024) else None
     _lib.call("l2i_conv2d_fwd", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
               _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
-              float(alpha), _p(nimg), _stream())
+              float(alpha), _p(nimg), _p(st), _ws(dev) if st is not None else None, _stream())
+    if st is not None:
+        out._l2i_stats = (st[0], st[1], out._version)
     if end is not None:
         end.record()
     return out, out_op, out_raw
@@ -281,7 +286,11 @@ def _norm_stats(x, spec: NormSpec):
     if not spec.training and spec.running is not None:
         rm, rv = spec.running
         return rm.view(1, C).clone(), (rv + rm * rm).view(1, C), 1.0, 0
-    sums, sq = channel_stats(x2)
+    st = getattr(x, "_l2i_stats", None)   # gathered by the epilogue of the convolution that produced x (fused_conv emit "stats")
+    if st is not None and st[2] == x._version and st[0].shape == (1, C):
+        sums, sq = st[0], st[1]
+    else:
+        sums, sq = channel_stats(x2)
     count = float(B * H * W)
     if spec.sync is not None:
         count = spec.sync(sums, sq, count)
@@ -439,10 +448,10 @@ class FusedConvFn(Function):
         out, o_relu, o_raw = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p, res=res,
                                       up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops, nimg=nimg,
                                       want_f32=not op_out, want_op=op_out or "relu" in emit, relu_op=True,
-                                      want_raw="raw" in emit)
+                                      want_raw="raw" in emit, stats="stats" in emit and not op_out)
         if op_out:
             out = o_relu
-        elif emit:
+        elif emit and (o_raw is not None or o_relu is not None):
             _attach(out, raw=o_raw, relu=o_relu)
         ctx.op_out = op_out
         ctx.flops, ctx.nimg, ctx.dx_raw, ctx.join = flops, nimg, dx_raw, join

@@ -105,6 +105,32 @@ def test_conv_forward(case, dt, epi):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 72, 3, False, False), (1, 32, 32, 128, 136, 3, False, True),
+                                  (9, 16, 16, 192, 128, 3, False, False), (2, 16, 16, 64, 64, 3, True, False),
+                                  (3, 8, 8, 136, 256, 3, False, False), (2, 16, 16, 40, 104, 1, False, False)])
+def test_conv_epilogue_statistics(case, dt):
+    """`stats`: the epilogue gathers per-channel sum / sum of squares of the f32 result (the batch statistics of the
+    normalisation that reads it, model/norm_module.py:163) -- equal to a pass over the result"""
+    from layout2img_amd import ops
+    B, H, W, Ci, Co, KH, up2, pool2 = case
+    g = torch.Generator().manual_seed(23)
+    x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    w = _rt(torch.randn(Co, Ci, KH, KH, generator=g) / math.sqrt(Ci * KH * KH), dt)
+    bias = torch.randn(Co, generator=g)
+    ref = _ref_conv(x, w, bias, up2, pool2)
+    res = torch.randn(ref.shape, generator=g)
+    pack, kpad = _pack(w, 64 if dt == torch.bfloat16 else 32)
+    out, _, _ = ops.conv_raw(x.to(_dev(), dt), pack.to(_dev(), dt), kpad, Co, KH, bias=bias.to(_dev()), res=res.to(_dev()),
+                             up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, stats=True)
+    sums, sq, ver = out._l2i_stats
+    assert ver == out._version and sums.shape == (1, Co)
+    o = out.double().cpu().view(-1, Co)
+    assert float((out.cpu() - (ref + res)).abs().max()) < 2e-5 * float((ref + res).abs().max()) + 1e-5
+    assert float((sums.cpu().double()[0] - o.sum(0)).abs().max()) < 1e-5 * float(o.abs().sum(0).max()) + 1e-4
+    assert float((sq.cpu().double()[0] - (o * o).sum(0)).abs().max()) < 1e-5 * float((o * o).sum(0).max()) + 1e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("case", [(2, 8, 8, 256, 64, 3, False, False), (4, 4, 4, 512, 136, 3, False, True),
                                   (3, 4, 4, 256, 128, 3, True, False), (8, 1, 1, 2048, 16, 1, False, False)])
 def test_conv_split_k(case, dt):
