@@ -837,7 +837,11 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
     (void)dy_keep;   // (formerly a scratch copy of dy for O > 8; object chunks now share the LDS tile)
     const int tiles_c = (C + NM_CC - 1) / NM_CC;
     const int subtiles = (HW + NB_PX - 1) / NB_PX;
-    int nseg = 2048 / (B * tiles_c);
+    // Workgroups a launch aims for: 512 = one round of two per CU. Every workgroup ends its run with a reduction of its 16 + 2
+    // per-channel accumulators through LDS and ~1000 atomics, so longer runs amortise it: same-box A/B of the training
+    // iteration 24.35 ms (2048), 24.10 (1024), 23.91 (512). (L2I_NORM_WGS: tuning)
+    static const int wg_target = getenv("L2I_NORM_WGS") ? atoi(getenv("L2I_NORM_WGS")) : 512;
+    int nseg = wg_target / (B * tiles_c);
     if (nseg > subtiles) nseg = subtiles;
     if (nseg < 1) nseg = 1;
     const int seg_pixels = ((subtiles + nseg - 1) / nseg) * NB_PX;
@@ -853,7 +857,7 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
         const size_t lds8 = sizeof(float) * (8 * NB_PX + NB_PX + 8 * NB_PX) + 32 * 1024 + 16;
         if (C <= 64) {
             const int t64 = (C + 63) / 64;
-            int ns = 2048 / (B * t64);
+            int ns = wg_target / (B * t64);
             if (ns > subtiles) ns = subtiles;
             if (ns < 1) ns = 1;
             const int sp = ((subtiles + ns - 1) / ns) * NB_PX;

@@ -504,7 +504,7 @@ class ResnetGenerator128_context(_GeneratorBase):
             res_out.append(x)
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
-        pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
+        pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba, dx_raw=True)   # (x: the last block's result, read by this layer alone)
         bn.commit()
         self._release_isla()
         self._bump_nbt()
@@ -549,7 +549,7 @@ class context_aware_generator(_GeneratorBase):
             x, _ = getattr(self, f"res{i}")(x, wp, mask, pc, self.sync, emit=("raw",) if i < 5 else ())
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
-        pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
+        pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba, dx_raw=True)   # (x: the last block's result, read by this layer alone)
         bn.commit()
         self._release_isla()
         self._bump_nbt()
@@ -602,7 +602,7 @@ class ResnetGenerator64_context(ResnetGenerator128_context):
             x, m = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",))
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
-        pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba)
+        pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba, dx_raw=True)   # (x: the last block's result, read by this layer alone)
         bn.commit()
         self._release_isla()
         self._bump_nbt()

@@ -1,0 +1,66 @@
+"""GPU checks of two reference behaviours no golden vector exercises (every golden runs with dropout 0 and an explicit
+z_im): PSPModule's train-mode nn.Dropout2d (reference model/resnet_generator_app_v2.py:744-747, 751-752) and the generator's
+own draw of the image latent when z_im is None (:444-446)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_psp_dropout2d_drops_whole_channels_per_sample(dt):
+    """train mode: every (sample, channel) plane of the PSP output is either zero or the undropped plane / (1 - p), and
+    the planes dropped are those a Bernoulli(1 - p) draw of shape (B, 1, 1, C) from the same seed keeps."""
+    from layout2img_amd.arena import FlatParams, WeightArena
+    from layout2img_amd.generator import PSPModule
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.psp = PSPModule(128, 100)
+    torch.manual_seed(0)
+    net = Net()
+    flat = FlatParams(net, DEV)
+    arena = WeightArena(net, flat, DEV, dt)
+    net.train()
+    B, H, C, p = 3, 16, 128, 0.5
+    feats = torch.randn(B, H, H, C, device=DEV)
+    net.psp.dropout_p = 0.0
+    y0 = net.psp(feats, arena.prepare(training=True), None).detach()
+    net.psp.dropout_p = p
+    torch.manual_seed(77)
+    y1 = net.psp(feats, arena.prepare(training=True), None).detach()
+    torch.manual_seed(77)
+    keep = (torch.rand(B, 1, 1, y1.shape[3], device=DEV) >= p)
+    assert 0 < int(keep.sum()) < keep.numel()
+    expect = y0 * keep.float() / (1 - p)
+    # (two train-mode passes: the batch statistics are the same, sums are accumulated in a different order)
+    assert float((y1 - expect).abs().max()) <= 1e-4 * float(y0.abs().max()) + 1e-5
+    dropped = (~keep).expand_as(y1)
+    assert float(y1[dropped].abs().max()) == 0.0
+    net.eval()   # eval mode: no dropout (nn.Dropout2d is the identity there)
+    ye = net.psp(feats, arena.prepare(training=False), None)
+    assert float((ye != 0).float().mean()) > 0.05
+
+
+def test_generator_draws_the_image_latent_when_z_im_is_none():
+    """z_im=None: the generator draws z_im ~ N(0, 1) of shape (b, 128) on the latents' device, as the reference does
+    (model/resnet_generator_app_v2.py:444-446) -- the same image as passing that draw explicitly."""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    g = L.ResnetGenerator128_context(num_classes=184).finalize(DEV, torch.float32)
+    g.eval()
+    _, label, bbox, z, _ = make_batch(2, 128, "coco", seed=5, device=torch.device(DEV))
+    with torch.no_grad():
+        torch.manual_seed(123)
+        a = g(z, bbox, z_im=None, y=label)
+        torch.manual_seed(123)
+        z_im = torch.randn((2, 128), device=DEV)
+        b = g(z, bbox, z_im=z_im, y=label)
+        torch.manual_seed(124)
+        c = g(z, bbox, z_im=None, y=label)
+    assert a.shape == (2, 3, 128, 128)
+    assert float((a - b).abs().max()) <= 1e-5
+    assert float((a - c).abs().max()) > 1e-4   # another draw, another image
