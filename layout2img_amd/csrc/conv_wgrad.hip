@@ -641,7 +641,8 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
     // the 128-row tile, 3 for the 64-row one: LDS-limited) -- every extra split costs Co*K atomics, and a grid of 1.1-1.9
     // waves leaves half the chip idle in its second round. Tile counts too large for that go to >= 3 waves instead.
     const bool nw2 = BMO == 128 && sizeof(T) == 2 && pow2 && (g_wgrad_nw2 < 0 ? false : g_wgrad_nw2 == 1);
-    const int cap = g_wgrad_blocks > 0 ? g_wgrad_blocks : (BMO == 64 ? 768 : (nw2 ? 1024 : (nw8 ? 256 : 512)));
+    static const int cap_env = getenv("L2I_WGRAD_CAP") ? atoi(getenv("L2I_WGRAD_CAP")) : 0;   // tuning: workgroups per round, 128-row tiles
+    const int cap = g_wgrad_blocks > 0 ? g_wgrad_blocks : (BMO == 64 ? 768 : (nw2 ? 1024 : (nw8 ? 256 : (cap_env > 0 ? cap_env : 512))));
     int splits = cap / tiles;
     if (splits < 1 || (long long)splits * tiles * 5 < (long long)cap * 4) {
         splits = (3 * cap + tiles - 1) / tiles;
