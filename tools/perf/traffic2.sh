@@ -43,7 +43,7 @@ res = {"conv(fwd+dgrad)": group(lambda k: k.startswith(("conv_halo", "conv_igemm
 json.dump(res, open(R + "/gpurun_out/r02_conv_traffic.json", "w"), indent=1)
 hbm = {}
 for k in ("norm_mod_kernel", "norm_bwd_a_kernel", "norm_bwd_a8_kernel<16>", "norm_bwd_a8_kernel<32>", "norm_bwd_b_kernel", "channel_stats_kernel", "cast_kernel", "adam_kernel", "sn_pack_kernel", "sn_wtu_kernel",
-          "sn_wv_kernel", "sn_apply_kernel", "sn_dot_kernel", "roi_align_kernel<false>", "roi_align_bwd_sep_kernel", "gram_head_fwd_kernel", "gram_head_bwd_kernel"):
+          "sn_wv_kernel", "sn_apply_kernel", "sn_dot_kernel", "roi_align_kernel<false>", "roi_align_bwd_sep_kernel", "wgrad_reduce_kernel", "ws_fold_kernel", "gram_head_fwd_kernel", "gram_head_bwd_kernel"):
     g = group(lambda n, k=k: n == k)
     if g["launches_profiled"] and g["avg_launch_us"] > 0:
         gbs = g["traffic_bytes_per_launch"] / (g["avg_launch_us"] * 1e-6) / 1e9
