@@ -1334,9 +1334,16 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         if (a.Ci % 64 == 0 && a.Ci >= 512 && a.Co >= 512 && ((Ml + 255) / 256) * ((a.Co + 127) / 128) >= 512) hc = 9;
         // (256x128 / 8-wave tiles are ~10 % faster on the 1024-channel ROI-head layers in isolation but not inside the
         //  iteration -- rocprofv3: 1.90 vs 1.77 ms for those 9 launches -- so they stay a tuning option: cfg 12)
+        // ROI heads (device-side live-row count; ~60 % of the rows live, spread over the XCDs by the dispatcher's round robin):
+        // smaller tiles balance the live tiles over the CUs. In-situ sweep after the remap change
+        // (profiles/r02b_insitu_cfg_sweep.txt): 1024 output channels 256x64 tiles (559 -> 448, 592 -> 455, 338 -> 259 us),
+        // 512 output channels 128x64 tiles (447 -> 356, 394 -> 321, 368 -> 300 us).
+        static const int roi_tiles = getenv("L2I_ROI_TILES") ? atoi(getenv("L2I_ROI_TILES")) : 1;
+        if (a.nimg && roi_tiles && a.Ci % 64 == 0 && a.Ci >= 256) hc = a.Co >= 1024 ? 19 : 5;
         if (g_conv_cfg_override >= 10) hc = g_conv_cfg_override - 10;
         if (small_map && hc != 7 && hc != 8 && hc != 9 && hc != 19)   // 256x128 tiles when they still make a full grid, else 256x64 + split-K
             hc = ((M + 255) / 256) * ((a.Co + 127) / 128) >= 256 ? 9 : 19;
+        if (small_map && a.nimg && roi_tiles && g_conv_cfg_override < 10) hc = 19;
         int rc;
         switch (hc) {
             case 1: rc = launch_halo2<128, 64, 2, 2, 3, false>(a, stream); break;

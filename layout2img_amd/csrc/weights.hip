@@ -46,8 +46,20 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const long long* __restrict
         const int col = e[1] * 1024 + 4 * threadIdx.x;
         if (col >= Kt) return;
         float4 t = make_float4(0, 0, 0, 0);
-#pragma unroll 8
-        for (int r = r0; r < r1; ++r) {
+        int r = r0;
+        // eight rows per batch, the eight loads issued back to back (an `unroll 8` of the plain loop keeps its per-row bound
+        // check between the loads and waits for each: 44 % of the HBM rate), then single rows
+        for (; r + 8 <= r1; r += 8) {
+            float4 w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const float4*>(W + (size_t)(r + j) * Kt + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float ur = u[r + j];
+                t.x = fmaf(ur, w[j].x, t.x); t.y = fmaf(ur, w[j].y, t.y); t.z = fmaf(ur, w[j].z, t.z); t.w = fmaf(ur, w[j].w, t.w);
+            }
+        }
+        for (; r < r1; ++r) {
             const float4 w = *reinterpret_cast<const float4*>(W + (size_t)r * Kt + col);
             const float ur = u[r];
             t.x = fmaf(ur, w.x, t.x); t.y = fmaf(ur, w.y, t.y); t.z = fmaf(ur, w.z, t.z); t.w = fmaf(ur, w.w, t.w);
@@ -339,7 +351,15 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const long long* __restrict
         const long long pr = p0 + threadIdx.x;
         const int co = (int)(pr / Ci), ci = (int)(pr - (long long)co * Ci);
         const float* g = G + (size_t)co * Kp + ci;
-        for (int tap = 0; tap < taps; ++tap) acc = fmaf(wl[threadIdx.x * taps + tap], g[tap * Ci_p], acc);
+        if (taps == 9) {   // the nine strided loads issued together (a run-time trip count waits for each in turn)
+            float gv[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) gv[tap] = g[tap * Ci_p];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc = fmaf(wl[threadIdx.x * 9 + tap], gv[tap], acc);
+        } else {
+            for (int tap = 0; tap < taps; ++tap) acc = fmaf(wl[threadIdx.x * taps + tap], g[tap * Ci_p], acc);
+        }
     }
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) atomicAdd(ws + (size_t)(blockIdx.x % L2I_WS_R) * n_layers + layer, acc);
@@ -374,16 +394,34 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
         const float* g = G + (size_t)co * Kp + ci;
         const float uc = sn ? pass_uv[LF(16) + co] * gw : 0.f;
         const float* v = pass_uv + LF(17) + (size_t)ci * taps;
-        for (int tap = 0; tap < taps; ++tap) {
-            float x = g[tap * Ci_p];
-            if (sn) x = (x - uc * v[tap]) * inv;
-            gl[threadIdx.x * taps + tap] = x;
+        if (taps == 9) {   // (loads issued together, see sn_dot_kernel)
+            float gv[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) gv[tap] = g[tap * Ci_p];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                float x = gv[tap];
+                if (sn) x = (x - uc * v[tap]) * inv;
+                gl[threadIdx.x * 9 + tap] = x;
+            }
+        } else {
+            for (int tap = 0; tap < taps; ++tap) {
+                float x = g[tap * Ci_p];
+                if (sn) x = (x - uc * v[tap]) * inv;
+                gl[threadIdx.x * taps + tap] = x;
+            }
         }
     }
     __syncthreads();
     float* dst = grads + LF(0) + p0 * taps;
     if (LF(18)) {   // rows of a multiply-applied weight update the same gradient concurrently
         for (int j = threadIdx.x; j < np * taps; j += 256) atomicAdd(dst + j, gl[j]);
+    } else if (np * taps == 9 * 256) {   // a full 3x3 block: the nine read-modify-writes of a thread in one batch
+        float dv[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) dv[q] = dst[threadIdx.x + 256 * q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) dst[threadIdx.x + 256 * q] = dv[q] + gl[threadIdx.x + 256 * q];
     } else {
         for (int j = threadIdx.x; j < np * taps; j += 256) dst[j] += gl[j];
     }

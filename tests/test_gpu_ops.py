@@ -750,7 +750,10 @@ def test_stage_mask_matches_the_composed_torch_ops(case):
 
 @pytest.mark.parametrize("n_live", [0, 3, 9, 20])
 @pytest.mark.parametrize("case", [(20, 8, 8, 64, 136, 3, False, False), (20, 8, 8, 128, 64, 3, False, True),
-                                  (20, 8, 8, 72, 128, 1, False, True), (20, 8, 8, 16, 40, 3, False, False)])
+                                  (20, 8, 8, 72, 128, 1, False, True), (20, 8, 8, 16, 40, 3, False, False),
+                                  # the ROI-head tile rule (Ci >= 256): 128x64 tiles, 256x64 tiles, and the 4 -> 8 data gradient
+                                  (20, 8, 8, 256, 512, 3, False, False), (20, 8, 8, 256, 1024, 3, False, True),
+                                  (20, 4, 4, 256, 1024, 3, True, False)])
 def test_conv_device_side_image_count(case, n_live, epi):
     """`nimg`: the ROI heads run over the first *nimg images only (device-side count, fixed launch shape): live images
     equal the full convolution, every row of a dead image is exactly zero -- forward/dgrad kernel (halo and generic
