@@ -201,6 +201,7 @@ def main():
             trainer.overlap = ov
         else:
             step()
+    trainer.flush()   # (data parallel: the last iteration's deferred generator all-reduce + Adam belong to the timed region)
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

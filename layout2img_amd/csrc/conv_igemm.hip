@@ -1325,6 +1325,9 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // (in-situ sweep, profiles/r02_insitu_cfg_sweep.txt: the single-halo 128x128 tile also beats the double-buffered one
         //  on the long reductions now -- 210 vs 270 us on 32x32x512->256 -- so 0 is only a tuning option)
         if (a.Co > 64 && t128h >= 512) hc = 4;
+        // (64-wide maps with <= 128 input channels -- 9-18 K-steps per tile -- and the 104 -> 528 PSP bottleneck: 128x64 tiles,
+        //  5-10 % in the sweep of profiles/r02b_insitu_cfg_sweep.txt)
+        if (hc == 4 && a.Ho == 64 && a.Ci <= 128 && (a.Co <= 128 || a.Ci == 104)) hc = 5;
         // 256-pixel tiles (conv_halo3_kernel; tools/perf/conv_sweep.py, profiles/r02_conv_sweep.txt): +4..11 % on the long
         // reductions whose 256x128 grid still fills both workgroup slots of every CU (obj4 conv2 at 32x32, the
         // 1024-channel ROI heads), and -- as 256x64 tiles -- on the upsampling layers from 32x32 outputs up.

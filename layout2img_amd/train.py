@@ -74,6 +74,7 @@ def main(argv=None):
             if rank == 0 and (idx + 1) % 500 == 0:   # (the only host synchronisation: logging, as :191-209)
                 print(f"Time Elapsed: {time.time() - t0:.0f}s  Epoch[{epoch + 1}/{args.total_epoch}], Step[{idx + 1}], "
                       f"d_loss: {float(r['d_loss']):.4f}, g_loss: {float(r['g_loss']):.4f}, pixel: {float(r['pixel']):.4f}", flush=True)
+        trainer.flush()   # (a deferred generator step of the last iteration, data parallel) before the weights are read
         if rank == 0 and (epoch + 1) % 5 == 0:       # :215-217
             L.save_checkpoint(out_path, epoch + 1, netG, netD, trainer.g_opt, trainer.d_opt)
     if rank == 0:

@@ -29,12 +29,26 @@ class FlatAdam:
         self.t = 0
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=net.flat.data.device)   # the count the kernel reads
 
-    def step(self):
+    _works = None
+
+    def begin_step(self):
+        """First half of step(): spectral-norm backward flush, then the gradient all-reduce LAUNCHED (asynchronously under
+        data parallelism: the collective runs on the communicator's stream while this stream goes on)."""
         self.net.arena.flush_grads()
-        parallel.allreduce_flat_(self.net.flat.grad)
+        self._works = parallel.allreduce_flat_(self.net.flat.grad, async_op=True)
+
+    def finish_step(self):
+        """Second half: the current stream waits for the all-reduce, then the fused Adam launch."""
+        for w in self._works or ():
+            w.wait()
+        self._works = None
         self.t += 1
         self.t_dev += 1   # (device-side: a captured graph of the iteration replays with the right bias corrections)
         ops.adam_step(self.net.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t, step_dev=self.t_dev)
+
+    def step(self):
+        self.begin_step()
+        self.finish_step()
 
 
 class GanTrainer:
@@ -48,6 +62,12 @@ class GanTrainer:
         # D(real) on a side stream next to G's forward (L2I_OVERLAP=0 turns it off)
         self.overlap = os.environ.get("L2I_OVERLAP", "1") != "0"
         self._side = None
+        # Data parallel: G's gradient all-reduce (163 MB) is launched at the end of an iteration and waited for -- together
+        # with G's Adam step -- only when the NEXT iteration needs G's weights, i.e. after that iteration's D(real) pass
+        # has been enqueued on the side stream: the collective overlaps D(real). (D's all-reduce has nothing independent
+        # next to it: the G step reads D's updated weights at once.) flush() completes a pending step; L2I_DEFER_G=0: off.
+        self.defer_g = self.world > 1 and self.overlap and os.environ.get("L2I_DEFER_G", "1") != "0"
+        self._pending_g = False
         if self.world > 1:
             netG.sync = parallel.sync_bn_stats
             parallel.broadcast_flat_(netG.flat.data)
@@ -63,6 +83,12 @@ class GanTrainer:
                 for buf in net.buffers():
                     if buf.untyped_storage().data_ptr() not in sn_ptrs:
                         parallel.broadcast_flat_(buf)
+
+    def flush(self):
+        """Complete a deferred generator step (see defer_g). Call before reading / saving the generator's parameters."""
+        if self._pending_g:
+            self.g_opt.finish_step()
+            self._pending_g = False
 
     def _counts(self, valid, b):
         if self.world == 1:
@@ -112,9 +138,11 @@ class GanTrainer:
                 d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
                 # the fake pass's power iteration + weight packs need only D's weights: done here, off the main stream
                 pc_fake = netD.arena.prepare(training=netD.training, need_wgrad=True)
+            self.flush()   # the previous iteration's G all-reduce + Adam: behind D(real)'s launches, in front of G's forward
             fake = netG(z, bbox, z_im=z_im, y=y)
             cur.wait_stream(self._side)
         else:
+            self.flush()
             pc_fake = None
             *outs_r, _, _ = netD.forward_padded(real, bbox, y, layout=layout)
             n_roi, n_img = self._counts(valid, b)
@@ -140,7 +168,11 @@ class GanTrainer:
             feat = self.vgg(fake, real)
             g_loss = g_loss + (feat if self.world == 1 else feat / self.world)
         g_loss.backward()
-        self.g_opt.step()
+        if self.defer_g:
+            self.g_opt.begin_step()
+            self._pending_g = True
+        else:
+            self.g_opt.step()
         return {"d_loss": d_loss.detach(), "g_loss": g_loss.detach(), "pixel": pixel.detach(), "fake": fake.detach()}
 
     # ---- whole-iteration HIP graph: the iteration is ~1700 launches and the Python / autograd side costs about as much

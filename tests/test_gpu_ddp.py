@@ -58,6 +58,8 @@ def _run(rank, world, port, out):
     args = [t[sl].to(DEV) for t in (real, label, bbox, z, z_im)]
     for _ in range(2):
         r = tr.step(*args)
+    assert world == 1 or tr._pending_g   # data parallel: the generator step of the last iteration is still in flight ...
+    tr.flush()                           # ... (its all-reduce overlaps the next iteration's D(real)) until flushed
     torch.cuda.synchronize()
     if rank == 0:
         out["g"] = g.flat.data.detach().cpu()
