@@ -349,6 +349,10 @@ def test_vgg_loss_vs_reference(dt):
     g = torch.from_numpy(fx["grad_x_sub"])
     err = float((x.grad[:, :, ::2, ::2].cpu() - g).norm() / g.norm())
     # bf16 operands: 13 layers of operand rounding in front of ReLU gates of a RANDOM-weight network -- the image
-    # gradient is only loosely reproduced (0.35 measured); the loss value itself is within 2 %
-    assert err < (1e-3 if f32 else 5e-1), err
+    # gradient is only loosely reproduced (0.35 measured); the loss value itself is within 2 %.
+    # f32 operands: the loss agrees to 3e-7; the gradient's relative L2 error is 9.3e-4 in 11 runs of 12 and 6.5e-3 in the
+    # twelfth (tools/perf/vgg_repeat.py on one box): whenever the f32 atomics of a split-K launch add in another
+    # order, one more pre-activation that is ~0 in the reference lands on the other side of its ReLU gate and its whole
+    # receptive field changes sign of contribution. The bar is set for that, not for the typical run.
+    assert err < (2e-2 if f32 else 5e-1), err
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in m.parameters())   # frozen
