@@ -47,15 +47,20 @@ def cpu_baseline(netG, netD, size, seconds_budget=20.0):
                 sample=f"{n} training iterations at batch {b}, {size}x{size}, fp32, oracle/model.py OracleTrainer (VGG term omitted)")
 
 
-def hbm_kernels():
-    """HBM-bound kernels against the 6.3 TB/s achievable HBM3E bandwidth: PMC bytes / profiler durations of this same
-    command, collected by tools/perf/traffic2.sh on the GPU box and committed under profiles/ (null if absent)."""
-    p = os.path.join(ROOT, "profiles", "r02_hbm_kernels.json")
-    if not os.path.exists(p):
-        return None
-    d = json.load(open(p))
-    return {k: {"gb_per_s": v["gb_per_s"], "frac_of_6300": v["frac_of_6300"], "avg_launch_us": v["avg_launch_us"]}
-            for k, v in d.items() if isinstance(v, dict)}
+RESULT_CHANGING_ENV = ("L2I_CONV_NOEPI", "L2I_WGRAD_NOEPI")   # ablation switches (results are wrong; -DL2I_ABLATIONS builds only)
+
+
+def l2i_env():
+    """Every L2I_* variable of this process: tuning / A-B switches change what is measured, so they are part of the line."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("L2I_")}
+
+
+def refuse_wrong_result_switches():
+    bad = [k for k in RESULT_CHANGING_ENV if os.environ.get(k, "0") not in ("", "0")]
+    if "L2I_ABLATIONS" in os.environ.get("L2I_EXTRA_FLAGS", ""):
+        bad.append("L2I_EXTRA_FLAGS=-DL2I_ABLATIONS")
+    if bad:
+        raise SystemExit("bench.py: refusing to print a headline with results-changing switches set: " + ", ".join(bad))
 
 
 def g_forward_figures(netG, args, z, bbox, z_im, label, op_dtype):
@@ -127,6 +132,7 @@ def main():
     ap.add_argument("--no-g-forward", action="store_true", help="skip the secondary generator-forward measurement (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="run every iteration eagerly (default: replay a captured HIP graph at N=1)")
     args = ap.parse_args()
+    refuse_wrong_result_switches()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: re-launch this script as N ranks (one process per GPU) under
@@ -215,11 +221,16 @@ def main():
             s = ops.TIMER.summary()["conv_igemm"]
             peak = 2500.0 if op_dtype == torch.bfloat16 else 157.3
             ach = s["work"] / (s["ms"] * 1e-3) / 1e12
+            # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come from separate
+            # rocprofv3 --pmc passes of this same command (tools/perf/traffic2.sh), committed under profiles/ with the commit
+            # they were taken at; labelled as not measured in this run. null when no file of THIS round exists.
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")   # PMC passes of this same command (tools/perf/traffic2.sh)
+            tpath = os.path.join(ROOT, "profiles", "r03_conv_traffic.json")
             if op_dtype == torch.bfloat16 and args.size == 128 and args.layout == "coco" and not args.vgg and os.path.exists(tpath):
-                traffic = round(json.load(open(tpath))["conv(fwd+dgrad)"]["traffic_bytes_per_launch"])
-                traffic_src = "profiles/r02_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE; separate passes)"
+                tj = json.load(open(tpath))
+                traffic = round(tj["conv(fwd+dgrad)"]["traffic_bytes_per_launch"])
+                traffic_src = {"file": "profiles/r03_conv_traffic.json", "measured_in_run": False, "commit": tj.get("commit"),
+                               "method": "rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE; separate passes"}
             roof = dict(bound="mfma", kernel="l2i_conv2d_fwd launches (conv_halo2/3_kernel + conv_igemm_kernel), forward and data-gradient",
                         timing="HIP events attached to each dispatch (hipExtLaunchKernelGGL) on the launching stream, inside the timed region",
                         achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
@@ -260,7 +271,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": ("HIP graph replay, D(real) on a side stream (last timed step eager on one stream, with HIP events)"
                                   if graphed else "eager")},
-            "roofline": roof, "hbm_kernels": hbm_kernels() if (args.size == 128 and args.layout == "coco" and args.dtype == "bf16") else None,
+            "roofline": roof, "env": l2i_env(),
             "cpu_baseline": cpu, "g_forward": g_fwd,
             "g_forward_images_per_sec": None if g_fwd is None else g_fwd["images_per_sec"],
         }

@@ -13,13 +13,16 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragme
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-// round-to-nearest-even f32 -> bf16 (NaN preserved as quiet NaN)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even f32 -> bf16: gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; the integer form -- add 0x7fff +
+// lsb, shift, NaN select -- was ~6 VALU per element and showed up in every epilogue / normalisation kernel that writes operands)
+typedef float l2i_f2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 l2i_b2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {   // two bf16 packed in one dword (lo in bits 0-15)
+    l2i_f2_t v;
+    v[0] = lo; v[1] = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, l2i_b2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(f2bf2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 template <typename T> struct OpT;
@@ -44,8 +47,8 @@ template <> struct Op4<bf16_t> {
     }
     __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
         uint2 u;
-        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        u.x = f2bf2(v[0], v[1]);
+        u.y = f2bf2(v[2], v[3]);
         *reinterpret_cast<uint2*>(p) = u;
     }
 };

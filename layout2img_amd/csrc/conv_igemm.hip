@@ -19,6 +19,35 @@
 #include <stdlib.h>
 #include "igemm.h"
 
+// Wave-level timestamps (builds with -DL2I_TRACE only; tools/perf/conv_trace.py): slot 0 kernel entry, 1 before the
+// reduction loop, 2 after it, 3 end of the epilogue -- s_memrealtime ticks (100 MHz) of every wave of the LAST launch.
+#ifdef L2I_TRACE
+#define L2I_TRACE_WAVES (8192 * 8)
+__device__ long long g_l2i_trace[L2I_TRACE_WAVES * 4];
+__device__ unsigned g_l2i_trace_id[L2I_TRACE_WAVES];
+#define L2I_TR(SLOT)                                                                                                   \
+    do {                                                                                                               \
+        const int w_ = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);                             \
+        if ((threadIdx.x & 63) == 0 && w_ < L2I_TRACE_WAVES) {                                                         \
+            long long t_ = (long long)wall_clock64();                                                                  \
+            if ((SLOT) == 0) {   /* low 16 bits of the entry stamp replaced by (XCC_ID << 12 | HW_ID[15:4]) */          \
+                const unsigned xcc_ = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));                            \
+                const unsigned hw_ = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                             \
+                g_l2i_trace_id[w_] = (xcc_ << 16) | (hw_ & 0xffffu);                                                   \
+            }                                                                                                          \
+            g_l2i_trace[w_ * 4 + (SLOT)] = t_;                                                                         \
+        }                                                                                                              \
+    } while (0)
+extern "C" int l2i_trace_read(long long* host, int nwaves) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l2i_trace), sizeof(long long) * 4 * (size_t)nwaves) == hipSuccess ? L2I_OK : L2I_ERR_LAUNCH;
+}
+extern "C" int l2i_trace_read_id(unsigned* host, int nwaves) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l2i_trace_id), sizeof(unsigned) * (size_t)nwaves) == hipSuccess ? L2I_OK : L2I_ERR_LAUNCH;
+}
+#else
+#define L2I_TR(SLOT) do { } while (0)
+#endif
+
 struct ConvArgs {
     const void* x;      // T  [B, Hi, Wi, Ci]
     const void* w;      // T  [Npad, Kpad], K order (ky, kx, ci)
@@ -44,7 +73,7 @@ struct ConvArgs {
     float* stat_ws;      // optional: the stream's replicated workspace (common.h) -- the epilogue adds every channel's sum and sum of squares
                          // of the f32 result there (what the batch-norm layer reading this result needs: no separate pass over it)
     int roi_remap;       // tuning (L2I_ROI_REMAP=1): keep the XCD remap on launches with a live-image count (A/B)
-    int no_epi;          // tuning (L2I_CONV_NOEPI=1, results are wrong): skip the epilogue to measure what it costs
+    int no_epi;          // ablation builds only (-DL2I_ABLATIONS + L2I_CONV_NOEPI=1, results are wrong): skip the epilogue to measure what it costs
     int epi_lds;         // 1: coalesced epilogue through LDS (conv_epilogue_lds; default), 0: direct stores from the accumulator layout (L2I_EPI=0, A/B)
 };
 
@@ -127,6 +156,7 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvArgs& p, f32x16_t
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane,
                                               int tile_r, int tile_c, int n0, int split, int rows_total, int rows_live) {
+#ifdef L2I_ABLATIONS
     if (p.no_epi) {   // (keeps the accumulators live)
         float s_ = 0.f;
 #pragma unroll
@@ -138,6 +168,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)
         if (s_ == 1.2345e30f && p.out) p.out[0] = s_;
         return;
     }
+#endif
     const int m = lane & 31, h = lane >> 5;
     T* __restrict__ OutOp = reinterpret_cast<T*>(p.out_op);
     T* __restrict__ OutRaw = reinterpret_cast<T*>(p.out_op_raw);
@@ -217,14 +248,54 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)
 
 // The same epilogue with COALESCED global accesses. In conv_epilogue a wave's store instruction touches 32 pixel rows
 // with 32 bytes each (the transposed accumulator gives a lane 4 consecutive channels of ONE pixel, and the 32 lanes of a
-// half-wave are 32 different pixels): in-situ ablation (L2I_CONV_NOEPI) put that epilogue at 29 % of all conv time, a
-// third of the HBM rate. Here each wave turns its 32-pixel x (32 TN)-channel slab through a private LDS patch (the ring
-// and the halo are idle by then) and reads it back pixel-major: one instruction then covers 64 / (8 TN) pixels with
-// 128 TN contiguous bytes each (f32; half of that for the bf16 copies / the ReLU mask), i.e. whole cache lines.
+// half-wave are 32 different pixels): in-situ ablation put that epilogue at 29 % of all conv time, a third of the HBM
+// rate. Here each wave turns its 32-pixel x (32 TN)-channel slab through a private LDS patch (the ring and the halo are
+// idle by then) and reads it back pixel-major: one instruction then covers 64 / (8 TN) pixels with 128 TN contiguous
+// bytes each (f32; half of that for the bf16 copies / the ReLU mask), i.e. whole cache lines.
 // The 2x2 average pool sums the 4 LDS rows of a quad (quad-major pixel order) instead of DPP permutes.
+//
+// Round 3: batched loads, no per-element branches. The round-2 form did, per 16-byte group, "load mask -> s_waitcnt
+// vmcnt(0) -> load residual -> s_waitcnt vmcnt(0) -> store", each step behind a branch (the disassembly showed one full
+// memory round trip per load, and vmcnt(0) also waits for the stores before it). Now every global access goes through a
+// buffer descriptor with a 32-bit byte offset, so a lane that must not touch memory (row past the tensor, channel past
+// Co, image past *nimg) simply carries an out-of-range offset (loads return zero, stores are dropped); the ReLU-mask and
+// residual loads of a batch of 4 stages are issued together with the stages' LDS reads, then the 4 stages are finished
+// and stored.
+template <typename T> struct EpiT;
+template <> struct EpiT<bf16_t> {
+    typedef unsigned __attribute__((ext_vector_type(2))) raw_t;
+    __device__ static __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
+    __device__ static __forceinline__ void unpack(raw_t u, float (&v)[4]) {
+        v[0] = __uint_as_float(u[0] << 16); v[1] = __uint_as_float(u[0] & 0xffff0000u);
+        v[2] = __uint_as_float(u[1] << 16); v[3] = __uint_as_float(u[1] & 0xffff0000u);
+    }
+    __device__ static __forceinline__ void store(__amdgpu_buffer_rsrc_t r, unsigned off, const float (&v)[4]) {
+        raw_t u;
+        u[0] = f2bf2(v[0], v[1]);
+        u[1] = f2bf2(v[2], v[3]);
+        __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0);
+    }
+};
+template <> struct EpiT<float> {
+    typedef unsigned __attribute__((ext_vector_type(4))) raw_t;
+    __device__ static __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+    __device__ static __forceinline__ void unpack(raw_t u, float (&v)[4]) {
+        v[0] = __uint_as_float(u[0]); v[1] = __uint_as_float(u[1]); v[2] = __uint_as_float(u[2]); v[3] = __uint_as_float(u[3]);
+    }
+    __device__ static __forceinline__ void store(__amdgpu_buffer_rsrc_t r, unsigned off, const float (&v)[4]) {
+        raw_t u;
+        u[0] = __float_as_uint(v[0]); u[1] = __float_as_uint(v[1]); u[2] = __float_as_uint(v[2]); u[3] = __float_as_uint(v[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 0);
+    }
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, unsigned nbytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base ? (int)nbytes : 0, 0x00020000);
+}
+
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane, int wave,
                                                   int tile_r, int tile_c, int n0, int rows_total, int rows_live, char* smem) {
+#ifdef L2I_ABLATIONS
     if (p.no_epi) {   // (keeps the accumulators live)
         float s_ = 0.f;
 #pragma unroll
@@ -236,12 +307,14 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
         if (s_ == 1.2345e30f && p.out) p.out[0] = s_;
         return;
     }
+#endif
+    typedef unsigned __attribute__((ext_vector_type(4))) u4_t;
     constexpr int NCH = TN * 32, LD = NCH + 4;   // floats per LDS row: +4 keeps 16-byte alignment and spreads the banks
     constexpr int L4 = NCH / 4, PPI = 64 / L4;   // float4 groups per pixel; pixels (or quads) per wave-instruction
+    constexpr int NIT = 32 / PPI;                // stages per 32-pixel slab (a quarter of them with the 2x2 pool)
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int SZT = (int)sizeof(T);
     float* patch = reinterpret_cast<float*>(smem) + wave * 32 * LD;
-    T* __restrict__ OutOp = reinterpret_cast<T*>(p.out_op);
-    T* __restrict__ OutRaw = reinterpret_cast<T*>(p.out_op_raw);
-    const T* __restrict__ Mask = reinterpret_cast<const T*>(p.relu_mask);
     const int m = lane & 31, h = lane >> 5;
     const int cq = lane % L4, pp0 = lane / L4;
     const int n = n0 + wcol + cq * 4;
@@ -251,94 +324,129 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
         const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
         bb[0] = b4.x; bb[1] = b4.y; bb[2] = b4.z; bb[3] = b4.w;
     }
+    // descriptors over the result-shaped tensors (null pointer -> zero records: every access out of range)
+    const unsigned out_elems = (unsigned)p.B * (unsigned)(p.Ho >> p.pool2) * (unsigned)(p.Wo >> p.pool2) * (unsigned)p.Co;
+    const __amdgpu_buffer_rsrc_t rs_out = epi_rsrc(p.out, out_elems * 4u), rs_res = epi_rsrc(p.res, out_elems * 4u);
+    const __amdgpu_buffer_rsrc_t rs_mask = epi_rsrc(p.relu_mask, out_elems * SZT), rs_op = epi_rsrc(p.out_op, out_elems * SZT);
+    const __amdgpu_buffer_rsrc_t rs_raw = epi_rsrc(p.out_op_raw, out_elems * SZT);
+    const bool has_mask = p.relu_mask != nullptr, has_res = p.res != nullptr, has_out = p.out != nullptr;
+    const bool has_raw = p.out_op_raw != nullptr, has_op = p.out_op != nullptr, has_stats = p.stat_ws != nullptr;
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};   // per-channel statistics of this lane's pixels (stat_ws)
     const int wrow_s = __builtin_amdgcn_readfirstlane(wrow);
-    const size_t tile_base = ((size_t)tile_r * p.PH * p.Wo + (size_t)tile_c * p.PW) * p.Co;
+    const unsigned tile_base = (unsigned)((tile_r * p.PH * p.Wo + tile_c * p.PW) * p.Co);
+    const int nstage = p.pool2 ? NIT / 4 : NIT;   // live stages per slab
+
+    // Stages are taken in BATCHES of B inside a real (not unrolled) loop: the loads + LDS reads of B stages are issued, then
+    // the B stages are finished and stored. The loop is deliberately NOT unrolled: this code runs once per workgroup, and a
+    // fully unrolled epilogue is 25-30 KB of straight-line code that every CU has to pull through its instruction cache
+    // cold at the end of every launch (a launch is one round of workgroups) -- the fetch, not the memory traffic, was the
+    // bulk of the "epilogue time" (the round-2 ablation priced the epilogue at 80-120 us on a layer whose 100 MB of
+    // results take 20 us to write).
+    constexpr int B = 4;
     __syncthreads();   // every wave is done reading the ring / the halo
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        // this wave's next 32-pixel slab -> its LDS patch (same wave wrote and reads: LDS operations of a wave complete in order)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(patch + m * LD + j * 32 + 8 * g + 4 * h) =
                     make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        // (same wave wrote and reads: LDS operations of a wave complete in order)
-        constexpr int NIT = (32 / PPI);
+#pragma unroll 1
+        for (int it0 = 0; it0 < nstage; it0 += B) {
+            float sv[B][4];
+            u4_t srr[B];
+            typename EpiT<T>::raw_t smk[B];
+            unsigned so_ld[B], so_st[B];   // f32 byte offsets: loads (OOB for rows that are not read), stores (OOB for rows that do not exist)
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            if (p.pool2 && it >= NIT / 4) break;   // 8 quads per 32-pixel slab
-            float v[4];
-            size_t rowoff;
-            bool live, dead;
-            if (p.pool2) {
-                const int ql = it * PPI + pp0;             // quad within the slab
-                const float* r0 = patch + (4 * ql) * LD + cq * 4;
-                const float4 a0 = *reinterpret_cast<const float4*>(r0), a1 = *reinterpret_cast<const float4*>(r0 + LD);
-                const float4 a2 = *reinterpret_cast<const float4*>(r0 + 2 * LD), a3 = *reinterpret_cast<const float4*>(r0 + 3 * LD);
-                v[0] = (a0.x + a1.x) + (a2.x + a3.x); v[1] = (a0.y + a1.y) + (a2.y + a3.y);
-                v[2] = (a0.z + a1.z) + (a2.z + a3.z); v[3] = (a0.w + a1.w) + (a2.w + a3.w);
-                const int q = (wrow + i * 32) / 4 + ql;
-                const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
-                const int r2 = tile_r * (p.PH >> 1) + qy;
-                const int Hq = p.Ho >> 1, Wq = p.Wo >> 1;
-                const int b = r2 / Hq, y2 = r2 - b * Hq, x2 = tile_c * (p.PW >> 1) + qx;
-                rowoff = ((size_t)(b * Hq + y2) * Wq + x2) * p.Co;
-                live = r2 < p.B * Hq;
-                dead = 2 * r2 >= rows_live;
-            } else {
-                const int pix = it * PPI + pp0;
-                const float4 a0 = *reinterpret_cast<const float4*>(patch + pix * LD + cq * 4);
-                v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w;
-                // pixel index = (wave-uniform base, a multiple of PPI) + pp0: the quad-major decode splits into a SCALAR part
-                // and lane constants (the per-instruction address arithmetic of this loop is what the direct form avoids)
-                const int pbase = wrow_s + i * 32 + it * PPI;
-                int py, px;
-                if (p.lin) { py = pbase + pp0; px = 0; }
-                else {
-                    const int q = (pbase >> 2) + (PPI >= 4 ? (pp0 >> 2) : 0);
-                    const int sq = PPI >= 4 ? (pp0 & 3) : ((pbase & 3) + pp0);
+            for (int k = 0; k < B; ++k) {
+                const int it = it0 + k;
+                unsigned rowoff;
+                bool live, dead;
+                if (p.pool2) {
+                    const int ql = min(it * PPI + pp0, 7);             // quad within the slab (clamped: stages past the slab are masked below)
+                    const float* r0 = patch + (4 * ql) * LD + cq * 4;
+                    const float4 a0 = *reinterpret_cast<const float4*>(r0), a1 = *reinterpret_cast<const float4*>(r0 + LD);
+                    const float4 a2 = *reinterpret_cast<const float4*>(r0 + 2 * LD), a3 = *reinterpret_cast<const float4*>(r0 + 3 * LD);
+                    sv[k][0] = (a0.x + a1.x) + (a2.x + a3.x); sv[k][1] = (a0.y + a1.y) + (a2.y + a3.y);
+                    sv[k][2] = (a0.z + a1.z) + (a2.z + a3.z); sv[k][3] = (a0.w + a1.w) + (a2.w + a3.w);
+                    const int q = (wrow + i * 32) / 4 + ql;
                     const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
-                    py = 2 * qy + (sq >> 1);
-                    px = 2 * qx + (sq & 1);
+                    const int r2 = tile_r * (p.PH >> 1) + qy;
+                    const int Hq = p.Ho >> 1, Wq = p.Wo >> 1;
+                    const int b = r2 / Hq, y2 = r2 - b * Hq, x2 = tile_c * (p.PW >> 1) + qx;
+                    rowoff = (unsigned)(((b * Hq + y2) * Wq + x2) * p.Co);
+                    live = r2 < p.B * Hq && it < nstage;
+                    dead = 2 * r2 >= rows_live;
+                } else {
+                    const int pix = min(it * PPI + pp0, 31);
+                    const float4 a0 = *reinterpret_cast<const float4*>(patch + pix * LD + cq * 4);
+                    sv[k][0] = a0.x; sv[k][1] = a0.y; sv[k][2] = a0.z; sv[k][3] = a0.w;
+                    // pixel index = (wave-uniform base, a multiple of PPI) + pp0: the quad-major decode splits into a SCALAR part
+                    // and lane constants
+                    const int pbase = wrow_s + i * 32 + it * PPI;
+                    int py, px;
+                    if (p.lin) { py = pbase + pp0; px = 0; }
+                    else {
+                        const int q = (pbase >> 2) + (PPI >= 4 ? (pp0 >> 2) : 0);
+                        const int sq = PPI >= 4 ? (pp0 & 3) : ((pbase & 3) + pp0);
+                        const int qy = q >> p.hw_shift, qx = q & ((1 << p.hw_shift) - 1);
+                        py = 2 * qy + (sq >> 1);
+                        px = 2 * qx + (sq & 1);
+                    }
+                    const int r = tile_r * p.PH + py;
+                    rowoff = tile_base + (unsigned)((py * p.Wo + px) * p.Co);
+                    live = r < rows_total && it < nstage;
+                    dead = r >= rows_live;
                 }
-                const int r = tile_r * p.PH + py;
-                rowoff = tile_base + (size_t)(unsigned)((py * p.Wo + px) * p.Co);
-                live = r < rows_total;
-                dead = r >= rows_live;
+                const unsigned off = (rowoff + (unsigned)n) * 4u;
+                so_st[k] = (live && nv) ? off : OOB;
+                so_ld[k] = (live && nv && !dead) ? off : OOB;
+                const unsigned off_t = SZT == 4 ? so_ld[k] : (unsigned)((int)so_ld[k] >> 1);   // (arithmetic shift: OOB stays out of range)
+                if (has_mask) smk[k] = EpiT<T>::load(rs_mask, off_t);
+                if (has_res) srr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, so_ld[k], 0, 0);
             }
-            if (!live || !nv) continue;
-            const size_t off = rowoff + n;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * p.alpha + bb[e];
-            if (Mask) {
-                float mk[4];
-                Op4<T>::load(Mask + off, mk);
+            for (int k = 0; k < B; ++k) {
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (!(mk[e] > 0.f)) v[e] = 0.f;
-            }
-            if (p.res) {
-                const float4 rr = *reinterpret_cast<const float4*>(p.res + off);
-                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-            }
-            if (dead) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-            if (p.stat_ws) {
+                for (int e = 0; e < 4; ++e) v[e] = sv[k][e] * p.alpha + bb[e];
+                if (has_mask) {
+                    float mk[4];
+                    EpiT<T>::unpack(smk[k], mk);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] = fmaf(v[e], v[e], ssq[e]); }
-            }
-            if (p.out) *reinterpret_cast<float4*>(p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
-            if (OutRaw) Op4<T>::store(OutRaw + off, v);
-            if (OutOp) {
-                if (p.relu_op) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e)
+                        if (!(mk[e] > 0.f)) v[e] = 0.f;
                 }
-                Op4<T>::store(OutOp + off, v);
+                if (has_res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(srr[k][e]);
+                }
+                if (so_ld[k] != so_st[k]) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }   // a row of an image past *nimg: zeros (a select)
+                if (has_stats) {
+                    const bool cnt = so_st[k] != OOB;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float w_ = cnt ? v[e] : 0.f; ssum[e] += w_; ssq[e] = fmaf(w_, w_, ssq[e]); }
+                }
+                const unsigned st_t = SZT == 4 ? so_st[k] : (unsigned)((int)so_st[k] >> 1);
+                if (has_out) {
+                    u4_t o_;
+                    o_[0] = __float_as_uint(v[0]); o_[1] = __float_as_uint(v[1]); o_[2] = __float_as_uint(v[2]); o_[3] = __float_as_uint(v[3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(o_, rs_out, so_st[k], 0, 0);
+                }
+                if (has_raw) EpiT<T>::store(rs_raw, st_t, v);
+                if (has_op) {
+                    if (p.relu_op) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    EpiT<T>::store(rs_op, st_t, v);
+                }
             }
         }
     }
-    if (p.stat_ws) {   // lanes that share a channel group are L4 apart: combine them, one atomic per channel and wave into a replica
+    if (has_stats) {   // lanes that share a channel group are L4 apart: combine them, one atomic per channel and wave into a replica
 #pragma unroll
         for (int o = L4; o < 64; o <<= 1)
 #pragma unroll
@@ -355,8 +463,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
 // MFMA tiles), NS-stage LDS ring.
 // HK = 1 halves the K-step (64-byte LDS rows): twice as many, half as large ring stages, so that two workgroups per
 // CU can each keep three tiles in flight within the 160 KB of LDS (the DMA round trip under load is ~1.5 us).
+// (second launch bound = waves per SIMD the LDS ring allows: keeps the register allocation of the -- fully unrolled,
+//  load-batching -- epilogue within the occupancy the main loop was tuned for)
 template <typename T, int BM, int BN, int WM, int WN, int NS, int HK>
-__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WM* WN * 64, ((160 * 1024) / (NS * (BM + BN) * (HK ? 64 : 128))) * (WM * WN) / 4) void conv_igemm_kernel(ConvArgs p) {
     constexpr int THREADS = WM * WN * 64;
     constexpr int ROWB = HK ? 64 : 128;     // bytes per LDS tile row
     constexpr int CPR = ROWB / 16;        // 16-byte chunks per LDS row
@@ -375,6 +485,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = (BM + BN) * ROWB;
 
+    L2I_TR(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = p.tiles_m * p.tiles_n;
     const int split = blockIdx.x / nblk;
@@ -501,6 +612,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
     // read. (__syncthreads() would drain vmcnt to 0 and serialise the ring.) One K-step of a single workgroup is
     // otherwise bound by the ~1.5 us DMA round trip, not by its 0.2 us of MFMA work.
     constexpr int LPT = AP + BP;  // LDS-DMA instructions per thread per tile
+    L2I_TR(1);
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (ks0 + s < nks) {
@@ -523,9 +635,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
         Mma2<T>::template step<TM, TN, HK>(cur, cur + BM * ROWB, wrow, wcol, lane, acc);
     }
 
+    L2I_TR(2);
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
     else if (p.epi_lds) conv_epilogue_lds<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
     else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
+    L2I_TR(3);
 }
 
 // ---------------------------------------------------------------- 3x3 convolution with an LDS-resident input halo
@@ -564,7 +678,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs p) {
                  : "memory")
 
 template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false, int ABL = 0>   // H1: ONE halo buffer, refilled at each chunk boundary
-__global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {   // ABL: ablations for tools/perf (results are wrong): 1 no weight DMA, 2 no DMA, 3 no DMA + no fragment reads, 4 no barrier
+__global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void conv_halo2_kernel(ConvArgs p) {   // ABL: ablations for tools/perf (results are wrong): 1 no weight DMA, 2 no DMA, 3 no DMA + no fragment reads, 4 no barrier
     typedef bf16_t T;
     constexpr int THREADS = WM * WN * 64, NW = WM * WN;
     constexpr int BK = 64, SZ = 2;
@@ -576,6 +690,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {  
     static_assert(BN % RPP == 0 && BP >= 1 && BP <= 4, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    L2I_TR(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int nblk = p.tiles_m * p.tiles_n;
@@ -728,6 +843,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {  
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
 
+    L2I_TR(1);
     if (c_begin < c_end) {
         // prologue: the whole first halo, then the weight tiles of taps 0 and 1
         {
@@ -793,9 +909,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo2_kernel(ConvArgs p) {  
 #undef H2_MFMA4
 #undef H2_MFMA
 #undef H2_READS
+    L2I_TR(2);
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
     else if (p.epi_lds) conv_epilogue_lds<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
     else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
+    L2I_TR(3);
 }
 
 // ---------------------------------------------------------------- 256-pixel tiles: conv_halo3_kernel
@@ -823,6 +941,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
     constexpr unsigned OOB = 0x80000000u, BSTAGE = BN * 128u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    L2I_TR(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int nblk = p.tiles_m * p.tiles_n;
@@ -1020,6 +1139,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
         H3_MM(3)                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
+    L2I_TR(1);
     if (PF) {
         if (c_begin < c_end) {
             {   // prologue: the first halo and the weight tiles of taps 0 and 1
@@ -1100,9 +1220,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
 #undef H3_HALO
 #undef H3_MM
 #undef H3_RD
+    L2I_TR(2);
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
     else if (p.epi_lds) conv_epilogue_lds<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
     else conv_epilogue<T, TM, TN>(p, acc, wrow, 0, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
+    L2I_TR(3);
 }
 
 static int ilog2(int v) {
@@ -1283,6 +1405,12 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         if (xb >= 0x80000000ull || wb >= 0x80000000ull) return L2I_ERR_ARG;
         a.x_bytes = (unsigned)xb;
         a.w_bytes = (unsigned)wb;
+        // conv_epilogue_lds addresses the result-shaped tensors through buffer descriptors with 32-bit byte offsets
+        const size_t ob = (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co * 4;
+        if (ob >= 0x80000000ull) {
+            if (a.stat_ws) return L2I_ERR_ARG;
+            a.epi_lds = 0;   // (64-bit addressing in the direct form)
+        }
     }
     a.lin = a.Wo < 2;
     if (a.lin) {
@@ -1439,8 +1567,12 @@ extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, c
     if (!x || !w || (!out && !out_op && !out_op_raw)) return L2I_ERR_ARG;
     if (stats && (!ws || !out || Co % 4 || 2LL * Co * L2I_WS_R > L2I_WS_FLOATS)) return L2I_ERR_ARG;
     ConvArgs a;
+#ifdef L2I_ABLATIONS   // wrong-result switches exist only in ablation builds (L2I_EXTRA_FLAGS=-DL2I_ABLATIONS), never in the shipped library
     static const int no_epi = getenv("L2I_CONV_NOEPI") ? atoi(getenv("L2I_CONV_NOEPI")) : 0;
     a.no_epi = no_epi;
+#else
+    a.no_epi = 0;
+#endif
     static const int roi_remap = getenv("L2I_ROI_REMAP") ? atoi(getenv("L2I_ROI_REMAP")) : 0;
     a.roi_remap = roi_remap;
     // Epilogue form. 2 (default): conv_epilogue_lds for every launch; 1: only when the epilogue touches operand-dtype

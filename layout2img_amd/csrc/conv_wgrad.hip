@@ -27,7 +27,7 @@ struct WgradArgs {
     unsigned x_bytes, dy_bytes;   // buffer-descriptor ranges of x and dy
     const int* nimg;              // device int (optional): reduce over the first *nimg images only
     float* dbias;                 // optional [Co]: += alpha * sum_m dYfull[m, co] (the bias gradient), by the tile_k == 0 workgroups
-    int no_epi;                   // tuning (L2I_WGRAD_NOEPI=1, results are wrong): skip the atomic epilogue to measure what it costs
+    int no_epi;                   // ablation builds only (-DL2I_ABLATIONS + L2I_WGRAD_NOEPI=1, results are wrong): skip the atomic epilogue to measure what it costs
     int lgbk;                     // log2 of the kernel's pixel step (6; 7 for the eight-wave kernel)
     float* part;                  // optional scratch: every workgroup STORES its partial tile there ([tile][split][BMO][128] f32) and
                                   // wgrad_reduce_kernel adds the splits into dw -- instead of one f32 atomic per element and split
@@ -525,6 +525,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
                 for (int e = 0; e < 16; ++e) acc[i][j][e] += xch[((wq * TM * TN + i * TN + j) * 16 + e) * 64 + lane];
     }
 
+#ifdef L2I_ABLATIONS
     if (p.no_epi) {   // (keeps the accumulators live)
         float s_ = 0.f;
 #pragma unroll
@@ -536,17 +537,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
         if (s_ == 1.2345e30f) p.dw[0] = s_;
         return;
     }
+#endif
     const int c = lane & 31, h = lane >> 5;
-    if (p.part) {   // plain stores of the whole tile (128-byte runs; dead splits store their zeros): measured 5.8 TB/s against
-                    // 1.3 TB/s for the same pattern of f32 atomics (tools/perf/t_atomic.hip)
-        float* t = p.part + ((size_t)(tile_co * p.tiles_k + tile_k) * p.splits + split) * (size_t)(BMO * BNK);
+    if (p.part) {   // plain stores of the whole tile (dead splits store their zeros): measured 5.8 TB/s against 1.3 TB/s for the
+                    // same bytes as f32 atomics (tools/perf/t_atomic.hip). The scratch tile is kept in REGISTER order --
+                    // [wave][i][j][register group g][lane] float4 -- so that one store instruction writes 64 x 16 contiguous
+                    // bytes (round 2 stored row-major: 64 four-byte store instructions per wave, a quarter of the bytes per
+                    // instruction); wgrad_reduce_kernel reads it in the same order and un-permutes on its (one per tile, not
+                    // per split) write to dw.
+        float4* t = reinterpret_cast<float4*>(p.part + ((size_t)(tile_co * p.tiles_k + tile_k) * p.splits + split) * (size_t)(BMO * BNK)) +
+                    wq * (TM * TN * 4 * 64) + lane;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    t[(wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * BNK + wcol + j * 32 + c] = acc[i][j][e];
+                for (int g = 0; g < 4; ++g)
+                    t[((i * TN + j) * 4 + g) * 64] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         return;
     }
 #pragma unroll
@@ -564,38 +571,43 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 }
 
 // dw[row][col] += alpha * sum over splits of the partial tiles stored by conv_wgrad_dma_kernel (WgradArgs::part).
-// One thread per float4 of a tile row; a layer's dw slice is written by one launch at a time (same stream), so the
-// read-modify-write needs no atomics.
+// One thread per float4 of a tile in the REGISTER order the main kernel stores it in (coalesced 16-byte reads over the
+// splits): float4 f = ((wave * TM + i) * 2 + j) * 4 + g) * 64 + lane holds accumulator registers 4g .. 4g+3 of lane
+// (c = lane & 31, h = lane >> 5) = rows wrow + 32 i + 8 g + 4 h + {0..3}, column wcol + 32 j + c of the tile. A layer's dw
+// slice is written by one launch at a time (same stream), so the read-modify-write needs no atomics.
+// nw2: the two-wave kernel's geometry (waves side by side, TM = BMO / 32), else four waves as 2 x 2 (TM = BMO / 64).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int BMO, int tiles_k,
-                                                           int ntiles, int splits, int Co, int K, int ldw, float alpha) {
+                                                           int ntiles, int splits, int Co, int K, int ldw, float alpha, int nw2) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int c4 = (int)(gid & 31);
-    const long long rr = gid >> 5;
-    const int r = (int)(rr % BMO), tile = (int)(rr / BMO);
+    const int per_tile = BMO * 32;                      // float4 per tile
+    const int tile = (int)(gid / per_tile), f = (int)(gid - (long long)tile * per_tile);
     if (tile >= ntiles) return;
     const int tile_k = tile % tiles_k, tile_co = tile / tiles_k;
-    const int row = tile_co * BMO + r, col = tile_k * 128 + c4 * 4;
-    if (row >= Co || col >= K) return;
-    const size_t tsz = (size_t)BMO * 128;
-    const float* src = part + (size_t)tile * splits * tsz + (size_t)r * 128 + c4 * 4;
+    const int lane = f & 63, g = (f >> 6) & 3, j = (f >> 8) & 1;
+    const int TM = nw2 ? BMO / 32 : BMO / 64;
+    const int wi = f >> 9, i = wi % TM, wq = wi / TM;
+    const int wrow = nw2 ? 0 : (wq >> 1) * (BMO / 2), wcol = (nw2 ? wq : (wq & 1)) * 64;
+    const int row0 = tile_co * BMO + wrow + i * 32 + 8 * g + 4 * (lane >> 5), col = tile_k * 128 + wcol + j * 32 + (lane & 31);
+    const size_t tsz4 = (size_t)BMO * 32;
+    const float4* src = reinterpret_cast<const float4*>(part) + (size_t)tile * splits * tsz4 + f;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     int s = 0;
     for (; s + 4 <= splits; s += 4) {
-        const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)s * tsz);
-        const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(s + 1) * tsz);
-        const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(s + 2) * tsz);
-        const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(s + 3) * tsz);
+        const float4 v0 = src[(size_t)s * tsz4], v1 = src[(size_t)(s + 1) * tsz4];
+        const float4 v2 = src[(size_t)(s + 2) * tsz4], v3 = src[(size_t)(s + 3) * tsz4];
         a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
         a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
     }
     for (; s < splits; ++s) {
-        const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)s * tsz);
+        const float4 v0 = src[(size_t)s * tsz4];
         a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
     }
-    float4* d = reinterpret_cast<float4*>(dw + (size_t)row * ldw + col);
-    float4 o = *d;
-    o.x += alpha * a.x; o.y += alpha * a.y; o.z += alpha * a.z; o.w += alpha * a.w;
-    *d = o;
+    if (col >= K) return;
+    float* d = dw + (size_t)row0 * ldw + col;   // (a half-wave writes 32 consecutive columns of one row per statement)
+    if (row0 < Co) d[0] += alpha * a.x;
+    if (row0 + 1 < Co) d[ldw] += alpha * a.y;
+    if (row0 + 2 < Co) d[2 * (size_t)ldw] += alpha * a.z;
+    if (row0 + 3 < Co) d[3 * (size_t)ldw] += alpha * a.w;
 }
 
 static int g_wgrad_blocks = 0;   // tuning hook l2i_set_wgrad_blocks: workgroups per wave of the grid (0 = from the tile's occupancy)
@@ -697,7 +709,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
         if (a.part) {
             const long long nthr = (long long)tiles * BMO * 32;
             L2I_LAUNCH(1, wgrad_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
-                       a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha);
+                       a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, (int)(nw2 && !nw8 && BMO == 128));
         }
         return l2i_check_launch();
     }
@@ -715,8 +727,12 @@ extern "C" int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dt
     if (!x || !dy || !dw) return L2I_ERR_ARG;
     if (nimg && (Ho * Wo) % 64) return L2I_ERR_ARG;
     WgradArgs a;
+#ifdef L2I_ABLATIONS   // wrong-result switch: ablation builds only (L2I_EXTRA_FLAGS=-DL2I_ABLATIONS)
     static const int no_epi = getenv("L2I_WGRAD_NOEPI") ? atoi(getenv("L2I_WGRAD_NOEPI")) : 0;
     a.no_epi = no_epi;
+#else
+    a.no_epi = 0;
+#endif
     a.nimg = nimg;
     a.dbias = dbias;
     a.x = x; a.dy = dy; a.dw = dw;

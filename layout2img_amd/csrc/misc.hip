@@ -123,14 +123,14 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, 
         if constexpr (sizeof(T) == 2) {
             if (raw) {
                 uint2 pk;
-                pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-                pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                pk.x = f2bf2(v.x, v.y);
+                pk.y = f2bf2(v.z, v.w);
                 reinterpret_cast<uint2*>(raw)[i] = pk;
             }
             if (act) {
                 uint2 pk;
-                pk.x = (uint32_t)f2bf(fmaxf(v.x, 0.f)) | ((uint32_t)f2bf(fmaxf(v.y, 0.f)) << 16);
-                pk.y = (uint32_t)f2bf(fmaxf(v.z, 0.f)) | ((uint32_t)f2bf(fmaxf(v.w, 0.f)) << 16);
+                pk.x = f2bf2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
+                pk.y = f2bf2(fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                 reinterpret_cast<uint2*>(act)[i] = pk;
             }
         } else {

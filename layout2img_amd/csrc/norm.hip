@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
                     const size_t off = (size_t)r * C + 4 * (cbase + tx);
                     if constexpr (sizeof(T) == 2) {
                         uint2 pk;
-                        pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-                        pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                        pk.x = f2bf2(v.x, v.y);
+                        pk.y = f2bf2(v.z, v.w);
                         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(raw) + off) = pk;
                     } else {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(raw) + off) = v;
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void norm_mod_kernel(NormArgs p) {
                 if (OutOp) {
                     if constexpr (sizeof(T) == 2) {
                         uint2 pk;
-                        pk.x = (uint32_t)f2bf(y.x) | ((uint32_t)f2bf(y.y) << 16);
-                        pk.y = (uint32_t)f2bf(y.z) | ((uint32_t)f2bf(y.w) << 16);
+                        pk.x = f2bf2(y.x, y.y);
+                        pk.y = f2bf2(y.z, y.w);
                         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(OutOp) + off) = pk;
                     } else {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(OutOp) + off) = y;

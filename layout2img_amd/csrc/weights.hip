@@ -160,10 +160,10 @@ template <typename T>
 __device__ __forceinline__ void store8(T* dst, const float (&v)[8]) {
     if constexpr (sizeof(T) == 2) {
         uint4 pk;
-        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-        pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        pk.x = f2bf2(v[0], v[1]);
+        pk.y = f2bf2(v[2], v[3]);
+        pk.z = f2bf2(v[4], v[5]);
+        pk.w = f2bf2(v[6], v[7]);
         *reinterpret_cast<uint4*>(dst) = pk;
     } else {
         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);

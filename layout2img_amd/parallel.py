@@ -41,15 +41,33 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def allreduce_flat_(flat_grad, chunk_bytes=64 << 20, async_op=False):
-    """SUM all-reduce of a flat buffer in large contiguous chunks (in place). Returns work handles."""
+_GRAD_GROUP = None
+
+
+def grad_group():
+    """A process group of its own for the gradient all-reduces. A ProcessGroup has ONE communicator stream per device, and
+    collectives of one group run in issue order: on the default group the small blocking collectives of the next iteration
+    (valid-ROI count, SyncBN statistics) would queue behind an asynchronously launched 163 MB gradient all-reduce and the
+    main stream would wait for all of it -- no overlap. Created collectively (every rank calls this at the same point:
+    GanTrainer.__init__); None at world size 1."""
+    global _GRAD_GROUP
+    if world_size() == 1:
+        return None
+    if _GRAD_GROUP is None:
+        _GRAD_GROUP = dist.new_group()
+    return _GRAD_GROUP
+
+
+def allreduce_flat_(flat_grad, chunk_bytes=64 << 20, async_op=False, group=None):
+    """SUM all-reduce of a flat buffer in large contiguous chunks (in place). Returns work handles.
+    group: the process group to run on (grad_group() for gradient exchanges that should overlap other collectives)."""
     if world_size() == 1:
         return []
     n = flat_grad.numel()
     step = max(1, chunk_bytes // flat_grad.element_size())
     works = []
     for s in range(0, n, step):
-        w = dist.all_reduce(flat_grad[s:min(n, s + step)], op=dist.ReduceOp.SUM, async_op=async_op)
+        w = dist.all_reduce(flat_grad[s:min(n, s + step)], op=dist.ReduceOp.SUM, async_op=async_op, group=group)
         if async_op:
             works.append(w)
     return works

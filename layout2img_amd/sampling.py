@@ -15,6 +15,43 @@ from collections import OrderedDict
 import torch
 
 
+def _flush(net):
+    f = getattr(net, "_l2i_flush", None)
+    if f is not None:
+        f()
+
+
+def _opt_state(o):
+    """Adam moments per PARAMETER NAME (sliced out of the flat buffers by the network's own offsets): independent of the
+    flat layout (alignment, parameter order), which has changed between revisions."""
+    flat = o.net.flat
+    out = {}
+    for name, p in flat._params:
+        off, k = flat.offsets[name], p.numel()
+        out[name] = (o.m[off:off + k].detach().cpu().clone().view(p.shape), o.v[off:off + k].detach().cpu().clone().view(p.shape))
+    return dict(state=out, t=o.t, lr=o.lr, betas=tuple(o.betas), eps=o.eps)
+
+
+def _load_opt_state(o, st):
+    flat = o.net.flat
+    names = {n for n, _ in flat._params}
+    if set(st["state"]) != names:
+        raise RuntimeError("optimizer checkpoint does not match this network: "
+                           f"{len(names - set(st['state']))} parameters missing, {len(set(st['state']) - names)} unknown")
+    with torch.no_grad():
+        o.m.zero_(), o.v.zero_()
+        for name, p in flat._params:
+            off, k = flat.offsets[name], p.numel()
+            m, v = st["state"][name]
+            if tuple(m.shape) != tuple(p.shape):
+                raise RuntimeError(f"optimizer checkpoint: {name} has shape {tuple(m.shape)}, the model {tuple(p.shape)}")
+            o.m[off:off + k].copy_(m.reshape(-1))
+            o.v[off:off + k].copy_(v.reshape(-1))
+    o.t = int(st["t"])
+    o.t_dev.fill_(o.t)
+    o.lr, o.betas, o.eps = float(st["lr"]), tuple(st["betas"]), float(st["eps"])
+
+
 def load_reference_checkpoint(net, state, prefix="module."):
     """state: a state_dict (or a path to one saved with torch.save). Returns (loaded, ignored) key lists."""
     if isinstance(state, (str, bytes)):
@@ -37,7 +74,9 @@ def load_reference_checkpoint(net, state, prefix="module."):
 def reference_state_dict(net, prefix="module."):
     """`net.state_dict()` as the reference writes it (train_context_app_v2.py:215-217: the nets are wrapped in
     nn.DataParallel there, hence the `module.` prefix): every entry cloned into its own CPU storage -- the parameters of
-    a finalized network are views into ONE flat buffer, which must not be what ends up in the file."""
+    a finalized network are views into ONE flat buffer, which must not be what ends up in the file.
+    A deferred optimizer step of a data-parallel trainer (GanTrainer.defer_g) is completed first."""
+    _flush(net)
     return OrderedDict((prefix + k, v.detach().cpu().clone()) for k, v in net.state_dict().items())
 
 
@@ -53,8 +92,7 @@ def save_checkpoint(out_path, epoch, netG, netD, g_opt=None, d_opt=None, prefix=
         torch.save(reference_state_dict(net, prefix), paths[name])
     if g_opt is not None and d_opt is not None:
         paths["opt"] = os.path.join(d, f"opt_{epoch}.pth")
-        torch.save({k: dict(m=o.m.detach().cpu(), v=o.v.detach().cpu(), t=o.t, lr=o.lr, betas=o.betas, eps=o.eps)
-                    for k, o in (("G", g_opt), ("D", d_opt))}, paths["opt"])
+        torch.save({k: _opt_state(o) for k, o in (("G", g_opt), ("D", d_opt))}, paths["opt"])
     return paths
 
 
@@ -68,10 +106,7 @@ def load_checkpoint(out_path, epoch, netG, netD, g_opt=None, d_opt=None, prefix=
     if g_opt is not None and d_opt is not None and os.path.exists(p):
         st = torch.load(p, map_location="cpu")
         for k, o in (("G", g_opt), ("D", d_opt)):
-            o.m.copy_(st[k]["m"])
-            o.v.copy_(st[k]["v"])
-            o.t = int(st[k]["t"])
-            o.t_dev.fill_(o.t)
+            _load_opt_state(o, st[k])   # per parameter name; lr / betas / eps restored too
     return epoch
 
 
@@ -86,6 +121,7 @@ def truncated_normal(shape, thres=1.0, device="cpu", generator=None, dtype=torch
 def sample(netG, label, bbox, thres=2.0, generator=None, return_latents=False):
     """Eval-mode images for layouts (label (b,o) int64, bbox (b,o,4)); truncated latents as the reference draws them
     (test_context_app_v2.py:68-77: z_obj (b,o,128) and z_im (b,128), both truncated at `thres` = 2)."""
+    _flush(netG)   # (a deferred generator step of a data-parallel trainer)
     was_training = netG.training
     netG.eval()
     try:

@@ -28,6 +28,7 @@ class FlatAdam:
         self.v = torch.zeros_like(net.flat.data)
         self.t = 0
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=net.flat.data.device)   # the count the kernel reads
+        self.group = None   # process group of the gradient all-reduce (GanTrainer: parallel.grad_group(), its own comm stream)
 
     _works = None
 
@@ -35,7 +36,7 @@ class FlatAdam:
         """First half of step(): spectral-norm backward flush, then the gradient all-reduce LAUNCHED (asynchronously under
         data parallelism: the collective runs on the communicator's stream while this stream goes on)."""
         self.net.arena.flush_grads()
-        self._works = parallel.allreduce_flat_(self.net.flat.grad, async_op=True)
+        self._works = parallel.allreduce_flat_(self.net.flat.grad, async_op=True, group=self.group)
 
     def finish_step(self):
         """Second half: the current stream waits for the all-reduce, then the fused Adam launch."""
@@ -68,7 +69,11 @@ class GanTrainer:
         # next to it: the G step reads D's updated weights at once.) flush() completes a pending step; L2I_DEFER_G=0: off.
         self.defer_g = self.world > 1 and self.overlap and os.environ.get("L2I_DEFER_G", "1") != "0"
         self._pending_g = False
+        # whoever reads the generator's parameters from outside the loop (sampling.sample, checkpoints) completes a deferred
+        # step first: the hook rides on the network
+        netG._l2i_flush = self.flush
         if self.world > 1:
+            self.g_opt.group = self.d_opt.group = parallel.grad_group()
             netG.sync = parallel.sync_bn_stats
             parallel.broadcast_flat_(netG.flat.data)
             parallel.broadcast_flat_(netD.flat.data)
