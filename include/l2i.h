@@ -148,12 +148,13 @@ int l2i_roi_align_bwd(const float* rois, const int* valid, const float* dout, fl
                       void* stream);
 
 /* box_attention core (model/resnet_generator_app_v2.py:79-120; geo == NULL gives the VG variant,
- * model/resnet_generator_vg.py:77-122). q,k,v,out [B][O][D]; geo, prob [B][O][O]; keyvalid [B][O]. */
+ * model/resnet_generator_vg.py:77-122). q, k, v: rows of D floats, `ld` floats apart (D, or the width of a grouped projection
+ * result they are column slices of); out [B][O][D]; geo, prob [B][O][O]; keyvalid [B][O]. bwd: dq, dk, dv rows `ldd` apart. */
 int l2i_box_attention_fwd(const float* q, const float* k, const float* v, const float* geo, const int* keyvalid, float* out,
-                          float* prob, int B, int O, int D, float scale, void* stream);
+                          float* prob, int B, int O, int D, int ld, float scale, void* stream);
 int l2i_box_attention_bwd(const float* q, const float* k, const float* v, const float* geo, const float* prob,
-                          const float* dout, float* dq, float* dk, float* dv, float* dgeo, int B, int O, int D, float scale,
-                          void* stream);
+                          const float* dout, float* dq, float* dk, float* dv, float* dgeo, int B, int O, int D, int ld, int ldd,
+                          float scale, void* stream);
 
 /* Hinge losses with fused backward (train_context_app_v2.py:159-172,180-187).
  * mode 0: mean relu(1-x); 1: mean relu(1+x); 2: -mean x. loss_out += weight*loss; grad = weight*dloss/dx.
@@ -241,6 +242,86 @@ int l2i_psp_expand_fwd(const float* feats, const float* y, const int* uidx, cons
                        int F, int NB, int n_stages, int dtype, void* stream);
 int l2i_psp_expand_bwd(const void* g, const float* wx, const float* wy, const int* xq, const int* qoff, float* dy, float* dfeats,
                        float* rows, int B, int H, int C, int F, int NB, int NQ, int n_stages, int dtype, void* stream);
+
+/* ---- layout-side glue of the generator (csrc/layout.hip): one launch per reference function instead of chains of
+ * elementwise torch ops. All tensors f32 unless noted; `*_op` are optional operand-dtype copies (dtype: 0 f32, 1 bf16). */
+
+/* relu(WGs(BoxRelationalEmbedding(bbox))) (model/resnet_generator_app_v2.py:17-76,175-180): bbox [B][O][4] (xywh read as corner
+ * boxes, as the reference does), dim_mat [8] = 1 / 1000^(k/8), wg [64] + wg_bias [1] = the Linear(64, 1); geo [B][O][O].
+ * bwd: dwg [64] += , dbias [1] += over the pairs with geo > 0. */
+int l2i_box_geometry_fwd(const float* bbox, const float* dim_mat, const float* wg, const float* wg_bias, float* geo, int B, int O,
+                         void* stream);
+int l2i_box_geometry_bwd(const float* bbox, const float* dim_mat, const float* geo, const float* dgeo, float* dwg, float* dbias,
+                         int B, int O, void* stream);
+
+/* sigmoid + masks_to_layout (utils/bilinear.py:137-192: F.grid_sample, bilinear, zeros, align_corners = False, on the
+ * box-relative grid) + bbox_mask (model/resnet_generator_app_v2.py:697-721). m: N maps of M x M logits, element stride
+ * m_stride (channel 0 of a padded NHWC tensor); bbox [N][4] xywh; lin [H] = torch.linspace(0, 1, H);
+ * bmask, boxm (optional) [N][H][H]. bwd: g [N][H][H] -> dm [N][M][M][d_stride] (element 0 the gradient, the rest zeros). */
+int l2i_layout_masks_fwd(const float* m, int m_stride, const float* bbox, const float* lin, float* bmask, float* boxm, int N, int M,
+                         int H, void* stream);
+int l2i_layout_masks_bwd(const float* m, int m_stride, const float* bbox, const float* lin, const float* g, float* dm, int d_stride,
+                         int N, int M, int H, void* stream);
+
+/* y[r, :D] = LayerNorm(a'[r] + b[r]) gamma + beta, y[r, D:ldy] = 0 (model/resnet_generator_app_v2.py:199-214). a' = a, or with
+ * perm_O > 0 the h = 1 "concat heads" shuffle of each image's (perm_O, D) matrix (:197-198):
+ * a'[img, r, c] = a[img, (r D + c) % O, (r D + c) / O]. mean, rstd [rows] are kept for bwd.
+ * bwd: da (a's layout, optional), db [rows][ldb] (optional) written; dgamma, dbeta [D] += . */
+int l2i_add_layernorm_fwd(const float* a, int lda, const float* b, int ldb, const float* gamma, const float* beta, float eps,
+                          float* y, int ldy, void* y_op, int op_dtype, float* mean, float* rstd, int rows, int D, int perm_O,
+                          void* stream);
+int l2i_add_layernorm_bwd(const float* a, int lda, const float* b, int ldb, const float* gamma, const float* mean, const float* rstd,
+                          const float* dy, int ldy, float* da, float* db, float* dgamma, float* dbeta, int rows, int D, int perm_O,
+                          void* stream);
+
+/* out[r] = [z[r] (Z) | emb[y[r]] (E) | zeros to ld] (model/resnet_generator_app_v2.py:437-441), keyvalid[r] = y[r] != 0
+ * (optional). bwd: demb[y[r]] += g[r, Z:Z+E]. */
+int l2i_latent_fwd(const float* z, const float* emb, const long long* y, float* out, void* out_op, int op_dtype, int* keyvalid,
+                   int rows, int Z, int E, int ld, void* stream);
+int l2i_latent_bwd(const float* g, const long long* y, float* demb, int rows, int Z, int E, int ld, void* stream);
+
+/* A Linear's rows [N][C*P] read as .view(N, C, 4, 4) (model/resnet_generator_app_v2.py:453, model/mask_regression.py:87)
+ * -> NHWC [N][P][C] (inverse = 0), or the gradient's way back (inverse = 1); out and / or out_op. */
+int l2i_fc_to_nhwc(const float* in, float* out, void* out_op, int op_dtype, long long N, int C, int P, int inverse, void* stream);
+
+/* img [B][C][HW] = tanh(pre [B][HW][Cp][:C]) (model/resnet_generator_app_v2.py:497-499);
+ * bwd: dpre [B][HW][Cp] = (1 - img^2) g on the first C channels, zeros on the pad (+ operand copy). */
+int l2i_tanh_nchw_fwd(const float* pre, float* img, long long B, int C, int Cp, int HW, void* stream);
+int l2i_tanh_nchw_bwd(const float* img, const float* g, float* dpre, void* dpre_op, int op_dtype, long long B, int C, int Cp, int HW,
+                      void* stream);
+
+/* Pyramid stages of the PSP head (model/resnet_generator_app_v2.py:741-746): per stage s (bins [off_s, off_s + sizes[s]^2) of
+ * every image) raw = pooled W_s^T, BatchNorm2d over the stage's B sizes[s]^2 rows (training: batch statistics, running
+ * statistics updated with `momentum` and the unbiased variance; else the running statistics), ReLU.
+ * pooled [B][NB][C]; W, gamma, beta, rmean, rvar: HOST arrays of S device pointers ([F][C] resp. [F] each: the stage
+ * modules' own tensors); raw, y [B][NB][F]; stat [S][2][F] (mean, rstd) kept.
+ * bwd: dy -> draw (scratch), dpooled [B][NB][C], dW [S][F][C], dgamma / dbeta [S][F], all written. */
+int l2i_psp_stages_fwd(const float* pooled, const float* const* W, const float* const* gamma, const float* const* beta,
+                       float* const* rmean, float* const* rvar, float* raw, float* y, float* stat, int B, int NB, int C, int F, int S,
+                       const int* sizes, int training, float eps, float momentum, void* stream);
+int l2i_psp_stages_bwd(const float* pooled, const float* const* W, const float* const* gamma, const float* const* beta,
+                       const float* raw, const float* stat, const float* dy, float* draw, float* dpooled, float* dW, float* dgamma,
+                       float* dbeta, int B, int NB, int C, int F, int S, const int* sizes, int training, void* stream);
+
+/* ROI bookkeeping of the discriminator on the device (model/rcnn_discriminator_app.py:131-146,402-417): xywh in [0,1] ->
+ * (batch index, x1, y1, x2, y2) * size, rows COMPACTED by a stable sort on 2 [label == 0] + [two_scale and both sides < 64]:
+ * real ROIs first (large, then small: the reference's output order), padding rows behind. bbox [R][4], label [R] int64 (R = b*o
+ * <= 1024, image of row r = r / o); rois [R][5], y [R] int64, valid [R] int32, count [1] int32 = number of real ROIs. */
+int l2i_roi_layout(const float* bbox, const long long* label, float size, int two_scale, int o, int R, float* rois, long long* y,
+                   int* valid, int* count, void* stream);
+
+/* img [B][C][H][W] -> x [B][H][W][Cp] (zero pad channels) and optionally its 2x2 average xs [B][H/2][W/2][Cp]
+ * (model/rcnn_discriminator_app.py:311-314), f32 + optional operand copies. bwd: dimg = dx[..., :C] + 0.25 dxs (either NULL). */
+int l2i_image_nhwc_fwd(const float* img, float* x, void* x_op, float* xs, void* xs_op, int op_dtype, long long B, int C, int Cp, int H,
+                       int W, void* stream);
+int l2i_image_nhwc_bwd(const float* dx, const float* dxs, float* dimg, long long B, int C, int Cp, int H, int W, void* stream);
+
+/* Adjoint of l2i_resize_bilinear: dx [N][h][w] (written) = the bilinear weights times g [N][H][W], gathered per input pixel. */
+int l2i_resize_bilinear_bwd(const float* g, float* dx, long long N, int h, int w, int H, int W, void* stream);
+
+/* nn.Dropout2d on an NHWC stream given uniform draws u [B][C] (model/resnet_generator_app_v2.py:739):
+ * out = in * (u >= prob) / (1 - prob); its own backward with in = dy. C % 4 == 0. */
+int l2i_channel_dropout(const float* in, const float* u, float* out, long long B, int HW, int C, float prob, void* stream);
 
 #ifdef __cplusplus
 }

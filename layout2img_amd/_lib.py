@@ -27,8 +27,8 @@ SIGNATURES = {
     "l2i_norm_bwd_b": [_p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _f, _f, _i, _p, _p],
     "l2i_roi_align_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f, _i, _p],
     "l2i_roi_align_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f, _i, _p],
-    "l2i_box_attention_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
-    "l2i_box_attention_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "l2i_box_attention_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "l2i_box_attention_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "l2i_hinge_fwd_bwd": [_p, _p, _i, _i, _f, _p, _p, _p, _p],
     "l2i_l1_fwd_bwd": [_p, _p, _ll, _f, _p, _p, _p],
     "l2i_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p, _p],
@@ -49,6 +49,24 @@ SIGNATURES = {
     "l2i_stage_mask_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "l2i_stage_mask_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "l2i_relu_bwd": [_p, _p, _p, _p, _ll, _p],
+    "l2i_box_geometry_fwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "l2i_box_geometry_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "l2i_layout_masks_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    "l2i_layout_masks_bwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "l2i_add_layernorm_fwd": [_p, _i, _p, _i, _p, _p, _f, _p, _i, _p, _i, _p, _p, _i, _i, _i, _p],
+    "l2i_add_layernorm_bwd": [_p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    "l2i_latent_fwd": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p],
+    "l2i_latent_bwd": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "l2i_fc_to_nhwc": [_p, _p, _p, _i, _ll, _i, _i, _i, _p],
+    "l2i_tanh_nchw_fwd": [_p, _p, _ll, _i, _i, _i, _p],
+    "l2i_tanh_nchw_bwd": [_p, _p, _p, _p, _i, _ll, _i, _i, _i, _p],
+    "l2i_roi_layout": [_p, _p, _f, _i, _i, _i, _p, _p, _p, _p, _p],
+    "l2i_image_nhwc_fwd": [_p, _p, _p, _p, _p, _i, _ll, _i, _i, _i, _i, _p],
+    "l2i_image_nhwc_bwd": [_p, _p, _p, _ll, _i, _i, _i, _i, _p],
+    "l2i_resize_bilinear_bwd": [_p, _p, _ll, _i, _i, _i, _i, _p],
+    "l2i_channel_dropout": [_p, _p, _p, _ll, _i, _i, _f, _p],
+    "l2i_psp_stages_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _f, _f, _p],
+    "l2i_psp_stages_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
 }
 
 _lib = None

@@ -197,7 +197,9 @@ class GemmGroup:
     def __init__(self, name, members):
         self.name, self.members = name, members
         h0 = members[0]
-        assert all(m.kh == 1 and m.ci == h0.ci and m.uses == 1 and m.co == m.co_p and m.bias is not None for m in members)
+        # (a member's bias owns a zero-padded slot of _round_up(co, ALIGN) = co_p floats in the flat buffer: the group's biases
+        #  are one contiguous vector of n_total floats whatever the members' channel counts)
+        assert all(m.kh == 1 and m.ci == h0.ci and m.uses == 1 and _round_up(m.co, ALIGN) == m.co_p and m.bias is not None for m in members)
         self.ci, self.ci_p = h0.ci, h0.ci_p
         self.offsets, n = [], 0
         for m in members:

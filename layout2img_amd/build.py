@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libl2i_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "weights.hip", "norm.hip", "roi_align.hip", "attention.hip", "misc.hip", "psp.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "weights.hip", "norm.hip", "roi_align.hip", "attention.hip", "misc.hip", "psp.hip", "layout.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"] + os.environ.get("L2I_EXTRA_FLAGS", "").split()
 
 

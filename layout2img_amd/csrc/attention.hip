@@ -20,6 +20,8 @@ struct AttnArgs {
     const float* dout;                                // bwd
     float* dq; float* dk; float* dv; float* dgeo;     // bwd outputs
     int B, O, D;
+    int ld, ldd;                                      // row strides (floats) of q / k / v and of dq / dk / dv: D, or the width of
+                                                      // the grouped projection's (rows, 3 Dp) result the three are slices of
     float scale;
 };
 
@@ -36,9 +38,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t base = (size_t)b * O * D;
     for (int i = tid; i < O * D; i += 256) {
-        qs[i] = p.q[base + i];
-        ks[i] = p.k[base + i];
-        vs[i] = p.v[base + i];
+        const int r = i / D, c = i - r * D;
+        const size_t src = ((size_t)b * O + r) * p.ld + c;
+        qs[i] = p.q[src];
+        ks[i] = p.k[src];
+        vs[i] = p.v[src];
         if (BWD) dos[i] = p.dout[base + i];
     }
     __syncthreads();
@@ -110,9 +114,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 ak += dSs[j * O + i] * qs[j * D + t];   // dk_i = scale * sum_j dS_ji q_j
                 av += Ps[j * O + i] * dos[j * D + t];   // dv_i = sum_j P_ji dout_j
             }
-            p.dq[base + idx] = aq * p.scale;
-            p.dk[base + idx] = ak * p.scale;
-            p.dv[base + idx] = av;
+            const size_t dst = ((size_t)b * O + i) * p.ldd + t;
+            p.dq[dst] = aq * p.scale;
+            p.dk[dst] = ak * p.scale;
+            p.dv[dst] = av;
         }
     }
 }
@@ -122,12 +127,12 @@ static size_t attn_lds(int O, int D, bool bwd) {
 }
 
 extern "C" int l2i_box_attention_fwd(const float* q, const float* k, const float* v, const float* geo, const int* keyvalid,
-                                     float* out, float* prob, int B, int O, int D, float scale, void* stream) {
-    if (!q || !k || !v || !out || !prob || O < 1 || O > AT_MAXO || B < 1) return L2I_ERR_ARG;
+                                     float* out, float* prob, int B, int O, int D, int ld, float scale, void* stream) {
+    if (!q || !k || !v || !out || !prob || O < 1 || O > AT_MAXO || B < 1 || ld < D) return L2I_ERR_ARG;
     if (attn_lds(O, D, false) > 160 * 1024) return L2I_ERR_ARG;
     AttnArgs a = {};
     a.q = q; a.k = k; a.v = v; a.geo = geo; a.keyvalid = keyvalid; a.out = out; a.prob = prob;
-    a.B = B; a.O = O; a.D = D; a.scale = scale;
+    a.B = B; a.O = O; a.D = D; a.ld = ld; a.ldd = D; a.scale = scale;
     const size_t lds = attn_lds(O, D, false);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -138,13 +143,13 @@ extern "C" int l2i_box_attention_fwd(const float* q, const float* k, const float
 
 extern "C" int l2i_box_attention_bwd(const float* q, const float* k, const float* v, const float* geo, const float* prob,
                                      const float* dout, float* dq, float* dk, float* dv, float* dgeo, int B, int O, int D,
-                                     float scale, void* stream) {
-    if (!q || !k || !v || !prob || !dout || !dq || !dk || !dv || O < 1 || O > AT_MAXO || B < 1) return L2I_ERR_ARG;
+                                     int ld, int ldd, float scale, void* stream) {
+    if (!q || !k || !v || !prob || !dout || !dq || !dk || !dv || O < 1 || O > AT_MAXO || B < 1 || ld < D || ldd < D) return L2I_ERR_ARG;
     if (dgeo && !geo) return L2I_ERR_ARG;
     if (attn_lds(O, D, true) > 160 * 1024) return L2I_ERR_ARG;
     AttnArgs a = {};
     a.q = q; a.k = k; a.v = v; a.geo = geo; a.prob = const_cast<float*>(prob); a.dout = dout;
-    a.dq = dq; a.dk = dk; a.dv = dv; a.dgeo = dgeo; a.B = B; a.O = O; a.D = D; a.scale = scale;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.dgeo = dgeo; a.B = B; a.O = O; a.D = D; a.ld = ld; a.ldd = ldd; a.scale = scale;
     const size_t lds = attn_lds(O, D, true);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -32,7 +32,9 @@ class OptimizedBlock(nn.Module):
         h = fused_conv(x, self.conv1, pc, relu_op_out=True)   # conv2's ReLU'd operand comes out of conv1's epilogue
         xs = x
         if self.downsample:
-            xs = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
+            xs = getattr(x, "_l2i_half", None)   # the 2x2 average made by the input-image kernel (ops.image_nhwc)
+            if xs is None:
+                xs = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
         sc = fused_conv(xs, self.c_sc, pc)
         return fused_conv(h, self.conv2, pc, prologue=RELU, res=sc, pool2=self.downsample, emit=emit, dx_raw=True)
 
@@ -142,25 +144,16 @@ class CombineDiscriminator128_app(nn.Module):
         order within each, :145-146), padding rows (label 0) behind them. Reference :402-417 without the
         host-synchronising nonzero(): the count stays on the device, the ROI heads read it there (`nimg`).
         The layout depends on (bbox, label) only: GanTrainer computes it once per iteration for the three D passes."""
-        b, o = bbox.size(0), bbox.size(1)
-        bb = bbox.to(device).float()
-        xyxy = torch.stack((bb[..., 0], bb[..., 1], bb[..., 0] + bb[..., 2], bb[..., 1] + bb[..., 3]), dim=-1) * size
-        idx = torch.arange(b, device=device, dtype=torch.float32).view(b, 1, 1).expand(b, o, 1)
-        rois = torch.cat((idx, xyxy), dim=2).view(-1, 5)
-        y = label.reshape(-1).to(device)
-        valid = y != 0
-        key = (~valid).to(torch.int64) * 2
-        if self.two_scale:
-            key = key + (((rois[:, 3] - rois[:, 1]) < 64) & ((rois[:, 4] - rois[:, 2]) < 64)).to(torch.int64)
-        order = torch.argsort(key, stable=True)
-        valid_c = valid[order].to(torch.int32).contiguous()
-        return rois[order].contiguous(), y[order].contiguous(), valid_c, valid_c.sum(dtype=torch.int32).view(1)
+        return ops.roi_layout(bbox.to(device).float(), label.to(device), float(size), self.two_scale)   # one launch (csrc/layout.hip)
 
     def _prepare(self, images, bbox, label, layout=None):
         """-> (rois, y, valid, count) as prepare_layout gives them, and the NHWC image padded to 8 channels."""
         if layout is None:
             layout = self.prepare_layout(bbox, label, images.size(2), images.device)
-        x = F.pad(images.permute(0, 2, 3, 1), (0, 8 - images.size(1))).contiguous()
+        # padded NHWC stream + operand copy (+ the 2x2 average the first block's shortcut reads): one launch
+        x, xs = ops.image_nhwc(images, 8, self.op_dtype, bool(getattr(self.obD.block1, "downsample", False)))
+        if xs is not None:
+            x._l2i_half = xs
         return (*layout, x)
 
     def forward_padded(self, images, bbox, label, need_wgrad=True, pc=None, layout=None):

@@ -182,28 +182,23 @@ class PSPModule(nn.Module):
     def forward(self, feats, pc, sync):
         """feats (B,H,W,C) f32. Each stage is AdaptiveAvgPool(s) -> 1x1 conv -> BatchNorm2d -> ReLU -> bilinear
         (align_corners=True) back to HxW; the two resamplings are fixed sparse linear maps over the pixels (psp_taps) applied
-        by csrc/psp.hip for all stages at once, the tiny per-stage conv / BN / ReLU between them stay torch ops."""
+        by csrc/psp.hip for all stages at once, the per-stage conv / BN / ReLU between them is one launch (csrc/layout.hip)."""
         B, H, W, C = feats.shape
         taps = psp_taps(H, self.SIZES, feats.device)
         j = ops.GradJoin()   # d feats: the concat branch's part enters the pooling branch's backward launch
         pooled = ops.psp_pool(feats, taps, j)                                                  # (B, 50, C)
-        ys = []
-        for st, part in zip(self.stages, pooled.split([s * s for s in self.SIZES], dim=1)):
-            conv, bn = st[1], st[2]
-            y = part.reshape(-1, C) @ conv.weight.view(conv.weight.shape[0], -1).t()         # (B*s*s, 100)
-            y = F.relu(F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps))
-            if bn.training and not getattr(bn, "_nbt_shared", False):
-                bn.num_batches_tracked += 1
-            ys.append(y.view(B, -1, y.shape[-1]))
-        cat = ops.psp_expand(feats, torch.cat(ys, dim=1), taps, pc.arena.op_dtype, j)          # (B,H,W,4*100+C), operand dtype
+        ys = ops.psp_stages(pooled, [st[1] for st in self.stages], [st[2] for st in self.stages], self.SIZES, self.training)   # (B, 50, F)
+        if self.training and not getattr(self.stages[0][2], "_nbt_shared", False):
+            for st in self.stages:
+                st[2].num_batches_tracked += 1
+        cat = ops.psp_expand(feats, ys, taps, pc.arena.op_dtype, j)                           # (B,H,W,4*100+C), operand dtype
         conv, bn = self.bottleneck
         h = fused_conv(cat, conv, pc, emit=("stats",) if self.training else ())
         spec, w, b = bn.spec(self.training, sync, conv.co_p)
         y = ops.norm_act(h, spec, w, b)
         bn.commit(conv.co_p)
-        if self.training and self.dropout_p > 0:  # nn.Dropout2d: whole channels per sample
-            keep = (torch.rand(B, 1, 1, y.shape[3], device=y.device) >= self.dropout_p).float() / (1 - self.dropout_p)
-            y = y * keep
+        if self.training and self.dropout_p > 0:  # nn.Dropout2d: whole channels per sample (the draws are torch's: same RNG stream as before)
+            y = ops.channel_dropout(y, torch.rand(B, 1, 1, y.shape[3], device=y.device).view(B, -1), self.dropout_p)
         return y
 
 
@@ -302,22 +297,27 @@ class BoxMultiHeadedAttention(nn.Module):
         self.layer_norm = nn.LayerNorm(d_model)
         self.layer_norm0 = nn.LayerNorm(d_model)
 
-    def forward(self, w0, bbox, y, pc):
-        B, O, D = w0.shape
-        dp = self.linears[0].ci_p
-        wp = _pad_last(w0, dp).reshape(B * O, 1, 1, dp)
-        q, k, v = [fused_conv(wp, l, pc).view(B, O, -1)[..., :D].contiguous() for l in self.linears[:3]]
-        geo = None
-        if self.geometry:
-            emb = box_relational_embedding(bbox)
-            geo = F.relu(self.WGs[0](emb.view(-1, 64))).view(B, O, O)
-        keyvalid = (y != 0).to(torch.int32).contiguous()
-        x = ops.box_attention(q, k, v, geo, keyvalid, 1.0 / math.sqrt(D))
-        # reference :197-198: with h = 1 this "concat heads" view shuffles each image's (o,d) matrix; kept as is
-        x = x.transpose(1, 2).contiguous().view(B, -1, D)
-        out0 = self.layer_norm0(x + w0)
-        o2 = fused_conv(_pad_last(out0, dp).reshape(B * O, 1, 1, dp), self.linears[3], pc).view(B, O, -1)[..., :D]
-        return self.layer_norm(o2 + out0)
+    def forward(self, w0, bbox, keyvalid, pc, B, O):
+        """w0: the latents as a (B*O, 1, 1, Dp) stream (columns D..Dp zero) with its operand copy attached (ops.latent);
+        keyvalid (B, O) int32 = label != 0. Returns the context-aware latents in the same form.
+        Launches: one grouped GEMM for q / k / v (they read the same rows), the geometry kernel, the attention kernel,
+        shuffle + add + LayerNorm, the output projection, add + LayerNorm (csrc/layout.hip) -- the reference's ~65 small ops."""
+        D, dp = self.d, self.linears[0].ci_p
+        opd = pc.arena.op_dtype
+        q, k, v = [_view_keep_sink(t, B, O) for t in ops.grouped_linear(w0, pc.arena.groups["qkv"], pc)]   # column slices of ONE (B*O, 3 Dp) result
+        geo = ops.box_geometry(bbox, self.WGs[0].weight, self.WGs[0].bias) if self.geometry else None
+        x = ops.box_attention(q, k, v, geo, keyvalid, 1.0 / math.sqrt(D), D)                    # (B, O, D)
+        # reference :197-198: with h = 1 the "concat heads" view shuffles each image's (o, d) matrix; kept as is (perm_O)
+        out0 = ops.add_layernorm(x, w0, self.layer_norm0, D, dp, opd, perm_O=O)
+        o2 = fused_conv(out0, self.linears[3], pc)
+        return ops.add_layernorm(o2, out0, self.layer_norm, D, dp, opd)
+
+
+def _view_keep_sink(t, B, O):
+    """(rows, C) slice of a grouped projection -> (B, O, C) view that keeps the gradient-sink coordinates (ops.GradSink)."""
+    v = t.view(B, O, -1)
+    v._l2i_sink = t._l2i_sink
+    return v
 
 
 def masks_to_layout(boxes, masks, H):
@@ -366,10 +366,11 @@ class MaskRegressNetv2(nn.Module):
             return NormSpec(2, eps=1e-5, relu=True, instance=True), None, None
         return blk[1].spec(self.training, sync)
 
-    def forward(self, w, bbox, pc, sync):
+    def forward(self, w, bbox, pc, sync, want_boxm=False):
+        """-> (regressed masks (b, o, map, map), hard box masks (b, o, map, map) | None)."""
         b, o, _ = bbox.shape
         N = b * o
-        x = fused_conv(w, self.fc, pc).view(N, self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
+        x = ops.fc_to_nhwc(fused_conv(w, self.fc, pc), self.ch, pc.arena.op_dtype)            # (N, 4, 4, ch)
         h = fused_conv(x, self.conv1[0], pc)
         for blk_prev, blk, size in ((self.conv1, self.conv2, 8), (self.conv2, self.conv3, 16)):
             spec, wa, ba = self._spec(blk_prev, sync)
@@ -379,11 +380,11 @@ class MaskRegressNetv2(nn.Module):
             a = torch.matmul(resample_matrix("bilinear", size // 2, size, a.device), a.view(N, -1, self.ch)).view(N, size, size, self.ch)
             h = fused_conv(a, blk[0], pc)
         spec, wa, ba = self._spec(self.conv3, sync)
-        m = fused_conv(h, self.conv3[3], pc, prologue=spec, wproj=wa, bproj=ba, dx_raw=True)[..., 0]
+        m = fused_conv(h, self.conv3[3], pc, prologue=spec, wproj=wa, bproj=ba, dx_raw=True)   # (N, 16, 16, 8): channel 0 = the logits
         if not self.instance:
             self.conv3[1].commit()
-        m = torch.sigmoid(m).view(b, o, self.mask_size, self.mask_size)
-        return masks_to_layout(bbox, m, self.map_size)
+        # sigmoid + masks_to_layout + bbox_mask: one launch (csrc/layout.hip)
+        return ops.layout_masks(m, bbox, self.map_size, want_boxm)
 
 
 class _GeneratorBase(nn.Module):
@@ -396,6 +397,8 @@ class _GeneratorBase(nn.Module):
         self._isla = [m for m in self.modules() if isinstance(m, ISLANorm)]
         for n in self._isla:
             n.weight_proj.group = n.bias_proj.group = "isla"
+        for l in self.context.linears[:3]:   # q, k, v projections of the context attention read the same rows: one GEMM
+            l.group = "qkv"
         self.flat = FlatParams(self, device)
         self.arena = WeightArena(self, self.flat, device, op_dtype)
         self.sync = None  # set by parallel.attach_sync_bn for world_size > 1
@@ -416,7 +419,7 @@ class _GeneratorBase(nn.Module):
 
     def _project_isla(self, wp, pc, b, o):
         """One GEMM for every ISLA projection of the pass; each norm layer picks up its (b, o, C) slices."""
-        outs = ops.grouped_linear(wp.view(b * o, 1, 1, -1), self.arena.groups["isla"], pc)
+        outs = ops.grouped_linear(wp if wp.dim() == 4 else wp.view(b * o, 1, 1, -1), self.arena.groups["isla"], pc)   # (keeps wp's operand copy)
         for i, n in enumerate(self._isla):
             gw, gb = outs[2 * i], outs[2 * i + 1]
             sw, sb = gw._l2i_sink, gb._l2i_sink
@@ -439,10 +442,9 @@ class _GeneratorBase(nn.Module):
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()  # pending pass contexts stay: they are consumed by FlatAdam.step()
 
-    def _latent(self, z, y):
-        b, o = z.size(0), z.size(1)
-        emb = self.label_embedding(y)
-        return torch.cat((z.reshape(b * o, -1), emb.reshape(b * o, -1)), dim=1).view(b, o, -1)
+    def _latent(self, z, y, ld):
+        """[z | label_embedding(y)] as a (b*o, 1, 1, ld) stream with its operand copy, and the attention key mask (y != 0)."""
+        return ops.latent(z, self.label_embedding.weight, y, ld, self.op_dtype)
 
 
 class ResnetGenerator128_context(_GeneratorBase):
@@ -485,14 +487,14 @@ class ResnetGenerator128_context(_GeneratorBase):
         b, o = z.size(0), z.size(1)
         bbox = bbox.to(z.device).float()
         pc = self.arena.prepare(training=self.training)
-        w = self.context(self._latent(z, y), bbox, y, pc)
-        wp = _pad_last(w.reshape(b * o, -1), self.res1.b1.weight_proj.ci_p).reshape(b * o, 1, 1, -1).contiguous()
+        w0, keyvalid = self._latent(z, y, self.context.linears[0].ci_p)
+        wp = self.context(w0, bbox, keyvalid, pc, b, o)                                          # (b*o, 1, 1, 312) + operand copy
+        w = wp.view(b, o, -1)[..., :self.context.d]
         self._project_isla(wp, pc, b, o)
-        bmask = self.mask_regress(wp, bbox, pc, self.sync)
+        bmask, bbox_mask_ = self.mask_regress(wp, bbox, pc, self.sync, want_boxm=True)
         if z_im is None:
             z_im = torch.randn((b, 128), device=z.device)
-        bbox_mask_ = bbox_mask(bbox, 64, 64)
-        x = fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc).view(b, 16 * self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
+        x = ops.fc_to_nhwc(fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc), 16 * self.ch, self.op_dtype)
         x, m = self.res1(x, wp, bmask, pc, self.sync, emit=("raw",))
         stage = bmask
         stages = []
@@ -508,7 +510,7 @@ class ResnetGenerator128_context(_GeneratorBase):
         bn.commit()
         self._release_isla()
         self._bump_nbt()
-        img = torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()
+        img = ops.tanh_nchw(pre, self.output_dim, self.op_dtype)
         if taps is not None:
             taps.update(w=w, bmask=bmask, stages=stages, pre_tanh=pre[..., :self.output_dim], res=res_out)
         return img
@@ -538,13 +540,13 @@ class context_aware_generator(_GeneratorBase):
         b, o = z.size(0), z.size(1)
         bbox = bbox.to(z.device).float()
         pc = self.arena.prepare(training=self.training)
-        w = self.context(self._latent(z, y), bbox, y, pc)
-        wp = _pad_last(w.reshape(b * o, -1), self.res1.b1.weight_proj.ci_p).reshape(b * o, 1, 1, -1).contiguous()
+        w0, keyvalid = self._latent(z, y, self.context.linears[0].ci_p)
+        wp = self.context(w0, bbox, keyvalid, pc, b, o)
         self._project_isla(wp, pc, b, o)
-        mask = self.mask_regress(wp, bbox, pc, self.sync)
+        mask, _ = self.mask_regress(wp, bbox, pc, self.sync)
         if z_im is None:
             z_im = torch.randn((b, 128), device=z.device)
-        x = fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc).view(b, 16 * self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
+        x = ops.fc_to_nhwc(fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc), 16 * self.ch, self.op_dtype)
         for i in range(1, 6):
             x, _ = getattr(self, f"res{i}")(x, wp, mask, pc, self.sync, emit=("raw",) if i < 5 else ())
         bn, _, conv, _ = self.final
@@ -553,7 +555,7 @@ class context_aware_generator(_GeneratorBase):
         bn.commit()
         self._release_isla()
         self._bump_nbt()
-        return torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()
+        return ops.tanh_nchw(pre, self.output_dim, self.op_dtype)
 
 
 class ResnetGenerator64_context(ResnetGenerator128_context):
@@ -588,14 +590,13 @@ class ResnetGenerator64_context(ResnetGenerator128_context):
         b, o = z.size(0), z.size(1)
         bbox = bbox.to(z.device).float()
         pc = self.arena.prepare(training=self.training)
-        w = self.context(self._latent(z, y), bbox, y, pc)
-        wp = _pad_last(w.reshape(b * o, -1), self.res2.b1.weight_proj.ci_p).reshape(b * o, 1, 1, -1).contiguous()
+        w0, keyvalid = self._latent(z, y, self.context.linears[0].ci_p)
+        wp = self.context(w0, bbox, keyvalid, pc, b, o)
         self._project_isla(wp, pc, b, o)
-        bmask = self.mask_regress(wp, bbox, pc, self.sync)
+        bmask, bbox_mask_ = self.mask_regress(wp, bbox, pc, self.sync, want_boxm=True)
         if z_im is None:
             z_im = torch.randn((b, 128), device=z.device)
-        bbox_mask_ = bbox_mask(bbox, 64, 64)
-        x = fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc).view(b, 16 * self.ch, 4, 4).permute(0, 2, 3, 1).contiguous()
+        x = ops.fc_to_nhwc(fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc), 16 * self.ch, self.op_dtype)
         x, m = self.res2(x, wp, bmask, pc, self.sync, emit=("raw",))
         for blk, alpha in ((self.res3, self.alpha1), (self.res4, self.alpha2), (self.res5, self.alpha3)):
             stage = self._stage_mask(m, bmask, bbox_mask_, alpha, y)
@@ -606,4 +607,4 @@ class ResnetGenerator64_context(ResnetGenerator128_context):
         bn.commit()
         self._release_isla()
         self._bump_nbt()
-        return torch.tanh(pre[..., :self.output_dim]).permute(0, 3, 1, 2).contiguous()
+        return ops.tanh_nchw(pre, self.output_dim, self.op_dtype)

@@ -435,7 +435,13 @@ class FusedConvFn(Function):
                 x_op, _ = cast_op(x, opd, raw=True, act=False)
         bias_p = None
         if bias is not None:
-            bias_p = bias if bias.numel() == holder.co_p else torch.nn.functional.pad(bias, (0, holder.co_p - bias.numel()))
+            if bias.numel() == holder.co_p:
+                bias_p = bias
+            elif bias.dim() == 1 and bias.is_contiguous() and getattr(bias, "_l2i_slot", 0) >= holder.co_p:
+                # a view over the parameter's zero-padded slot of the flat buffer (arena.FlatParams): no pad launches
+                bias_p = torch.as_strided(bias.detach(), (holder.co_p,), (1,), bias.storage_offset())
+            else:
+                bias_p = torch.nn.functional.pad(bias, (0, holder.co_p - bias.numel()))
         Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
         flops = 2.0 * B * Ho * Wo * holder.co * holder.ci * holder.kh * holder.kh  # algorithmic (unpadded) work
         # `emit`: operand copies of the RESULT written by this launch's epilogue for the layers that read it next
@@ -645,7 +651,9 @@ class GroupedLinearFn(Function):
         ctx.set_materialize_grads(False)
         opd = pc.arena.op_dtype
         rows = x.shape[0]
-        x_op, _ = cast_op(x, opd, raw=True, act=False)
+        x_op = _sibling(x, "raw", opd)
+        if x_op is None:
+            x_op, _ = cast_op(x, opd, raw=True, act=False)
         flat = pc.arena.flat
         b0 = flat.offset_of(group.members[0].bias)
         bias = flat.data[b0:b0 + group.n_total]
@@ -753,33 +761,48 @@ def roi_align(feat_s, feat_l, rois, valid, P=8, scale_s=0.25, scale_l=0.125, thr
 
 # ----------------------------------------------------------------------------- attention core
 class BoxAttentionFn(Function):
+    """q, k, v: (B, O, Dp) f32 views with unit column stride whose first D columns are read -- contiguous tensors or column
+    slices of ONE grouped projection result (ops.grouped_linear: same row stride); in the latter case the backward writes
+    dq / dk / dv straight into the group's gradient sink."""
+
     @staticmethod
-    def forward(ctx, q, k, v, geo, keyvalid, scale):
-        q, k, v = _chk(q.contiguous(), torch.float32), _chk(k.contiguous(), torch.float32), _chk(v.contiguous(), torch.float32)
-        B, O, D = q.shape
+    def forward(ctx, q, k, v, geo, keyvalid, scale, D):
+        for t in (q, k, v):
+            if not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1 or t.stride() != q.stride() or t.shape != q.shape:
+                raise RuntimeError("box_attention: q, k, v must be f32 GPU tensors of one shape and stride with unit column stride")
+        B, O, _ = q.shape
+        ld = q.stride(1)
+        assert q.stride(0) == O * ld
         geo_c = None if geo is None else _chk(geo.contiguous(), torch.float32)
-        out = torch.empty_like(q)
+        out = torch.empty((B, O, D), dtype=torch.float32, device=q.device)
         prob = torch.empty((B, O, O), dtype=torch.float32, device=q.device)
         _lib.call("l2i_box_attention_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(geo_c), _p(keyvalid), out.data_ptr(),
-                  prob.data_ptr(), B, O, D, float(scale), _stream())
+                  prob.data_ptr(), B, O, D, ld, float(scale), _stream())
         ctx.save_for_backward(q, k, v, geo_c, prob)
-        ctx.scale = scale
+        ctx.scale, ctx.D = scale, D
+        ctx.sinks = tuple(getattr(t, "_l2i_sink", None) for t in (q, k, v))
         return out
 
     @staticmethod
     def backward(ctx, g):
         q, k, v, geo, prob = ctx.saved_tensors
-        B, O, D = q.shape
+        B, O, Dp = q.shape
+        D = ctx.D
         g = g.contiguous()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        sk = ctx.sinks
+        if all(s_ is not None for s_ in sk) and sk[0][0] is sk[1][0] is sk[2][0]:
+            dq, dk, dv = (s_[0].slice(s_[1], Dp, B, O) for s_ in sk)   # (pad columns D..Dp stay at the sink's zeros)
+        else:
+            dq, dk, dv = (torch.zeros((B, O, Dp), dtype=torch.float32, device=g.device) if Dp != D else
+                          torch.empty((B, O, D), dtype=torch.float32, device=g.device) for _ in range(3))
         dgeo = torch.empty_like(geo) if geo is not None else None
         _lib.call("l2i_box_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(geo), prob.data_ptr(), g.data_ptr(),
-                  dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(dgeo), B, O, D, float(ctx.scale), _stream())
-        return dq, dk, dv, dgeo, None, None
+                  dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(dgeo), B, O, D, q.stride(1), dq.stride(1), float(ctx.scale), _stream())
+        return dq, dk, dv, dgeo, None, None, None
 
 
-def box_attention(q, k, v, geo, keyvalid, scale):
-    return BoxAttentionFn.apply(q, k, v, geo, keyvalid, scale)
+def box_attention(q, k, v, geo, keyvalid, scale, D=None):
+    return BoxAttentionFn.apply(q, k, v, geo, keyvalid, scale, q.shape[-1] if D is None else D)
 
 
 # ----------------------------------------------------------------------------- losses
@@ -1083,8 +1106,7 @@ def psp_expand(feats, y, taps, op_dtype, join=None):
 
 
 class ResizeBilinearFn(Function):
-    """F.interpolate(x, size=(H, W), mode="bilinear") for planar (b, o, h, w) f32 maps; the (cheap) backward is
-    torch's own adjoint kernel."""
+    """F.interpolate(x, size=(H, W), mode="bilinear") for planar (b, o, h, w) f32 maps, and its adjoint."""
 
     @staticmethod
     def forward(ctx, x, H, W):
@@ -1098,7 +1120,10 @@ class ResizeBilinearFn(Function):
     @staticmethod
     def backward(ctx, g):
         b, o, h, w = ctx.in_shape
-        return torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), [g.shape[2], g.shape[3]], [b, o, h, w], False), None, None
+        g = _chk(g.contiguous(), torch.float32)
+        dx = torch.empty((b, o, h, w), dtype=torch.float32, device=g.device)
+        _lib.call("l2i_resize_bilinear_bwd", g.data_ptr(), dx.data_ptr(), b * o, h, w, g.shape[2], g.shape[3], _stream())
+        return dx, None, None
 
 
 def resize_bilinear(x, H, W):
@@ -1130,3 +1155,385 @@ def adam_step(flat, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=
     """step_dev: 1-element int32 device tensor with the step count (read on the device; graph-capturable)."""
     _lib.call("l2i_adam_step", flat.data.data_ptr(), flat.grad.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel, float(lr),
               float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _p(step_dev), _stream())
+
+
+# ----------------------------------------------------------------------------- layout-side glue (csrc/layout.hip)
+_CONST = {}
+
+
+def _const(key, make):
+    """Small device constants computed ONCE by the torch op the reference uses (so their bits are the reference's)."""
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = make()
+    return t
+
+
+def geometry_dim_mat(device):
+    """1 / 1000^(k/8), k = 0..7 (reference model/resnet_generator_app_v2.py:66-68)."""
+    return _const(("dim_mat", str(device)), lambda: (1.0 / torch.pow(1000.0, torch.arange(8.0, device=device) / 8.0)).contiguous())
+
+
+def unit_linspace(n, device):
+    return _const(("lin", n, str(device)), lambda: torch.linspace(0, 1, steps=n, device=device).contiguous())
+
+
+class BoxGeometryFn(Function):
+    """relu(WGs(BoxRelationalEmbedding(bbox))) -> (B, O, O): reference model/resnet_generator_app_v2.py:17-76,175-180."""
+
+    @staticmethod
+    def forward(ctx, bbox, wg_w, wg_b):
+        bbox = _chk(bbox.contiguous(), torch.float32)
+        B, O, _ = bbox.shape
+        dm = geometry_dim_mat(bbox.device)
+        geo = torch.empty((B, O, O), dtype=torch.float32, device=bbox.device)
+        _lib.call("l2i_box_geometry_fwd", bbox.data_ptr(), dm.data_ptr(), wg_w.data_ptr(), wg_b.data_ptr(), geo.data_ptr(), B, O, _stream())
+        ctx.save_for_backward(bbox, geo)
+        ctx.shapes = (wg_w.shape, wg_b.shape)
+        return geo
+
+    @staticmethod
+    def backward(ctx, g):
+        bbox, geo = ctx.saved_tensors
+        B, O, _ = bbox.shape
+        g = g.contiguous()
+        dm = geometry_dim_mat(bbox.device)
+        d = _zeros((65,), bbox.device)
+        _lib.call("l2i_box_geometry_bwd", bbox.data_ptr(), dm.data_ptr(), geo.data_ptr(), g.data_ptr(), d.data_ptr(), d.data_ptr() + 256,
+                  B, O, _stream())
+        return None, d[:64].view(ctx.shapes[0]), d[64:65].view(ctx.shapes[1])
+
+
+def box_geometry(bbox, wg_w, wg_b):
+    return BoxGeometryFn.apply(bbox, wg_w, wg_b)
+
+
+class LayoutMasksFn(Function):
+    """sigmoid + masks_to_layout (utils/bilinear.py:137-192) + bbox_mask (app_v2.py:697-721) in one launch.
+    m (N, M, M, Cp) f32: channel 0 holds the mask logits (the padded result of the 1-channel conv)."""
+
+    @staticmethod
+    def forward(ctx, m, bbox, H, want_boxm):
+        m = _chk(m, torch.float32)
+        b, o, _ = bbox.shape
+        N, M, _, Cp = m.shape
+        assert N == b * o
+        bb = _chk(bbox.contiguous(), torch.float32)
+        lin = unit_linspace(H, m.device)
+        bmask = torch.empty((b, o, H, H), dtype=torch.float32, device=m.device)
+        boxm = torch.empty((b, o, H, H), dtype=torch.float32, device=m.device) if want_boxm else None
+        _lib.call("l2i_layout_masks_fwd", m.data_ptr(), Cp, bb.data_ptr(), lin.data_ptr(), bmask.data_ptr(), _p(boxm), N, M, H, _stream())
+        ctx.save_for_backward(m, bb)
+        ctx.H = H
+        if boxm is not None:
+            ctx.mark_non_differentiable(boxm)
+        return bmask, boxm
+
+    @staticmethod
+    def backward(ctx, g, _g2):
+        m, bb = ctx.saved_tensors
+        N, M, _, Cp = m.shape
+        H = ctx.H
+        g = g.contiguous()
+        dm = torch.empty_like(m)
+        _lib.call("l2i_layout_masks_bwd", m.data_ptr(), Cp, bb.data_ptr(), unit_linspace(H, m.device).data_ptr(), g.data_ptr(),
+                  dm.data_ptr(), Cp, N, M, H, _stream())
+        return dm, None, None, None
+
+
+def layout_masks(m, bbox, H, want_boxm=True):
+    return LayoutMasksFn.apply(m, bbox, H, want_boxm)
+
+
+class AddLayerNormFn(Function):
+    """y = LayerNorm(a' + b) gamma + beta as a (rows, 1, 1, ldy) stream (pad columns zero) with its operand copy attached;
+    a' = a or, perm_O > 0, the reference's h = 1 "concat heads" shuffle of a (app_v2.py:197-198). a: (rows, lda)-like,
+    b: (rows, ldb)-like (leading dimensions = last dimension of the contiguous tensors)."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps, D, ldy, perm_O, op_dtype):
+        a, b = _chk(a, torch.float32), _chk(b, torch.float32)
+        lda, ldb = a.shape[-1], b.shape[-1]
+        rows = a.numel() // lda
+        assert b.numel() // ldb == rows
+        dev = a.device
+        y = torch.empty((rows, 1, 1, ldy), dtype=torch.float32, device=dev)
+        y_op = torch.empty((rows, 1, 1, ldy), dtype=op_dtype, device=dev)
+        st = torch.empty((2, rows), dtype=torch.float32, device=dev)
+        _lib.call("l2i_add_layernorm_fwd", a.data_ptr(), lda, b.data_ptr(), ldb, gamma.data_ptr(), beta.data_ptr(), float(eps), y.data_ptr(),
+                  ldy, y_op.data_ptr(), _code(op_dtype), st[0].data_ptr(), st[1].data_ptr(), rows, D, perm_O, _stream())
+        ctx.save_for_backward(a, b, gamma, st)
+        ctx.meta = (D, ldy, perm_O, a.shape, b.shape)
+        ctx.mark_non_differentiable(y_op)
+        return y, y_op
+
+    @staticmethod
+    def backward(ctx, g, _g2):
+        a, b, gamma, st = ctx.saved_tensors
+        D, ldy, perm_O, a_shape, b_shape = ctx.meta
+        lda, ldb = a_shape[-1], b_shape[-1]
+        rows = a.numel() // lda
+        g = g.contiguous()
+        dev = g.device
+        da = torch.empty(a_shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        db = torch.empty(b_shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        dgb = _zeros((2, D), dev)
+        _lib.call("l2i_add_layernorm_bwd", a.data_ptr(), lda, b.data_ptr(), ldb, gamma.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
+                  g.data_ptr(), ldy, _p(da), _p(db), dgb[0].data_ptr(), dgb[1].data_ptr(), rows, D, perm_O, _stream())
+        return da, db, dgb[0], dgb[1], None, None, None, None, None
+
+
+def add_layernorm(a, b, ln, D, ldy, op_dtype, perm_O=0):
+    """ln: an nn.LayerNorm(D). Returns the (rows, 1, 1, ldy) f32 stream; its operand-dtype copy rides on it (ops._sibling)."""
+    y, y_op = AddLayerNormFn.apply(a, b, ln.weight, ln.bias, ln.eps, D, ldy, perm_O, op_dtype)
+    _attach(y, raw=y_op)
+    return y
+
+
+class LatentFn(Function):
+    """[z | label_embedding(y)] padded to ld columns, as a (rows, 1, 1, ld) stream + operand copy, plus the attention's key mask
+    (y != 0) -- reference model/resnet_generator_app_v2.py:437-441."""
+
+    @staticmethod
+    def forward(ctx, z, emb, y, ld, op_dtype):
+        z, emb = _chk(z.contiguous(), torch.float32), _chk(emb, torch.float32)
+        y = y.contiguous()
+        rows, Z, E = y.numel(), z.shape[-1], emb.shape[1]
+        dev = z.device
+        out = torch.empty((rows, 1, 1, ld), dtype=torch.float32, device=dev)
+        out_op = torch.empty((rows, 1, 1, ld), dtype=op_dtype, device=dev)
+        kv = torch.empty(y.shape, dtype=torch.int32, device=dev)
+        _lib.call("l2i_latent_fwd", z.data_ptr(), emb.data_ptr(), y.data_ptr(), out.data_ptr(), out_op.data_ptr(), _code(op_dtype),
+                  kv.data_ptr(), rows, Z, E, ld, _stream())
+        ctx.save_for_backward(y)
+        ctx.meta = (rows, Z, E, ld, emb.shape)
+        ctx.mark_non_differentiable(out_op, kv)
+        return out, out_op, kv
+
+    @staticmethod
+    def backward(ctx, g, _g2, _g3):
+        (y,) = ctx.saved_tensors
+        rows, Z, E, ld, eshape = ctx.meta
+        g = g.contiguous()
+        demb = _zeros(tuple(eshape), g.device)
+        _lib.call("l2i_latent_bwd", g.data_ptr(), y.data_ptr(), demb.data_ptr(), rows, Z, E, ld, _stream())
+        return None, demb, None, None, None
+
+
+def latent(z, emb_weight, y, ld, op_dtype):
+    out, out_op, kv = LatentFn.apply(z, emb_weight, y, ld, op_dtype)
+    _attach(out, raw=out_op)
+    return out, kv
+
+
+class FcToNhwcFn(Function):
+    """A Linear's (N, 1, 1, C*P) result seen as .view(N, C, 4, 4) (reference :453, mask_regression.py:87), delivered as the
+    NHWC (N, 4, 4, C) f32 stream + its operand copy in one launch; the backward returns the (N, 1, 1, C*P) gradient with ITS
+    operand copy (what the Linear's weight gradient reads)."""
+
+    @staticmethod
+    def forward(ctx, x, C, op_dtype):
+        x = _chk(x, torch.float32)
+        N = x.shape[0]
+        P = x.numel() // (N * C)
+        side = int(round(P ** 0.5))
+        out = torch.empty((N, side, side, C), dtype=torch.float32, device=x.device)
+        out_op = torch.empty((N, side, side, C), dtype=op_dtype, device=x.device)
+        _lib.call("l2i_fc_to_nhwc", x.data_ptr(), out.data_ptr(), out_op.data_ptr(), _code(op_dtype), N, C, P, 0, _stream())
+        ctx.meta = (N, C, P, op_dtype, tuple(x.shape))
+        ctx.mark_non_differentiable(out_op)
+        return out, out_op
+
+    @staticmethod
+    def backward(ctx, g, _g2):
+        N, C, P, op_dtype, shape = ctx.meta
+        g = _chk(g.contiguous(), torch.float32)
+        d = torch.empty(shape, dtype=torch.float32, device=g.device)
+        d_op = torch.empty(shape, dtype=op_dtype, device=g.device)
+        _lib.call("l2i_fc_to_nhwc", g.data_ptr(), d.data_ptr(), d_op.data_ptr(), _code(op_dtype), N, C, P, 1, _stream())
+        _attach(d, raw=d_op)
+        return d, None, None
+
+
+def fc_to_nhwc(x, C, op_dtype):
+    out, out_op = FcToNhwcFn.apply(x, C, op_dtype)
+    _attach(out, raw=out_op)
+    return out
+
+
+class TanhNchwFn(Function):
+    """img (B, C, H, W) = tanh(pre[..., :C]) from the NHWC to-RGB result (reference :497-499); the backward writes the padded
+    NHWC gradient and its operand copy (the to-RGB convolution's dY) in one launch."""
+
+    @staticmethod
+    def forward(ctx, pre, C, op_dtype):
+        pre = _chk(pre, torch.float32)
+        B, H, W, Cp = pre.shape
+        img = torch.empty((B, C, H, W), dtype=torch.float32, device=pre.device)
+        _lib.call("l2i_tanh_nchw_fwd", pre.data_ptr(), img.data_ptr(), B, C, Cp, H * W, _stream())
+        ctx.save_for_backward(img)
+        ctx.meta = (B, H, W, Cp, C, op_dtype)
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        (img,) = ctx.saved_tensors
+        B, H, W, Cp, C, op_dtype = ctx.meta
+        g = _chk(g.contiguous(), torch.float32)
+        d = torch.empty((B, H, W, Cp), dtype=torch.float32, device=g.device)
+        d_op = torch.empty((B, H, W, Cp), dtype=op_dtype, device=g.device)
+        _lib.call("l2i_tanh_nchw_bwd", img.data_ptr(), g.data_ptr(), d.data_ptr(), d_op.data_ptr(), _code(op_dtype), B, C, Cp, H * W, _stream())
+        _attach(d, raw=d_op)
+        return d, None, None
+
+
+def tanh_nchw(pre, C, op_dtype):
+    return TanhNchwFn.apply(pre, C, op_dtype)
+
+
+class PspStagesFn(Function):
+    """The four pyramid stages of the PSP head between the pooling and the expansion kernels (reference
+    model/resnet_generator_app_v2.py:741-746: Conv2d(C, F, 1, bias=False) -> BatchNorm2d -> ReLU on the s x s pooled maps):
+    pooled (B, NB, C) -> (B, NB, F), one launch (two backward). apply(pooled, meta, *W, *gamma, *beta) with the stage modules'
+    own parameters (S each) and meta = (sizes, training, eps, momentum, running_means, running_vars): running statistics are
+    updated in place in train mode (momentum, unbiased variance), read in eval mode."""
+
+    @staticmethod
+    def _ptrs(ts):
+        return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+    @staticmethod
+    def forward(ctx, pooled, meta, *params):
+        sizes, training, eps, momentum, rms, rvs = meta
+        S = len(sizes)
+        Ws, gs, bs = params[:S], params[S:2 * S], params[2 * S:]
+        pooled = _chk(pooled, torch.float32)
+        for t in (*Ws, *gs, *bs, *rms, *rvs):
+            _chk(t, torch.float32)
+        B, NB, C = pooled.shape
+        F_ = Ws[0].shape[0]
+        dev = pooled.device
+        raw = torch.empty((B, NB, F_), dtype=torch.float32, device=dev)
+        y = torch.empty((B, NB, F_), dtype=torch.float32, device=dev)
+        stat = torch.empty((S, 2, F_), dtype=torch.float32, device=dev)
+        sz = (ctypes.c_int * S)(*sizes)
+        P = PspStagesFn._ptrs
+        _lib.call("l2i_psp_stages_fwd", pooled.data_ptr(), P(Ws), P(gs), P(bs), P(rms), P(rvs), raw.data_ptr(), y.data_ptr(), stat.data_ptr(),
+                  B, NB, C, F_, S, sz, int(training), float(eps), float(momentum), _stream())
+        ctx.save_for_backward(pooled, raw, stat, *params)
+        ctx.meta = (tuple(sizes), bool(training), tuple(Ws[0].shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        pooled, raw, stat, *params = ctx.saved_tensors
+        sizes, training, wshape = ctx.meta
+        S = len(sizes)
+        Ws, gs, bs = params[:S], params[S:2 * S], params[2 * S:]
+        B, NB, C = pooled.shape
+        F_ = wshape[0]
+        dev = g.device
+        g = g.contiguous()
+        draw = torch.empty_like(raw)
+        dpooled = torch.empty_like(pooled)
+        dW = torch.empty((S, F_, C), dtype=torch.float32, device=dev)
+        dgb = torch.empty((2, S, F_), dtype=torch.float32, device=dev)
+        sz = (ctypes.c_int * S)(*sizes)
+        P = PspStagesFn._ptrs
+        _lib.call("l2i_psp_stages_bwd", pooled.data_ptr(), P(Ws), P(gs), P(bs), raw.data_ptr(), stat.data_ptr(), g.data_ptr(), draw.data_ptr(),
+                  dpooled.data_ptr(), dW.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), B, NB, C, F_, S, sz, int(training), _stream())
+        return (dpooled, None, *[dW[i].view(wshape) for i in range(S)], *[dgb[0, i] for i in range(S)], *[dgb[1, i] for i in range(S)])
+
+
+def psp_stages(pooled, convs, bns, sizes, training):
+    """convs / bns: the stage modules (nn.Conv2d(C, F, 1, bias=False), nn.BatchNorm2d(F)) in stage order."""
+    meta = (tuple(sizes), training, bns[0].eps, bns[0].momentum, [b.running_mean for b in bns], [b.running_var for b in bns])
+    return PspStagesFn.apply(pooled, meta, *[c.weight for c in convs], *[b.weight for b in bns], *[b.bias for b in bns])
+
+
+def roi_layout(bbox, label, size, two_scale):
+    """(rois (R, 5), y (R,), valid (R,) int32, count (1,) int32) with the R = b*o rows compacted in the reference's output
+    order (csrc/layout.hip roi_layout_kernel; reference model/rcnn_discriminator_app.py:131-146,402-417). One launch."""
+    bb = _chk(bbox.contiguous(), torch.float32)
+    b, o, _ = bb.shape
+    lab = label.reshape(b, o).contiguous()
+    if lab.dtype != torch.int64:
+        lab = lab.to(torch.int64)
+    R, dev = b * o, bb.device
+    rois = torch.empty((R, 5), dtype=torch.float32, device=dev)
+    y = torch.empty((R,), dtype=torch.int64, device=dev)
+    valid = torch.empty((R,), dtype=torch.int32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    _lib.call("l2i_roi_layout", bb.data_ptr(), lab.data_ptr(), float(size), int(two_scale), o, R, rois.data_ptr(), y.data_ptr(),
+              valid.data_ptr(), count.data_ptr(), _stream())
+    return rois, y, valid, count
+
+
+class ImageNhwcFn(Function):
+    """(b, 3, H, W) image -> the padded NHWC stream (b, H, W, 8) the discriminator's first block reads and its 2x2 average
+    (the OptimizedBlock shortcut pools BEFORE its 1x1 conv), each with its operand copy: one launch instead of permute + pad +
+    contiguous + avg_pool2d + two casts; one launch backward."""
+
+    @staticmethod
+    def forward(ctx, img, cp, op_dtype, want_half):
+        img = _chk(img.contiguous(), torch.float32)
+        B, C, H, W = img.shape
+        dev = img.device
+        x = torch.empty((B, H, W, cp), dtype=torch.float32, device=dev)
+        x_op = torch.empty((B, H, W, cp), dtype=op_dtype, device=dev)
+        xs = torch.empty((B, H // 2, W // 2, cp), dtype=torch.float32, device=dev) if want_half else None
+        xs_op = torch.empty((B, H // 2, W // 2, cp), dtype=op_dtype, device=dev) if want_half else None
+        _lib.call("l2i_image_nhwc_fwd", img.data_ptr(), x.data_ptr(), x_op.data_ptr(), _p(xs), _p(xs_op), _code(op_dtype), B, C, cp, H, W,
+                  _stream())
+        ctx.meta = (B, C, cp, H, W)
+        ctx.mark_non_differentiable(x_op)
+        if want_half:
+            ctx.mark_non_differentiable(xs_op)
+        return x, x_op, xs, xs_op
+
+    @staticmethod
+    def backward(ctx, dx, _a, dxs, _b):
+        B, C, cp, H, W = ctx.meta
+        dx = None if dx is None else _chk(dx.contiguous(), torch.float32)
+        dxs = None if dxs is None else _chk(dxs.contiguous(), torch.float32)
+        ref = dx if dx is not None else dxs
+        dimg = torch.empty((B, C, H, W), dtype=torch.float32, device=ref.device)
+        _lib.call("l2i_image_nhwc_bwd", _p(dx), _p(dxs), dimg.data_ptr(), B, C, cp, H, W, _stream())
+        return dimg, None, None, None
+
+
+def image_nhwc(img, cp, op_dtype, want_half):
+    """-> (x, xs | None): f32 NHWC streams with their operand copies attached (ops._sibling "raw")."""
+    x, x_op, xs, xs_op = ImageNhwcFn.apply(img, cp, op_dtype, want_half)
+    _attach(x, raw=x_op)
+    if xs is not None:
+        _attach(xs, raw=xs_op)
+    return x, xs
+
+
+class ChannelDropoutFn(Function):
+    """nn.Dropout2d on an NHWC stream given the uniform draws u (B, C): y = x * (u >= p) / (1 - p)."""
+
+    @staticmethod
+    def forward(ctx, x, u, prob):
+        x, u = _chk(x, torch.float32), _chk(u, torch.float32)
+        B, H, W, C = x.shape
+        out = torch.empty_like(x)
+        _lib.call("l2i_channel_dropout", x.data_ptr(), u.data_ptr(), out.data_ptr(), B, H * W, C, float(prob), _stream())
+        ctx.save_for_backward(u)
+        ctx.prob = prob
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (u,) = ctx.saved_tensors
+        g = _chk(g.contiguous(), torch.float32)
+        B, H, W, C = g.shape
+        d = torch.empty_like(g)
+        _lib.call("l2i_channel_dropout", g.data_ptr(), u.data_ptr(), d.data_ptr(), B, H * W, C, float(ctx.prob), _stream())
+        return d, None, None
+
+
+def channel_dropout(x, u, prob):
+    return ChannelDropoutFn.apply(x, u, prob)
+
