@@ -153,3 +153,37 @@ static inline int l2i_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? L2I_OK : L2I_ERR_LAUNCH;
 }
+
+// ---------------------------------------------------------------- wave-level timestamps (builds with -DL2I_TRACE only)
+// tools/perf/conv_trace.py: slot 0 kernel entry, 1 before the reduction loop, 2 after it, 3 end of the epilogue --
+// s_memrealtime ticks (100 MHz) of every wave of the LAST launch of a translation unit, plus (XCC_ID << 16 | HW_ID) of the
+// wave. L2I_TRACE_DEFINE(tag) in a .hip file defines its buffers and the readers l2i_trace_read_<tag> / l2i_trace_ids_<tag>.
+#ifdef L2I_TRACE
+#define L2I_TRACE_WAVES (8192 * 8)
+#define L2I_TRACE_DEFINE(TAG)                                                                                          \
+    __device__ long long g_l2i_trace[L2I_TRACE_WAVES * 4];                                                             \
+    __device__ unsigned g_l2i_trace_id[L2I_TRACE_WAVES];                                                               \
+    extern "C" int l2i_trace_read_##TAG(long long* host, int nwaves) {                                                 \
+        return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l2i_trace), sizeof(long long) * 4 * (size_t)nwaves) == hipSuccess ? L2I_OK : L2I_ERR_LAUNCH; \
+    }                                                                                                                  \
+    extern "C" int l2i_trace_ids_##TAG(unsigned* host, int nwaves) {                                                   \
+        return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l2i_trace_id), sizeof(unsigned) * (size_t)nwaves) == hipSuccess ? L2I_OK : L2I_ERR_LAUNCH; \
+    }
+#define L2I_TR(SLOT)                                                                                                   \
+    do {                                                                                                               \
+        const int w_ = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);                             \
+        if ((threadIdx.x & 63) == 0 && w_ < L2I_TRACE_WAVES) {                                                         \
+            const long long t_ = (long long)wall_clock64();                                                            \
+            if ((SLOT) == 0) {                                                                                         \
+                const unsigned xcc_ = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));                            \
+                const unsigned hw_ = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                             \
+                g_l2i_trace_id[w_] = (xcc_ << 16) | (hw_ & 0xffffu);                                                   \
+            }                                                                                                          \
+            g_l2i_trace[w_ * 4 + (SLOT)] = t_;                                                                         \
+        }                                                                                                              \
+    } while (0)
+#else
+#define L2I_TRACE_DEFINE(TAG)
+#define L2I_TR(SLOT) do { } while (0)
+#endif
+

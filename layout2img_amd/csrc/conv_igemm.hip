@@ -19,34 +19,7 @@
 #include <stdlib.h>
 #include "igemm.h"
 
-// Wave-level timestamps (builds with -DL2I_TRACE only; tools/perf/conv_trace.py): slot 0 kernel entry, 1 before the
-// reduction loop, 2 after it, 3 end of the epilogue -- s_memrealtime ticks (100 MHz) of every wave of the LAST launch.
-#ifdef L2I_TRACE
-#define L2I_TRACE_WAVES (8192 * 8)
-__device__ long long g_l2i_trace[L2I_TRACE_WAVES * 4];
-__device__ unsigned g_l2i_trace_id[L2I_TRACE_WAVES];
-#define L2I_TR(SLOT)                                                                                                   \
-    do {                                                                                                               \
-        const int w_ = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);                             \
-        if ((threadIdx.x & 63) == 0 && w_ < L2I_TRACE_WAVES) {                                                         \
-            long long t_ = (long long)wall_clock64();                                                                  \
-            if ((SLOT) == 0) {   /* low 16 bits of the entry stamp replaced by (XCC_ID << 12 | HW_ID[15:4]) */          \
-                const unsigned xcc_ = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));                            \
-                const unsigned hw_ = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                             \
-                g_l2i_trace_id[w_] = (xcc_ << 16) | (hw_ & 0xffffu);                                                   \
-            }                                                                                                          \
-            g_l2i_trace[w_ * 4 + (SLOT)] = t_;                                                                         \
-        }                                                                                                              \
-    } while (0)
-extern "C" int l2i_trace_read(long long* host, int nwaves) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l2i_trace), sizeof(long long) * 4 * (size_t)nwaves) == hipSuccess ? L2I_OK : L2I_ERR_LAUNCH;
-}
-extern "C" int l2i_trace_read_id(unsigned* host, int nwaves) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l2i_trace_id), sizeof(unsigned) * (size_t)nwaves) == hipSuccess ? L2I_OK : L2I_ERR_LAUNCH;
-}
-#else
-#define L2I_TR(SLOT) do { } while (0)
-#endif
+L2I_TRACE_DEFINE(conv)   // wave-level timestamps of the last launch (-DL2I_TRACE builds only; common.h)
 
 struct ConvArgs {
     const void* x;      // T  [B, Hi, Wi, Ci]
@@ -69,6 +42,7 @@ struct ConvArgs {
     // halo kernel geometry (conv_halo_kernel): sub-patches of PHs x PW pixels, halo rows h = sp*SUBH + hy*P + hx
     int PHs, sub_shift, P, SUBH, HR, HWd, halo_pieces;
     int compact;         // conv_halo3_kernel: sub-patches are whole images, no border rows are stored
+    unsigned mg_tn, mg_tc, mg_ho, mg_subh, mg_p;   // fastdiv magics of tiles_n, tiles_c, Ho, SUBH, P (igemm.h)
     float alpha;
     float* stat_ws;      // optional: the stream's replicated workspace (common.h) -- the epilogue adds every channel's sum and sum of squares
                          // of the f32 result there (what the batch-norm layer reading this result needs: no separate pass over it)
@@ -314,7 +288,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
     constexpr int NIT = 32 / PPI;                // stages per 32-pixel slab (a quarter of them with the 2x2 pool)
     constexpr unsigned OOB = 0x80000000u;
     constexpr int SZT = (int)sizeof(T);
-    float* patch = reinterpret_cast<float*>(smem) + wave * 32 * LD;
+    float* patch = reinterpret_cast<float*>(smem) + wave * ((TN == 1 && TM % 2 == 0) ? 2 : 1) * 32 * LD;
     const int m = lane & 31, h = lane >> 5;
     const int cq = lane % L4, pp0 = lane / L4;
     const int n = n0 + wcol + cq * 4;
@@ -342,31 +316,40 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
     // cold at the end of every launch (a launch is one round of workgroups) -- the fetch, not the memory traffic, was the
     // bulk of the "epilogue time" (the round-2 ablation priced the epilogue at 80-120 us on a layer whose 100 MB of
     // results take 20 us to write).
-    constexpr int B = 4;
+    // B stages per batch = loads in flight per wave: one memory round trip (~2 us under load) per batch is what the epilogue
+    // costs, so narrow tiles (TN = 1: 4 stages per slab) take TWO slabs per pass (SP) -- one round trip for the wave's whole tile.
+    constexpr int SP = (TN == 1 && TM % 2 == 0) ? 2 : 1;   // slabs per pass (the wave's LDS patch holds SP x 32 pixel rows)
+    constexpr int B = TN >= 4 ? 4 : 8;
+    constexpr int NST = SP * NIT;                          // stage slots per pass
     __syncthreads();   // every wave is done reading the ring / the halo
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        // this wave's next 32-pixel slab -> its LDS patch (same wave wrote and reads: LDS operations of a wave complete in order)
+    for (int i0 = 0; i0 < TM; i0 += SP) {
+        // this wave's next SP 32-pixel slabs -> its LDS patch (same wave wrote and reads: LDS operations of a wave complete in order)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int sl = 0; sl < SP; ++sl)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(patch + m * LD + j * 32 + 8 * g + 4 * h) =
-                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(patch + (sl * 32 + m) * LD + j * 32 + 8 * g + 4 * h) =
+                        make_float4(acc[i0 + sl][j][4 * g], acc[i0 + sl][j][4 * g + 1], acc[i0 + sl][j][4 * g + 2], acc[i0 + sl][j][4 * g + 3]);
 #pragma unroll 1
-        for (int it0 = 0; it0 < nstage; it0 += B) {
+        for (int st0 = 0; st0 < NST; st0 += B) {
             float sv[B][4];
             u4_t srr[B];
             typename EpiT<T>::raw_t smk[B];
             unsigned so_ld[B], so_st[B];   // f32 byte offsets: loads (OOB for rows that are not read), stores (OOB for rows that do not exist)
 #pragma unroll
             for (int k = 0; k < B; ++k) {
-                const int it = it0 + k;
+                const int st = st0 + k;
+                const int sl = SP == 1 ? 0 : st / NIT, it = SP == 1 ? st : st % NIT;
+                const int i = i0 + sl;
+                const float* pslab = patch + sl * 32 * LD;
                 unsigned rowoff;
                 bool live, dead;
                 if (p.pool2) {
                     const int ql = min(it * PPI + pp0, 7);             // quad within the slab (clamped: stages past the slab are masked below)
-                    const float* r0 = patch + (4 * ql) * LD + cq * 4;
+                    const float* r0 = pslab + (4 * ql) * LD + cq * 4;
                     const float4 a0 = *reinterpret_cast<const float4*>(r0), a1 = *reinterpret_cast<const float4*>(r0 + LD);
                     const float4 a2 = *reinterpret_cast<const float4*>(r0 + 2 * LD), a3 = *reinterpret_cast<const float4*>(r0 + 3 * LD);
                     sv[k][0] = (a0.x + a1.x) + (a2.x + a3.x); sv[k][1] = (a0.y + a1.y) + (a2.y + a3.y);
@@ -381,7 +364,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
                     dead = 2 * r2 >= rows_live;
                 } else {
                     const int pix = min(it * PPI + pp0, 31);
-                    const float4 a0 = *reinterpret_cast<const float4*>(patch + pix * LD + cq * 4);
+                    const float4 a0 = *reinterpret_cast<const float4*>(pslab + pix * LD + cq * 4);
                     sv[k][0] = a0.x; sv[k][1] = a0.y; sv[k][2] = a0.z; sv[k][3] = a0.w;
                     // pixel index = (wave-uniform base, a multiple of PPI) + pp0: the quad-major decode splits into a SCALAR part
                     // and lane constants
@@ -492,8 +475,8 @@ __global__ __launch_bounds__(WM* WN * 64, ((160 * 1024) / (NS * (BM + BN) * (HK 
     // (ROI heads: the live rows are compacted to the FRONT, so the contiguous-run-per-XCD remap would give all live tiles
     //  to the first XCDs and leave the others idle; the dispatcher's own round robin spreads them evenly)
     const int bid = (p.nimg && !p.roi_remap) ? (int)blockIdx.x - split * nblk : xcd_remap(blockIdx.x - split * nblk, nblk);
-    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-    const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
+    const int tile_m = fastdiv(bid, p.mg_tn), tile_n = bid - tile_m * p.tiles_n;
+    const int tile_r = fastdiv(tile_m, p.mg_tc), tile_c = tile_m - tile_r * p.tiles_c;
     const int n0 = tile_n * BN;
     const int rows_total = p.B * p.Ho;
     const int rows_live = p.nimg ? min(rows_total, *p.nimg * p.Ho) : rows_total;   // (scalar load)
@@ -514,16 +497,23 @@ __global__ __launch_bounds__(WM* WN * 64, ((160 * 1024) / (NS * (BM + BN) * (HK 
         int py, px;
         idx2pix(lrow + RPP * q, p.hw_shift, p.lin, py, px);
         const int r = tile_r * p.PH + py;
-        const int b = r / p.Ho;
+        const int b = fastdiv(r, p.mg_ho);
         const bool rv = r < rows_total;
         const int y = r - b * p.Ho, x = tile_c * p.PW + px;
         a_y[q] = y;
         a_x[q] = x;
         a_off[q] = (unsigned)(((b * p.Hi + (y >> p.up2)) * p.Wi + (x >> p.up2)) * p.Ci) * SZ;
+        // 9-bit tap validity without per-tap divisions (the loop over t with t / KH, t % KH cost ~3000 instructions of
+        // prologue per workgroup: 8 us of an 13-us workgroup on the 3-channel image conv, tools/perf/conv_trace.py)
         unsigned m = 0;
-        for (int t = 0; t < p.KH * p.KH; ++t) {
-            const int yy = y + t / p.KH - pad, xx = x + t % p.KH - pad;
-            if (rv && yy >= 0 && yy < p.Ho && xx >= 0 && xx < p.Wo) m |= 1u << t;
+        if (p.KH == 1) m = rv ? 1u : 0u;
+        else {
+            const unsigned ry = (y >= 1 ? 1u : 0u) | 2u | (y + 1 < p.Ho ? 4u : 0u);   // rows ky = 0, 1, 2 inside the map
+            const unsigned rx = (x >= 1 ? 1u : 0u) | 2u | (x + 1 < p.Wo ? 4u : 0u);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+                if ((ry >> ky) & 1u) m |= rx << (3 * ky);
+            if (!rv) m = 0;
         }
         a_mask[q] = m;
     }
@@ -578,16 +568,24 @@ __global__ __launch_bounds__(WM* WN * 64, ((160 * 1024) / (NS * (BM + BN) * (HK 
                 buf_load_lds16(rsrc_w, b_off[q] + kadd, stage + (BM + q * RPP) * ROWB + wbase);
         } else {
             const int k0 = it_ks * BK + lane_c;
-            const int tap = k0 / p.Ci, ci = k0 - tap * p.Ci;
-            const int ky = tap / p.KH, kx = tap - ky * p.KH;
             const bool kvalid = k0 < p.K;
+            if (p.KH == 1) {   // 1x1 / Linear (wave-uniform branch): no tap arithmetic, no integer divisions in the K loop
 #pragma unroll
-            for (int q = 0; q < AP; ++q) {
-                const int ys = (a_y[q] + ky - pad) >> p.up2, xs = (a_x[q] + kx - pad) >> p.up2;
-                const int y0 = a_y[q] >> p.up2, x0 = a_x[q] >> p.up2;
-                const unsigned off = a_off[q] + (unsigned)((((ys - y0) * p.Wi + (xs - x0)) * p.Ci + ci) * SZ);
-                const unsigned voff = (kvalid && ((a_mask[q] >> tap) & 1u)) ? off : OOB;
-                buf_load_lds16(rsrc_x, voff, stage + q * RPP * ROWB + wbase);
+                for (int q = 0; q < AP; ++q) {
+                    const unsigned voff = (kvalid && (a_mask[q] & 1u)) ? a_off[q] + (unsigned)(k0 * SZ) : OOB;
+                    buf_load_lds16(rsrc_x, voff, stage + q * RPP * ROWB + wbase);
+                }
+            } else {
+                const int tap = k0 / p.Ci, ci = k0 - tap * p.Ci;
+                const int ky = tap / p.KH, kx = tap - ky * p.KH;
+#pragma unroll
+                for (int q = 0; q < AP; ++q) {
+                    const int ys = (a_y[q] + ky - pad) >> p.up2, xs = (a_x[q] + kx - pad) >> p.up2;
+                    const int y0 = a_y[q] >> p.up2, x0 = a_x[q] >> p.up2;
+                    const unsigned off = a_off[q] + (unsigned)((((ys - y0) * p.Wi + (xs - x0)) * p.Ci + ci) * SZ);
+                    const unsigned voff = (kvalid && ((a_mask[q] >> tap) & 1u)) ? off : OOB;
+                    buf_load_lds16(rsrc_x, voff, stage + q * RPP * ROWB + wbase);
+                }
             }
 #pragma unroll
             for (int q = 0; q < BP; ++q)
@@ -698,8 +696,8 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void 
     // (ROI heads: the live rows are compacted to the FRONT, so the contiguous-run-per-XCD remap would give all live tiles
     //  to the first XCDs and leave the others idle; the dispatcher's own round robin spreads them evenly)
     const int bid = (p.nimg && !p.roi_remap) ? (int)blockIdx.x - split * nblk : xcd_remap(blockIdx.x - split * nblk, nblk);
-    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-    const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
+    const int tile_m = fastdiv(bid, p.mg_tn), tile_n = bid - tile_m * p.tiles_n;
+    const int tile_r = fastdiv(tile_m, p.mg_tc), tile_c = tile_m - tile_r * p.tiles_c;
     const int n0 = tile_n * BN;
     const int rows_total = p.B * p.Ho;
     const int rows_live = p.nimg ? min(rows_total, *p.nimg * p.Ho) : rows_total;   // (scalar load)
@@ -717,10 +715,10 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void 
     for (int q = 0; q < HPMAX; ++q) {
         const int piece = wv + NW * q;
         const int h = piece * 8 + (lane >> 3), pch = lane & 7;
-        const int sp = h / p.SUBH, rem = h - sp * p.SUBH;
-        const int hy = rem / p.P, hx = rem - hy * p.P;
+        const int sp = fastdiv(h, p.mg_subh), rem = h - sp * p.SUBH;
+        const int hy = fastdiv(rem, p.mg_p), hx = rem - hy * p.P;
         const int gr0 = tile_r * p.PH + sp * p.PHs;
-        const int b = gr0 / p.Ho, y0 = gr0 - b * p.Ho, x0 = tile_c * p.PW;
+        const int b = fastdiv(gr0, p.mg_ho), y0 = gr0 - b * p.Ho, x0 = tile_c * p.PW;
         const int iy = (y0 >> p.up2) + hy - 1, ix = (x0 >> p.up2) + hx - 1;
         const bool ok = h < p.HR && hx < p.HWd && gr0 < rows_total && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         const int lch = pch ^ (((hx >> 1) + 4 * hy + 2 * sp) & 7);
@@ -949,8 +947,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
     // (ROI heads: the live rows are compacted to the FRONT, so the contiguous-run-per-XCD remap would give all live tiles
     //  to the first XCDs and leave the others idle; the dispatcher's own round robin spreads them evenly)
     const int bid = (p.nimg && !p.roi_remap) ? (int)blockIdx.x - split * nblk : xcd_remap(blockIdx.x - split * nblk, nblk);
-    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-    const int tile_c = tile_m % p.tiles_c, tile_r = tile_m / p.tiles_c;
+    const int tile_m = fastdiv(bid, p.mg_tn), tile_n = bid - tile_m * p.tiles_n;
+    const int tile_r = fastdiv(tile_m, p.mg_tc), tile_c = tile_m - tile_r * p.tiles_c;
     const int n0 = tile_n * BN;
     const int rows_total = p.B * p.Ho;
     const int rows_live = p.nimg ? min(rows_total, *p.nimg * p.Ho) : rows_total;
@@ -971,11 +969,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
     for (int q = 0; q < HPMAX; ++q) {
         const int piece = wv + NW * q;
         const int h = piece * 8 + (lane >> 3), pch = lane & 7;
-        const int sp = h / p.SUBH, rem = h - sp * p.SUBH;
-        const int hy = rem / p.P, hx = rem - hy * p.P;
+        const int sp = fastdiv(h, p.mg_subh), rem = h - sp * p.SUBH;
+        const int hy = fastdiv(rem, p.mg_p), hx = rem - hy * p.P;
         const int hyp = hy + 1 - border, hxp = hx + 1 - border;
         const int gr0 = tile_r * p.PH + sp * p.PHs;
-        const int b = gr0 / p.Ho, y0 = gr0 - b * p.Ho, x0 = tile_c * p.PW;
+        const int b = fastdiv(gr0, p.mg_ho), y0 = gr0 - b * p.Ho, x0 = tile_c * p.PW;
         const int iy = (y0 >> p.up2) + hyp - 1, ix = (x0 >> p.up2) + hxp - 1;
         const bool ok = h < p.HR && hx < p.HWd && gr0 < rows_total && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         const int lch = pch ^ (((hxp >> 1) + 4 * hyp + 2 * sp) & 7);
@@ -1241,7 +1239,8 @@ template <typename T, int BM, int BN, int WM, int WN, int NS, int HK = 0>
 static int launch_cfg(ConvArgs a, hipStream_t stream) {
     constexpr int BK = Mma<T>::BK >> HK;
     constexpr size_t ring = (size_t)NS * (BM + BN) * (HK ? 64 : 128);
-    constexpr size_t epi = (size_t)WM * WN * 32 * (BN / WN + 4) * 4;   // conv_epilogue_lds: a 32-pixel slab per wave
+    constexpr int TMc = BM / (WM * 32), TNc = BN / (WN * 32);
+    constexpr size_t epi = (size_t)WM * WN * ((TNc == 1 && TMc % 2 == 0) ? 2 : 1) * 32 * (BN / WN + 4) * 4;   // conv_epilogue_lds: one (narrow tiles: two) 32-pixel slabs per wave
     constexpr size_t lds = ring > epi ? ring : epi;
     a.chunk_major = (a.KH == 3 && a.Ci >= BK) ? 1 : 0;
     a.nks = a.chunk_major ? 9 * ((a.Ci + BK - 1) / BK) : a.Kpad / BK;
@@ -1250,6 +1249,8 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     const int rows = a.B * a.Ho;
     a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
     a.tiles_n = (a.Co + BN - 1) / BN;
+    a.mg_tn = fastdiv_magic(a.tiles_n); a.mg_tc = fastdiv_magic(a.tiles_c); a.mg_ho = fastdiv_magic(a.Ho);
+    a.mg_subh = fastdiv_magic(a.SUBH); a.mg_p = fastdiv_magic(a.P);
     const int nblk = a.tiles_m * a.tiles_n;
     const int nks = a.nks;
     // split-K for small grids with a long reduction (D block5/6, G res1/res2, ROI heads): fill the 256 CUs
@@ -1295,13 +1296,16 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     if (a.halo_pieces > 7 * WM * WN) return -100;
     size_t lds = (size_t)(H1 ? 1 : 2) * a.halo_pieces * 1024 + (size_t)NSB * BN * 128;
     if (lds > 160 * 1024) return -100;
-    constexpr size_t epi = (size_t)WM * WN * 32 * (BN / WN + 4) * 4;   // conv_epilogue_lds: a 32-pixel slab per wave
+    constexpr int TMc = BM / (WM * 32), TNc = BN / (WN * 32);
+    constexpr size_t epi = (size_t)WM * WN * ((TNc == 1 && TMc % 2 == 0) ? 2 : 1) * 32 * (BN / WN + 4) * 4;   // conv_epilogue_lds: one (narrow tiles: two) 32-pixel slabs per wave
     if (lds < epi) lds = epi;
     const int nchunks = (a.Ci + 63) / 64;
     a.nks = 9 * nchunks;
     const int rows = a.B * a.Ho;
     a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
     a.tiles_n = (a.Co + BN - 1) / BN;
+    a.mg_tn = fastdiv_magic(a.tiles_n); a.mg_tc = fastdiv_magic(a.tiles_c); a.mg_ho = fastdiv_magic(a.Ho);
+    a.mg_subh = fastdiv_magic(a.SUBH); a.mg_p = fastdiv_magic(a.P);
     const int nblk = a.tiles_m * a.tiles_n;
     int splits = 1;
     if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 192 && nchunks >= 4) {
@@ -1350,6 +1354,8 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     const int rows = a.B * a.Ho;
     a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
     a.tiles_n = (a.Co + BN - 1) / BN;
+    a.mg_tn = fastdiv_magic(a.tiles_n); a.mg_tc = fastdiv_magic(a.tiles_c); a.mg_ho = fastdiv_magic(a.Ho);
+    a.mg_subh = fastdiv_magic(a.SUBH); a.mg_p = fastdiv_magic(a.P);
     const int nblk = a.tiles_m * a.tiles_n;
     int splits = 1;
     if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 256 && nchunks >= 4) {   // fill the 512 workgroup slots (two per CU); more than 8
@@ -1567,6 +1573,7 @@ extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, c
     if (!x || !w || (!out && !out_op && !out_op_raw)) return L2I_ERR_ARG;
     if (stats && (!ws || !out || Co % 4 || 2LL * Co * L2I_WS_R > L2I_WS_FLOATS)) return L2I_ERR_ARG;
     ConvArgs a;
+    a.SUBH = 1; a.P = 1;   // (halo geometry: set by the halo launchers)
 #ifdef L2I_ABLATIONS   // wrong-result switches exist only in ablation builds (L2I_EXTRA_FLAGS=-DL2I_ABLATIONS), never in the shipped library
     static const int no_epi = getenv("L2I_CONV_NOEPI") ? atoi(getenv("L2I_CONV_NOEPI")) : 0;
     a.no_epi = no_epi;

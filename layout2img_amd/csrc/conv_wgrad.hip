@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include "igemm.h"
 
+L2I_TRACE_DEFINE(wgrad)
+
 struct WgradArgs {
     const void* x;   // T [B, Hi, Wi, Ci]
     const void* dy;  // T [B, Hd, Wd, Co]
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
     constexpr int A_Q = 16 / A_ROWS;             // A instructions per wave per step (4 | 2)
     constexpr int A_CH = RSA / 16;               // 16-byte chunks per A row (16 | 8)
 
+    L2I_TR(0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
             }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     }
+    L2I_TR(1);
     if (m_begin < m_end) {
         // (whole pairs of steps in the loop, an odd last step after it: a conditional second step inside the loop makes
         // the compiler merge two accumulator register sets with 64 AGPR<->VGPR copies per iteration)
@@ -487,6 +491,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 #undef WG_STEP
 #undef WG_TR
 #undef WG_BIAS
+    L2I_TR(2);
     if (do_bias) {   // lanes that share a chunk within a wave are A_CH apart; waves combine through LDS: one atomic per channel
         float* red = reinterpret_cast<float*>(smem);   // [NW waves][BMO]
         __syncthreads();                                // every wave is done with the stages
@@ -554,6 +559,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     t[((i * TN + j) * 4 + g) * 64] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        L2I_TR(3);
         return;
     }
 #pragma unroll
@@ -577,7 +583,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 // slice is written by one launch at a time (same stream), so the read-modify-write needs no atomics.
 // nw2: the two-wave kernel's geometry (waves side by side, TM = BMO / 32), else four waves as 2 x 2 (TM = BMO / 64).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int BMO, int tiles_k,
-                                                           int ntiles, int splits, int Co, int K, int ldw, float alpha, int nw2) {
+                                                           int ntiles, int splits, int Co, int K, int ldw, float alpha, int nw2, int sper) {
+    // blockIdx.y = group of `sper` consecutive splits: layers with few tiles and many splits (the 64-channel layers at
+    // 128 x 128: 5 tiles x 153 splits) otherwise run on 40 workgroups, each thread walking 153 partial tiles one dependent
+    // load after the other (18 us of a 69-us weight gradient). Groups combine with f32 atomics (gridDim.y > 1 only).
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const int per_tile = BMO * 32;                      // float4 per tile
     const int tile = (int)(gid / per_tile), f = (int)(gid - (long long)tile * per_tile);
@@ -591,19 +600,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const size_t tsz4 = (size_t)BMO * 32;
     const float4* src = reinterpret_cast<const float4*>(part) + (size_t)tile * splits * tsz4 + f;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = 0;
-    for (; s + 4 <= splits; s += 4) {
+    int s = blockIdx.y * sper;
+    const int s_end = min(splits, s + sper);
+    for (; s + 4 <= s_end; s += 4) {
         const float4 v0 = src[(size_t)s * tsz4], v1 = src[(size_t)(s + 1) * tsz4];
         const float4 v2 = src[(size_t)(s + 2) * tsz4], v3 = src[(size_t)(s + 3) * tsz4];
         a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
         a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
     }
-    for (; s < splits; ++s) {
+    for (; s < s_end; ++s) {
         const float4 v0 = src[(size_t)s * tsz4];
         a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
     }
     if (col >= K) return;
     float* d = dw + (size_t)row0 * ldw + col;   // (a half-wave writes 32 consecutive columns of one row per statement)
+    if (gridDim.y > 1) {
+        if (row0 < Co) atomicAdd(d, alpha * a.x);
+        if (row0 + 1 < Co) atomicAdd(d + ldw, alpha * a.y);
+        if (row0 + 2 < Co) atomicAdd(d + 2 * (size_t)ldw, alpha * a.z);
+        if (row0 + 3 < Co) atomicAdd(d + 3 * (size_t)ldw, alpha * a.w);
+        return;
+    }
     if (row0 < Co) d[0] += alpha * a.x;
     if (row0 + 1 < Co) d[ldw] += alpha * a.y;
     if (row0 + 2 < Co) d[2 * (size_t)ldw] += alpha * a.z;
@@ -708,8 +725,17 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
         }
         if (a.part) {
             const long long nthr = (long long)tiles * BMO * 32;
-            L2I_LAUNCH(1, wgrad_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
-                       a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, (int)(nw2 && !nw8 && BMO == 128));
+            const unsigned nbx = (unsigned)((nthr + 255) / 256);
+            // split groups: enough workgroups to fill the chip (>= ~512), at least 8 splits per group
+            int sg = 1;
+            if (nbx < 512 && a.splits > 8) {
+                sg = (int)((512 + nbx - 1) / nbx);
+                if (sg > (a.splits + 7) / 8) sg = (a.splits + 7) / 8;
+            }
+            const int sper = (a.splits + sg - 1) / sg;
+            sg = (a.splits + sper - 1) / sper;
+            L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
+                       a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, (int)(nw2 && !nw8 && BMO == 128), sper);
         }
         return l2i_check_launch();
     }

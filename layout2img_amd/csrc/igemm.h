@@ -139,6 +139,13 @@ template <> struct Mma2<float> {
     }
 };
 
+// Exact n / d by one v_mul_hi_u32 for n * d < 2^32 (tile and halo-row indices: both far below 65536): the integer divisions
+// of the kernels' prologues (each ~35 instructions, 25-37 of them per workgroup) were a third of a 3.5-us prologue that a
+// workgroup of a short-reduction layer pays in front of a 6-us main loop (tools/perf/conv_trace.py).
+// magic = ceil(2^32 / d); 0 encodes d = 1.
+static inline unsigned fastdiv_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ int fastdiv(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
+
 // XCD-aware bijective block remap: the dispatcher places block b on XCD b % 8;
 // give each XCD a contiguous run of tiles so neighbouring tiles share its L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

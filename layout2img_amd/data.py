@@ -207,18 +207,19 @@ class VgLayoutDataset(Dataset):
         return image, objs, boxes
 
 
-def get_dataset(dataset, img_size, root="."):
-    """The two configurations of train_context_app_v2.py:25-35."""
+def get_dataset(dataset, img_size, root=".", raw_images=False):
+    """The two configurations of train_context_app_v2.py:25-35. raw_images: the samples carry the decoded uint8 image at its
+    source resolution and DeviceBatcher resizes + normalises on the GPU (the training entry's default)."""
     if dataset == "coco":
         return CocoLayoutDataset(os.path.join(root, "datasets/coco/images/train2017/"),
                                  os.path.join(root, "datasets/coco/annotations/instances_train2017.json"),
                                  os.path.join(root, "datasets/coco/annotations/stuff_train2017.json"),
-                                 stuff_only=True, image_size=(img_size, img_size), left_right_flip=True)
+                                 stuff_only=True, image_size=(img_size, img_size), left_right_flip=True, raw_images=raw_images)
     if dataset == "vg":
         h5 = os.path.join(root, "data/tmp/preprocess_vg/train.h5")
         return VgLayoutDataset(os.path.join(root, "data/tmp/vocab.json"), h5 if os.path.exists(h5) else h5[:-3] + ".npz",
                                os.path.join(root, "datasets/vg/"), image_size=(img_size, img_size), max_objects=30,
-                               left_right_flip=True)
+                               left_right_flip=True, raw_images=raw_images)
     raise ValueError(dataset)
 
 

@@ -187,8 +187,9 @@ class PSPModule(nn.Module):
         taps = psp_taps(H, self.SIZES, feats.device)
         j = ops.GradJoin()   # d feats: the concat branch's part enters the pooling branch's backward launch
         pooled = ops.psp_pool(feats, taps, j)                                                  # (B, 50, C)
-        ys = ops.psp_stages(pooled, [st[1] for st in self.stages], [st[2] for st in self.stages], self.SIZES, self.training)   # (B, 50, F)
-        if self.training and not getattr(self.stages[0][2], "_nbt_shared", False):
+        bn_training = self.stages[0][2].training   # (the stage norms' own mode: they are plain nn.BatchNorm2d and may be frozen separately)
+        ys = ops.psp_stages(pooled, [st[1] for st in self.stages], [st[2] for st in self.stages], self.SIZES, bn_training)   # (B, 50, F)
+        if bn_training and not getattr(self.stages[0][2], "_nbt_shared", False):
             for st in self.stages:
                 st[2].num_batches_tracked += 1
         cat = ops.psp_expand(feats, ys, taps, pc.arena.op_dtype, j)                           # (B,H,W,4*100+C), operand dtype

@@ -29,7 +29,7 @@ def _opt_state(o):
     for name, p in flat._params:
         off, k = flat.offsets[name], p.numel()
         out[name] = (o.m[off:off + k].detach().cpu().clone().view(p.shape), o.v[off:off + k].detach().cpu().clone().view(p.shape))
-    return dict(state=out, t=o.t, lr=o.lr, betas=tuple(o.betas), eps=o.eps)
+    return dict(state=out, t=int(o.t_dev.item()), lr=o.lr, betas=tuple(o.betas), eps=o.eps)   # (the device-side count: graph replays advance only that one)
 
 
 def _load_opt_state(o, st):

@@ -29,6 +29,9 @@ def main(argv=None):
     ap.add_argument("--vgg_weights", type=str, default="", help="torchvision vgg19 state_dict (.pth) for the perceptual loss; empty = term omitted")
     ap.add_argument("--img_size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--host_resize", action="store_true", help="resize images in the loader workers (PIL, as the reference) instead of on the GPU")
+    ap.add_argument("--num_workers", type=int, default=2)
+    ap.add_argument("--no_graph", action="store_true", help="run every iteration eagerly (default at one GPU: replay the captured HIP graph of the iteration)")
     args = ap.parse_args(argv)
 
     import layout2img_amd as L
@@ -58,8 +61,8 @@ def main(argv=None):
         batches = lambda epoch: (make_batch(args.batch_size, args.img_size, args.dataset, seed=epoch * 100003 + i * world + rank, device=dev)[:3]
                                  for i in range(args.synthetic))
     else:
-        ds = data.get_dataset(args.dataset, args.img_size, args.data_root)
-        loader = data.make_loader(ds, args.batch_size, num_workers=2, shuffle=True, rank=rank, world=world)
+        ds = data.get_dataset(args.dataset, args.img_size, args.data_root, raw_images=not args.host_resize)
+        loader = data.make_loader(ds, args.batch_size, num_workers=args.num_workers, shuffle=True, rank=rank, world=world)
         to_dev = data.DeviceBatcher(dev, (args.img_size, args.img_size))
 
         def batches(epoch):
@@ -68,9 +71,32 @@ def main(argv=None):
             return (to_dev(b) for b in loader)
     netG.train(), netD.train()
     t0 = time.time()
+    # One GPU: the iteration is ~900 launches and costs the host as long as the GPU, so it is captured ONCE (on the first
+    # batch: shapes are fixed, drop_last) as a HIP graph and replayed with each batch copied into the graph's static inputs
+    # (GanTrainer.capture / step_graphed -- what bench.py times). The latents z are drawn per iteration and passed in, as the
+    # eager step would draw them. Data parallel runs stay eager (collectives are not captured).
+    graphed = False
+    z_dim, n_obj = trainer.z_dim, None
+
+    def run(real, label, bbox):
+        nonlocal graphed, n_obj
+        b, o = label.shape[0], label.shape[1]
+        z = torch.randn(b, o, z_dim, device=real.device)
+        z_im = torch.randn(b, 128, device=real.device)
+        if world == 1 and not args.no_graph:
+            if not graphed:
+                from layout2img_amd.trainer import restore_state, snapshot_state
+                st = snapshot_state(trainer)       # the capture runs warm-up iterations on this batch: undo them, the
+                graphed = trainer.capture(real, label, bbox, z, z_im)
+                restore_state(trainer, st)         # first REPLAY is the first training iteration
+                n_obj = (b, o)
+            if graphed and (b, o) == n_obj:
+                return trainer.step_graphed(real, label, bbox, z, z_im)
+        return trainer.step(real, label, bbox, z, z_im)
+
     for epoch in range(start, args.total_epoch):
         for idx, (real, label, bbox) in enumerate(batches(epoch)):
-            r = trainer.step(real, label, bbox)
+            r = run(real, label, bbox)
             if rank == 0 and (idx + 1) % 500 == 0:   # (the only host synchronisation: logging, as :191-209)
                 print(f"Time Elapsed: {time.time() - t0:.0f}s  Epoch[{epoch + 1}/{args.total_epoch}], Step[{idx + 1}], "
                       f"d_loss: {float(r['d_loss']):.4f}, g_loss: {float(r['g_loss']):.4f}, pixel: {float(r['pixel']):.4f}", flush=True)

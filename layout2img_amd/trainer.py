@@ -226,4 +226,30 @@ class GanTrainer:
             if dst is not None and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self._graph.replay()
+        self.g_opt.t += 1   # (host-side mirrors of the device-side step counts the replayed Adam launches advance)
+        self.d_opt.t += 1
         return self._graph_out
+
+
+def snapshot_state(tr):
+    """Everything one training iteration changes (parameters, spectral-norm u / v, batch-norm buffers, Adam moments and
+    step counts) as clones: `restore_state` puts a trainer back, e.g. to compare two ways of running the SAME iteration."""
+    nets = (tr.netG, tr.netD)
+    return dict(flat=[n.flat.data.clone() for n in nets], sn=[n.arena.sn_flat.data.clone() for n in nets],
+                bufs=[[b.detach().clone() for b in n.buffers()] for n in nets],
+                opt=[(o.m.clone(), o.v.clone(), o.t, o.t_dev.clone()) for o in (tr.g_opt, tr.d_opt)])
+
+
+def restore_state(tr, st):
+    nets = (tr.netG, tr.netD)
+    with torch.no_grad():
+        for n, f, s_, bufs in zip(nets, st["flat"], st["sn"], st["bufs"]):
+            n.flat.data.copy_(f)
+            n.arena.sn_flat.data.copy_(s_)
+            for b, v in zip(n.buffers(), bufs):
+                b.copy_(v)
+            n.arena.drop_pending()
+        for o, (m, v, t, td) in zip((tr.g_opt, tr.d_opt), st["opt"]):
+            o.m.copy_(m), o.v.copy_(v), o.t_dev.copy_(td)
+            o.t = t
+

@@ -88,3 +88,60 @@ def test_two_ranks_equal_single_process():
         frac = float(((a - b).abs() < 1e-4).float().mean())
         assert frac > 0.97, (k, frac)
         assert float((a - b).abs().max()) <= 2e-3   # a few opposite-sign Adam steps of <= sqrt(2) * lr each
+
+
+def _run_grads(rank, world, port, out, dt_name):
+    """One iteration at 128x128 with bf16 / f32 operands; rank 0 returns both networks' flat gradients (after the SUM
+    all-reduce under data parallelism = the gradient of the global batch)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import layout2img_amd as L
+    from layout2img_amd import parallel
+    from layout2img_amd.synthetic import make_batch
+    if world > 1:
+        parallel.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    dt = getattr(torch, dt_name)
+    torch.manual_seed(7)
+    g = L.ResnetGenerator128_context(num_classes=184).finalize(DEV, dt)
+    d = L.CombineDiscriminator128_app(num_classes=184).finalize(DEV, dt)
+    for m in g.modules():
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = 0.0
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()  # the PSP stage norms are per-replica (un-synchronised) in the reference too: freeze them
+    tr = L.GanTrainer(g, d)
+    real, label, bbox, z, z_im = make_batch(16, 128, "coco", seed=11, device="cpu")
+    n = 16 // world
+    sl = slice(rank * n, (rank + 1) * n)
+    tr.step(*[t[sl].to(DEV) for t in (real, label, bbox, z, z_im)])
+    tr.flush()
+    torch.cuda.synchronize()
+    if rank == 0:
+        out["g"] = g.flat.grad.detach().cpu()
+        out["d"] = d.flat.grad.detach().cpu()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("dt_name", ["bfloat16", "float32"])
+def test_two_rank_gradients_equal_single_process_at_128(dt_name):
+    """BASELINE config 4's arithmetic at its resolution and operand dtype: two data-parallel ranks (8 images each) produce the
+    single-process gradient of the 16-image batch -- SyncBN statistics in both directions, global-count losses, SUM
+    all-reduce of the flat gradients (on its own process group), compared BEFORE Adam's sign amplification.
+    The bar calibrates itself: two SINGLE-process runs of the same iteration already differ (f32 atomics reorder sums, a
+    pre-activation at ~0 lands on the other side of its ReLU gate, a value on a bf16 rounding boundary rounds the other way;
+    measured here at b = 16: generator gradient relative L2 ~4e-4 f32, ~1.5e-2 bf16), and the two-rank gradient must lie
+    within 2.5 x that run-to-run distance (+ 1e-5). A broken exchange -- unsynchronised batch statistics, local loss
+    counts, a missing all-reduce -- moves the gradient by O(0.1 - 1)."""
+    mgr = mp.Manager()
+    single, again, multi = mgr.dict(), mgr.dict(), mgr.dict()
+    mp.spawn(_run_grads, args=(1, _free_port(), single, dt_name), nprocs=1, join=True)
+    mp.spawn(_run_grads, args=(1, _free_port(), again, dt_name), nprocs=1, join=True)
+    mp.spawn(_run_grads, args=(2, _free_port(), multi, dt_name), nprocs=2, join=True)
+    for k in ("g", "d"):
+        b = single[k]
+        floor = float((again[k] - b).norm() / b.norm())
+        err = float((multi[k] - b).norm() / b.norm())
+        assert err < 2.5 * floor + 1e-5, (k, err, floor)
+        assert err < (5e-3 if dt_name == "float32" else 8e-2), (k, err)   # (and an absolute ceiling, far below a broken exchange)

@@ -168,19 +168,35 @@ def test_discriminator_vs_reference(dt):
         assert maxdiff(e, fx[f"eval_{k}"]) < rel * max(1.0, float(np.abs(fx[f"eval_{k}"]).max())), k
 
 
-@pytest.mark.parametrize("dt", [torch.float32])
-def test_train_loop_vs_reference(dt):
-    """Two iterations of the training loop (reference train_context_app_v2.py:148-189, VGG term omitted)."""
+# Bars of the loop tests: (loss relative error, image L_inf) per iteration, and the parameter-sum slack in units of "every
+# element of the tensor moved by 2 lr". f32: as in rounds 1-2. bf16: from the values measured by tools/parity/measure_bars.py
+# on an MI355X -- COCO: losses 4.0e-4 (iteration 0) and 4.0e-4 / 7.5e-4 in two runs (iteration 1), image 3.9e-2 / 8.9e-2,
+# parameter sums 0.087; VG: losses 8.6e-4 / 2.5e-3, image 3.7e-2 / 1.32e-1, parameter sums 0.069. Iteration 0 is a pure
+# forward quantity: 1.5 x measured. Iteration 1 starts from parameters that took one Adam(beta1 = 0) step, i.e. +-lr per
+# element by the SIGN of a bf16-noisy gradient, and varies by 2 x from run to run: 2 x the larger measured value.
+_LOOP_BARS = {
+    ("coco", True): ((5e-4, 1e-3), (3e-2, 2e-2), 0.05),
+    ("coco", False): ((6e-4, 5.8e-2), (1.5e-3, 1.8e-1), 0.13),
+    ("vg", True): ((5e-4, 1e-3), (3e-2, 2e-2), 0.05),
+    ("vg", False): ((1.3e-3, 5.6e-2), (5e-3, 2.6e-1), 0.105),
+}
+
+
+def _loop_vs_reference(kind, dt):
     import layout2img_amd as L
-    fx = load_fixture("train_loop.npz")
-    g = _build_g(load_fixture("g_coco.npz"), 31, dt)
-    d = _build_d(load_fixture("d_coco.npz"), 32, dt)
+    vg = kind == "vg"
+    f32 = dt == torch.float32
+    fx = load_fixture("train_loop_vg.npz" if vg else "train_loop.npz")
+    g = _build_g(load_fixture("g_vg_img.npz" if vg else "g_coco.npz"), 53 if vg else 31, dt, kind="vg" if vg else "coco")
+    d = _build_d(load_fixture("d_vg.npz" if vg else "d_coco.npz"), 54 if vg else 32, dt, num_classes=179 if vg else 184)
     g.train(), d.train()
     tr = L.GanTrainer(g, d)
+    bars = _LOOP_BARS[(kind, f32)]
     for it in range(2):
-        inp = {k: v.to(DEV) for k, v in recipe.make_inputs(2, 8, 184, 200 + it).items()}
+        mk = recipe.make_inputs_vg(2, 31, 179, 300 + it) if vg else recipe.make_inputs(2, 8, 184, 200 + it)
+        inp = {k: v.to(DEV) for k, v in mk.items()}
         r = tr.step(inp["real"], inp["y"], inp["bbox"], inp["z"], inp["z_im"])
-        rel, tol_img = (5e-4, 1e-3) if it == 0 else (3e-2, 2e-2)
+        rel, tol_img = bars[it]
         for k in ("d_loss", "g_loss"):
             ref = float(fx[f"{k}{it}"])
             assert abs(float(r[k]) - ref) < rel * max(1.0, abs(ref)), (k, it, float(r[k]), ref)
@@ -190,9 +206,16 @@ def test_train_loop_vs_reference(dt):
         names = [str(n) for n in fx[f"{pre}_param_names"]]
         sums = np.array([float(named[n].detach().double().sum()) for n in names])
         numel = np.array([named[n].numel() for n in names])
-        tol = 1e-3 * (np.abs(fx[f"{pre}_param_sums"]) + 1.0) + 2 * 2e-4 * numel * 0.05
+        tol = 1e-3 * (np.abs(fx[f"{pre}_param_sums"]) + 1.0) + 2 * 2e-4 * numel * bars[2]
         bad = np.abs(sums - fx[f"{pre}_param_sums"]) - tol
         assert np.all(bad < 0), (pre, names[int(bad.argmax())])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_train_loop_vs_reference(dt):
+    """Two iterations of the training loop (reference train_context_app_v2.py:148-189, VGG term omitted) against the losses,
+    images and parameter sums captured from the reference loop -- f32 operands and the bf16 operands of the headline."""
+    _loop_vs_reference("coco", dt)
 
 
 def test_full_size_step_properties():
@@ -269,30 +292,10 @@ def test_vg_models_with_image_slot_vs_reference(dt):
         assert maxdiff(e, fx[f"eval_{k}"]) < rel * max(1.0, float(np.abs(fx[f"eval_{k}"]).max())), k
 
 
-def test_vg_train_loop_vs_reference():
-    """Two iterations of the loop with the VG models on `__image__`-slot layouts (f32 operands)."""
-    import layout2img_amd as L
-    fx = load_fixture("train_loop_vg.npz")
-    g = _build_g(load_fixture("g_vg_img.npz"), 53, torch.float32, kind="vg")
-    d = _build_d(load_fixture("d_vg.npz"), 54, torch.float32, num_classes=179)
-    g.train(), d.train()
-    tr = L.GanTrainer(g, d)
-    for it in range(2):
-        inp = {k: v.to(DEV) for k, v in recipe.make_inputs_vg(2, 31, 179, 300 + it).items()}
-        r = tr.step(inp["real"], inp["y"], inp["bbox"], inp["z"], inp["z_im"])
-        rel, tol_img = (5e-4, 1e-3) if it == 0 else (3e-2, 2e-2)
-        for k in ("d_loss", "g_loss"):
-            ref = float(fx[f"{k}{it}"])
-            assert abs(float(r[k]) - ref) < rel * max(1.0, abs(ref)), (k, it, float(r[k]), ref)
-        assert maxdiff(r["fake"][:, :, ::4, ::4], fx[f"fake_sub{it}"]) < tol_img
-    for net, pre in ((g, "g"), (d, "d")):
-        named = dict(net.named_parameters())
-        names = [str(n) for n in fx[f"{pre}_param_names"]]
-        sums = np.array([float(named[n].detach().double().sum()) for n in names])
-        numel = np.array([named[n].numel() for n in names])
-        tol = 1e-3 * (np.abs(fx[f"{pre}_param_sums"]) + 1.0) + 2 * 2e-4 * numel * 0.05
-        bad = np.abs(sums - fx[f"{pre}_param_sums"]) - tol
-        assert np.all(bad < 0), (pre, names[int(bad.argmax())])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_vg_train_loop_vs_reference(dt):
+    """Two iterations of the loop with the VG models on `__image__`-slot layouts."""
+    _loop_vs_reference("vg", dt)
 
 
 def test_full_size_vg_step_properties():
@@ -326,33 +329,120 @@ def test_full_size_vg_step_properties():
     assert maxdiff(a, b) > 1e-3   # its full-canvas mask contributes to ISLA
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_vgg_loss_vs_reference(dt):
-    """VGG19 perceptual loss (reference utils/util.py:49-94, train_context_app_v2.py:141,185) on the MFMA conv path
-    against the reference's own VGGLoss run on recipe weights (tests/golden/vgg.npz): loss value, the gradient with
-    respect to the fake image, and state_dict keys = the reference's."""
+def _vgg(dt):
     import layout2img_amd as L
-    from tests.helpers import vgg_inputs, vgg_state
+    from tests.helpers import vgg_state
     fx = load_fixture("vgg.npz")
     m = L.VGGLoss()
     sd = vgg_state(fx)
     assert set(m.state_dict().keys()) == set(sd.keys())
     m.load_state_dict(sd)
-    m.finalize(DEV, dt)
+    return m.finalize(DEV, dt), fx
+
+
+def test_vgg_loss_vs_reference_f32():
+    """VGG19 perceptual loss (reference utils/util.py:49-94, train_context_app_v2.py:141,185) on the MFMA conv path with
+    exact-f32 operands against the reference's own VGGLoss run on recipe weights (tests/golden/vgg.npz): loss value, the
+    gradient with respect to the fake image, state_dict keys = the reference's.
+    The launches are made DETERMINISTIC for this test (split-K off: l2i_set_conv_config(1001)): with f32 atomics combining
+    split-K partials in a varying order, one run in twelve put a ~0 pre-activation on the other side of its ReLU gate and
+    moved the gradient error from 9.3e-4 to 6.5e-3 (tools/perf/vgg_repeat.py); round 2 had widened the bar for that."""
+    from layout2img_amd import _lib
+    from tests.helpers import vgg_inputs
+    m, fx = _vgg(torch.float32)
     x, y = vgg_inputs()
     x = x.to(DEV).requires_grad_(True)
-    loss = m(x, y.to(DEV))
-    loss.backward()
-    f32 = dt == torch.float32
+    _lib.call("l2i_set_conv_config", 1001)
+    try:
+        loss = m(x, y.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        _lib.call("l2i_set_conv_config", 1512)
     ref = float(fx["loss"])
-    assert abs(float(loss) - ref) < (1e-4 if f32 else 2e-2) * abs(ref), (float(loss), ref)
+    assert abs(float(loss) - ref) < 1e-4 * abs(ref), (float(loss), ref)
     g = torch.from_numpy(fx["grad_x_sub"])
     err = float((x.grad[:, :, ::2, ::2].cpu() - g).norm() / g.norm())
-    # bf16 operands: 13 layers of operand rounding in front of ReLU gates of a RANDOM-weight network -- the image
-    # gradient is only loosely reproduced (0.35 measured); the loss value itself is within 2 %.
-    # f32 operands: the loss agrees to 3e-7; the gradient's relative L2 error is 9.3e-4 in 11 runs of 12 and 6.5e-3 in the
-    # twelfth (tools/perf/vgg_repeat.py on one box): whenever the f32 atomics of a split-K launch add in another
-    # order, one more pre-activation that is ~0 in the reference lands on the other side of its ReLU gate and its whole
-    # receptive field changes sign of contribution. The bar is set for that, not for the typical run.
-    assert err < (2e-2 if f32 else 5e-1), err
+    assert err < 1.5e-3, err
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in m.parameters())   # frozen
+
+
+def test_vgg_loss_bf16_operands_tap_by_tap():
+    """bf16 operands: the loss against the reference's (2 %), and -- instead of one loose bound on the image gradient -- every
+    feature tap (relu1_1 ... relu5_1, the five terms of the loss) and the image gradient against the SAME kernels run with
+    exact-f32 operands (which the test above pins to the reference). Bars = 1.5 x the values measured on an MI355X:
+    per-tap relative L2 error of relu(tap) 2.2e-3, 3.7e-3, 4.2e-3, 5.9e-3, 7.2e-3 (13 layers of 2^-9 operand rounding,
+    growing with depth); image gradient: relative L2 error 0.35, cosine 0.940 -- the gradient passes 13 ReLU gates of a
+    RANDOM-weight network, where a rounding-sized change of a pre-activation near 0 switches its whole receptive field."""
+    from tests.helpers import vgg_inputs
+    x0, y0 = vgg_inputs()
+    taps, grads, losses = {}, {}, {}
+    for dt in (torch.float32, torch.bfloat16):
+        m, fx = _vgg(dt)
+        x = x0.to(DEV).requires_grad_(True)
+        losses[dt] = m(x, y0.to(DEV))
+        losses[dt].backward()
+        with torch.no_grad():
+            taps[dt] = [torch.relu(t).float().cpu() for t in m.vgg(m._nhwc8(x0.to(DEV)))]
+        grads[dt] = x.grad.detach().float().cpu()
+    ref = float(fx["loss"])
+    assert abs(float(losses[torch.bfloat16]) - ref) < 2e-2 * abs(ref)
+    errs = [float((a - b).norm() / b.norm()) for a, b in zip(taps[torch.bfloat16], taps[torch.float32])]
+    for e, bar in zip(errs, (3.4e-3, 5.6e-3, 6.4e-3, 8.8e-3, 1.1e-2)):
+        assert e < bar, errs
+    ga, gb = grads[torch.bfloat16], grads[torch.float32]
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    rel = float((ga - gb).norm() / gb.norm())
+    assert cos > 0.91 and rel < 0.52, (cos, rel, errs)
+
+
+def _grads_after_one_iteration(dt, mode, b=32, seed=5):
+    """Flat gradients of both networks after ONE training iteration from a fixed state, run eagerly or as the replayed HIP
+    graph (GanTrainer.capture: its warm-up iterations are undone by restoring the state before the replay)."""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_batch
+    from layout2img_amd.trainer import restore_state, snapshot_state
+    torch.manual_seed(seed)
+    g = L.ResnetGenerator128_context(num_classes=184).finalize(DEV, dt)
+    d = L.CombineDiscriminator128_app(num_classes=184).finalize(DEV, dt)
+    for m in g.modules():
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = 0.0   # (the graph replays its own Philox offsets: draws differ from an eager run's)
+    tr = L.GanTrainer(g, d)
+    real, label, bbox, z, z_im = make_batch(b, 128, "coco", seed=3, device=DEV)
+    if mode == "graph":
+        st = snapshot_state(tr)
+        assert tr.capture(real, label, bbox, z, z_im)
+        restore_state(tr, st)
+        tr.step_graphed(real, label, bbox, z, z_im)
+    else:
+        tr.step(real, label, bbox, z, z_im)
+    torch.cuda.synchronize()
+    out = {"g." + n: p.grad.detach().float().cpu().clone() for n, p in g.named_parameters()}
+    out.update({"d." + n: p.grad.detach().float().cpu().clone() for n, p in d.named_parameters()})
+    return out
+
+
+def _grad_errors(a, b):
+    """(whole-gradient relative L2, median per-parameter relative L2) of gradient dict a against b."""
+    cat = lambda t: torch.cat([t[k].reshape(-1) for k in sorted(t)])
+    whole = float((cat(a) - cat(b)).norm() / cat(b).norm())
+    per = [float((a[k] - b[k]).norm() / b[k].norm()) for k in b if float(b[k].norm()) > 0]
+    return whole, float(np.median(per))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_graph_replay_gradients_match_eager_at_full_size(dt):
+    """What BENCH times -- the graph-replayed 128x128, b = 32 iteration -- computes the eager iteration's GRADIENTS: both
+    networks' flat gradients after one iteration from the same state (before Adam's sign amplification).
+    Two eager runs of the same iteration already differ (f32 atomics reorder sums; a pre-activation that is ~0 lands on the
+    other side of its ReLU gate, a value on a bf16 rounding boundary rounds the other way): measured on an MI355X
+    (tools/parity/measure_bars.py) eager vs eager = whole-gradient relative L2 1.6e-4 (f32) / 5.8e-3 (bf16), median
+    per-parameter 5.9e-4 / 1.05e-2; graph vs eager = 1.7e-4 / 5.8e-3 and 5.6e-4 / 1.1e-2 -- the same floor. Bars: 1.5 x those.
+    (Per-parameter MAXIMA are not bounded: conv biases in front of a batch norm have a true gradient of 0 and see only noise.)"""
+    f32 = dt == torch.float32
+    eager = _grads_after_one_iteration(dt, "eager")
+    graph = _grads_after_one_iteration(dt, "graph")
+    whole, med = _grad_errors(graph, eager)
+    assert whole < (2.5e-4 if f32 else 8.7e-3), whole
+    assert med < (9e-4 if f32 else 1.7e-2), med

@@ -6,7 +6,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 from layout2img_amd import ops, _lib
 lib = _lib.load()
-lib.l2i_trace_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 _lib.call('l2i_set_conv_config', int(os.environ.get('L2I_CFG', '-1')))
 dev = torch.device('cuda:0')
 B, H, W, Ci, Co, KH, up2, pool2, mode = [int(v) for v in sys.argv[1:10]]
@@ -34,10 +33,11 @@ with ops.POOL.step(dev):
 us = s.elapsed_time(e) * 100
 nw = 8192 * 8
 buf = np.zeros(nw * 4, dtype=np.int64)
-rc = lib.l2i_trace_read(buf.ctypes.data, nw)
+lib.l2i_trace_read_conv.argtypes = [ctypes.c_void_p, ctypes.c_int]
+rc = lib.l2i_trace_read_conv(buf.ctypes.data, nw)
 ids = np.zeros(nw, dtype=np.uint32)
-lib.l2i_trace_read_id.argtypes = [ctypes.c_void_p, ctypes.c_int]
-lib.l2i_trace_read_id(ids.ctypes.data, nw)
+lib.l2i_trace_ids_conv.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.l2i_trace_ids_conv(ids.ctypes.data, nw)
 t = buf.reshape(nw, 4)
 keep = t[:, 0] > 0
 t, ids = t[keep], ids[keep]
