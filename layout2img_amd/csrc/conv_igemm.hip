@@ -266,7 +266,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, uns
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base ? (int)nbytes : 0, 0x00020000);
 }
 
-template <typename T, int TM, int TN>
+template <typename T, int TM, int TN, int BMAX = 8>   // BMAX: cap on the stages per batch (registers: 12-14 per stage in flight)
 __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane, int wave,
                                                   int tile_r, int tile_c, int n0, int rows_total, int rows_live, char* smem) {
 #ifdef L2I_ABLATIONS
@@ -319,7 +319,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
     // B stages per batch = loads in flight per wave: one memory round trip (~2 us under load) per batch is what the epilogue
     // costs, so narrow tiles (TN = 1: 4 stages per slab) take TWO slabs per pass (SP) -- one round trip for the wave's whole tile.
     constexpr int SP = (TN == 1 && TM % 2 == 0) ? 2 : 1;   // slabs per pass (the wave's LDS patch holds SP x 32 pixel rows)
-    constexpr int B = TN >= 4 ? 4 : 8;
+    constexpr int B = (TN >= 4 || sizeof(T) == 4 || BMAX < 8) ? 4 : 8;
     constexpr int NST = SP * NIT;                          // stage slots per pass
     __syncthreads();   // every wave is done reading the ring / the halo
 #pragma unroll
@@ -931,8 +931,10 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void 
 //     reads a 256-byte zero region at the bank slot the border row would have had (conflict-free by the same argument
 //     as the bordered layout: tools/perf/halo_check.py);
 //   * needs Ci % 64 == 0 (every layer this is used for); everything else as above (transposed accumulator, epilogue).
+// (launch bounds: the 256 x 64 tile fits three workgroups per CU -- 161 VGPRs in round 2; without the bound the batched epilogue
+//  took 207 and the ROI heads, which run on this tile, lost a quarter of their speed to the missing third workgroup)
 template <int BN, int ABL = 0, bool PF = false>
-__global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_halo3_kernel(ConvArgs p) {
     typedef bf16_t T;
     constexpr int NW = 4, TM = 2, TN = BN / 32, BP = BN / 32, SZ = 2;
     constexpr int HPMAX = 11;                       // 18 x 18 halo rows = 41 KB-pieces over 4 waves
@@ -1220,7 +1222,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo3_kernel(ConvArgs p) {
 #undef H3_RD
     L2I_TR(2);
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
-    else if (p.epi_lds) conv_epilogue_lds<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
+    else if (p.epi_lds) conv_epilogue_lds<T, TM, TN, 4>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);   // (4: the 256 x 64 tile runs three workgroups per CU on 168 VGPRs)
     else conv_epilogue<T, TM, TN>(p, acc, wrow, 0, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
     L2I_TR(3);
 }

@@ -67,7 +67,9 @@ class GanTrainer:
         # with G's Adam step -- only when the NEXT iteration needs G's weights, i.e. after that iteration's D(real) pass
         # has been enqueued on the side stream: the collective overlaps D(real). (D's all-reduce has nothing independent
         # next to it: the G step reads D's updated weights at once.) flush() completes a pending step; L2I_DEFER_G=0: off.
-        self.defer_g = self.world > 1 and self.overlap and os.environ.get("L2I_DEFER_G", "1") != "0"
+        # (one GPU: off by default -- L2I_DEFER_G=1 turns it on there too: G's spectral-norm backward + Adam then run next to the
+        #  following iteration's D(real) pass instead of at the end of their own iteration)
+        self.defer_g = self.overlap and os.environ.get("L2I_DEFER_G", "1" if self.world > 1 else "0") != "0"
         self._pending_g = False
         # whoever reads the generator's parameters from outside the loop (sampling.sample, checkpoints) completes a deferred
         # step first: the hook rides on the network

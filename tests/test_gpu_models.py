@@ -169,16 +169,16 @@ def test_discriminator_vs_reference(dt):
 
 
 # Bars of the loop tests: (loss relative error, image L_inf) per iteration, and the parameter-sum slack in units of "every
-# element of the tensor moved by 2 lr". f32: as in rounds 1-2. bf16: from the values measured by tools/parity/measure_bars.py
-# on an MI355X -- COCO: losses 4.0e-4 (iteration 0) and 4.0e-4 / 7.5e-4 in two runs (iteration 1), image 3.9e-2 / 8.9e-2,
-# parameter sums 0.087; VG: losses 8.6e-4 / 2.5e-3, image 3.7e-2 / 1.32e-1, parameter sums 0.069. Iteration 0 is a pure
-# forward quantity: 1.5 x measured. Iteration 1 starts from parameters that took one Adam(beta1 = 0) step, i.e. +-lr per
-# element by the SIGN of a bf16-noisy gradient, and varies by 2 x from run to run: 2 x the larger measured value.
+# element of the tensor moved by 2 lr". f32: as in rounds 1-2. bf16: 1.5 x the LARGEST value of four runs of
+# tools/parity/measure_bars.py on MI355X boxes -- the run-to-run spread is wide because already iteration 0's g_loss is
+# taken after D's first Adam(beta1 = 0) step, i.e. +-lr per element by the SIGN of a bf16-noisy gradient:
+#   COCO  d/g loss it 0: 4.0-4.4e-4 / 2.2e-4-1.07e-3, it 1: 0.5-5.0e-4 / 2.0e-4-1.5e-3; image 3.7-4.3e-2, 8.2-9.6e-2; sums 0.087-0.185
+#   VG    d/g loss it 0: 7.5-8.0e-4 / 8.1e-4-9.9e-4,  it 1: 6.7-8.0e-4 / 5.1e-4-3.2e-3; image 3.7-4.9e-2, 1.15-1.57e-1; sums 0.069-0.165
 _LOOP_BARS = {
     ("coco", True): ((5e-4, 1e-3), (3e-2, 2e-2), 0.05),
-    ("coco", False): ((6e-4, 5.8e-2), (1.5e-3, 1.8e-1), 0.13),
+    ("coco", False): ((1.6e-3, 6.5e-2), (2.3e-3, 1.45e-1), 0.28),
     ("vg", True): ((5e-4, 1e-3), (3e-2, 2e-2), 0.05),
-    ("vg", False): ((1.3e-3, 5.6e-2), (5e-3, 2.6e-1), 0.105),
+    ("vg", False): ((1.5e-3, 7.5e-2), (4.9e-3, 2.4e-1), 0.25),
 }
 
 
