@@ -245,6 +245,19 @@ def main():
                 roof["wgrad_frac"] = round(w["work"] / (w["ms"] * 1e-3) / 1e12 / peak, 4)
             ops.TIMER.close()
             ops.TIMER = None
+        # the eager iteration (python + autograd enqueue every launch): what layout2img_amd.train falls back to when it cannot
+        # replay a graph (data parallel), measured OUTSIDE the timed region on a few iterations (kernel timer closed)
+        eager = None
+        if world == 1 and graphed:
+            for _ in range(2):
+                trainer.step(real, label, bbox, z, None)
+            trainer.flush(); sync()
+            te, ne = time.perf_counter(), 5
+            for _ in range(ne):
+                trainer.step(real, label, bbox, z, None)
+            trainer.flush(); sync()
+            te = time.perf_counter() - te
+            eager = dict(images_per_sec=round(args.batch * ne / te, 1), ms_per_step=round(1e3 * te / ne, 3), steps=ne)
         # secondary figures of SURVEY section 8d: the generator forward alone (train-mode statistics, no autograd tape),
         # replayed as its own HIP graph, against the MFMA roofline (26.35 GFLOP per image), and the batch-1
         # sampling latency (test_context_app_v2.py:68-77)
@@ -272,7 +285,7 @@ def main():
                        "launch": ("HIP graph replay, D(real) on a side stream (last timed step eager on one stream, with HIP events)"
                                   if graphed else "eager")},
             "roofline": roof, "env": l2i_env(),
-            "cpu_baseline": cpu, "g_forward": g_fwd,
+            "cpu_baseline": cpu, "g_forward": g_fwd, "eager": eager,
             "g_forward_images_per_sec": None if g_fwd is None else g_fwd["images_per_sec"],
         }
         print(json.dumps(out), flush=True)

@@ -788,6 +788,102 @@ static size_t norm_bwd_lds(const NormArgs& a) {
     return sizeof(float) * ((size_t)2 * O * NM_CC + (size_t)2 * O * NB_PX + NB_PX + tile) + 16;
 }
 
+// ISLA forward for layouts with at most 8 objects (COCO): the register-resident form. norm_mod_kernel re-reads the
+// projections W[o][c], B[o][c] of every object from LDS for EVERY pixel (16 ds_read_b128 per 16 bytes of input: LDS traffic
+// 16 x the HBM traffic -- 0.46 of the HBM rate, and half its lanes idle on the 64-channel layers, the largest ones). Here a
+// thread owns 4 fixed channels, keeps their 8 + 8 projection rows in registers for a run of 256 pixels, and reads only the 8
+// normalised mask values of a pixel (two broadcast ds_read_b128). CV float4 columns per block: 32 (>= 128 channels) or 16.
+template <typename T, int CV>
+__global__ __launch_bounds__(256) void norm_mod8_kernel(NormArgs p) {
+    constexpr int PT = 256, ROWS = 256 / CV;
+    __shared__ __attribute__((aligned(16))) float mnl[PT][8];
+    const int tiles_p = (p.HW + PT - 1) / PT, tiles_c = (p.C + 4 * CV - 1) / (4 * CV);
+    int bid = blockIdx.x;
+    const int tc = bid % tiles_c; bid /= tiles_c;
+    const int tp = bid % tiles_p, b = bid / tiles_p;
+    const int p0 = tp * PT, tid = threadIdx.x;
+    {   // normalised masks of this block's pixels: m_o / (sum_o m_o + 1e-6)
+        const int px = p0 + tid;
+        float m[8], S = 1e-6f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            m[o] = (o < p.O && px < p.HW) ? p.mask[((size_t)b * p.O + o) * p.HW + px] : 0.f;
+            S += m[o];
+        }
+        const float inv = 1.f / S;
+        *reinterpret_cast<float4*>(&mnl[tid][0]) = make_float4(m[0] * inv, m[1] * inv, m[2] * inv, m[3] * inv);
+        *reinterpret_cast<float4*>(&mnl[tid][4]) = make_float4(m[4] * inv, m[5] * inv, m[6] * inv, m[7] * inv);
+    }
+    const int cv = tid % CV, prow = tid / CV;
+    const int c = tc * 4 * CV + 4 * cv;
+    const bool con = c < p.C;
+    float4 Wr[8], Br[8];
+    float4 mean = make_float4(0, 0, 0, 0), istd = make_float4(1, 1, 1, 1);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        Wr[o] = make_float4(0, 0, 0, 0); Br[o] = make_float4(0, 0, 0, 0);
+        if (con && o < p.O) {
+            const size_t off = (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + c;
+            Wr[o] = *reinterpret_cast<const float4*>(p.wproj + off);
+            Br[o] = *reinterpret_cast<const float4*>(p.bproj + off);
+        }
+    }
+    if (con) {
+        const size_t so = (size_t)b * p.stat_stride + c;
+        const float4 s = *reinterpret_cast<const float4*>(p.sums + so);
+        const float4 q = *reinterpret_cast<const float4*>(p.sqsums + so);
+        const float ic = 1.f / p.count;
+        mean = make_float4(s.x * ic, s.y * ic, s.z * ic, s.w * ic);
+        const float4 var = make_float4(fmaxf(q.x * ic - mean.x * mean.x, 0.f), fmaxf(q.y * ic - mean.y * mean.y, 0.f),
+                                       fmaxf(q.z * ic - mean.z * mean.z, 0.f), fmaxf(q.w * ic - mean.w * mean.w, 0.f));
+        istd = make_float4(rsqrtf(var.x + p.eps), rsqrtf(var.y + p.eps), rsqrtf(var.z + p.eps), rsqrtf(var.w + p.eps));
+        if (p.run_mean && b == 0 && tp == 0 && prow == 0) {
+            // nn.BatchNorm2d train-mode side effect (momentum update with the UNBIASED batch variance), once per channel
+            const float ub = p.count / fmaxf(p.count - 1.f, 1.f), mo = p.momentum;
+            float4 rm = *reinterpret_cast<float4*>(p.run_mean + c), rv = *reinterpret_cast<float4*>(p.run_var + c);
+            rm.x = (1.f - mo) * rm.x + mo * mean.x; rm.y = (1.f - mo) * rm.y + mo * mean.y;
+            rm.z = (1.f - mo) * rm.z + mo * mean.z; rm.w = (1.f - mo) * rm.w + mo * mean.w;
+            rv.x = (1.f - mo) * rv.x + mo * ub * var.x; rv.y = (1.f - mo) * rv.y + mo * ub * var.y;
+            rv.z = (1.f - mo) * rv.z + mo * ub * var.z; rv.w = (1.f - mo) * rv.w + mo * ub * var.w;
+            *reinterpret_cast<float4*>(p.run_mean + c) = rm;
+            *reinterpret_cast<float4*>(p.run_var + c) = rv;
+        }
+    }
+    __syncthreads();
+    T* OutOp = reinterpret_cast<T*>(p.out_op);
+    const int npx = min(PT, p.HW - p0);
+#pragma unroll 2
+    for (int pl = prow; pl < npx; pl += ROWS) {
+        if (!con) continue;
+        const size_t off = ((size_t)b * p.HW + p0 + pl) * p.C + c;
+        const float4 xv = *reinterpret_cast<const float4*>(p.x + off);
+        const float4 m0 = *reinterpret_cast<const float4*>(&mnl[pl][0]), m1 = *reinterpret_cast<const float4*>(&mnl[pl][4]);
+        const float4 xh = make_float4((xv.x - mean.x) * istd.x, (xv.y - mean.y) * istd.y, (xv.z - mean.z) * istd.z, (xv.w - mean.w) * istd.w);
+        float4 ga = make_float4(1, 1, 1, 1), be = make_float4(0, 0, 0, 0);
+        ga = f4mad(m0.x, Wr[0], ga); be = f4mad(m0.x, Br[0], be);
+        ga = f4mad(m0.y, Wr[1], ga); be = f4mad(m0.y, Br[1], be);
+        ga = f4mad(m0.z, Wr[2], ga); be = f4mad(m0.z, Br[2], be);
+        ga = f4mad(m0.w, Wr[3], ga); be = f4mad(m0.w, Br[3], be);
+        ga = f4mad(m1.x, Wr[4], ga); be = f4mad(m1.x, Br[4], be);
+        ga = f4mad(m1.y, Wr[5], ga); be = f4mad(m1.y, Br[5], be);
+        ga = f4mad(m1.z, Wr[6], ga); be = f4mad(m1.z, Br[6], be);
+        ga = f4mad(m1.w, Wr[7], ga); be = f4mad(m1.w, Br[7], be);
+        float4 y = make_float4(fmaf(ga.x, xh.x, be.x), fmaf(ga.y, xh.y, be.y), fmaf(ga.z, xh.z, be.z), fmaf(ga.w, xh.w, be.w));
+        if (p.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+        if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + off) = y;
+        if (OutOp) {
+            if constexpr (sizeof(T) == 2) {
+                uint2 pk;
+                pk.x = f2bf2(y.x, y.y);
+                pk.y = f2bf2(y.z, y.w);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(OutOp) + off) = pk;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(OutOp) + off) = y;
+            }
+        }
+    }
+}
+
 static size_t norm_lds(const NormArgs& a) {
     const int O = a.mode == 0 ? a.O : 0;
     return sizeof(float) * ((size_t)2 * O * NM_CC + (size_t)O * NM_PT + NM_PT) + 16;
@@ -812,6 +908,17 @@ extern "C" int l2i_norm_mod_fwd(const float* x, int B, int HW, int C, const floa
     a.stat_stride = stat_stride; a.mask = mask; a.O = O; a.wproj = wproj; a.bproj = bproj;
     a.pstride_b = pstride_b; a.pstride_o = pstride_o; a.mode = mode; a.relu = relu; a.out_op = out_op; a.out_f32 = out_f32;
     if (norm_check(a) != L2I_OK || (!out_op && !out_f32)) return L2I_ERR_ARG;
+    if (dtype != 0 && dtype != 1) return L2I_ERR_ARG;
+    static const bool no_m8 = getenv("L2I_NORM_M8") && atoi(getenv("L2I_NORM_M8")) == 0;   // tuning: the LDS form for every layer
+    if (mode == 0 && O <= 8 && !no_m8) {   // COCO layouts: projections in registers (norm_mod8_kernel)
+        const int cvw = C <= 64 ? 16 : 32;
+        const int nb8 = B * ((HW + 255) / 256) * ((C + 4 * cvw - 1) / (4 * cvw));
+        if (dtype == 1 && cvw == 32) hipLaunchKernelGGL((norm_mod8_kernel<bf16_t, 32>), dim3(nb8), dim3(256), 0, (hipStream_t)stream, a);
+        else if (dtype == 1) hipLaunchKernelGGL((norm_mod8_kernel<bf16_t, 16>), dim3(nb8), dim3(256), 0, (hipStream_t)stream, a);
+        else if (cvw == 32) hipLaunchKernelGGL((norm_mod8_kernel<float, 32>), dim3(nb8), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((norm_mod8_kernel<float, 16>), dim3(nb8), dim3(256), 0, (hipStream_t)stream, a);
+        return l2i_check_launch();
+    }
     const int nblk = B * ((HW + NM_PT - 1) / NM_PT) * ((C + NM_CC - 1) / NM_CC);
     if (dtype == 0)
         hipLaunchKernelGGL((norm_mod_kernel<float, false>), dim3(nblk), dim3(256), norm_lds(a), (hipStream_t)stream, a);

@@ -49,8 +49,12 @@ class ZeroPool:
         self.buf, self.off, self.active = None, 0, False
 
     def begin(self, device, nfloats=8 << 20):
-        if self.buf is None or self.buf.device != torch.device(device) or self.buf.numel() != nfloats:
-            self.buf = torch.empty(nfloats, dtype=torch.float32, device=device)
+        key = (str(torch.device(device)), nfloats)   # one slab per (device, size): a training step and a stand-alone forward
+        slabs = self.__dict__.setdefault("slabs", {})   # use different sizes and must not re-allocate each other's buffer
+        buf = slabs.get(key)
+        if buf is None:
+            buf = slabs[key] = torch.empty(nfloats, dtype=torch.float32, device=device)
+        self.buf = buf
         self.buf.zero_()
         self.off, self.active = 0, True
 
