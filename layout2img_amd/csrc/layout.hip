@@ -433,19 +433,19 @@ struct PspStArgs {
     int off[8], ns[8];
     float eps, momentum;
 };
-__global__ __launch_bounds__(256) void psp_stages_fwd_kernel(PspStArgs p) {
+__global__ __launch_bounds__(1024) void psp_stages_fwd_kernel(PspStArgs p) {
     __shared__ float ws[PSP_FT][512];
     __shared__ float red[16];
     // (the raw values go to p.raw and are read back by the SAME thread in the later passes: no size limit, no fence needed)
     const int s = blockIdx.y, f0 = blockIdx.x * PSP_FT, tid = threadIdx.x;
     const int ns = p.ns[s], off = p.off[s], rows = p.B * ns;
-    for (int i = tid; i < PSP_FT * p.C; i += 256) {
+    for (int i = tid; i < PSP_FT * p.C; i += blockDim.x) {
         const int ff = i / p.C, c = i - ff * p.C;
         ws[ff][c] = f0 + ff < p.F ? p.W[s][(size_t)(f0 + ff) * p.C + c] : 0.f;
     }
     __syncthreads();
     float sum[PSP_FT] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = tid; r < rows; r += 256) {
+    for (int r = tid; r < rows; r += blockDim.x) {
         const int b = r / ns, k = r - b * ns;
         const float* x = p.pooled + ((size_t)b * p.NB + off + k) * p.C;
         float a[PSP_FT] = {0.f, 0.f, 0.f, 0.f};
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void psp_stages_fwd_kernel(PspStArgs p) {
 #pragma unroll
         for (int ff = 0; ff < PSP_FT; ++ff) mean[ff] = block_sum(sum[ff], red) / rows;
         float sq[PSP_FT] = {0.f, 0.f, 0.f, 0.f};
-        for (int r = tid; r < rows; r += 256) {
+        for (int r = tid; r < rows; r += blockDim.x) {
             const int b = r / ns, k = r - b * ns;
             const float* rw = p.raw + ((size_t)b * p.NB + off + k) * p.F + f0;
 #pragma unroll
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void psp_stages_fwd_kernel(PspStArgs p) {
 #pragma unroll
         for (int ff = 0; ff < PSP_FT; ++ff)
             if (f0 + ff < p.F) { p.stat[((size_t)s * 2) * p.F + f0 + ff] = mean[ff]; p.stat[((size_t)s * 2 + 1) * p.F + f0 + ff] = rstd[ff]; }
-    for (int r = tid; r < rows; r += 256) {
+    for (int r = tid; r < rows; r += blockDim.x) {
         const int b = r / ns, k = r - b * ns;
         const size_t o = ((size_t)b * p.NB + off + k) * p.F + f0;
 #pragma unroll
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void psp_stages_fwd_kernel(PspStArgs p) {
 }
 // BatchNorm + ReLU backward per (stage, 4 channels): draw = gamma rstd (g - mean(g) - xhat mean(g xhat)), g = dy 1[y > 0];
 // dgamma / dbeta written (each (stage, channel) belongs to one workgroup).
-__global__ __launch_bounds__(256) void psp_stages_bwd_bn_kernel(PspStArgs p) {
+__global__ __launch_bounds__(1024) void psp_stages_bwd_bn_kernel(PspStArgs p) {
     __shared__ float red[16];
     const int s = blockIdx.y, f0 = blockIdx.x * PSP_FT, tid = threadIdx.x;
     const int ns = p.ns[s], off = p.off[s], rows = p.B * ns;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void psp_stages_bwd_bn_kernel(PspStArgs p) {
         bet[ff] = p.beta[s][f];
     }
     float s1[PSP_FT] = {0.f, 0.f, 0.f, 0.f}, s2[PSP_FT] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = tid; r < rows; r += 256) {
+    for (int r = tid; r < rows; r += blockDim.x) {
         const int b = r / ns, k = r - b * ns;
         const size_t o = ((size_t)b * p.NB + off + k) * p.F + f0;
 #pragma unroll
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void psp_stages_bwd_bn_kernel(PspStArgs p) {
         s2[ff] = block_sum(s2[ff], red);
         if (tid == 0 && f0 + ff < p.F) { p.dgamma[(size_t)s * p.F + f0 + ff] = s2[ff]; p.dbeta[(size_t)s * p.F + f0 + ff] = s1[ff]; }
     }
-    for (int r = tid; r < rows; r += 256) {
+    for (int r = tid; r < rows; r += blockDim.x) {
         const int b = r / ns, k = r - b * ns;
         const size_t o = ((size_t)b * p.NB + off + k) * p.F + f0;
 #pragma unroll
@@ -637,7 +637,8 @@ extern "C" int l2i_psp_stages_fwd(const float* pooled, const float* const* W, co
     }
     p.pooled = pooled; p.raw = raw; p.y = y; p.stat = stat;
     p.training = training; p.eps = eps; p.momentum = momentum;
-    hipLaunchKernelGGL(psp_stages_fwd_kernel, dim3((F + PSP_FT - 1) / PSP_FT, S), dim3(256), 0, (hipStream_t)stream, p);
+    // (1024 threads: the largest stage has B x 36 rows and its batch statistics need all of them in one workgroup)
+    hipLaunchKernelGGL(psp_stages_fwd_kernel, dim3((F + PSP_FT - 1) / PSP_FT, S), dim3(1024), 0, (hipStream_t)stream, p);
     return l2i_check_launch();
 }
 extern "C" int l2i_psp_stages_bwd(const float* pooled, const float* const* W, const float* const* gamma, const float* const* beta,
@@ -652,7 +653,7 @@ extern "C" int l2i_psp_stages_bwd(const float* pooled, const float* const* W, co
     }
     p.pooled = pooled; p.raw = const_cast<float*>(raw); p.stat = const_cast<float*>(stat);
     p.dy = dy; p.draw = draw; p.dgamma = dgamma; p.dbeta = dbeta; p.training = training;
-    hipLaunchKernelGGL(psp_stages_bwd_bn_kernel, dim3((F + PSP_FT - 1) / PSP_FT, S), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(psp_stages_bwd_bn_kernel, dim3((F + PSP_FT - 1) / PSP_FT, S), dim3(1024), 0, (hipStream_t)stream, p);
     const long long n0 = ((long long)B * NB * (C / 4) + 255) / 256, n1 = ((long long)S * F * C + 63) / 64;   // workgroups of the two roles
     const long long nmax = n0 > n1 ? n0 : n1;
     hipLaunchKernelGGL(psp_stages_bwd_mm_kernel, dim3((unsigned)nmax, 2), dim3(256), 0, (hipStream_t)stream, p, dpooled, dW);

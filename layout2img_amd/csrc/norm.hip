@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256) void norm_mod8_kernel(NormArgs p) {
     const int tc = bid % tiles_c; bid /= tiles_c;
     const int tp = bid % tiles_p, b = bid / tiles_p;
     const int p0 = tp * PT, tid = threadIdx.x;
-    {   // normalised masks of this block's pixels: m_o / (sum_o m_o + 1e-6)
+    if (p.mode == 0) {   // normalised masks of this block's pixels: m_o / (sum_o m_o + 1e-6)
         const int px = p0 + tid;
         float m[8], S = 1e-6f;
 #pragma unroll
@@ -819,10 +819,15 @@ __global__ __launch_bounds__(256) void norm_mod8_kernel(NormArgs p) {
     const bool con = c < p.C;
     float4 Wr[8], Br[8];
     float4 mean = make_float4(0, 0, 0, 0), istd = make_float4(1, 1, 1, 1);
+    float4 ga0 = make_float4(1, 1, 1, 1), be0 = make_float4(0, 0, 0, 0);   // mode 1: the affine weight / bias; mode 2: identity
+    if (p.mode == 1 && con) {
+        ga0 = *reinterpret_cast<const float4*>(p.wproj + c);
+        be0 = *reinterpret_cast<const float4*>(p.bproj + c);
+    }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         Wr[o] = make_float4(0, 0, 0, 0); Br[o] = make_float4(0, 0, 0, 0);
-        if (con && o < p.O) {
+        if (p.mode == 0 && con && o < p.O) {
             const size_t off = (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + c;
             Wr[o] = *reinterpret_cast<const float4*>(p.wproj + off);
             Br[o] = *reinterpret_cast<const float4*>(p.bproj + off);
@@ -857,17 +862,19 @@ __global__ __launch_bounds__(256) void norm_mod8_kernel(NormArgs p) {
         if (!con) continue;
         const size_t off = ((size_t)b * p.HW + p0 + pl) * p.C + c;
         const float4 xv = *reinterpret_cast<const float4*>(p.x + off);
-        const float4 m0 = *reinterpret_cast<const float4*>(&mnl[pl][0]), m1 = *reinterpret_cast<const float4*>(&mnl[pl][4]);
         const float4 xh = make_float4((xv.x - mean.x) * istd.x, (xv.y - mean.y) * istd.y, (xv.z - mean.z) * istd.z, (xv.w - mean.w) * istd.w);
-        float4 ga = make_float4(1, 1, 1, 1), be = make_float4(0, 0, 0, 0);
-        ga = f4mad(m0.x, Wr[0], ga); be = f4mad(m0.x, Br[0], be);
-        ga = f4mad(m0.y, Wr[1], ga); be = f4mad(m0.y, Br[1], be);
-        ga = f4mad(m0.z, Wr[2], ga); be = f4mad(m0.z, Br[2], be);
-        ga = f4mad(m0.w, Wr[3], ga); be = f4mad(m0.w, Br[3], be);
-        ga = f4mad(m1.x, Wr[4], ga); be = f4mad(m1.x, Br[4], be);
-        ga = f4mad(m1.y, Wr[5], ga); be = f4mad(m1.y, Br[5], be);
-        ga = f4mad(m1.z, Wr[6], ga); be = f4mad(m1.z, Br[6], be);
-        ga = f4mad(m1.w, Wr[7], ga); be = f4mad(m1.w, Br[7], be);
+        float4 ga = ga0, be = be0;
+        if (p.mode == 0) {
+            const float4 m0 = *reinterpret_cast<const float4*>(&mnl[pl][0]), m1 = *reinterpret_cast<const float4*>(&mnl[pl][4]);
+            ga = f4mad(m0.x, Wr[0], ga); be = f4mad(m0.x, Br[0], be);
+            ga = f4mad(m0.y, Wr[1], ga); be = f4mad(m0.y, Br[1], be);
+            ga = f4mad(m0.z, Wr[2], ga); be = f4mad(m0.z, Br[2], be);
+            ga = f4mad(m0.w, Wr[3], ga); be = f4mad(m0.w, Br[3], be);
+            ga = f4mad(m1.x, Wr[4], ga); be = f4mad(m1.x, Br[4], be);
+            ga = f4mad(m1.y, Wr[5], ga); be = f4mad(m1.y, Br[5], be);
+            ga = f4mad(m1.z, Wr[6], ga); be = f4mad(m1.z, Br[6], be);
+            ga = f4mad(m1.w, Wr[7], ga); be = f4mad(m1.w, Br[7], be);
+        }
         float4 y = make_float4(fmaf(ga.x, xh.x, be.x), fmaf(ga.y, xh.y, be.y), fmaf(ga.z, xh.z, be.z), fmaf(ga.w, xh.w, be.w));
         if (p.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
         if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + off) = y;
@@ -910,7 +917,8 @@ extern "C" int l2i_norm_mod_fwd(const float* x, int B, int HW, int C, const floa
     if (norm_check(a) != L2I_OK || (!out_op && !out_f32)) return L2I_ERR_ARG;
     if (dtype != 0 && dtype != 1) return L2I_ERR_ARG;
     static const bool no_m8 = getenv("L2I_NORM_M8") && atoi(getenv("L2I_NORM_M8")) == 0;   // tuning: the LDS form for every layer
-    if (mode == 0 && O <= 8 && !no_m8) {   // COCO layouts: projections in registers (norm_mod8_kernel)
+    if (((mode == 0 && O <= 8) || mode == 1 || mode == 2) && !no_m8) {   // COCO layouts (projections in registers),
+                                                                                           // plain batch norms: norm_mod8_kernel
         const int cvw = C <= 64 ? 16 : 32;
         const int nb8 = B * ((HW + 255) / 256) * ((C + 4 * cvw - 1) / (4 * cvw));
         if (dtype == 1 && cvw == 32) hipLaunchKernelGGL((norm_mod8_kernel<bf16_t, 32>), dim3(nb8), dim3(256), 0, (hipStream_t)stream, a);
