@@ -189,7 +189,7 @@ def main():
     # iteration (both forwards, both backwards, both Adam steps) is captured once as a HIP graph and replayed. The last
     # timed iteration always runs eagerly so that HIP events can bracket the conv launches inside the timed region.
     graphed = False
-    if world == 1 and not args.no_graph:
+    if (world == 1 or os.environ.get("L2I_DDP_GRAPH", "0") == "1") and not args.no_graph:   # (N > 1: opt-in, see GanTrainer.capture)
         try:
             graphed = trainer.capture(real, label, bbox, z)
         except Exception as e:   # stay on the eager path

@@ -259,17 +259,25 @@ __device__ __forceinline__ bf16x8_t wg_frag(const char* tile, int pixbase, int c
 //   pixels; group g multiplies pixels [64 g, 64 g + 64) of it into its own accumulators, and at the end group 1 hands its
 //   tile to group 0 through LDS. Half as many partial tiles leave the chip for the same occupancy: combining the
 //   splits (stores + wgrad_reduce_kernel, or atomics) is what a weight-gradient launch pays per resident wave.
-template <int BMO, int MODE, int NW = 4>
+// DEEP (NW = 4 only): 32-pixel steps in a FOUR-stage ring instead of 64-pixel steps in two stages -- the same 64 KB of LDS
+//   (two workgroups per CU), but three stages (48 KB) in flight instead of one (32 KB); one barrier per 32 pixels. An
+//   experiment that answered "is the 64-pixel step (~2500 cycles against 2 x 512 cycles of MFMA work per SIMD,
+//   tools/perf/wgrad_trace.py) waiting for its DMA?" with NO: it is 7-19 % slower on every layer (see launch_wgrad). Off by default.
+template <int BMO, int MODE, int NW = 4, bool DEEP = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kernel(WgradArgs p, int lgW, int lgH) {
+    static_assert(!DEEP || NW == 4, "deep pipeline: four-wave kernel only");
     constexpr bool FAST = MODE == 1, SEMI = MODE == 2;
-    constexpr int BNK = 128, BK = 16 * NW, NT = 64 * NW, LGBK = NW == 8 ? 7 : (NW == 4 ? 6 : 5);
+    constexpr int BNK = 128, BK = DEEP ? 32 : 16 * NW, NT = 64 * NW, LGBK = DEEP ? 5 : (NW == 8 ? 7 : (NW == 4 ? 6 : 5));
+    constexpr int NST = DEEP ? 4 : 2;            // ring stages
+    constexpr int RPW = BK / NW;                 // pixel rows a wave stages per step (16 | 8)
     constexpr int RSA = BMO * 2, RSB = BNK * 2;
     constexpr int WM = NW >= 4 ? 2 : 1;          // waves along the channel (row) dimension of the tile (of a group)
     constexpr int TM = BMO / (32 * WM), TN = 2;
     constexpr int STAGE = BK * (RSA + RSB);
     constexpr int KS16 = (NW == 8 ? 64 : BK) / 16;   // k16 sub-steps a wave multiplies per step (its group's 64 pixels)
     constexpr int A_ROWS = 1024 / RSA;           // pixel rows per wave-instruction (4 | 8)
-    constexpr int A_Q = 16 / A_ROWS;             // A instructions per wave per step (4 | 2)
+    constexpr int A_Q = RPW / A_ROWS;            // A instructions per wave per step (4 | 2; deep: 2 | 1)
+    constexpr int B_Q = RPW / 4;                 // im2col instructions per wave per step (4 rows each)
     constexpr int A_CH = RSA / 16;               // 16-byte chunks per A row (16 | 8)
 
     L2I_TR(0);
@@ -317,28 +325,28 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
     const unsigned smem_addr = lds_addr_of(smem);
     constexpr unsigned OOB = 0x80000000u;
     unsigned a_base[A_Q];      // fast path: byte offset of this lane's chunk for pixel (prow + a_row), without the step base
-    int b_mlane[4];
-    unsigned b_base[4];        // fast path: ((ky-1)*Wo + (kx-1) + prow + b_row) * Ci + b_ci, in bytes (may wrap below 0)
+    int b_mlane[B_Q];
+    unsigned b_base[B_Q];      // fast path: ((ky-1)*Wo + (kx-1) + prow + b_row) * Ci + b_ci, in bytes (may wrap below 0)
 #pragma unroll
     for (int q = 0; q < A_Q; ++q)
-        a_base[q] = a_on ? (unsigned)((wv * 16 + q * A_ROWS + a_row) * p.Co + a_chan) * 2u : OOB;
+        a_base[q] = a_on ? (unsigned)((wv * RPW + q * A_ROWS + a_row) * p.Co + a_chan) * 2u : OOB;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        b_mlane[q] = wv * 16 + q * 4 + b_row;
+    for (int q = 0; q < B_Q; ++q) {
+        b_mlane[q] = wv * RPW + q * 4 + b_row;
         b_base[q] = (unsigned)(((b_ky - pad) * p.Wo + (b_kx - pad) + b_mlane[q]) * p.Ci + b_ci) * 2u + x_shift;
     }
     const unsigned co2 = (unsigned)p.Co * 2u, ci2 = (unsigned)p.Ci * 2u;
     // SEMI: lane constants -- position (xl, yl) of the lane's pixel within a step, folded into offsets
     unsigned a_semi[A_Q];
-    int b_cy[4], b_cx[4];
+    int b_cy[B_Q], b_cx[B_Q];
 #pragma unroll
     for (int q = 0; q < A_Q; ++q) {
-        const int pl = wv * 16 + q * A_ROWS + a_row;
+        const int pl = wv * RPW + q * A_ROWS + a_row;
         const int xl = pl & (p.Wo - 1), yl = pl >> lgW;
         a_semi[q] = a_on ? (unsigned)(((yl >> p.pool2) * Wd + (xl >> p.pool2)) * p.Co + a_chan) * 2u : OOB;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < B_Q; ++q) {
         const int pl = b_mlane[q];
         b_cx[q] = (pl & (p.Wo - 1)) + b_kx - pad;
         b_cy[q] = (pl >> lgW) + b_ky - pad;
@@ -350,21 +358,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
         const unsigned soff_b = (unsigned)(sb * p.Hi * p.Wi) * ci2;
 #pragma unroll
         for (int q = 0; q < A_Q; ++q) {
-            const unsigned dst = stage + (unsigned)(wv * 16 + q * A_ROWS) * RSA;
+            const unsigned dst = stage + (unsigned)(wv * RPW + q * A_ROWS) * RSA;
             if constexpr (FAST) {
                 L2I_DMA16_S(rs_dy, a_base[q], (unsigned)mstep * co2, dst);
             } else if constexpr (SEMI) {
                 L2I_DMA16_S(rs_dy, a_semi[q], soff_a, dst);
             } else {
-                const int m = mstep + wv * 16 + q * A_ROWS + a_row;
+                const int m = mstep + wv * RPW + q * A_ROWS + a_row;
                 const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1), b = m >> (lgW + lgH);
                 const unsigned off = (unsigned)(((b * Hd + (y >> p.pool2)) * Wd + (x >> p.pool2)) * p.Co + a_chan) * 2u;
                 L2I_DMA16_S(rs_dy, (a_on && m < m_end) ? off : OOB, 0u, dst);   // (select, not a branch: keeps the loop straight-line)
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned dst = stage + BK * RSA + (unsigned)(wv * 16 + q * 4) * RSB;
+        for (int q = 0; q < B_Q; ++q) {
+            const unsigned dst = stage + BK * RSA + (unsigned)(wv * RPW + q * 4) * RSB;
             if constexpr (SEMI) {
                 const int yy = sy + b_cy[q], xx = sx + b_cx[q];
                 const bool in = b_on && (unsigned)yy < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo;
@@ -461,6 +469,29 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     }
     L2I_TR(1);
+    if constexpr (DEEP) {
+        if (m_begin < m_end) {
+            constexpr int IPS = A_Q + B_Q;   // DMA instructions a wave issues per step (vmcnt counts them in order)
+            const int nsteps = (m_end - m_begin + BK - 1) >> LGBK;
+#pragma unroll
+            for (int s_ = 0; s_ < NST - 1; ++s_)
+                if (s_ < nsteps) issue(m_begin + s_ * BK, smem_addr + (unsigned)(s_ * STAGE));
+            for (int it = 0; it < nsteps; ++it) {
+                // step `it` must have landed; the (up to two) steps issued after it may stay in flight
+                const int rem = nsteps - 1 - it;
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPS) : "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();   // everyone's pieces landed, and stage (it - 1) % NST is free
+                asm volatile("" ::: "memory");
+                if (it + NST - 1 < nsteps) issue(m_begin + (it + NST - 1) * BK, smem_addr + (unsigned)(((it + NST - 1) & (NST - 1)) * STAGE));
+                const int stg = it & (NST - 1);
+                const int ms = m_begin + it * BK;
+                WG_BIAS(stg, ms)
+                WG_STEP(stg)
+            }
+        }
+    } else
     if (m_begin < m_end) {
         // (whole pairs of steps in the loop, an odd last step after it: a conditional second step inside the loop makes
         // the compiler merge two accumulator register sets with 64 AGPR<->VGPR copies per iteration)
@@ -663,9 +694,17 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
     // kernels gain 0.15 ms, the eight-wave main loops lose 0.55 ms): a tuning option, off by default
     const bool nw8 = nw8_env && g_wgrad_nw2 != 1 && BMO == 128 && sizeof(T) == 2 && pow2 && a.M % 128 == 0 &&
                      ((!a.pool2 && !a.up2) || (a.Ho * a.Wo) % 128 == 0) && (!a.nimg || (a.Ho * a.Wo) % 128 == 0);   // (live pixels: whole steps)
-    const int SBK = nw8 ? 128 : BK;   // pixels per step of the kernel that will run
-    a.lgbk = nw8 ? 7 : 6;
+    // deep pipeline (32-pixel steps, four-stage ring; conv_wgrad_dma_kernel<.., DEEP>): bf16 DMA kernel, four waves. Measured SLOWER
+    // (tools/perf/wgrad_tune.py, MI355X: 32x32x512->512 868 -> 707 TFLOP/s, 256x8x8x512->512 838 -> 725, every shape loses
+    // 7-19 %): the main loop is not waiting for its DMA -- halving the MFMA work between two barriers costs more than the two
+    // extra stages in flight bring. Kept as a tuning option: L2I_WGRAD_DEEP=1.
+    static const int deep_env = getenv("L2I_WGRAD_DEEP") ? atoi(getenv("L2I_WGRAD_DEEP")) : 0;
+    const bool nw2_ = BMO == 128 && sizeof(T) == 2 && pow2 && g_wgrad_nw2 == 1;
+    const bool deep = deep_env && sizeof(T) == 2 && pow2 && !nw8 && !nw2_;
+    const int SBK = nw8 ? 128 : (deep ? 32 : BK);   // pixels per step of the kernel that will run
+    a.lgbk = nw8 ? 7 : (deep ? 5 : 6);
     const int steps = (a.M + SBK - 1) / SBK;
+    const int steps64 = nw8 ? steps * 2 : (a.M + 63) / 64;   // (the split heuristics count 64-pixel units whatever the kernel's step)
     // Split the pixel (reduction) dimension so that the grid is ONE full wave of co-resident workgroups (2 per CU for
     // the 128-row tile, 3 for the 64-row one: LDS-limited) -- every extra split costs Co*K atomics, and a grid of 1.1-1.9
     // waves leaves half the chip idle in its second round. Tile counts too large for that go to >= 3 waves instead.
@@ -675,9 +714,9 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
     int splits = cap / tiles;
     if (splits < 1 || (long long)splits * tiles * 5 < (long long)cap * 4) {
         splits = (3 * cap + tiles - 1) / tiles;
-        if (splits > steps / 32) splits = steps / 32;   // short reductions: extra splits are all prologue + atomics
+        if (splits > steps64 / 32) splits = steps64 / 32;   // short reductions: extra splits are all prologue + atomics
     }
-    if (splits > steps / 4) splits = steps / 4;
+    if (splits > steps64 / 4) splits = steps64 / 4;
     if (splits < 1) splits = 1;
     int per = (steps + splits - 1) / splits;
     a.Mper = per * SBK;
@@ -696,10 +735,18 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
         int lgW = 0, lgH = 0;
         while ((1 << lgW) < a.Wo) ++lgW;
         while ((1 << lgH) < a.Ho) ++lgH;
-        const size_t lds2 = (size_t)2 * 64 * (BMO * 2 + 256);
-        const bool whole = a.M % 64 == 0;
-        const int mode = !whole ? 0 : (!a.pool2 && !a.up2) ? 1 : ((a.Ho * a.Wo) % 64 == 0 ? 2 : 0);
-        if (BMO == 64) {
+        const size_t lds2 = (size_t)2 * 64 * (BMO * 2 + 256);   // (= 4 stages of 32 pixels for the deep pipeline)
+        const bool whole = a.M % SBK == 0;
+        const int mode = !whole ? 0 : (!a.pool2 && !a.up2) ? 1 : ((a.Ho * a.Wo) % SBK == 0 ? 2 : 0);
+        if (deep && BMO == 64) {
+            if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 1, 4, true>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 2, 4, true>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 0, 4, true>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+        } else if (deep) {
+            if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 1, 4, true>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 2, 4, true>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+            else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 0, 4, true>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
+        } else if (BMO == 64) {
             if (mode == 1) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 1>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
             else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
             else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<64, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);

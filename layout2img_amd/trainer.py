@@ -188,7 +188,15 @@ class GanTrainer:
         """Capture one iteration on static copies of the inputs (shapes are fixed: the padded-ROI form has no host
         syncs). Returns True on success; afterwards `step_graphed` copies new inputs in and replays."""
         if self.world > 1:
-            return False   # collectives stay eager
+            # Data parallel: the iteration's collectives (SyncBN statistics, ROI count, flat-gradient all-reduces) are RCCL
+            # calls on communicator streams that fork from / join the capture stream, which torch can capture into the graph
+            # like any other stream dependency -- but this path has never run on a multi-GPU node (none was available to
+            # rounds 1-3) and gloo (the backend of the tests' shared-GPU ranks) cannot be captured at all, so it is OPT-IN:
+            # L2I_DDP_GRAPH=1 on an RCCL process group. Every rank must take the same decision. Default: eager
+            # (host enqueue 15.8 ms against 21 ms of GPU time per iteration: GPU-bound with ~25 % headroom, tools/perf/cpu_time.py).
+            import torch.distributed as dist
+            if os.environ.get("L2I_DDP_GRAPH", "0") != "1" or dist.get_backend() != "nccl":
+                return False
         if ops.TIMER is not None:
             raise RuntimeError("capture with the kernel timer on")
         self._static = [None if t is None else t.detach().clone() for t in (real, label, bbox, z, z_im)]
