@@ -8,6 +8,7 @@ kernels read; per-pass arenas keep W/sigma, u, v alive for that pass's backward,
 reference's autograd does implicitly when netD is called twice before backward
 (train_context_app_v2.py:158,167,173).
 """
+import os
 import struct
 
 import numpy as np
@@ -17,6 +18,10 @@ import torch.nn as nn
 from . import _lib
 
 ALIGN = 8  # elements: every parameter owns a zero-padded slot of a multiple of 8 floats (ops.pad_param reads the pad)
+
+
+WTU_RPW = int(os.environ.get("L2I_SN_WTU_RPW", "16"))   # rows per wave of a W^T u block
+WV_R = int(os.environ.get("L2I_SN_WV_R", "4"))          # rows per wave of a W v block (the library reads the same variable)
 
 
 def _round_up(v, m):
@@ -294,11 +299,11 @@ class WeightArena:
             row[18] = 1 if h.uses > 1 else 0
             pair_chunks = (h.co * h.ci + 255) // 256      # csrc/weights.hip: BW_PAIRS
             if h.sn:
-                for cc in range((kt + 1023) // 1024):
-                    for rc in range((h.co + 63) // 64):   # WTU_ROWS
-                        t_wtu[use].append((i, cc, rc))
-                for rc in range((h.co + 15) // 16):
-                    t_wv[use].append((i, rc))
+                for c0 in range(0, kt, 256):              # csrc/weights.hip sn_wtu_kernel: 256 columns x 4 waves x rpw rows
+                    for r0 in range(0, h.co, 4 * WTU_RPW):
+                        t_wtu[use].append((i, c0, r0, WTU_RPW))
+                for r0 in range(0, h.co, 4 * WV_R):       # sn_wv_kernel<R>: 4 R rows per block
+                    t_wv[use].append((i, r0))
                 t_dot += [(i, c) for c in range(pair_chunks)]
             tci = 256 if taps == 1 else 32
             for ct in range((h.co_p + 63) // 64):         # PK_TCO
@@ -314,7 +319,7 @@ class WeightArena:
             arr = np.array(a if a else [(0,) * width], dtype=np.int32).reshape(-1)
             return torch.from_numpy(np.ascontiguousarray(arr)).to(device), len(a)
         self.layers = torch.from_numpy(tab.reshape(-1)).to(device)
-        self.t_wtu = [dev(t, 3) for t in t_wtu]
+        self.t_wtu = [dev(t, 4) for t in t_wtu]
         self.t_wv = [dev(t, 2) for t in t_wv]
         self.t_pack = [dev(t, 3) for t in t_pack]
         self.t_fin = [dev(t, 1) for t in t_fin]

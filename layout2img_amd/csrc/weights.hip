@@ -30,57 +30,68 @@
 __device__ __forceinline__ float layer_eps(const long long* L) { return __uint_as_float((uint32_t)L[15]); }
 
 // ---------------------------------------------------------------- phase 1: t = W^T u
-// table (layer, colchunk, rowchunk): 1024 columns (4 per thread, one 16-byte load per row) x 64 rows per block.
-#define WTU_ROWS 64
+// table (layer, col0, row0, rows per wave): a block covers 256 columns (one 16-byte load per lane and row) x 4 x `rows per wave`
+// rows; its four waves walk different rows of the SAME columns, their partial column sums meet in LDS and leave as one
+// atomic per column and block. (Round 2's form -- 1024 columns x 64 rows per block, four atomics per thread -- left the
+// last column chunk of most layers half empty (Kt = 9 Ci is a multiple of 256, rarely of 1024) and gave the discriminator
+// 960 blocks for 256 CUs: 2.5 TB/s.)
 __global__ __launch_bounds__(256) void sn_wtu_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                      const float* __restrict__ params, const float* __restrict__ sn_state,
                                                      float* __restrict__ pass_uv) {
-    const int* e = table + 3 * blockIdx.x;
+    __shared__ float part[4][256];
+    const int* e = table + 4 * blockIdx.x;
     const long long* L = layers + L2I_LSTRIDE * e[0];
     const int Co = (int)LF(3), Kt = (int)(LF(4) * LF(5) * LF(5));
-    const int r0 = e[2] * WTU_ROWS, r1 = min(Co, r0 + WTU_ROWS);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = min(Co, e[2] + wave * e[3]), r1 = min(Co, r0 + e[3]);
     const float* W = params + LF(0);
     const float* u = sn_state + LF(1);
     float* t_out = pass_uv + LF(17);
     if ((Kt & 3) == 0) {
-        const int col = e[1] * 1024 + 4 * threadIdx.x;
-        if (col >= Kt) return;
+        const int col = e[1] + 4 * lane;
         float4 t = make_float4(0, 0, 0, 0);
-        int r = r0;
-        // eight rows per batch, the eight loads issued back to back (an `unroll 8` of the plain loop keeps its per-row bound
-        // check between the loads and waits for each: 44 % of the HBM rate), then single rows
-        for (; r + 8 <= r1; r += 8) {
-            float4 w[8];
+        if (col < Kt) {
+            int r = r0;
+            // eight rows per batch, the eight loads issued back to back (an `unroll 8` of the plain loop keeps its per-row
+            // bound check between the loads and waits for each), then single rows
+            for (; r + 8 <= r1; r += 8) {
+                float4 w[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const float4*>(W + (size_t)(r + j) * Kt + col);
+                for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const float4*>(W + (size_t)(r + j) * Kt + col);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float ur = u[r + j];
-                t.x = fmaf(ur, w[j].x, t.x); t.y = fmaf(ur, w[j].y, t.y); t.z = fmaf(ur, w[j].z, t.z); t.w = fmaf(ur, w[j].w, t.w);
+                for (int j = 0; j < 8; ++j) {
+                    const float ur = u[r + j];
+                    t.x = fmaf(ur, w[j].x, t.x); t.y = fmaf(ur, w[j].y, t.y); t.z = fmaf(ur, w[j].z, t.z); t.w = fmaf(ur, w[j].w, t.w);
+                }
+            }
+            for (; r < r1; ++r) {
+                const float4 w = *reinterpret_cast<const float4*>(W + (size_t)r * Kt + col);
+                const float ur = u[r];
+                t.x = fmaf(ur, w.x, t.x); t.y = fmaf(ur, w.y, t.y); t.z = fmaf(ur, w.z, t.z); t.w = fmaf(ur, w.w, t.w);
             }
         }
-        for (; r < r1; ++r) {
-            const float4 w = *reinterpret_cast<const float4*>(W + (size_t)r * Kt + col);
-            const float ur = u[r];
-            t.x = fmaf(ur, w.x, t.x); t.y = fmaf(ur, w.y, t.y); t.z = fmaf(ur, w.z, t.z); t.w = fmaf(ur, w.w, t.w);
-        }
-        atomicAdd(t_out + col + 0, t.x); atomicAdd(t_out + col + 1, t.y);
-        atomicAdd(t_out + col + 2, t.z); atomicAdd(t_out + col + 3, t.w);
+        *reinterpret_cast<float4*>(&part[wave][4 * lane]) = t;
     } else {   // rows not 16-byte aligned (Ci = 3, odd class counts): scalar columns
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int col = e[1] * 1024 + c * 256 + threadIdx.x;
-            if (col >= Kt) continue;
+            const int col = e[1] + c * 64 + lane;
             float t = 0.f;
+            if (col < Kt) {
 #pragma unroll 8
-            for (int r = r0; r < r1; ++r) t = fmaf(u[r], W[(size_t)r * Kt + col], t);
-            atomicAdd(t_out + col, t);
+                for (int r = r0; r < r1; ++r) t = fmaf(u[r], W[(size_t)r * Kt + col], t);
+            }
+            part[wave][c * 64 + lane] = t;
         }
     }
+    __syncthreads();
+    const int col = e[1] + threadIdx.x;
+    if (col < Kt) atomicAdd(t_out + col, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // ---------------------------------------------------------------- phase 2: s = W vhat
-// (train: vhat = t / max(||t||, eps); eval: vhat = stored v). 16 rows per block, 4 per wave read together so the
-// vector chunk is loaded once per 4 rows. table: (layer, rowchunk)
+// (train: vhat = t / max(||t||, eps); eval: vhat = stored v). 4 R rows per block, R per wave read together so the
+// vector chunk is loaded once per R rows. table: (layer, row0)
+template <int R>
 __global__ __launch_bounds__(256) void sn_wv_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                     const float* __restrict__ params, const float* __restrict__ sn_state,
                                                     float* __restrict__ pass_uv, float* __restrict__ norms, int training) {
@@ -92,18 +103,38 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const long long* __restrict_
     const float* W = params + LF(0);
     const float* vsrc = training ? pass_uv + LF(17) : sn_state + LF(2);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rbase = e[1] * 16 + wave * 4;
-    float dot[4] = {0.f, 0.f, 0.f, 0.f}, tn2 = 0.f;
-    const float* Wr[4];
+    const int rbase = e[1] + wave * R;
+    float dot[R], tn2 = 0.f;
+    const float* Wr[R];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) Wr[rr] = W + (size_t)min(rbase + rr, Co - 1) * Kt;   // clamped rows are discarded below
+    for (int rr = 0; rr < R; ++rr) {
+        dot[rr] = 0.f;
+        Wr[rr] = W + (size_t)min(rbase + rr, Co - 1) * Kt;   // clamped rows are discarded below
+    }
     if ((Kt & 3) == 0) {
-#pragma unroll 2
-        for (int k = 4 * lane; k < Kt; k += 256) {
+        constexpr int U = 8 / R;   // eight 16-byte loads of W in flight per lane
+        int k = 4 * lane;
+        for (; k + 256 * (U - 1) < Kt; k += 256 * U) {
+            float4 t[U], w[U][R];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                t[q] = *reinterpret_cast<const float4*>(vsrc + k + 256 * q);
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) w[q][rr] = *reinterpret_cast<const float4*>(Wr[rr] + k + 256 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                tn2 += t[q].x * t[q].x + t[q].y * t[q].y + t[q].z * t[q].z + t[q].w * t[q].w;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+                    dot[rr] += w[q][rr].x * t[q].x + w[q][rr].y * t[q].y + w[q][rr].z * t[q].z + w[q][rr].w * t[q].w;
+            }
+        }
+        for (; k < Kt; k += 256) {
             const float4 t = *reinterpret_cast<const float4*>(vsrc + k);
             tn2 += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+            for (int rr = 0; rr < R; ++rr) {
                 const float4 w = *reinterpret_cast<const float4*>(Wr[rr] + k);
                 dot[rr] += w.x * t.x + w.y * t.y + w.z * t.z + w.w * t.w;
             }
@@ -113,13 +144,13 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const long long* __restrict_
             const float t = vsrc[k];
             tn2 += t * t;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) dot[rr] += Wr[rr][k] * t;
+            for (int rr = 0; rr < R; ++rr) dot[rr] += Wr[rr][k] * t;
         }
     }
     tn2 = wave_sum(tn2);
     float blk = 0.f;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < R; ++rr) {
         const int r = rbase + rr;
         const float d = wave_sum(dot[rr]);
         if (r >= Co) continue;
@@ -136,7 +167,7 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const long long* __restrict_
     __syncthreads();
     if (lane == 0) red[wave] = blk;
     __syncthreads();
-    if (threadIdx.x == 0) {   // one atomic per block (<= 64 per layer)
+    if (threadIdx.x == 0) {   // one atomic per block
         atomicAdd(norms + 4 * layer + 1, red[0] + red[1] + red[2] + red[3]);
         if (e[1] == 0) norms[4 * layer + 0] = tn2;
     }
@@ -297,30 +328,32 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restr
     const int layer = table[blockIdx.x];
     const long long* L = layers + L2I_LSTRIDE * layer;
     if (LF(1) < 0) {
-        if (threadIdx.x == 0) norms[4 * layer + 2] = 1.f;
+        if (threadIdx.x == 0 && blockIdx.y == 0) norms[4 * layer + 2] = 1.f;
         return;
     }
     const int Co = (int)LF(3), Kt = (int)(LF(4) * LF(5) * LF(5));
     const float eps = layer_eps(L);
     const float sn2 = norms[4 * layer + 1], tn2 = norms[4 * layer + 0];
+    // (gridDim.y blocks share a layer's vectors: one block per layer took 16 us for the 9216-element v of a 1024-channel 3x3 layer)
+    const int i0 = blockIdx.y * 256 + threadIdx.x, istep = 256 * gridDim.y;
     if (training) {
         const float iu = 1.f / fmaxf(sqrtf(sn2), eps), iv = 1.f / fmaxf(sqrtf(tn2), eps);
-        for (int i = threadIdx.x; i < Co; i += 256) {
+        for (int i = i0; i < Co; i += istep) {
             const float u = pass_uv[LF(16) + i] * iu;
             pass_uv[LF(16) + i] = u;
             sn_state[LF(1) + i] = u;
         }
-        for (int i = threadIdx.x; i < Kt; i += 256) {
+        for (int i = i0; i < Kt; i += istep) {
             const float v = pass_uv[LF(17) + i] * iv;
             pass_uv[LF(17) + i] = v;
             sn_state[LF(2) + i] = v;
         }
     } else {
-        for (int i = threadIdx.x; i < Co; i += 256) pass_uv[LF(16) + i] = sn_state[LF(1) + i];
-        for (int i = threadIdx.x; i < Kt; i += 256) pass_uv[LF(17) + i] = sn_state[LF(2) + i];
+        for (int i = i0; i < Co; i += istep) pass_uv[LF(16) + i] = sn_state[LF(1) + i];
+        for (int i = i0; i < Kt; i += istep) pass_uv[LF(17) + i] = sn_state[LF(2) + i];
     }
     __syncthreads();   // every thread has read sn2 before sigma's slot (a different one) is written
-    if (threadIdx.x == 0) norms[4 * layer + 2] = layer_sigma(L, norms, layer, training);
+    if (threadIdx.x == 0 && blockIdx.y == 0) norms[4 * layer + 2] = layer_sigma(L, norms, layer, training);
 }
 
 // ---------------------------------------------------------------- backward
@@ -440,9 +473,13 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
     }
     if (training && n_wtu > 0)
         hipLaunchKernelGGL(sn_wtu_kernel, dim3(n_wtu), dim3(256), 0, stream, layers, tab_wtu, params, sn_state, pass_uv);
-    if (n_wv > 0)
-        hipLaunchKernelGGL(sn_wv_kernel, dim3(n_wv), dim3(256), 0, stream, layers, tab_wv, params, sn_state, pass_uv, norms,
-                           training);
+    if (n_wv > 0) {
+        static const int wv_r = getenv("L2I_SN_WV_R") ? atoi(getenv("L2I_SN_WV_R")) : 4;   // must match layout2img_amd/arena.py (rows per block = 4 R)
+        if (wv_r == 2)
+            hipLaunchKernelGGL(sn_wv_kernel<2>, dim3(n_wv), dim3(256), 0, stream, layers, tab_wv, params, sn_state, pass_uv, norms, training);
+        else
+            hipLaunchKernelGGL(sn_wv_kernel<4>, dim3(n_wv), dim3(256), 0, stream, layers, tab_wv, params, sn_state, pass_uv, norms, training);
+    }
     if (n_pack > 0) {
         const size_t lds = (dtype == 0 ? sizeof(float) : sizeof(bf16_t)) * PK_TCO * (32 * 9 + 2);   // >= 64 * (256 + 2) elements
         static bool ready = false;
@@ -459,7 +496,7 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
                                (bf16_t*)packed, training);
     }
     if (n_fin > 0)
-        hipLaunchKernelGGL(sn_finish_kernel, dim3(n_fin), dim3(256), 0, stream, layers, tab_fin, sn_state, pass_uv, norms,
+        hipLaunchKernelGGL(sn_finish_kernel, dim3(n_fin, 8), dim3(256), 0, stream, layers, tab_fin, sn_state, pass_uv, norms,
                            training);
     return l2i_check_launch();
 }
