@@ -50,6 +50,20 @@ int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float*
                    int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats,
                    float* ws, void* stream);
 
+/* The same launch with a residual block's 1x1 shortcut folded in (reference model/resnet_generator_app_v2.py:664-678:
+ * `out = conv2(h) + c_sc(upsample(x))`; model/rcnn_discriminator_app.py:317-344: `pool(conv2(h)) + pool(c_sc(x))`):
+ *   out = alpha * pool?( conv(x) + conv1x1(sc_x at (y >> sc_up2, x >> sc_up2)) ) + bias + sc_bias
+ * sc_x [B, sc_Hi, sc_Wi, sc_Ci] T, sc_w [Npad, sc_Kpad] T (forward pack of the 1x1 weight), sc_bias [Co] or null. The
+ * shortcut becomes sc_Ci / 64 more K-steps of the 3x3 tile (conv_sc_tail): its result is neither written nor read back as
+ * `res`. `res` and `relu_mask` must be null. sc_out (f32, shape of out, caller-owned, contents undefined afterwards) is
+ * where the shortcut goes on launches that cannot fold it (split-K grids, the generic kernel, f32 operands, sc_Ci % 64,
+ * L2I_SC_FOLD=0): there the library runs it as a separate 1x1 launch and adds it as the residual -- same result. */
+int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias, const float* res, const void* relu_mask,
+                      float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
+                      int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats,
+                      float* ws, const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi,
+                      int sc_Wi, int sc_Ci, int sc_up2, int sc_Kpad, void* stream);
+
 /* Per-launch timing of the two MFMA entry points (bench.py's roofline leg). l2i_timing(1): from now on every kernel
  * launched by l2i_conv2d_fwd (class 0) / l2i_conv2d_wgrad (class 1) carries a start / stop HIP event pair attached to
  * its dispatch (hipExtLaunchKernelGGL: the kernel's own begin / end on the stream it runs on); l2i_timing_read

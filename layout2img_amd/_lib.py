@@ -15,6 +15,8 @@ _p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 SIGNATURES = {
     "l2i_version": [],
     "l2i_conv2d_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p],
+    "l2i_conv2d_fwd_sc": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p,
+                          _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "l2i_set_conv_config": [_i],
     "l2i_timing": [_i],
     "l2i_timing_read": [_i, _p, _p],

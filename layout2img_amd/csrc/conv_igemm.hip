@@ -21,6 +21,20 @@
 
 L2I_TRACE_DEFINE(conv)   // wave-level timestamps of the last launch (-DL2I_TRACE builds only; common.h)
 
+// Folded 1x1 shortcut of a residual block (l2i_conv2d_fwd_sc): result += conv1x1(x) + bias, accumulated as extra K-chunks
+// of the launch (conv_sc_tail) -- the shortcut's own result is never written and never read back as `res`.
+// The kernels read these fields through late_sc() only, AFTER their 3x3 reduction: loaded with the other kernel arguments
+// at kernel entry they stay live in SGPRs across the main loop, and the 128x64 tile (capped at 168 VGPRs for three
+// workgroups per CU) then spills -- every launch, folded or not, ran 3 % slower.
+struct ScArgs {
+    const void* x;       // T [B, Hi, Wi, Ci], read at (y >> up2, x >> up2) of the launch's pre-pool output grid; null = none
+    const void* w;       // T [Npad, Kpad] forward pack of the 1x1 weight
+    const float* bias;   // [Co] or null
+    float* out;          // f32, shape of out: where the shortcut goes when it cannot be folded (split-K, generic kernel): it then runs as its own launch and is read back as `res`
+    int Ci, Hi, Wi, up2, Kpad, stages;
+    unsigned x_bytes, w_bytes;
+};
+
 struct ConvArgs {
     const void* x;      // T  [B, Hi, Wi, Ci]
     const void* w;      // T  [Npad, Kpad], K order (ky, kx, ci)
@@ -49,7 +63,16 @@ struct ConvArgs {
     int roi_remap;       // tuning (L2I_ROI_REMAP=1): keep the XCD remap on launches with a live-image count (A/B)
     int no_epi;          // ablation builds only (-DL2I_ABLATIONS + L2I_CONV_NOEPI=1, results are wrong): skip the epilogue to measure what it costs
     int epi_lds;         // 1: coalesced epilogue through LDS (conv_epilogue_lds; default), 0: direct stores from the accumulator layout (L2I_EPI=0, A/B)
+    ScArgs sc;           // folded 1x1 shortcut (see ScArgs); sc.x == null: none
 };
+
+typedef const ScArgs __attribute__((address_space(4)))* ScArgsPtr;
+__device__ __forceinline__ ScArgsPtr late_sc() {   // the shortcut arguments, from the kernel-argument segment, not before this point
+    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return (ScArgsPtr)(ka + offsetof(ConvArgs, sc));
+}
+
 
 __device__ __forceinline__ void idx2pix(int idx, int hw_shift, int lin, int& py, int& px) {
     if (lin) { py = idx; px = 0; return; }
@@ -119,7 +142,7 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvArgs& p, f32x16_t
                 if (!live || n >= p.Co) continue;
                 // out = mask * (sum of partials + bias) + res: bias and res enter once (first split, first pixel of a quad)
                 const bool once = split == 0 && (!p.pool2 || (idx & 3) == 0);
-                if (p.bias && once) v += p.bias[n];
+                if (p.bias && once) v += p.bias[n];   // (launches with a folded shortcut never run split-K)
                 if (Mask && !(OpT<T>::to(Mask[rowoff + n]) > 0.f)) v = 0.f;
                 if (p.res && once) v += p.res[rowoff + n];
                 atomicAdd(p.out + rowoff + n, v);
@@ -127,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvArgs& p, f32x16_t
         }
 }
 
-template <typename T, int TM, int TN>
+template <typename T, int TM, int TN, bool SC = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane,
                                               int tile_r, int tile_c, int n0, int split, int rows_total, int rows_live) {
 #ifdef L2I_ABLATIONS
@@ -148,6 +171,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)
     T* __restrict__ OutRaw = reinterpret_cast<T*>(p.out_op_raw);
     const T* __restrict__ Mask = reinterpret_cast<const T*>(p.relu_mask);
     const bool lead = split == 0;   // bias and residual are added by the first split only
+    const float* sc_bias = SC ? late_sc()->bias : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int idx = wrow + i * 32 + m;   // this lane's pixel (GEMM row)
@@ -187,6 +211,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16_t (&acc)
                 const size_t off = rowoff + n;
                 if (p.bias && lead) {
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (SC && sc_bias) {   // folded shortcut: its bias (never on a split-K launch)
+                    const float4 bb = *reinterpret_cast<const float4*>(sc_bias + n);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
                 }
                 if (Mask) {
@@ -266,7 +294,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, uns
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base ? (int)nbytes : 0, 0x00020000);
 }
 
-template <typename T, int TM, int TN, int BMAX = 8>   // BMAX: cap on the stages per batch (registers: 12-14 per stage in flight)
+template <typename T, int TM, int TN, int BMAX = 8, bool SC = false>   // BMAX: cap on the stages per batch (registers: 12-14 per stage in flight)
 __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane, int wave,
                                                   int tile_r, int tile_c, int n0, int rows_total, int rows_live, char* smem) {
 #ifdef L2I_ABLATIONS
@@ -297,6 +325,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
     if (p.bias && nv) {
         const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
         bb[0] = b4.x; bb[1] = b4.y; bb[2] = b4.z; bb[3] = b4.w;
+    }
+    const float* sc_bias = SC ? late_sc()->bias : nullptr;
+    if (SC && sc_bias && nv) {   // folded shortcut: its bias
+        const float4 b4 = *reinterpret_cast<const float4*>(sc_bias + n);
+        bb[0] += b4.x; bb[1] += b4.y; bb[2] += b4.z; bb[3] += b4.w;
     }
     // descriptors over the result-shaped tensors (null pointer -> zero records: every access out of range)
     const unsigned out_elems = (unsigned)p.B * (unsigned)(p.Ho >> p.pool2) * (unsigned)(p.Wo >> p.pool2) * (unsigned)p.Co;
@@ -675,7 +708,99 @@ __global__ __launch_bounds__(WM* WN * 64, ((160 * 1024) / (NS * (BM + BN) * (HK 
                  "s"(soff), "s"(ldsaddr)                                                                              \
                  : "memory")
 
-template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false, int ABL = 0>   // H1: ONE halo buffer, refilled at each chunk boundary
+// ---------------------------------------------------------------- folded 1x1 shortcut: extra K-chunks behind the 3x3 reduction
+// A residual block's result is conv2(h) + c_sc(x) (reference model/resnet_generator_app_v2.py:664-678,
+// model/rcnn_discriminator_app.py:317-344). As its own launch the 1x1 shortcut is bound by the f32 result it writes and
+// that conv2's epilogue reads back (a 32x32, 256 -> 512 shortcut moves 84 MB in 27 us for 1 GFLOP); here it is sc_Ci / 64
+// more K-steps of conv2's tile: after the 3x3 reduction the workgroup stages, per 64 input channels, the BM centre pixels of
+// the shortcut's input ([BM][64] operand rows, read at (y >> sc_up2, x >> sc_up2): nearest upsampling of the generator
+// blocks) and BN rows of the 1x1 pack in the LDS the halo and the ring no longer need, and multiplies them into the same
+// accumulators. Two stages when the kernel's LDS allocation holds them (p.sc_stages), else one.
+template <int BM, int BN, int TM, int TN, int THREADS = 256>
+__device__ __forceinline__ void conv_sc_tail(const ConvArgs& p, ScArgsPtr sc, f32x16_t (&acc)[TM][TN], char* smem, unsigned smem_addr, int tid, int lane,
+                                             int wv, int wrow, int wcol, int tile_r, int tile_c, int n0, int rows_total) {
+    constexpr int RPP = THREADS / 8, AP = BM / RPP, BPS = BN / RPP;   // the workgroup stages RPP rows x 128 bytes per pass
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile geometry");
+    constexpr unsigned ASZ = BM * 128u, STG = (BM + BN) * 128u, OOB = 0x80000000u;
+    const u32x4_t rx = make_rsrc(sc->x, sc->x_bytes), rw = make_rsrc(sc->w, sc->w_bytes);
+    const int sc_Hi = sc->Hi, sc_Wi = sc->Wi, sc_Ci = sc->Ci, sc_up2 = sc->up2, sc_Kpad = sc->Kpad;
+    const int lrow = tid >> 3, hh = lane >> 5;
+    unsigned aoff[AP], boff[BPS];
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int row = lrow + RPP * q;
+        int py, px;
+        idx2pix(row, p.hw_shift, 0, py, px);
+        const int gr = tile_r * p.PH + py, x = tile_c * p.PW + px;
+        const int b = fastdiv(gr, p.mg_ho), y = gr - b * p.Ho;
+        const int ch = (tid & 7) ^ ig2_swz(row);
+        aoff[q] = (gr < rows_total && x < p.Wo)
+                      ? (unsigned)((((b * sc_Hi + (y >> sc_up2)) * sc_Wi + (x >> sc_up2)) * sc_Ci + ch * 8) * 2)
+                      : OOB;
+    }
+#pragma unroll
+    for (int q = 0; q < BPS; ++q) {
+        const int row = lrow + RPP * q;
+        boff[q] = (unsigned)(((n0 + row) * sc_Kpad + ((tid & 7) ^ ig2_swz(row)) * 8) * 2);
+    }
+    unsigned a_rd[TM], b_rd[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wrow + i * 32 + (lane & 31);
+        a_rd[i] = (unsigned)(row * 128 + ((hh ^ ig2_swz(row)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wcol + j * 32 + (lane & 31);
+        b_rd[j] = ASZ + (unsigned)(row * 128 + ((hh ^ ig2_swz(row)) << 4));
+    }
+    const int nch = sc_Ci >> 6;
+    const bool two = sc->stages >= 2;
+#define SC_ISSUE(C, S)                                                                                                 \
+    {                                                                                                                  \
+        const unsigned so_ = (unsigned)(C) * 128u, base_ = smem_addr + (unsigned)(S) * STG + (unsigned)wv * 1024u;     \
+        _Pragma("unroll") for (int q_ = 0; q_ < AP; ++q_) H2_DMA(rx, aoff[q_], so_, base_ + (unsigned)q_ * (RPP * 128u));     \
+        _Pragma("unroll") for (int q_ = 0; q_ < BPS; ++q_) H2_DMA(rw, boff[q_], so_, base_ + ASZ + (unsigned)q_ * (RPP * 128u)); \
+    }
+    __syncthreads();   // every wave is past its last fragment read of the 3x3 reduction: halo and ring are free
+    SC_ISSUE(0, 0)
+    for (int c = 0; c < nch; ++c) {
+        const unsigned st = two ? (unsigned)(c & 1) * STG : 0u;
+        if (two && c + 1 < nch) {
+            SC_ISSUE(c + 1, (c + 1) & 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BPS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(smem + st + (a_rd[i] ^ (unsigned)(kk << 5)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(smem + st + (b_rd[j] ^ (unsigned)(kk << 5)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[j]),   // weights first: transposed tile
+                        __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[i]), acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // the stage is free again
+        asm volatile("" ::: "memory");
+        if (!two && c + 1 < nch) SC_ISSUE(c + 1, 0)
+    }
+#undef SC_ISSUE
+}
+
+// SC: the instantiation that folds a block's 1x1 shortcut behind the 3x3 reduction (conv_sc_tail). A separate instantiation:
+// with the tail compiled into every kernel the 128x64 tile (168-VGPR cap) spilled 37 registers to scratch in its epilogue,
+// and a kernel that uses scratch at all pays for it at dispatch -- every launch, folded or not, took 2.6 us longer.
+template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false, int ABL = 0, bool SC = false>   // H1: ONE halo buffer, refilled at each chunk boundary
 __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void conv_halo2_kernel(ConvArgs p) {   // ABL: ablations for tools/perf (results are wrong): 1 no weight DMA, 2 no DMA, 3 no DMA + no fragment reads, 4 no barrier
     typedef bf16_t T;
     constexpr int THREADS = WM * WN * 64, NW = WM * WN;
@@ -907,10 +1032,15 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void 
 #undef H2_MFMA4
 #undef H2_MFMA
 #undef H2_READS
+    if constexpr (SC) {
+        const ScArgsPtr sc = late_sc();
+        if (sc->x && !tile_dead)
+            conv_sc_tail<BM, BN, TM, TN, THREADS>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, wcol, tile_r, tile_c, n0, rows_total);
+    }
     L2I_TR(2);
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
-    else if (p.epi_lds) conv_epilogue_lds<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
-    else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
+    else if (p.epi_lds) conv_epilogue_lds<T, TM, TN, (SC && TN == 1) ? 4 : 8, SC>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);   // (the folding 128x64 tile: 4 stages in flight keep it under its 168-VGPR cap without scratch)
+    else conv_epilogue<T, TM, TN, SC>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
     L2I_TR(3);
 }
 
@@ -933,7 +1063,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void 
 //   * needs Ci % 64 == 0 (every layer this is used for); everything else as above (transposed accumulator, epilogue).
 // (launch bounds: the 256 x 64 tile fits three workgroups per CU -- 161 VGPRs in round 2; without the bound the batched epilogue
 //  took 207 and the ROI heads, which run on this tile, lost a quarter of their speed to the missing third workgroup)
-template <int BN, int ABL = 0, bool PF = false>
+template <int BN, int ABL = 0, bool PF = false, bool SC = false>   // SC: see conv_halo2_kernel
 __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_halo3_kernel(ConvArgs p) {
     typedef bf16_t T;
     constexpr int NW = 4, TM = 2, TN = BN / 32, BP = BN / 32, SZ = 2;
@@ -1220,10 +1350,14 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_halo3_kernel(ConvA
 #undef H3_HALO
 #undef H3_MM
 #undef H3_RD
+    if constexpr (SC) {
+        const ScArgsPtr sc = late_sc();
+        if (sc->x && !tile_dead) conv_sc_tail<256, BN, TM, TN, 256>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, 0, tile_r, tile_c, n0, rows_total);
+    }
     L2I_TR(2);
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
-    else if (p.epi_lds) conv_epilogue_lds<T, TM, TN, 4>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);   // (4: the 256 x 64 tile runs three workgroups per CU on 168 VGPRs)
-    else conv_epilogue<T, TM, TN>(p, acc, wrow, 0, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
+    else if (p.epi_lds) conv_epilogue_lds<T, TM, TN, 4, SC>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);   // (4: the 256 x 64 tile runs three workgroups per CU on 168 VGPRs)
+    else conv_epilogue<T, TM, TN, SC>(p, acc, wrow, 0, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
     L2I_TR(3);
 }
 
@@ -1234,6 +1368,7 @@ static int ilog2(int v) {
 }
 
 static int g_split_target = 512;   // tuning hook: workgroups a split-K launch aims for
+static int g_no_sc_fold = 0;       // A/B switch (L2I_SC_FOLD=0): a block's 1x1 shortcut always runs as its own launch
 static int g_force_splits = 0;     // tuning hook (l2i_set_conv_config(2000 + n)): split count of the 256-pixel-tile kernel
 static int g_generic_cfg = -1;     // tuning hook (l2i_set_conv_config(3000 + n)): tile configuration of the generic kernel only
 // Launch one instantiation; LDS rings above 64 KB need the opt-in attribute (set once per instantiation).
@@ -1283,7 +1418,35 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
 
 // Halo kernel launch (bf16, 3x3, Ci >= 64, Wo >= 8, no upsample into 8-wide maps). Returns -100 when the shape is
 // not covered so that the caller falls through to the generic kernel.
-template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false, int ABL = 0>
+template <typename T> static int launch_conv(ConvArgs& a, hipStream_t stream);
+
+// A shortcut that cannot ride on this launch (split-K, the generic kernel, channel counts that are not multiples of 64)
+// runs as its own 1x1 launch into `sc_out` and comes back as the residual -- what the caller would have done itself.
+template <typename T>
+static int sc_unfold(ConvArgs& a, hipStream_t stream) {
+    if (!a.sc.x) return L2I_OK;
+    if (!a.sc.out || a.res) return L2I_ERR_ARG;
+    ConvArgs s = a;
+    s.x = a.sc.x; s.w = a.sc.w; s.bias = a.sc.bias; s.res = nullptr; s.relu_mask = nullptr;
+    s.out = a.sc.out; s.out_op = nullptr; s.out_op_raw = nullptr; s.stat_ws = nullptr;
+    s.Hi = a.sc.Hi; s.Wi = a.sc.Wi; s.Ci = a.sc.Ci; s.KH = 1; s.up2 = a.sc.up2; s.Kpad = a.sc.Kpad; s.relu_op = 0;
+    s.sc.x = nullptr; s.sc.w = nullptr; s.sc.bias = nullptr; s.sc.out = nullptr;
+    s.SUBH = 1; s.P = 1;
+    const int rc = launch_conv<T>(s, stream);
+    a.res = a.sc.out;
+    a.sc.x = nullptr; a.sc.w = nullptr; a.sc.bias = nullptr;
+    return rc;
+}
+
+// LDS a folded shortcut needs behind a BM x BN tile: one stage of (BM + BN) 128-byte rows, two when the allocation has room
+static void sc_plan(ConvArgs& a, size_t& lds, int BM, int BN) {
+    if (!a.sc.x) return;
+    const size_t stg = (size_t)(BM + BN) * 128;
+    if (lds < stg) lds = stg;
+    a.sc.stages = lds >= 2 * stg ? 2 : 1;
+}
+
+template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false, int ABL = 0, bool CAN_SC = false>   // CAN_SC: the folding twin of this tile is compiled
 static int launch_halo2(ConvArgs a, hipStream_t stream) {
     a.PH = BM / a.PW;
     a.PHs = a.PH < a.Ho ? a.PH : a.Ho;
@@ -1318,6 +1481,11 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     const int cper = (nchunks + splits - 1) / splits;
     a.ks_per = 9 * cper;
     a.splits = (nchunks + cper - 1) / cper;
+    if (a.sc.x && (!CAN_SC || a.splits > 1 || a.sc.Ci % 64 || g_no_sc_fold)) {
+        const int rc = sc_unfold<bf16_t>(a, stream);
+        if (rc != L2I_OK) return rc;
+    }
+    sc_plan(a, lds, BM, BN);
     if (a.splits > 1) {
         const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
         if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
@@ -1325,14 +1493,22 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     static bool ready = false;
     if (!ready) {
         (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (CAN_SC)
+            (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ready = true;
+    }
+    if constexpr (CAN_SC) {
+        if (a.sc.x) {
+            L2I_LAUNCH(0, (conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL, true>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+            return l2i_check_launch();
+        }
     }
     L2I_LAUNCH(0, (conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
     return l2i_check_launch();
 }
 
 // conv_halo3_kernel launch (bf16, 3x3, Ci % 64 == 0, Wo >= 8). Returns -100 when the shape is not covered.
-template <int BN, int ABL = 0, bool PF = false>
+template <int BN, int ABL = 0, bool PF = false, bool CAN_SC = false>
 static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     if (a.Ci % 64 || a.Wo < 4 || (a.up2 && a.Wo < 8)) return -100;
     if (force_splits == 0) force_splits = g_force_splits;
@@ -1370,6 +1546,11 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     const int cper = (nchunks + splits - 1) / splits;
     a.ks_per = 9 * cper;
     a.splits = (nchunks + cper - 1) / cper;
+    if (a.sc.x && (!CAN_SC || a.splits > 1 || a.sc.Ci % 64 || g_no_sc_fold)) {
+        const int rc = sc_unfold<bf16_t>(a, stream);
+        if (rc != L2I_OK) return rc;
+    }
+    sc_plan(a, lds, 256, BN);
     if (a.splits > 1) {
         const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
         if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
@@ -1377,7 +1558,15 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     static bool ready = false;
     if (!ready) {
         (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<BN, ABL, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (CAN_SC)
+            (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<BN, ABL, PF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ready = true;
+    }
+    if constexpr (CAN_SC) {
+        if (a.sc.x) {
+            L2I_LAUNCH(0, (conv_halo3_kernel<BN, ABL, PF, true>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
+            return l2i_check_launch();
+        }
     }
     L2I_LAUNCH(0, (conv_halo3_kernel<BN, ABL, PF>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
     return l2i_check_launch();
@@ -1488,13 +1677,13 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
             case 1: rc = launch_halo2<128, 64, 2, 2, 3, false>(a, stream); break;
             case 2: rc = launch_halo2<256, 128, 4, 2, 2, false>(a, stream); break;
             case 3: rc = launch_halo2<128, 128, 2, 2, 3, false>(a, stream); break;   // one workgroup per CU
-            case 4: rc = launch_halo2<128, 128, 2, 2, 3, false, true>(a, stream); break;   // single halo buffer: 72 KB, two per CU, 2 tiles ahead
-            case 5: rc = launch_halo2<128, 64, 2, 2, 3, false, true>(a, stream); break;    // 48 KB: three per CU
+            case 4: rc = launch_halo2<128, 128, 2, 2, 3, false, true, 0, true>(a, stream); break;   // single halo buffer: 72 KB, two per CU, 2 tiles ahead
+            case 5: rc = launch_halo2<128, 64, 2, 2, 3, false, true, 0, true>(a, stream); break;    // 48 KB: three per CU
             case 6: rc = launch_halo2<128, 64, 2, 2, 2, false, true>(a, stream); break;    // 40 KB: four per CU
             case 7: rc = launch_halo3<128>(a, stream); break;    // 256 x 128 tiles, 4 waves of 64 x 128
             case 8: rc = launch_halo3<64>(a, stream); break;     // 256 x 64 tiles
-            case 9: rc = launch_halo3<128, 0, true>(a, stream); break;   // the same with the barrier moved inside the K-step (PF)
-            case 19: rc = launch_halo3<64, 0, true>(a, stream); break;
+            case 9: rc = launch_halo3<128, 0, true, true>(a, stream); break;   // the same with the barrier moved inside the K-step (PF)
+            case 19: rc = launch_halo3<64, 0, true, true>(a, stream); break;
 #ifdef L2I_ABLATIONS
             case 41: rc = launch_halo3<128, 1>(a, stream); break;
             case 42: rc = launch_halo3<128, 2>(a, stream); break;
@@ -1511,6 +1700,10 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
             default: rc = launch_halo2<128, 128, 2, 2, 2, false>(a, stream); break;
         }
         if (rc != -100) return rc;
+    }
+    if (a.sc.x) {   // the generic kernel does not fold shortcuts
+        const int rc = sc_unfold<T>(a, stream);
+        if (rc != L2I_OK) return rc;
     }
     const long long t128 = ((M + 127) / 128) * ((a.Co + 127) / 128);
     const long long t256x128 = ((M + 255) / 256) * ((a.Co + 127) / 128);
@@ -1568,11 +1761,30 @@ extern "C" int l2i_timing_read(int cls, double* total_ms, int* launches) {
     return L2I_OK;
 }
 
+extern "C" int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias, const float* res,
+                                 const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                                 int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
+                                 const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
+                                 int sc_up2, int sc_Kpad, void* stream);
+
 extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float* res,
                               const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                               int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
                               void* stream) {
+    return l2i_conv2d_fwd_sc(x, w, bias, res, relu_mask, out, out_op, out_op_raw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu_op,
+                             Kpad, alpha, nimg, stats, ws, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, stream);
+}
+
+extern "C" int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias, const float* res,
+                                 const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                                 int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
+                                 const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
+                                 int sc_up2, int sc_Kpad, void* stream) {
     if (!x || !w || (!out && !out_op && !out_op_raw)) return L2I_ERR_ARG;
+    if (sc_x) {   // folded shortcut: 1x1 on the (optionally nearest-upsampled) pre-pool grid of this launch; its result stands in for `res`
+        if (!sc_w || !sc_out || res || relu_mask || sc_Ci <= 0 || sc_Ci % 8 || sc_Kpad < sc_Ci) return L2I_ERR_ARG;
+        if (sc_Hi << (sc_up2 ? 1 : 0) != Ho || sc_Wi << (sc_up2 ? 1 : 0) != Wo) return L2I_ERR_ARG;
+    }
     if (stats && (!ws || !out || Co % 4 || 2LL * Co * L2I_WS_R > L2I_WS_FLOATS)) return L2I_ERR_ARG;
     ConvArgs a;
     a.SUBH = 1; a.P = 1;   // (halo geometry: set by the halo launchers)
@@ -1597,6 +1809,14 @@ extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, c
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.relu_op = relu_op ? 1 : 0;
     a.Kpad = Kpad; a.alpha = alpha;
     a.stat_ws = stats ? ws : nullptr;
+    static const int sc_fold_env = getenv("L2I_SC_FOLD") ? atoi(getenv("L2I_SC_FOLD")) : 1;
+    g_no_sc_fold = !sc_fold_env;
+    const size_t esz = dtype == 0 ? 4 : 2;
+    a.sc.x = sc_x; a.sc.w = sc_x ? sc_w : nullptr; a.sc.bias = sc_x ? sc_bias : nullptr; a.sc.out = sc_out;
+    a.sc.Hi = sc_Hi; a.sc.Wi = sc_Wi; a.sc.Ci = sc_Ci; a.sc.up2 = sc_up2 ? 1 : 0; a.sc.Kpad = sc_Kpad; a.sc.stages = 1;
+    a.sc.x_bytes = sc_x ? (unsigned)((size_t)B * sc_Hi * sc_Wi * sc_Ci * esz) : 0;
+    a.sc.w_bytes = sc_x ? (unsigned)((size_t)((Co + 127) / 128 * 128) * sc_Kpad * esz) : 0;
+    if (sc_x && ((size_t)B * sc_Hi * sc_Wi * sc_Ci * esz >= (1ull << 31))) return L2I_ERR_ARG;
     if (stats) a.epi_lds = 1;   // (the statistics are gathered by the LDS form of the epilogue; no split-K on such a launch)
     int rc;
     if (dtype == 0) rc = launch_conv<float>(a, (hipStream_t)stream);

@@ -61,7 +61,7 @@ class ResBlock(nn.Module):
             ops.precast(x, pc.arena.op_dtype)   # conv1 reads relu(x), the shortcut reads x: one cast launch for both (if not emitted upstream)
         j = ops.GradJoin()   # dx of the shortcut branch enters conv1's data-gradient epilogue instead of a separate add
         h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, relu_op_out=True, join=(j, "take"))
-        sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg, join=(j, "give")) if self.learnable_sc else x
+        sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg, join=(j, "give"), lazy_sc=True) if self.learnable_sc else x
         return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample, nimg=nimg, emit=emit,
                           dx_raw=True, join=None if self.learnable_sc else (j, "give_res"))
 

@@ -255,7 +255,7 @@ class ResBlock(nn.Module):
                        wproj=gw1, bproj=gb1, up2=up, join=(j, "take"),
                        emit=("stats",) if self.training else ())   # b2's batch statistics come out of this epilogue
         H2, W2 = h.shape[1], h.shape[2]
-        sc = fused_conv(x, self.c_sc, pc, up2=up, join=(j, "give")) if self.learnable_sc else x
+        sc = fused_conv(x, self.c_sc, pc, up2=up, join=(j, "give"), lazy_sc=True) if self.learnable_sc else x
         gw2, gb2 = self.b2.project(w, pc, B, O)
         out = fused_conv(h, self.conv2, pc, prologue=self.b2.spec(self.training, sync),
                          mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc, emit=tuple(emit) + (("stats",) if self.training else ()),

@@ -149,9 +149,11 @@ LIVE_IMAGE_FRACTION = 1.0   # bench.py: real ROIs / ROI slots of its batch, so t
 
 
 def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, up2=False, pool2=False, alpha=1.0,
-             want_f32=True, want_op=False, relu_op=False, want_raw=False, flops=None, nimg=None, stats=False):
+             want_f32=True, want_op=False, relu_op=False, want_raw=False, flops=None, nimg=None, stats=False, sc=None):
     """out = alpha*pool?(conv(up?(x))) + bias, masked, + res.  x_op (B,Hi,Wi,Ci) operand dtype.
     nimg: 1-element int32 device tensor = number of leading images that are live (the rest come out as zeros).
+    sc: a residual block's 1x1 shortcut to fold into this launch (l2i_conv2d_fwd_sc) -- dict(x_op, wpack, kpad, bias, up2,
+    out, flops): the launch adds conv1x1(sc.x_op) + sc.bias on its pre-pool grid instead of reading a residual.
     stats: the epilogue also gathers the per-channel sum / sum of squares of `out` (the batch statistics of a following
     normalisation); they ride on `out` (`_l2i_stats`) for ops._norm_stats."""
     _chk(x_op)
@@ -174,11 +176,25 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
         nbytes = (x_op.numel() + wpack.numel()) * esz + B * Hq * Wq * co * (
             4 * (want_f32 + (res is not None)) + esz * (want_op + want_raw + (relu_mask is not None)))
         live = LIVE_IMAGE_FRACTION if nimg is not None else 1.0
-        end = TIMER.time("conv_igemm", live * (flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci), live * nbytes)
+        fl = flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci
+        if sc is not None:   # the folded shortcut's work and operands belong to this launch
+            fl += sc["flops"]
+            nbytes += (sc["x_op"].numel() + sc["wpack"].numel()) * esz
+        end = TIMER.time("conv_igemm", live * fl, live * nbytes)
     st = _zeros((2, 1, co), dev) if (stats and out is not None and co <= 1024) else None
-    _lib.call("l2i_conv2d_fwd", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
-              _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
-              float(alpha), _p(nimg), _p(st), _ws(dev) if st is not None else None, _stream())
+    if sc is None:
+        _lib.call("l2i_conv2d_fwd", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
+                  _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
+                  float(alpha), _p(nimg), _p(st), _ws(dev) if st is not None else None, _stream())
+    else:
+        sx = sc["x_op"]
+        _chk(sx, x_op.dtype)
+        assert res is None and relu_mask is None and sc["out"].shape == (B, Hq, Wq, co) and sx.shape[0] == B
+        _lib.call("l2i_conv2d_fwd_sc", x_op.data_ptr(), wpack.data_ptr(), _p(bias), None, None, _p(out), _p(out_op),
+                  _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
+                  float(alpha), _p(nimg), _p(st), _ws(dev) if st is not None else None,
+                  sx.data_ptr(), sc["wpack"].data_ptr(), _p(sc["bias"]), sc["out"].data_ptr(), sx.shape[1], sx.shape[2], sx.shape[3],
+                  int(sc["up2"]), sc["kpad"], _stream())
     if st is not None:
         out._l2i_stats = (st[0], st[1], out._version)
     if end is not None:
@@ -417,7 +433,7 @@ class FusedConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None,
-                emit=(), dx_raw=False, join=None, op_out=False):
+                emit=(), dx_raw=False, join=None, op_out=False, lazy_sc=False):
         opd = pc.arena.op_dtype
         _chk(x, opd if pro.kind in ("op", "opraw") else torch.float32)
         B, H, W, C = x.shape
@@ -453,16 +469,33 @@ class FusedConvFn(Function):
         # result tensor (`_sibling`) and replace separate cast launches over the f32 stream.
         if emit and ((B * Ho * Wo + 127) // 128) * ((holder.co_p + 127) // 128) < 192:
             emit = ()   # small grids run split-K (partial sums combined by atomics): no epilogue copies there
+        # `lazy_sc`: this is a residual block's 1x1 shortcut and its ONLY reader is the `res` input of the block's second 3x3
+        # fused_conv: nothing is launched here; the operands ride on an unwritten placeholder of the result's shape and the
+        # consumer folds the shortcut into its own launch (conv_raw sc=, csrc conv_sc_tail). Backward is unchanged: the
+        # consumer hands dY through as the residual's gradient and this node computes the 1x1's gradients from it.
+        sc = getattr(res, "_l2i_lazy_sc", None) if res is not None else None
+        if sc is not None and (sc["ver"] != res._version or sc["pool2"] != bool(pool2) or sc["nimg"] is not nimg):
+            raise RuntimeError("a lazy shortcut can only be the residual of the conv it was made for")
+        if sc is not None:
+            sc = dict(sc, out=res)   # (the placeholder itself: where the library puts the shortcut when it cannot fold it)
+        if lazy_sc:
+            assert holder.kh == 1 and res is None and not emit and not op_out and pro.kind not in ("norm",)
+            Hq, Wq = (Ho // 2, Wo // 2) if pool2 else (Ho, Wo)
+            out = torch.empty((B, Hq, Wq, holder.co_p), dtype=torch.float32, device=x.device)
+            out._l2i_lazy_sc = dict(x_op=x_op, wpack=pc.fwd_pack(holder), kpad=holder.kpad, bias=bias_p, up2=bool(up2),
+                                    pool2=bool(pool2), nimg=nimg, flops=flops, ver=out._version)
+        else:
         # `op_out`: the ONLY reader of the result is a pre-activation conv -- the epilogue writes relu(result) in the operand
         # dtype and nothing else; that tensor is the autograd edge (its gradient arrives, and is used, in the operand dtype)
-        out, o_relu, o_raw = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p, res=res,
-                                      up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops, nimg=nimg,
-                                      want_f32=not op_out, want_op=op_out or "relu" in emit, relu_op=True,
-                                      want_raw="raw" in emit, stats="stats" in emit and not op_out)
-        if op_out:
-            out = o_relu
-        elif emit and (o_raw is not None or o_relu is not None):
-            _attach(out, raw=o_raw, relu=o_relu)
+            out, o_relu, o_raw = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p,
+                                          res=None if sc is not None else res, sc=sc,
+                                          up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops, nimg=nimg,
+                                          want_f32=not op_out, want_op=op_out or "relu" in emit, relu_op=True,
+                                          want_raw="raw" in emit, stats="stats" in emit and not op_out)
+            if op_out:
+                out = o_relu
+            elif emit and (o_raw is not None or o_relu is not None):
+                _attach(out, raw=o_raw, relu=o_relu)
         ctx.op_out = op_out
         ctx.flops, ctx.nimg, ctx.dx_raw, ctx.join = flops, nimg, dx_raw, join
         sw, sb = getattr(wproj, "_l2i_sink", None), getattr(bproj, "_l2i_sink", None)
@@ -534,7 +567,7 @@ class FusedConvFn(Function):
         d_res = dy if ctx.has_res else None
         if d_res is not None and ctx.join is not None and ctx.join[1] == "give_res":
             d_res = ctx.join[0].give(d_res)
-        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None, None
+        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _attach(t, raw=None, relu=None):
@@ -564,7 +597,7 @@ def precast(x, op_dtype):
 
 
 def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False, nimg=None,
-               emit=(), dx_raw=False, join=None, relu_op_out=False):
+               emit=(), dx_raw=False, join=None, relu_op_out=False, lazy_sc=False):
     """emit: operand copies of the result to write in the epilogue ("relu", "raw") for the layers that read it next.
     dx_raw: x is read by this layer ONLY and was produced by another fused_conv -- the data-gradient launch then also
     writes the operand copy of dx that the producer's backward needs (no separate cast pass over dx).
@@ -587,7 +620,7 @@ def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None,
         if res is not None or pool2 or ((B * Ho * Wo + 127) // 128) * ((holder.co_p + 127) // 128) < 192 or not OP_EDGES:
             relu_op_out, emit = False, tuple(emit) + ("relu",)
     out = FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg, tuple(emit), dx_raw, join,
-                            relu_op_out)
+                            relu_op_out, bool(lazy_sc) and SC_FOLD)
     if relu_op_out:
         out._l2i_relu_op = True
     return out
@@ -599,6 +632,7 @@ class _Simple(Prologue):
 
 
 _CAST, RELU, _OP, _OPRAW = _Simple("cast"), _Simple("relu"), _Simple("op"), _Simple("opraw")
+SC_FOLD = __import__("os").environ.get("L2I_SC_LAZY", "1") != "0"   # blocks hand their 1x1 shortcut to conv2's launch (A/B switch; L2I_SC_FOLD=0 keeps the hand-over but un-folds in the library)
 OP_EDGES = __import__("os").environ.get("L2I_OP_EDGES", "1") != "0"   # operand-dtype autograd edges inside D blocks (A/B switch)
 
 

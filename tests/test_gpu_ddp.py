@@ -132,8 +132,10 @@ def test_two_rank_gradients_equal_single_process_at_128(dt_name):
     The bar calibrates itself: two SINGLE-process runs of the same iteration already differ (f32 atomics reorder sums, a
     pre-activation at ~0 lands on the other side of its ReLU gate, a value on a bf16 rounding boundary rounds the other way;
     measured here at b = 16: generator gradient relative L2 ~4e-4 f32, ~1.5e-2 bf16), and the two-rank gradient must lie
-    within 2.5 x that run-to-run distance (+ 1e-5). A broken exchange -- unsynchronised batch statistics, local loss
-    counts, a missing all-reduce -- moves the gradient by O(0.1 - 1)."""
+    within 2.5 x that run-to-run distance (+ 1e-5). One pair of runs is a noisy estimate of that distance (a pair that happens
+    to flip no gate reads 4x lower than the typical pair and failed the test once in ~15 runs), so it is floored at half the
+    typical value. A broken exchange -- unsynchronised batch statistics, local loss counts, a missing all-reduce -- moves
+    the gradient by O(0.1 - 1)."""
     mgr = mp.Manager()
     single, again, multi = mgr.dict(), mgr.dict(), mgr.dict()
     mp.spawn(_run_grads, args=(1, _free_port(), single, dt_name), nprocs=1, join=True)
@@ -141,7 +143,7 @@ def test_two_rank_gradients_equal_single_process_at_128(dt_name):
     mp.spawn(_run_grads, args=(2, _free_port(), multi, dt_name), nprocs=2, join=True)
     for k in ("g", "d"):
         b = single[k]
-        floor = float((again[k] - b).norm() / b.norm())
+        floor = max(float((again[k] - b).norm() / b.norm()), 2e-4 if dt_name == "float32" else 7e-3)
         err = float((multi[k] - b).norm() / b.norm())
         assert err < 2.5 * floor + 1e-5, (k, err, floor)
         assert err < (5e-3 if dt_name == "float32" else 8e-2), (k, err)   # (and an absolute ceiling, far below a broken exchange)

@@ -182,6 +182,61 @@ def test_conv_halo_tiles(case, cfg, epi):
     assert float((out.cpu() - ref).abs().max()) < 3e-5 * float(ref.abs().max())
 
 
+# (B, H, W, Ci, Co, sc_Ci, sc_up2, pool2, live images or None): the block shapes of the two networks in miniature
+SC_CASES = [(2, 16, 16, 64, 72, 128, False, False, None), (1, 32, 32, 128, 136, 64, True, False, None),
+            (3, 16, 16, 192, 128, 64, False, True, None), (5, 8, 8, 128, 264, 192, False, True, 3),
+            (2, 32, 32, 64, 64, 128, True, False, None), (9, 8, 8, 64, 128, 64, True, False, None),
+            (1, 64, 64, 64, 64, 128, False, True, None), (2, 16, 16, 64, 64, 72, False, False, None)]
+
+
+@pytest.mark.parametrize("cfg", [-1, 14, 15, 19, 29])
+@pytest.mark.parametrize("case", SC_CASES)
+def test_conv_folded_shortcut(case, cfg, epi):
+    """l2i_conv2d_fwd_sc: conv3x3(h) + conv1x1(x at (y >> up, x >> up)) + both biases (+ 2x2 pool of the sum) in ONE launch
+    (reference model/resnet_generator_app_v2.py:664-678, model/rcnn_discriminator_app.py:317-344) equals the torch
+    composition, on every halo tile shape (folded: conv_sc_tail) and where the library un-folds (the heuristic's generic
+    / split-K choices for the small cases; sc_Ci = 72 is not a multiple of 64) -- with a live-image count as the ROI heads
+    pass it, and with the epilogue's operand copy and batch statistics riding on the same launch."""
+    from layout2img_amd import ops, _lib
+    B, H, W, Ci, Co, sCi, sup, pool2, live = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(17)
+    x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    w = _rt(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9), dt)
+    hs, ws_ = (H // 2, W // 2) if sup else (H, W)
+    xs = _rt(torch.randn(B, hs, ws_, sCi, generator=g), dt)
+    wsc = _rt(torch.randn(Co, sCi, 1, 1, generator=g) / math.sqrt(sCi), dt)
+    bias, bias_sc = torch.randn(Co, generator=g), torch.randn(Co, generator=g)
+    ref = _ref_conv(x, w, bias, False, pool2) + _ref_conv(xs, wsc, bias_sc, sup, pool2)
+    pack, kpad = _pack(w, 64)
+    pack_sc, kpad_sc = _pack(wsc, 64)
+    dev = _dev()
+    nimg = None
+    if live is not None:
+        nimg = torch.tensor([live], dtype=torch.int32, device=dev)
+        ref[live:] = 0
+    co_p = (Co + 7) // 8 * 8
+    pad = lambda b: torch.nn.functional.pad(b, (0, co_p - Co)).to(dev)
+    placeholder = torch.full(ref.shape[:3] + (co_p,), float("nan"), device=dev)
+    sc = dict(x_op=xs.to(dev, dt), wpack=pack_sc.to(dev, dt), kpad=kpad_sc, bias=pad(bias_sc), up2=sup, out=placeholder,
+              flops=0.0)
+    _lib.call("l2i_set_conv_config", cfg)
+    try:
+        out, op, _ = ops.conv_raw(x.to(dev, dt), pack.to(dev, dt), kpad, co_p, 3, bias=pad(bias), pool2=pool2,
+                                  alpha=0.25 if pool2 else 1.0, nimg=nimg, sc=sc, want_op=True, relu_op=True,
+                                  stats=live is None)
+    finally:
+        _lib.call("l2i_set_conv_config", -1)
+    tol = 3e-5 * float(ref.abs().max())
+    assert float((out.cpu()[..., :Co] - ref).abs().max()) < tol
+    assert float((op.float().cpu()[..., :Co] - torch.relu(ref)).abs().max()) < 1e-2 * float(ref.abs().max())
+    if cfg >= 10:   # a forced halo tile with sc_Ci % 64 == 0 must FOLD: the placeholder is never written
+        assert bool(torch.isnan(placeholder).all()) == (sCi % 64 == 0)
+    if live is None:
+        s1, s2, _ = out._l2i_stats
+        assert float((s1.cpu().view(-1)[:Co] - ref.sum(dim=(0, 1, 2))).abs().max()) < 1e-3 * float(ref.abs().sum(dim=(0, 1, 2)).max())
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_conv_relu_mask(dt, epi):
     from layout2img_amd import ops

@@ -35,6 +35,8 @@ def run(path, steps=3):
     def call(name, *a):
         if name == "l2i_conv2d_fwd":
             calls.append(("fwd",) + tuple(a[9:20]) + (a[22] is not None,))
+        elif name == "l2i_conv2d_fwd_sc":   # 3x3 conv with a block's 1x1 shortcut handed over (folded, or un-folded by the library)
+            calls.append(("fwd",) + tuple(a[9:20]) + (a[22] is not None, int(a[31])))
         elif name == "l2i_conv2d_wgrad":
             calls.append(("wgr",) + tuple(a[4:14]) + (0, a[16] is not None))
         orig(name, *a)
@@ -54,13 +56,41 @@ def join(path, trace, out=None):
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     conv = [r for r in rows if r["Kernel_Name"].startswith(("void conv_", "conv_"))]
-    conv = conv[-len(calls):]
-    assert len(conv) == len(calls), (len(conv), len(calls))
+    # a hand-over call is ONE kernel when the shortcut was folded, TWO (generic 1x1, then the 3x3) when the library un-folded it
+    def pair(i, k):
+        return len(calls[i]) == 14 and "conv_igemm" in conv[k]["Kernel_Name"] and k + 1 < len(conv) and "conv_halo" in conv[k + 1]["Kernel_Name"]
+    n_sc = sum(1 for c in calls if len(c) == 14)
+    for extra in range(n_sc + 1):   # find the alignment from the end: the trace has len(calls) + (number of un-folded) conv kernels
+        cand = conv[-(len(calls) + extra):]
+        k, ok = 0, True
+        for i in range(len(calls)):
+            k += 2 if (len(calls[i]) == 14 and "conv_igemm" in cand[k]["Kernel_Name"] and k + 1 < len(cand)
+                       and "conv_halo" in cand[k + 1]["Kernel_Name"]) else 1
+            if k > len(cand):
+                ok = False
+                break
+        if ok and k == len(cand):
+            conv = cand
+            break
+    else:
+        raise AssertionError((len(conv), len(calls)))
     agg = collections.OrderedDict()
-    for c, r in zip(calls, conv):
+    k = 0
+    for i, c in enumerate(calls):
+        r = conv[k]
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        k += 1
+        sc_ci = 0
+        if len(c) == 14:
+            sc_ci = c[13]
+            if "conv_igemm" in r["Kernel_Name"] and k < len(conv) and "conv_halo" in conv[k]["Kernel_Name"]:
+                r = conv[k]   # un-folded: the 1x1 launch, then the 3x3 -- both belong to this call
+                us += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                k += 1
+                sc_ci = -sc_ci
+            c = c[:13]
         kind, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu, limited = c
-        kern = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        kern = r["Kernel_Name"].split("(")[0].replace("void ", "") + (f" +sc{sc_ci}" if sc_ci else "")
         d = agg.setdefault((tuple(c), kern), [0, 0.0])
         d[0] += 1
         d[1] += us
@@ -70,6 +100,8 @@ def join(path, trace, out=None):
         kind, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu, limited = c
         ci = 3 if Ci == 8 and Hi >= 64 and kind == "fwd" and Co == 64 else Ci   # (the image is padded 3 -> 8 channels)
         fl = 2.0 * B * Ho * Wo * Co * ci * KH * KH * (live if limited else 1.0)
+        if "+sc" in kern:
+            fl += 2.0 * B * Ho * Wo * Co * abs(int(kern.split("+sc")[1])) * (live if limited else 1.0)
         tot[kind][0] += fl * n / steps
         tot[kind][1] += us / steps
         lines.append((us / steps, n // steps, fl * n / us / 1e6, c, kern))
