@@ -133,7 +133,7 @@ def test_two_rank_gradients_equal_single_process_at_128(dt_name):
     pre-activation at ~0 lands on the other side of its ReLU gate, a value on a bf16 rounding boundary rounds the other way;
     measured here at b = 16: generator gradient relative L2 ~4e-4 f32, ~1.5e-2 bf16), and the two-rank gradient must lie
     within 2.5 x that run-to-run distance (+ 1e-5). One pair of runs is a noisy estimate of that distance (a pair that happens
-    to flip no gate reads 4x lower than the typical pair and failed the test once in ~15 runs), so it is floored at half the
+    to flip no gate reads several times lower than the typical pair: the f32 case failed once that way), so it is floored at half the
     typical value. A broken exchange -- unsynchronised batch statistics, local loss counts, a missing all-reduce -- moves
     the gradient by O(0.1 - 1)."""
     mgr = mp.Manager()
