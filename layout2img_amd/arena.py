@@ -350,13 +350,14 @@ class WeightArena:
         from .ops import WgradSide
         WgradSide.join()   # weight-gradient launches run on side streams (ops.WgradSide)
         self.flat.flush_loose()
-        for p in self.pending:
-            if p.dwbar is None:
-                continue
-            _lib.call("l2i_weights_backward", self.layers.data_ptr(), self.n_layers, self.t_dot.data_ptr(), self.n_dot,
+        live = [p for p in self.pending if p.dwbar is not None]
+        for i in range(0, len(live), 2):   # two passes per launch pair (D(real) + D(fake)): W and the gradient buffer are walked once
+            p, q = live[i], (live[i + 1] if i + 1 < len(live) else None)
+            _lib.call("l2i_weights_backward2", self.layers.data_ptr(), self.n_layers, self.t_dot.data_ptr(), self.n_dot,
                       self.t_apply.data_ptr(), self.n_apply, self.flat.data.data_ptr(), p.dwbar.data_ptr(),
-                      p.pass_uv.data_ptr(), p.norms.data_ptr(), self.flat.grad.data_ptr(), _lib.workspace(self.device),
-                      _lib.raw_stream())
+                      p.pass_uv.data_ptr(), p.norms.data_ptr(), q.dwbar.data_ptr() if q else None,
+                      q.pass_uv.data_ptr() if q else None, q.norms.data_ptr() if q else None, self.flat.grad.data_ptr(),
+                      _lib.workspace(self.device), _lib.raw_stream())
         self.pending = []
 
     def drop_pending(self):

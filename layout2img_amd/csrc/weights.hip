@@ -362,10 +362,13 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restr
 // converts between the two orders so that every global access is a run. table: (layer, pairchunk)
 #define BW_PAIRS 256
 
-// phase a: <G, W> per SN layer, one atomic per block into replica (block % 32) of ws[r * n_layers + layer].
+// phase a: <G, W> per SN layer, one atomic per block into replica (block % 32) of ws[(r * NP + pass) * n_layers + layer].
+// NP = 2: the two passes of one optimiser step that share W (D(real) and D(fake), train_context_app_v2.py:158,167) in one
+// launch -- W is read once, each pass's G once.
+template <int NP>
 __global__ __launch_bounds__(256) void sn_dot_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
-                                                     const float* __restrict__ params, const float* __restrict__ dwbar,
-                                                     float* __restrict__ ws, int n_layers) {
+                                                     const float* __restrict__ params, const float* __restrict__ dwbar0,
+                                                     const float* __restrict__ dwbar1, float* __restrict__ ws, int n_layers) {
     __shared__ float red[16];
     __shared__ float wl[BW_PAIRS * 9];
     const int* e = table + 2 * blockIdx.x;
@@ -376,33 +379,46 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const long long* __restrict
     const long long p0 = (long long)e[1] * BW_PAIRS;
     const int np = (int)min((long long)BW_PAIRS, (long long)Co * Ci - p0);
     const float* W = params + LF(0) + p0 * taps;
-    const float* G = dwbar + LF(14);
     for (int j = threadIdx.x; j < np * taps; j += 256) wl[j] = W[j];
     __syncthreads();
-    float acc = 0.f;
+    float acc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) acc[q] = 0.f;
     if ((int)threadIdx.x < np) {
         const long long pr = p0 + threadIdx.x;
         const int co = (int)(pr / Ci), ci = (int)(pr - (long long)co * Ci);
-        const float* g = G + (size_t)co * Kp + ci;
-        if (taps == 9) {   // the nine strided loads issued together (a run-time trip count waits for each in turn)
-            float gv[9];
+        const size_t goff = (size_t)LF(14) + (size_t)co * Kp + ci;
+        if (taps == 9) {   // the strided loads issued together (a run-time trip count waits for each in turn)
+            float gv[NP][9];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) gv[tap] = g[tap * Ci_p];
+            for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) acc = fmaf(wl[threadIdx.x * 9 + tap], gv[tap], acc);
+                for (int tap = 0; tap < 9; ++tap) gv[q][tap] = (q == 0 ? dwbar0 : dwbar1)[goff + tap * Ci_p];
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) acc[q] = fmaf(wl[threadIdx.x * 9 + tap], gv[q][tap], acc[q]);
         } else {
-            for (int tap = 0; tap < taps; ++tap) acc = fmaf(wl[threadIdx.x * taps + tap], g[tap * Ci_p], acc);
+            for (int tap = 0; tap < taps; ++tap)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) acc[q] = fmaf(wl[threadIdx.x * taps + tap], (q == 0 ? dwbar0 : dwbar1)[goff + tap * Ci_p], acc[q]);
         }
     }
-    acc = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(ws + (size_t)(blockIdx.x % L2I_WS_R) * n_layers + layer, acc);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const float t = block_sum(acc[q], red);
+        if (threadIdx.x == 0) atomicAdd(ws + ((size_t)(blockIdx.x % L2I_WS_R) * NP + q) * n_layers + layer, t);
+        __syncthreads();   // `red` is reused by the next pass's sum
+    }
 }
 
-// phase b: grads[w] += (G - <G,Wbar> u v^T) / sigma   (non-SN layers: grads[w] += G)
+// phase b: grads[w] += sum over the passes of (G - <G,Wbar> u v^T) / sigma   (non-SN layers: grads[w] += sum of G)
+template <int NP>
 __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
-                                                       const float* __restrict__ dwbar, const float* __restrict__ pass_uv,
-                                                       float* __restrict__ norms, const float* __restrict__ ws, int n_layers,
-                                                       float* __restrict__ grads) {
+                                                       const float* __restrict__ dwbar0, const float* __restrict__ dwbar1,
+                                                       const float* __restrict__ uv0, const float* __restrict__ uv1,
+                                                       float* __restrict__ norms0, float* __restrict__ norms1,
+                                                       const float* __restrict__ ws, int n_layers, float* __restrict__ grads) {
     __shared__ float gl[BW_PAIRS * 9];
     const int* e = table + 2 * blockIdx.x;
     const int layer = e[0];
@@ -411,36 +427,49 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
     const int taps = KH * KH, Kp = taps * Ci_p;
     const long long p0 = (long long)e[1] * BW_PAIRS;
     const int np = (int)min((long long)BW_PAIRS, (long long)Co * Ci - p0);
-    const float* G = dwbar + LF(14);
     const bool sn = LF(1) >= 0;
-    const float inv = 1.f / norms[4 * layer + 2];
-    float gw = 0.f;
-    if (sn) {
-        float d = 0.f;
-        for (int r = 0; r < L2I_WS_R; ++r) d += ws[(size_t)r * n_layers + layer];
-        gw = d * inv;  // <G, Wbar>
-        if (e[1] == 0 && threadIdx.x == 0) norms[4 * layer + 3] = d;
+    float inv[NP], gw[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        float* norms = q == 0 ? norms0 : norms1;
+        inv[q] = 1.f / norms[4 * layer + 2];
+        gw[q] = 0.f;
+        if (sn) {
+            float d = 0.f;
+            for (int r = 0; r < L2I_WS_R; ++r) d += ws[((size_t)r * NP + q) * n_layers + layer];
+            gw[q] = d * inv[q];  // <G, Wbar>
+            if (e[1] == 0 && threadIdx.x == 0) norms[4 * layer + 3] = d;
+        }
     }
     if ((int)threadIdx.x < np) {
         const long long pr = p0 + threadIdx.x;
         const int co = (int)(pr / Ci), ci = (int)(pr - (long long)co * Ci);
-        const float* g = G + (size_t)co * Kp + ci;
-        const float uc = sn ? pass_uv[LF(16) + co] * gw : 0.f;
-        const float* v = pass_uv + LF(17) + (size_t)ci * taps;
-        if (taps == 9) {   // (loads issued together, see sn_dot_kernel)
-            float gv[9];
+        const size_t goff = (size_t)LF(14) + (size_t)co * Kp + ci;
+        float uc[NP];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) gv[tap] = g[tap * Ci_p];
+        for (int q = 0; q < NP; ++q) uc[q] = sn ? (q == 0 ? uv0 : uv1)[LF(16) + co] * gw[q] : 0.f;
+        const size_t voff = (size_t)LF(17) + (size_t)ci * taps;
+        if (taps == 9) {   // (loads issued together, see sn_dot_kernel)
+            float gv[NP][9];
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) gv[q][tap] = (q == 0 ? dwbar0 : dwbar1)[goff + tap * Ci_p];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                float x = gv[tap];
-                if (sn) x = (x - uc * v[tap]) * inv;
+                float x = 0.f;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) x += sn ? (gv[q][tap] - uc[q] * (q == 0 ? uv0 : uv1)[voff + tap]) * inv[q] : gv[q][tap];
                 gl[threadIdx.x * 9 + tap] = x;
             }
         } else {
             for (int tap = 0; tap < taps; ++tap) {
-                float x = g[tap * Ci_p];
-                if (sn) x = (x - uc * v[tap]) * inv;
+                float x = 0.f;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const float g = (q == 0 ? dwbar0 : dwbar1)[goff + tap * Ci_p];
+                    x += sn ? (g - uc[q] * (q == 0 ? uv0 : uv1)[voff + tap]) * inv[q] : g;
+                }
                 gl[threadIdx.x * taps + tap] = x;
             }
         }
@@ -501,17 +530,34 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
     return l2i_check_launch();
 }
 
+extern "C" int l2i_weights_backward2(const long long* layers, int n_layers, const int* tab_dot, int n_dot,
+                                     const int* tab_apply, int n_apply, const float* params, const float* dwbar0,
+                                     const float* pass_uv0, float* norms0, const float* dwbar1, const float* pass_uv1,
+                                     float* norms1, float* grads, float* ws, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!layers || !params || !dwbar0 || !norms0 || !grads || !ws) return L2I_ERR_ARG;
+    const int np = dwbar1 ? 2 : 1;
+    if (np == 2 && (!pass_uv1 || !norms1)) return L2I_ERR_ARG;
+    if ((long long)n_layers * L2I_WS_R * np > 32 * 4 * 1024) return L2I_ERR_ARG;   // L2I_WS_FLOATS
+    if (n_dot > 0) {
+        if (np == 2) hipLaunchKernelGGL(sn_dot_kernel<2>, dim3(n_dot), dim3(256), 0, stream, layers, tab_dot, params, dwbar0, dwbar1, ws, n_layers);
+        else hipLaunchKernelGGL(sn_dot_kernel<1>, dim3(n_dot), dim3(256), 0, stream, layers, tab_dot, params, dwbar0, dwbar0, ws, n_layers);
+    }
+    if (n_apply > 0) {
+        if (np == 2)
+            hipLaunchKernelGGL(sn_apply_kernel<2>, dim3(n_apply), dim3(256), 0, stream, layers, tab_apply, dwbar0, dwbar1, pass_uv0, pass_uv1,
+                               norms0, norms1, ws, n_layers, grads);
+        else
+            hipLaunchKernelGGL(sn_apply_kernel<1>, dim3(n_apply), dim3(256), 0, stream, layers, tab_apply, dwbar0, dwbar0, pass_uv0, pass_uv0,
+                               norms0, norms0, ws, n_layers, grads);
+    }
+    if (n_dot > 0 && hipMemsetAsync(ws, 0, sizeof(float) * L2I_WS_R * np * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+    return l2i_check_launch();
+}
+
 extern "C" int l2i_weights_backward(const long long* layers, int n_layers, const int* tab_dot, int n_dot,
                                     const int* tab_apply, int n_apply, const float* params, const float* dwbar,
                                     const float* pass_uv, float* norms, float* grads, float* ws, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!layers || !params || !dwbar || !norms || !grads || !ws) return L2I_ERR_ARG;
-    if ((long long)n_layers * L2I_WS_R > 32 * 4 * 1024) return L2I_ERR_ARG;   // L2I_WS_FLOATS
-    if (n_dot > 0)
-        hipLaunchKernelGGL(sn_dot_kernel, dim3(n_dot), dim3(256), 0, stream, layers, tab_dot, params, dwbar, ws, n_layers);
-    if (n_apply > 0)
-        hipLaunchKernelGGL(sn_apply_kernel, dim3(n_apply), dim3(256), 0, stream, layers, tab_apply, dwbar, pass_uv, norms, ws,
-                           n_layers, grads);
-    if (n_dot > 0 && hipMemsetAsync(ws, 0, sizeof(float) * L2I_WS_R * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
-    return l2i_check_launch();
+    return l2i_weights_backward2(layers, n_layers, tab_dot, n_dot, tab_apply, n_apply, params, dwbar, pass_uv, norms, nullptr, nullptr,
+                                 nullptr, grads, ws, stream_);
 }

@@ -344,6 +344,42 @@ def test_weight_arena_spectral_norm(training):
                 assert float((h.weight_v.cpu() - sd["c.weight_v"]).abs().max()) < 1e-5
 
 
+def test_spectral_norm_backward_two_passes_in_one_launch():
+    """l2i_weights_backward2: the sigma-corrections of two passes over the same weights (D(real) + D(fake),
+    train_context_app_v2.py:158,167 -- each with its own u, v, sigma) applied by one launch pair equal the two single-pass
+    launches (whose formula the model-level gradient tests pin against the reference), incl. a non-SN layer, a 1x1 layer,
+    a weight applied twice per forward, and an odd number of pending passes."""
+    from layout2img_amd import _lib
+    from layout2img_amd.arena import GemmWeight
+    torch.manual_seed(3)
+    hs = [GemmWeight("conv", 72, 40, 3, sn=True, eps=1e-4), GemmWeight("linear", 300, 308, sn=True, eps=1e-12),
+          GemmWeight("conv", 100, 40, 1, sn=False), GemmWeight("conv", 64, 64, 3, sn=True, uses=2)]
+    net, flat, arena = _mk(hs, torch.float32)
+    g = torch.Generator(device="cpu").manual_seed(5)
+
+    def passes(n):
+        out = []
+        for _ in range(n):
+            pc = arena.prepare(training=True)
+            pc.dw().copy_(torch.randn(pc.dw().shape, generator=g))
+            out.append(pc)
+        return out
+
+    for n in (2, 3):
+        pcs = passes(n)
+        flat.grad.zero_()
+        arena.flush_grads()
+        fused = flat.grad.clone()
+        flat.grad.zero_()
+        for pc in pcs:
+            _lib.call("l2i_weights_backward", arena.layers.data_ptr(), arena.n_layers, arena.t_dot.data_ptr(), arena.n_dot,
+                      arena.t_apply.data_ptr(), arena.n_apply, flat.data.data_ptr(), pc.dwbar.data_ptr(), pc.pass_uv.data_ptr(),
+                      pc.norms.data_ptr(), flat.grad.data_ptr(), _lib.workspace(arena.device), _lib.raw_stream())
+        torch.cuda.synchronize()
+        assert float(fused.abs().max()) > 0
+        assert float((fused - flat.grad).abs().max()) < 1e-5 * float(flat.grad.abs().max())
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("pro", ["cast", "relu", "isla", "affine", "instance", "isla_big"])
 def test_fused_conv_fwd_bwd(pro, dt):
