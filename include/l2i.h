@@ -343,6 +343,15 @@ int l2i_resize_bilinear_bwd(const float* g, float* dx, long long N, int h, int w
  * out = in * (u >= prob) / (1 - prob); its own backward with in = dy. C % 4 == 0. */
 int l2i_channel_dropout(const float* in, const float* u, float* out, long long B, int HW, int C, float prob, void* stream);
 
+/* Mask regressor, between two of its convolutions (reference model/mask_regression.py:64-95): InstanceNorm2d (no affine,
+ * biased variance) -> ReLU -> F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) of the per-object maps
+ * x [N][S][S][C] f32, S = 4 or 8 -> out [N][2S][2S][C] f32 and (optional) its operand copy out_op (op_dtype 0 f32 / 1 bf16).
+ * bwd: dx [N][S][S][C] (+ optional operand copy dx_op) from g = dL/dout [N][2S][2S][C] and x alone (statistics are
+ * recomputed in registers). */
+int l2i_in_relu_up2_fwd(const float* x, float* out, void* out_op, int op_dtype, long long N, int S, int C, float eps, void* stream);
+int l2i_in_relu_up2_bwd(const float* x, const float* g, float* dx, void* dx_op, int op_dtype, long long N, int S, int C, float eps,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

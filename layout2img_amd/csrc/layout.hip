@@ -884,3 +884,139 @@ extern "C" int l2i_channel_dropout(const float* in, const float* u, float* out, 
     hipLaunchKernelGGL(channel_dropout_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, u, out, total4, C, HW, prob);
     return l2i_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------ mask regression: IN + ReLU + bilinear x2
+// The step between two convolutions of the mask regressor (reference model/mask_regression.py:64-95): InstanceNorm2d (no affine,
+// biased variance, eps) -> ReLU -> F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) on the per-object maps
+// x [N][S][S][C] (N = b*o objects, S = 4 or 8). It ran as channel_stats + normalise + a batched GEMM with the resampling matrix +
+// the operand cast (and their four backward counterparts); here one thread owns one (object, channel) plane in registers:
+// statistics, normalisation, ReLU and the separable 2-tap interpolation, written once as the f32 stream and once as the
+// operand copy the next convolution reads. Backward: the adjoint of the interpolation row by row, the ReLU gate and the
+// instance-norm backward dx = istd (g - mean(g) - xhat mean(g xhat)), from x alone (nothing else is saved).
+__device__ __forceinline__ void up2_tap(int o, int S, int& i0, int& i1, float& l) {   // align_corners = False, scale 2
+    const float src = fmaxf(((float)o + 0.5f) * 0.5f - 0.5f, 0.f);
+    i0 = (int)src;
+    i1 = min(i0 + 1, S - 1);
+    l = src - (float)i0;
+}
+template <int S>
+__global__ __launch_bounds__(256) void in_relu_up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, void* out_op, int op_dtype,
+                                                             int C, float eps) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long long n = blockIdx.x;
+    const float* xp = x + n * S * S * C + c;
+    float v[S * S];
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) v[i] = xp[(long long)i * C];
+    float mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) mean += v[i];
+    mean *= 1.f / (S * S);
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) var = fmaf(v[i] - mean, v[i] - mean, var);
+    const float istd = rsqrtf(var * (1.f / (S * S)) + eps);
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) v[i] = fmaxf((v[i] - mean) * istd, 0.f);
+    float* op = out + n * 4 * S * S * C + c;
+#pragma unroll
+    for (int oy = 0; oy < 2 * S; ++oy) {
+        int y0, y1; float ly;
+        up2_tap(oy, S, y0, y1, ly);
+        float row[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) row[i] = (1.f - ly) * v[y0 * S + i] + ly * v[y1 * S + i];
+#pragma unroll
+        for (int ox = 0; ox < 2 * S; ++ox) {
+            int x0, x1; float lx;
+            up2_tap(ox, S, x0, x1, lx);
+            const float a = (1.f - lx) * row[x0] + lx * row[x1];
+            const long long o = (long long)(oy * 2 * S + ox) * C;
+            op[o] = a;
+            if (out_op) {
+                const long long oo = n * 4 * S * S * C + c + o;
+                if (op_dtype == 1) reinterpret_cast<bf16_t*>(out_op)[oo] = f2bf(a);
+                else reinterpret_cast<float*>(out_op)[oo] = a;
+            }
+        }
+    }
+}
+template <int S>
+__global__ __launch_bounds__(256) void in_relu_up2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dx,
+                                                             void* dx_op, int op_dtype, int C, float eps) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long long n = blockIdx.x;
+    const float* xp = x + n * S * S * C + c;
+    float v[S * S], d[S * S];
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) { v[i] = xp[(long long)i * C]; d[i] = 0.f; }
+    float mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) mean += v[i];
+    mean *= 1.f / (S * S);
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) var = fmaf(v[i] - mean, v[i] - mean, var);
+    const float istd = rsqrtf(var * (1.f / (S * S)) + eps);
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) v[i] = (v[i] - mean) * istd;   // xhat
+    const float* gp = g + n * 4 * S * S * C + c;
+#pragma unroll
+    for (int oy = 0; oy < 2 * S; ++oy) {   // adjoint of the interpolation: along x inside the row, then the row into its two source rows
+        int y0, y1; float ly;
+        up2_tap(oy, S, y0, y1, ly);
+        float t[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) t[i] = 0.f;
+#pragma unroll
+        for (int ox = 0; ox < 2 * S; ++ox) {
+            int x0, x1; float lx;
+            up2_tap(ox, S, x0, x1, lx);
+            const float gv = gp[(long long)(oy * 2 * S + ox) * C];
+            t[x0] = fmaf(1.f - lx, gv, t[x0]);
+            t[x1] = fmaf(lx, gv, t[x1]);
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            d[y0 * S + i] = fmaf(1.f - ly, t[i], d[y0 * S + i]);
+            d[y1 * S + i] = fmaf(ly, t[i], d[y1 * S + i]);
+        }
+    }
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) {
+        d[i] = v[i] > 0.f ? d[i] : 0.f;   // ReLU gate
+        m1 += d[i];
+        m2 = fmaf(d[i], v[i], m2);
+    }
+    m1 *= 1.f / (S * S);
+    m2 *= 1.f / (S * S);
+    float* dp = dx + n * S * S * C + c;
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) {
+        const float r = istd * (d[i] - m1 - v[i] * m2);
+        dp[(long long)i * C] = r;
+        if (dx_op) {   // the operand copy the producing convolution's backward reads as its dY
+            const long long oo = n * S * S * C + c + (long long)i * C;
+            if (op_dtype == 1) reinterpret_cast<bf16_t*>(dx_op)[oo] = f2bf(r);
+            else reinterpret_cast<float*>(dx_op)[oo] = r;
+        }
+    }
+}
+extern "C" int l2i_in_relu_up2_fwd(const float* x, float* out, void* out_op, int op_dtype, long long N, int S, int C, float eps, void* stream) {
+    if (!x || !out || N < 1 || C < 1 || (S != 4 && S != 8) || (op_dtype != 0 && op_dtype != 1)) return L2I_ERR_ARG;
+    const dim3 grid((unsigned)N, (unsigned)((C + 255) / 256));
+    if (S == 4) hipLaunchKernelGGL(in_relu_up2_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, out, out_op, op_dtype, C, eps);
+    else hipLaunchKernelGGL(in_relu_up2_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, out, out_op, op_dtype, C, eps);
+    return l2i_check_launch();
+}
+extern "C" int l2i_in_relu_up2_bwd(const float* x, const float* g, float* dx, void* dx_op, int op_dtype, long long N, int S, int C, float eps,
+                                   void* stream) {
+    if (!x || !g || !dx || N < 1 || C < 1 || (S != 4 && S != 8) || (op_dtype != 0 && op_dtype != 1)) return L2I_ERR_ARG;
+    const dim3 grid((unsigned)N, (unsigned)((C + 255) / 256));
+    if (S == 4) hipLaunchKernelGGL(in_relu_up2_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, g, dx, dx_op, op_dtype, C, eps);
+    else hipLaunchKernelGGL(in_relu_up2_bwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, g, dx, dx_op, op_dtype, C, eps);
+    return l2i_check_launch();
+}

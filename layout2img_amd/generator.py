@@ -374,6 +374,9 @@ class MaskRegressNetv2(nn.Module):
         x = ops.fc_to_nhwc(fused_conv(w, self.fc, pc), self.ch, pc.arena.op_dtype)            # (N, 4, 4, ch)
         h = fused_conv(x, self.conv1[0], pc)
         for blk_prev, blk, size in ((self.conv1, self.conv2, 8), (self.conv2, self.conv3, 16)):
+            if self.instance:   # InstanceNorm -> ReLU -> bilinear x2 + the operand copy: one launch (csrc/layout.hip)
+                h = fused_conv(ops.in_relu_up2(h, 1e-5, pc.arena.op_dtype), blk[0], pc)
+                continue
             spec, wa, ba = self._spec(blk_prev, sync)
             a = ops.norm_act(h, spec, wa, ba)
             if not self.instance:

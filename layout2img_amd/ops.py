@@ -1429,6 +1429,41 @@ def tanh_nchw(pre, C, op_dtype):
     return TanhNchwFn.apply(pre, C, op_dtype)
 
 
+class InReluUp2Fn(Function):
+    """InstanceNorm2d (no affine) -> ReLU -> bilinear x2 (align_corners=False) of per-object maps x (N, S, S, C), S in (4, 8):
+    the step between two convolutions of the mask regressor (reference model/mask_regression.py:64-95) as one launch each
+    way; the result carries its operand copy for the convolution that reads it next."""
+
+    @staticmethod
+    def forward(ctx, x, eps, op_dtype):
+        x = _chk(x, torch.float32)
+        N, S, S2, C = x.shape
+        assert S == S2 and S in (4, 8)
+        out = torch.empty((N, 2 * S, 2 * S, C), dtype=torch.float32, device=x.device)
+        op = torch.empty((N, 2 * S, 2 * S, C), dtype=op_dtype, device=x.device)
+        _lib.call("l2i_in_relu_up2_fwd", x.data_ptr(), out.data_ptr(), op.data_ptr(), _code(op_dtype), N, S, C, float(eps), _stream())
+        _attach(out, raw=op)
+        ctx.save_for_backward(x)
+        ctx.eps, ctx.op_dtype = float(eps), op_dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        N, S, _, C = x.shape
+        g = _chk(g.contiguous(), torch.float32)
+        dx = torch.empty_like(x)
+        dx_op = torch.empty(x.shape, dtype=ctx.op_dtype, device=x.device)
+        _lib.call("l2i_in_relu_up2_bwd", x.data_ptr(), g.data_ptr(), dx.data_ptr(), dx_op.data_ptr(), _code(ctx.op_dtype), N, S, C,
+                  ctx.eps, _stream())
+        _attach(dx, raw=dx_op)
+        return dx, None, None
+
+
+def in_relu_up2(x, eps, op_dtype):
+    return InReluUp2Fn.apply(x, eps, op_dtype)
+
+
 class PspStagesFn(Function):
     """The four pyramid stages of the PSP head between the pooling and the expansion kernels (reference
     model/resnet_generator_app_v2.py:741-746: Conv2d(C, F, 1, bias=False) -> BatchNorm2d -> ReLU on the s x s pooled maps):

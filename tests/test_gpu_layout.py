@@ -218,3 +218,26 @@ def test_image_nhwc_resize_adjoint_and_dropout():
     go = torch.randn(y.shape, generator=g).to(_dev())
     assert float((out - ref).abs().max()) < 1e-6
     assert float((torch.autograd.grad(out, y, go)[0] - torch.autograd.grad(ref, y, go)[0]).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("S,C,N", [(4, 256, 7), (8, 256, 5), (8, 128, 3), (4, 320, 2)])
+def test_in_relu_up2_matches_the_torch_chain(S, C, N, dt):
+    """InstanceNorm2d -> ReLU -> F.interpolate(x2, bilinear, align_corners=False) (reference model/mask_regression.py:64-95)
+    forward and backward in one launch each, incl. the operand copies both directions carry."""
+    from layout2img_amd import ops
+    g = torch.Generator().manual_seed(S * 1000 + C)
+    x = torch.randn(N, S, S, C, generator=g)
+    gout = torch.randn(N, 2 * S, 2 * S, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(torch.relu(F.instance_norm(xr.permute(0, 3, 1, 2), eps=1e-5)), scale_factor=2, mode="bilinear", align_corners=False)
+    ref = ref.permute(0, 2, 3, 1)
+    ref.backward(gout)
+    xd = x.to(_dev()).requires_grad_(True)
+    out = ops.in_relu_up2(xd, 1e-5, dt)
+    out.backward(gout.to(_dev()))
+    err = (out.detach().cpu() - ref.detach()).abs()
+    assert float(err.max()) < 2e-5
+    op = ops._sibling(out, "raw", dt)
+    assert op is not None and float((op.float().cpu() - ref.detach()).abs().max()) < (2e-5 if dt == torch.float32 else 2e-2)
+    assert float((xd.grad.cpu() - xr.grad).abs().max()) < 2e-4 * max(1.0, float(xr.grad.abs().max()))

@@ -25,7 +25,7 @@ R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 TAG = os.environ.get("TAG", "r03")
 def short(n):
     n = n.split("(")[0].replace("void ", "")
-    return n.split("<")[0] if n.startswith(("conv_", "channel_stats", "cast_kernel", "norm_mod", "sn_pack")) else n.replace(", ", ",")
+    return n.split("<")[0] if n.startswith(("conv_", "channel_stats", "cast_kernel", "norm_mod", "sn_")) else n.replace(", ", ",")
 stats = {}
 for r in csv.DictReader(open(glob.glob("/tmp/tr_stats/**/*kernel_stats.csv", recursive=True)[0])):
     d = stats.setdefault(short(r["Name"]), [0, 0.0])
@@ -49,7 +49,7 @@ res = {"conv(fwd+dgrad)": group(lambda k: k.startswith(("conv_halo", "conv_igemm
                 "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); WRITE_SIZE uncalibrated; durations from a third pass without counters"}
 json.dump(res, open(R + "/gpurun_out/" + TAG + "_conv_traffic.json", "w"), indent=1)
 hbm = {}
-for k in ("norm_mod_kernel", "norm_bwd_a_kernel", "norm_bwd_a8_kernel<16>", "norm_bwd_a8_kernel<32>", "norm_bwd_b_kernel", "channel_stats_kernel", "cast_kernel", "adam_kernel", "sn_pack_kernel", "sn_wtu_kernel",
+for k in ("norm_mod_kernel", "norm_mod8_kernel", "norm_bwd_a_kernel", "norm_bwd_a8_kernel<16>", "norm_bwd_a8_kernel<32>", "norm_bwd_b_kernel", "channel_stats_kernel", "cast_kernel", "adam_kernel", "sn_pack_kernel", "sn_wtu_kernel",
           "sn_wv_kernel", "sn_apply_kernel", "sn_dot_kernel", "roi_align_kernel<false>", "roi_align_bwd_sep_kernel", "wgrad_reduce_kernel", "ws_fold_kernel", "gram_head_fwd_kernel", "gram_head_bwd_kernel"):
     g = group(lambda n, k=k: n == k)
     if g["launches_profiled"] and g["avg_launch_us"] > 0:
