@@ -236,7 +236,7 @@ def main():
                         achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
                         traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=round(s["bytes"] / s["launches"]),
-                        launches_per_step=s["launches"], timed_steps=1, live_roi_fraction=round(ops.LIVE_IMAGE_FRACTION, 4),
+                        launches_per_step=s["launches"], kernels_per_step=s["kernels"], timed_steps=1, live_roi_fraction=round(ops.LIVE_IMAGE_FRACTION, 4),
                         avg_launch_us=round(1e3 * s["ms"] / s["launches"], 2),
                         gflop_per_launch=round(s["work"] / s["launches"] / 1e9, 3))
             w = ops.TIMER.summary().get("conv_wgrad")
