@@ -375,8 +375,10 @@ class PassCtx:
         # The pack kernel writes only the true (co < Co_p, ci < Ci_p) elements; padding rows and K tails must be
         # zero, so buffers are zero-filled once and recycled through the arena when their pass dies.
         self.packed = arena.free_packs.pop() if arena.free_packs else torch.zeros(arena.packed_len, dtype=arena.op_dtype, device=dev)
-        self.pass_uv = torch.empty(arena.uv_len, dtype=torch.float32, device=dev)
-        self.norms = torch.empty(4 * arena.n_layers, dtype=torch.float32, device=dev)
+        # (one allocation: the library clears norms and pass_uv with a single memset when they are adjacent)
+        nn4 = _round_up(4 * arena.n_layers, ALIGN)
+        buf = torch.empty(nn4 + arena.uv_len, dtype=torch.float32, device=dev)
+        self.norms, self.pass_uv = buf[:4 * arena.n_layers], buf[nn4:]
         self.dwbar = None
 
     def __del__(self):

@@ -497,8 +497,13 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
     if (!layers || !params || !packed || !norms) return L2I_ERR_ARG;
     if (dtype != 0 && dtype != 1) return L2I_ERR_ARG;
     if (clear) {  // first round of a pass
-        if (hipMemsetAsync(norms, 0, sizeof(float) * 4 * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
-        if (uv_len > 0 && hipMemsetAsync(pass_uv, 0, sizeof(float) * uv_len, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+        const long long gap = pass_uv - norms;   // adjacent buffers (layout2img_amd/arena.py PassCtx): one memset for both
+        if (uv_len > 0 && gap >= 4LL * n_layers && gap <= 4LL * n_layers + 64) {
+            if (hipMemsetAsync(norms, 0, sizeof(float) * (size_t)(gap + uv_len), stream) != hipSuccess) return L2I_ERR_LAUNCH;
+        } else {
+            if (hipMemsetAsync(norms, 0, sizeof(float) * 4 * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+            if (uv_len > 0 && hipMemsetAsync(pass_uv, 0, sizeof(float) * uv_len, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+        }
     }
     if (training && n_wtu > 0)
         hipLaunchKernelGGL(sn_wtu_kernel, dim3(n_wtu), dim3(256), 0, stream, layers, tab_wtu, params, sn_state, pass_uv);
