@@ -33,6 +33,14 @@ struct WgradArgs {
     int lgbk;                     // log2 of the kernel's pixel step (6; 7 for the eight-wave kernel)
     float* part;                  // optional scratch: every workgroup STORES its partial tile there ([tile][split][BMO][128] f32) and
                                   // wgrad_reduce_kernel adds the splits into dw -- instead of one f32 atomic per element and split
+    // Folded 1x1 shortcut (l2i_conv2d_wgrad_sc): a residual block's conv2 and its shortcut receive the SAME dY, so the
+    // shortcut's weight gradient dW_sc = dY^T x_sc is tiles_k - tiles_k_main more column tiles of this launch: they stage the
+    // same dY steps and read x_sc [B, Ho, Wo, sc_Ci] (centre tap, no upsampling) instead of im2col(x). null sc_x: none.
+    const void* sc_x;
+    float* sc_dw;                 // f32 [Co, sc_ldw]
+    float* dbias2;                // optional: the shortcut's bias gradient (= this layer's: the same sum over dY)
+    int sc_Ci, sc_ldw, tiles_k_main;
+    unsigned sc_x_bytes;
 };
 
 // The reduction range [m_begin, m_end) of one split. With a device-side image count the live pixels are divided over
@@ -287,8 +295,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
     int bid = blockIdx.x;
     const int split = bid % p.splits; bid /= p.splits;
     const int tile_k = bid % p.tiles_k, tile_co = bid / p.tiles_k;
-    const int co0 = tile_co * BMO, kc0 = tile_k * BNK;
+    // column tiles past tiles_k_main belong to the folded 1x1 shortcut: another source tensor, one (centre) tap, no upsampling
+    const bool is_sc = tile_k >= p.tiles_k_main;   // (workgroup-uniform)
+    const int co0 = tile_co * BMO, kc0 = (is_sc ? tile_k - p.tiles_k_main : tile_k) * BNK;
     const int pad = p.KH >> 1;
+    const int Ci_ = is_sc ? p.sc_Ci : p.Ci, K_ = is_sc ? p.sc_Ci : p.K, up2_ = is_sc ? 0 : p.up2;
+    const int Hi_ = is_sc ? p.Ho : p.Hi, Wi_ = is_sc ? p.Wo : p.Wi;
     const int Hd = p.Ho >> p.pool2, Wd = p.Wo >> p.pool2;
     int m_begin, m_end;
     wgrad_range(p, split, m_begin, m_end);
@@ -302,9 +314,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
     const int b_row = lane >> 4;
     const int b_lchunk = (lane & 15) ^ wg_swz<RSB>(b_row);
     const int kc = kc0 + b_lchunk * 8;
-    const int tap = kc / p.Ci, b_ci = kc - tap * p.Ci;
-    const int b_ky = tap / p.KH, b_kx = tap - b_ky * p.KH;
-    const bool b_on = kc < p.K;
+    const int tap = is_sc ? 0 : kc / p.Ci, b_ci = kc - tap * Ci_;
+    const int b_ky = is_sc ? pad : tap / p.KH, b_kx = is_sc ? pad : tap - b_ky * p.KH;
+    const bool b_on = kc < K_;
 
     // LDS-DMA through buffer descriptors (inline asm, see igemm.h): masked lanes use an out-of-range offset -> zeros.
     // The loop below is written to ISSUE few instructions (a wave issues one per ~4 cycles; the first version spent
@@ -315,13 +327,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
     //  * the im2col offset is linear in the pixel index, only the border test needs the pixel's (x, y);
     //  * two steps are unrolled so the LDS stage is an immediate; fragment addresses are loop constants; all 32
     //    transposing reads of a step are issued before its 16 MFMAs.
-    const u32x4_t rs_dy = make_rsrc(p.dy, p.dy_bytes), rs_x = make_rsrc(p.x, p.x_bytes);
+    const void* xsrc = is_sc ? p.sc_x : p.x;
+    const unsigned xsrc_bytes = is_sc ? p.sc_x_bytes : p.x_bytes;
+    const u32x4_t rs_dy = make_rsrc(p.dy, p.dy_bytes), rs_x = make_rsrc(xsrc, xsrc_bytes);
     // The range check of a buffer access looks at the LANE offset only (not at the SGPR offset), so fast-path lane
     // offsets must be non-negative and may not rely on the check for the step base: the im2col descriptor starts
     // (Wo + 1) pixels BEFORE x (lanes that would read there are masked by the border test), and steps that cross the
     // end of the tensor take the general path.
-    const unsigned x_shift = (unsigned)((p.Wo + 1) * p.Ci) * 2u;
-    const u32x4_t rs_xs = make_rsrc(reinterpret_cast<const char*>(p.x) - x_shift, p.x_bytes + x_shift);
+    const unsigned x_shift = (unsigned)((p.Wo + 1) * Ci_) * 2u;
+    const u32x4_t rs_xs = make_rsrc(reinterpret_cast<const char*>(xsrc) - x_shift, xsrc_bytes + x_shift);
     const unsigned smem_addr = lds_addr_of(smem);
     constexpr unsigned OOB = 0x80000000u;
     unsigned a_base[A_Q];      // fast path: byte offset of this lane's chunk for pixel (prow + a_row), without the step base
@@ -333,9 +347,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 #pragma unroll
     for (int q = 0; q < B_Q; ++q) {
         b_mlane[q] = wv * RPW + q * 4 + b_row;
-        b_base[q] = (unsigned)(((b_ky - pad) * p.Wo + (b_kx - pad) + b_mlane[q]) * p.Ci + b_ci) * 2u + x_shift;
+        b_base[q] = (unsigned)(((b_ky - pad) * p.Wo + (b_kx - pad) + b_mlane[q]) * Ci_ + b_ci) * 2u + x_shift;
     }
-    const unsigned co2 = (unsigned)p.Co * 2u, ci2 = (unsigned)p.Ci * 2u;
+    const unsigned co2 = (unsigned)p.Co * 2u, ci2 = (unsigned)Ci_ * 2u;
     // SEMI: lane constants -- position (xl, yl) of the lane's pixel within a step, folded into offsets
     unsigned a_semi[A_Q];
     int b_cy[B_Q], b_cx[B_Q];
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
         // SEMI: scalar image / row / column of the step
         const int sb = mstep >> (lgW + lgH), sy = (mstep >> lgW) & (p.Ho - 1), sx = mstep & (p.Wo - 1);
         const unsigned soff_a = (unsigned)(((sb * Hd + (sy >> p.pool2)) * Wd + (sx >> p.pool2)) * p.Co) * 2u;
-        const unsigned soff_b = (unsigned)(sb * p.Hi * p.Wi) * ci2;
+        const unsigned soff_b = (unsigned)(sb * Hi_ * Wi_) * ci2;
 #pragma unroll
         for (int q = 0; q < A_Q; ++q) {
             const unsigned dst = stage + (unsigned)(wv * RPW + q * A_ROWS) * RSA;
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
             if constexpr (SEMI) {
                 const int yy = sy + b_cy[q], xx = sx + b_cx[q];
                 const bool in = b_on && (unsigned)yy < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo;
-                const unsigned off = (unsigned)(((yy >> p.up2) * p.Wi + (xx >> p.up2)) * p.Ci + b_ci) * 2u;
+                const unsigned off = (unsigned)(((yy >> up2_) * Wi_ + (xx >> up2_)) * Ci_ + b_ci) * 2u;
                 L2I_DMA16_S(rs_x, in ? off : OOB, soff_b, dst);
                 continue;
             }
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
                 L2I_DMA16_S(rs_xs, in ? b_base[q] : OOB, (unsigned)mstep * ci2, dst);
             } else {
                 const int b = m >> (lgW + lgH);
-                const unsigned off = (unsigned)(((b * p.Hi + (yy >> p.up2)) * p.Wi + (xx >> p.up2)) * p.Ci + b_ci) * 2u;
+                const unsigned off = (unsigned)(((b * Hi_ + (yy >> up2_)) * Wi_ + (xx >> up2_)) * Ci_ + b_ci) * 2u;
                 L2I_DMA16_S(rs_x, (in && m < m_end) ? off : OOB, 0u, dst);
             }
         }
@@ -428,8 +442,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
     // 256 / A_CH partial sums per channel are combined at the end.
     // (Shared by only min(tiles_k, 4) of them, and combined across the four waves in LDS: every atomic on a bias
     // address costs ~0.09 us of serialised tail, and 500+ workgroups adding to the same 128 addresses tripled the launch.)
-    const int nb_bias = p.tiles_k >= 4 ? 4 : (p.tiles_k >= 2 ? 2 : 1);   // (a power of two)
-    const bool do_bias = p.dbias != nullptr && tile_k < nb_bias;
+    const int nb_bias = p.tiles_k_main >= 4 ? 4 : (p.tiles_k_main >= 2 ? 2 : 1);   // (a power of two)
+    const bool do_bias = (p.dbias != nullptr || p.dbias2 != nullptr) && tile_k < nb_bias;
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr int BS_PG = NT / A_CH, BS_PP = BK / BS_PG;   // pixel groups, pixels per thread per step
 #define WG_BIAS(STG, MS)                                                                                              \
@@ -537,7 +551,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
             float v = 0.f;
 #pragma unroll
             for (int w_ = 0; w_ < NW; ++w_) v += red[w_ * BMO + tid];
-            if (co0 + tid < p.Co && v != 0.f) atomicAdd(p.dbias + co0 + tid, p.alpha * v);
+            if (co0 + tid < p.Co && v != 0.f) {
+                if (p.dbias) atomicAdd(p.dbias + co0 + tid, p.alpha * v);
+                if (p.dbias2) atomicAdd(p.dbias2 + co0 + tid, p.alpha * v);
+            }
         }
     }
     if (NW == 8) {   // group 1 hands its tile to group 0: [wave of the group][register][lane] f32, 64 KB
@@ -598,11 +615,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = kc0 + wcol + j * 32 + c;
-            if (col >= p.K) continue;
+            if (col >= K_) continue;
+            float* dw_ = is_sc ? p.sc_dw : p.dw;
+            const int ldw_ = is_sc ? p.sc_ldw : p.ldw;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = co0 + wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < p.Co) atomicAdd(p.dw + (size_t)row * p.ldw + col, p.alpha * acc[i][j][e]);
+                if (row < p.Co) atomicAdd(dw_ + (size_t)row * ldw_ + col, p.alpha * acc[i][j][e]);
             }
         }
 }
@@ -614,7 +633,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 // slice is written by one launch at a time (same stream), so the read-modify-write needs no atomics.
 // nw2: the two-wave kernel's geometry (waves side by side, TM = BMO / 32), else four waves as 2 x 2 (TM = BMO / 64).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int BMO, int tiles_k,
-                                                           int ntiles, int splits, int Co, int K, int ldw, float alpha, int nw2, int sper) {
+                                                           int ntiles, int splits, int Co, int K, int ldw, float alpha, int nw2, int sper,
+                                                           int tiles_k_main, float* __restrict__ dw2, int K2, int ldw2) {
     // blockIdx.y = group of `sper` consecutive splits: layers with few tiles and many splits (the 64-channel layers at
     // 128 x 128: 5 tiles x 153 splits) otherwise run on 40 workgroups, each thread walking 153 partial tiles one dependent
     // load after the other (18 us of a 69-us weight gradient). Groups combine with f32 atomics (gridDim.y > 1 only).
@@ -622,7 +642,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int per_tile = BMO * 32;                      // float4 per tile
     const int tile = (int)(gid / per_tile), f = (int)(gid - (long long)tile * per_tile);
     if (tile >= ntiles) return;
-    const int tile_k = tile % tiles_k, tile_co = tile / tiles_k;
+    int tile_k = tile % tiles_k;
+    const int tile_co = tile / tiles_k;
+    if (tile_k >= tiles_k_main) {   // column tiles of the folded shortcut: their own gradient buffer
+        tile_k -= tiles_k_main;
+        dw = dw2; K = K2; ldw = ldw2;
+    }
     const int lane = f & 63, g = (f >> 6) & 3, j = (f >> 8) & 1;
     const int TM = nw2 ? BMO / 32 : BMO / 64;
     const int wi = f >> 9, i = wi % TM, wq = wi / TM;
@@ -685,9 +710,30 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
     a.M = a.B * a.Ho * a.Wo;
     const int BMO = (a.Co <= 64 || g_wgrad_force64) ? 64 : 128;
     a.tiles_co = (a.Co + BMO - 1) / BMO;
-    a.tiles_k = (a.K + 127) / 128;
-    const int tiles = a.tiles_co * a.tiles_k;
+    a.tiles_k = a.tiles_k_main = (a.K + 127) / 128;
     const bool pow2 = !(a.Ho & (a.Ho - 1)) && !(a.Wo & (a.Wo - 1));
+    if (a.sc_x) {
+        // The shortcut's columns ride on this launch when the LDS-DMA kernel with four waves runs in one of its scalar-step modes
+        // (bf16, whole 64-pixel steps, power-of-two maps); otherwise it is its own 1x1 launch, exactly as the caller would have issued it.
+        static const int sc_env = getenv("L2I_SC_WGRAD") ? atoi(getenv("L2I_SC_WGRAD")) : 1;
+        const bool whole64 = (a.B * a.Ho * a.Wo) % 64 == 0 && ((!a.pool2 && !a.up2) || (a.Ho * a.Wo) % 64 == 0);
+        const bool can = sc_env && sizeof(T) == 2 && pow2 && whole64 && a.KH == 3 && a.sc_Ci % EPG == 0 && g_wgrad_nw2 != 1 &&
+                         !(getenv("L2I_WGRAD_NW8") && atoi(getenv("L2I_WGRAD_NW8"))) && !(getenv("L2I_WGRAD_DEEP") && atoi(getenv("L2I_WGRAD_DEEP")));
+        if (!can) {
+            WgradArgs s = a;
+            s.x = a.sc_x; s.dw = a.sc_dw; s.Ci = a.sc_Ci; s.Hi = a.Ho; s.Wi = a.Wo; s.KH = 1; s.up2 = 0; s.ldw = a.sc_ldw;
+            s.dbias = a.dbias2; s.dbias2 = nullptr; s.sc_x = nullptr; s.sc_dw = nullptr;
+            const int rc = launch_wgrad<T>(s, stream, scratch, scratch_floats);
+            if (rc != L2I_OK) return rc;
+            a.sc_x = nullptr; a.sc_dw = nullptr; a.dbias2 = nullptr;
+        } else {
+            a.tiles_k += (a.sc_Ci + 127) / 128;
+            const size_t sb = (size_t)a.B * a.Ho * a.Wo * a.sc_Ci * sizeof(T);
+            if (sb >= 0x80000000ull) return L2I_ERR_ARG;
+            a.sc_x_bytes = (unsigned)sb;
+        }
+    }
+    const int tiles = a.tiles_co * a.tiles_k;
     // eight-wave / two-group kernel (128-pixel steps): bf16, 128-row tiles, whole steps, and -- with pool / upsample -- steps
     // that stay inside one image
     static const int nw8_env = getenv("L2I_WGRAD_NW8") ? atoi(getenv("L2I_WGRAD_NW8")) : 0;   // measured: 25.04 vs 24.86 ms per iteration with it ON (the reduce
@@ -782,7 +828,8 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             const int sper = (a.splits + sg - 1) / sg;
             sg = (a.splits + sper - 1) / sper;
             L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
-                       a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, (int)(nw2 && !nw8 && BMO == 128), sper);
+                       a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, (int)(nw2 && !nw8 && BMO == 128), sper,
+                       a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw);
         }
         return l2i_check_launch();
     }
@@ -794,10 +841,24 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
     return l2i_check_launch();
 }
 
+extern "C" int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
+                                   int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
+                                   const int* nimg, float* dbias, float* scratch, long long scratch_floats,
+                                   const void* sc_x, float* sc_dw, int sc_Ci, int sc_ldw, float* sc_dbias, void* stream);
+
 extern "C" int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
                                 int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
                                 const int* nimg, float* dbias, float* scratch, long long scratch_floats, void* stream) {
+    return l2i_conv2d_wgrad_sc(x, dy, dw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, ldw, alpha, nimg, dbias, scratch, scratch_floats,
+                               nullptr, nullptr, 0, 0, nullptr, stream);
+}
+
+extern "C" int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
+                                   int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
+                                   const int* nimg, float* dbias, float* scratch, long long scratch_floats,
+                                   const void* sc_x, float* sc_dw, int sc_Ci, int sc_ldw, float* sc_dbias, void* stream) {
     if (!x || !dy || !dw) return L2I_ERR_ARG;
+    if (sc_x && (!sc_dw || sc_Ci <= 0 || sc_ldw < sc_Ci)) return L2I_ERR_ARG;
     if (nimg && (Ho * Wo) % 64) return L2I_ERR_ARG;
     WgradArgs a;
 #ifdef L2I_ABLATIONS   // wrong-result switch: ablation builds only (L2I_EXTRA_FLAGS=-DL2I_ABLATIONS)
@@ -808,6 +869,8 @@ extern "C" int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dt
 #endif
     a.nimg = nimg;
     a.dbias = dbias;
+    a.sc_x = sc_x; a.sc_dw = sc_x ? sc_dw : nullptr; a.dbias2 = sc_x ? sc_dbias : nullptr; a.sc_Ci = sc_Ci; a.sc_ldw = sc_ldw;
+    a.sc_x_bytes = 0; a.tiles_k_main = 0;
     a.x = x; a.dy = dy; a.dw = dw;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.ldw = ldw; a.alpha = alpha;

@@ -243,8 +243,10 @@ def wgrad_side(x_op, dy_op, dw, *args, **kw):
     dy_op.record_stream(side)
 
 
-def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None, nimg=None, dbias=None):
-    """dbias: optional (co,) f32 tensor the bias gradient is atomically added to (summed from the staged dY tiles)."""
+def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None, nimg=None, dbias=None, sc=None):
+    """dbias: optional (co,) f32 tensor the bias gradient is atomically added to (summed from the staged dY tiles).
+    sc: a block's 1x1 shortcut that received the same dY -- dict(x_op (B, Ho, Wo, Ci_sc), dw, ldw, dbias, flops): its weight (and
+    bias) gradient become extra column tiles of this launch (l2i_conv2d_wgrad_sc)."""
     _chk(x_op)
     _chk(dy_op, x_op.dtype)
     B, Hi, Wi, Ci = x_op.shape
@@ -252,10 +254,19 @@ def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0
     end = None
     if TIMER is not None:
         live = LIVE_IMAGE_FRACTION if nimg is not None else 1.0
-        end = TIMER.time("conv_wgrad", live * (flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci))
+        fl = flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci
+        end = TIMER.time("conv_wgrad", live * (fl + (sc["flops"] if sc is not None else 0.0)))
     scratch, nscratch = _lib.wgrad_scratch(x_op.device)
-    _lib.call("l2i_conv2d_wgrad", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
-              Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch, _stream())
+    if sc is None:
+        _lib.call("l2i_conv2d_wgrad", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
+                  Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch, _stream())
+    else:
+        sx = sc["x_op"]
+        _chk(sx, x_op.dtype)
+        assert sx.shape[:3] == (B, Ho, Wo)
+        _lib.call("l2i_conv2d_wgrad_sc", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
+                  Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch,
+                  sx.data_ptr(), sc["dw"].data_ptr(), sx.shape[3], sc["ldw"], _p(sc["dbias"]), _stream())
     if end is not None:
         end.record()
 
@@ -478,6 +489,7 @@ class FusedConvFn(Function):
         sc = getattr(res, "_l2i_lazy_sc", None) if res is not None else None
         if sc is not None and (sc["ver"] != res._version or sc["pool2"] != bool(pool2) or sc["nimg"] is not nimg):
             raise RuntimeError("a lazy shortcut can only be the residual of the conv it was made for")
+        ctx.sc_lazy = sc         # the shortcut node's own record (its backward looks at `wgrad_done`)
         if sc is not None:
             sc = dict(sc, out=res)   # (the placeholder itself: where the library puts the shortcut when it cannot fold it)
         if lazy_sc:
@@ -485,7 +497,8 @@ class FusedConvFn(Function):
             Hq, Wq = (Ho // 2, Wo // 2) if pool2 else (Ho, Wo)
             out = torch.empty((B, Hq, Wq, holder.co_p), dtype=torch.float32, device=x.device)
             out._l2i_lazy_sc = dict(x_op=x_op, wpack=pc.fwd_pack(holder), kpad=holder.kpad, bias=bias_p, up2=bool(up2),
-                                    pool2=bool(pool2), nimg=nimg, flops=flops, ver=out._version)
+                                    pool2=bool(pool2), nimg=nimg, flops=flops, ver=out._version, holder=holder, wgrad_done=False)
+            ctx.lazy = out._l2i_lazy_sc   # (shared with the consumer: its backward may compute this node's weight gradient, see below)
         else:
         # `op_out`: the ONLY reader of the result is a pre-activation conv -- the epilogue writes relu(result) in the operand
         # dtype and nothing else; that tensor is the autograd edge (its gradient arrives, and is used, in the operand dtype)
@@ -538,9 +551,23 @@ class FusedConvFn(Function):
             dy_op, _ = cast_op(dy, opd, raw=True, act=False)
         if not ctx.op_out and _sibling(dy, "raw", opd) is None:
             _attach(dy, raw=dy_op)
-        if pc.need_wgrad:
+        lazy = getattr(ctx, "lazy", None)
+        if pc.need_wgrad and lazy is not None and lazy["wgrad_done"]:
+            pass   # a lazy shortcut whose consumer (conv2) already computed its weight and bias gradient with its own launch
+        elif pc.need_wgrad:
+            # conv2 of a block whose shortcut was handed over: the shortcut sees the same dY, so its weight gradient (no
+            # upsampling: the discriminator's blocks) becomes extra column tiles of this launch, its bias gradient the same sum
+            scw = None
+            sl = getattr(ctx, "sc_lazy", None)
+            if sl is not None and SC_WGRAD and not sl["up2"] and sl["holder"].kh == 1:
+                hs = sl["holder"]
+                bgs = hs.bias.grad if hs.bias is not None else None
+                direct_s = hs.bias is None or (bgs is not None and hs.co == hs.co_p and bgs.is_contiguous() and bgs.dtype == torch.float32)
+                if direct_s and hs.co_p == h.co_p:
+                    scw = dict(x_op=sl["x_op"], dw=pc.dw_slice(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"])
+                    sl["wgrad_done"] = True
             wgrad_side(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
-                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias)
+                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw)
         dx = d_mask = d_w = d_b = None
         if need_x or need_mod:
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
@@ -634,6 +661,7 @@ class _Simple(Prologue):
 
 
 _CAST, RELU, _OP, _OPRAW = _Simple("cast"), _Simple("relu"), _Simple("op"), _Simple("opraw")
+SC_WGRAD = __import__("os").environ.get("L2I_SC_WGRAD_PY", "1") != "0"   # conv2's weight-gradient launch also computes the handed-over shortcut's (A/B switch)
 SC_FOLD = __import__("os").environ.get("L2I_SC_LAZY", "1") != "0"   # blocks hand their 1x1 shortcut to conv2's launch (A/B switch; L2I_SC_FOLD=0 keeps the hand-over but un-folds in the library)
 OP_EDGES = __import__("os").environ.get("L2I_OP_EDGES", "1") != "0"   # operand-dtype autograd edges inside D blocks (A/B switch)
 
