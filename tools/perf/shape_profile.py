@@ -39,6 +39,8 @@ def run(path, steps=3):
             calls.append(("fwd",) + tuple(a[9:20]) + (a[22] is not None, int(a[31])))
         elif name == "l2i_conv2d_wgrad":
             calls.append(("wgr",) + tuple(a[4:14]) + (0, a[16] is not None))
+        elif name == "l2i_conv2d_wgrad_sc":   # conv2's weight gradient carrying the shortcut's (one launch; assumed folded)
+            calls.append(("wgr",) + tuple(a[4:14]) + (0, a[16] is not None, -int(a[22])))
         orig(name, *a)
     _lib.call = call
     ops._lib.call = call
@@ -59,12 +61,12 @@ def join(path, trace, out=None):
     # a hand-over call is ONE kernel when the shortcut was folded, TWO (generic 1x1, then the 3x3) when the library un-folded it
     def pair(i, k):
         return len(calls[i]) == 14 and "conv_igemm" in conv[k]["Kernel_Name"] and k + 1 < len(conv) and "conv_halo" in conv[k + 1]["Kernel_Name"]
-    n_sc = sum(1 for c in calls if len(c) == 14)
+    n_sc = sum(1 for c in calls if len(c) == 14 and c[0] == "fwd")
     for extra in range(n_sc + 1):   # find the alignment from the end: the trace has len(calls) + (number of un-folded) conv kernels
         cand = conv[-(len(calls) + extra):]
         k, ok = 0, True
         for i in range(len(calls)):
-            k += 2 if (len(calls[i]) == 14 and "conv_igemm" in cand[k]["Kernel_Name"] and k + 1 < len(cand)
+            k += 2 if (len(calls[i]) == 14 and calls[i][0] == "fwd" and "conv_igemm" in cand[k]["Kernel_Name"] and k + 1 < len(cand)
                        and "conv_halo" in cand[k + 1]["Kernel_Name"]) else 1
             if k > len(cand):
                 ok = False
@@ -82,8 +84,8 @@ def join(path, trace, out=None):
         k += 1
         sc_ci = 0
         if len(c) == 14:
-            sc_ci = c[13]
-            if "conv_igemm" in r["Kernel_Name"] and k < len(conv) and "conv_halo" in conv[k]["Kernel_Name"]:
+            sc_ci = abs(c[13])
+            if c[0] == "fwd" and "conv_igemm" in r["Kernel_Name"] and k < len(conv) and "conv_halo" in conv[k]["Kernel_Name"]:
                 r = conv[k]   # un-folded: the 1x1 launch, then the 3x3 -- both belong to this call
                 us += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
                 k += 1
