@@ -210,7 +210,7 @@ class WgradSide:
     stream (one per launching stream) the chain of data-gradient launches no longer waits for them, and the two kinds of
     kernels fill each other's tails and under-occupied grids. Joined in WeightArena.flush_grads (before the
     spectral-norm backward / Adam read the accumulators). L2I_WGRAD_STREAM=1 turns it on."""
-    enabled = __import__("os").environ.get("L2I_WGRAD_STREAM", "0") != "0"   # measured: 31.4 vs 30.0 ms per iteration with it ON (the two kernel
+    enabled = __import__("os").environ.get("L2I_WGRAD_STREAM", "0") == "1"   # measured: 31.4 vs 30.0 ms per iteration with it ON (the two kernel
     # kinds thrash each other's L2 more than they fill tails): kept as an option, off by default
     _streams, _dirty = {}, {}
 

@@ -52,6 +52,9 @@ class FlatAdam:
         self.finish_step()
 
 
+_WGRAD_SIDE_G = os.environ.get("L2I_WGRAD_STREAM", "0") == "2"
+
+
 class GanTrainer:
     def __init__(self, netG, netD, g_lr=1e-4, d_lr=1e-4, lamb_obj=1.0, lamb_app=1.0, lamb_img=0.1, z_dim=128, vgg=None):
         """vgg: an optional layout2img_amd.VGGLoss (finalized) -- the perceptual term of the G loss
@@ -174,7 +177,12 @@ class GanTrainer:
         if self.vgg is not None:
             feat = self.vgg(fake, real)
             g_loss = g_loss + (feat if self.world == 1 else feat / self.world)
+        if _WGRAD_SIDE_G:   # (tuning, L2I_WGRAD_STREAM=2: the generator's weight gradients on a side stream during the G step only)
+            ops.WgradSide.enabled = True
         g_loss.backward()
+        if _WGRAD_SIDE_G:
+            ops.WgradSide.enabled = False
+            ops.WgradSide.join()
         if self.defer_g:
             self.g_opt.begin_step()
             self._pending_g = True
