@@ -125,10 +125,13 @@ int l2i_weights_backward(const long long* layers, int n_layers, const int* tab_d
                          float* grads, float* ws, void* stream);
 /* The same for TWO passes that share the weights and are flushed together (the discriminator's real and fake forward of one
  * optimiser step, train_context_app_v2.py:158,167): grads += corr0(dwbar0) + corr1(dwbar1) with each pass's own u, v,
- * sigma -- W is read once, the gradient buffer is read and written once. dwbar1 == NULL: one pass (= l2i_weights_backward). */
+ * sigma -- W is read once, the gradient buffer is read and written once. dwbar1 == NULL: one pass (= l2i_weights_backward).
+ * overwrite != 0: the caller guarantees that the weights' slices of `grads` are ZERO (first flush after zero_grad): they are
+ * written, not read-modify-written (weights applied several times per forward still add atomically onto the zeros). */
 int l2i_weights_backward2(const long long* layers, int n_layers, const int* tab_dot, int n_dot, const int* tab_apply,
                           int n_apply, const float* params, const float* dwbar0, const float* pass_uv0, float* norms0,
-                          const float* dwbar1, const float* pass_uv1, float* norms1, float* grads, float* ws, void* stream);
+                          const float* dwbar1, const float* pass_uv1, float* norms1, float* grads, float* ws, int overwrite,
+                          void* stream);
 
 /* Per-channel sum / sum of squares over rows of x [rows][C] (grouped): sums/sqsums [G][C] +=.
  * Batch statistics of SynchronizedBatchNorm2d (model/sync_batchnorm/batchnorm.py:51-68), of

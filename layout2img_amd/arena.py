@@ -71,6 +71,7 @@ class FlatParams:
 
     def zero_grad(self):
         self.grad.zero_()
+        self.fresh = True   # nothing has been added to the weights' slices yet: the first flush may write instead of accumulate
         base = self.grad.data_ptr()
         for _, p in self._params:  # re-attach a view if someone set .grad to None
             o = self._by_id[id(p)]
@@ -357,7 +358,9 @@ class WeightArena:
                       self.t_apply.data_ptr(), self.n_apply, self.flat.data.data_ptr(), p.dwbar.data_ptr(),
                       p.pass_uv.data_ptr(), p.norms.data_ptr(), q.dwbar.data_ptr() if q else None,
                       q.pass_uv.data_ptr() if q else None, q.norms.data_ptr() if q else None, self.flat.grad.data_ptr(),
-                      _lib.workspace(self.device), _lib.raw_stream())
+                      _lib.workspace(self.device), 1 if (getattr(self.flat, "fresh", False) and i == 0) else 0, _lib.raw_stream())
+        if live:
+            self.flat.fresh = False
         self.pending = []
 
     def drop_pending(self):

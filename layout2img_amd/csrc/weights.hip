@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
                                                        const float* __restrict__ dwbar0, const float* __restrict__ dwbar1,
                                                        const float* __restrict__ uv0, const float* __restrict__ uv1,
                                                        float* __restrict__ norms0, float* __restrict__ norms1,
-                                                       const float* __restrict__ ws, int n_layers, float* __restrict__ grads) {
+                                                       const float* __restrict__ ws, int n_layers, float* __restrict__ grads, int overwrite) {
     __shared__ float gl[BW_PAIRS * 9];
     const int* e = table + 2 * blockIdx.x;
     const int layer = e[0];
@@ -478,6 +478,8 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
     float* dst = grads + LF(0) + p0 * taps;
     if (LF(18)) {   // rows of a multiply-applied weight update the same gradient concurrently
         for (int j = threadIdx.x; j < np * taps; j += 256) atomicAdd(dst + j, gl[j]);
+    } else if (overwrite) {   // the gradient buffer is known to be zero here (first flush after zero_grad): no read
+        for (int j = threadIdx.x; j < np * taps; j += 256) dst[j] = gl[j];
     } else if (np * taps == 9 * 256) {   // a full 3x3 block: the nine read-modify-writes of a thread in one batch
         float dv[9];
 #pragma unroll
@@ -538,7 +540,7 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
 extern "C" int l2i_weights_backward2(const long long* layers, int n_layers, const int* tab_dot, int n_dot,
                                      const int* tab_apply, int n_apply, const float* params, const float* dwbar0,
                                      const float* pass_uv0, float* norms0, const float* dwbar1, const float* pass_uv1,
-                                     float* norms1, float* grads, float* ws, void* stream_) {
+                                     float* norms1, float* grads, float* ws, int overwrite, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!layers || !params || !dwbar0 || !norms0 || !grads || !ws) return L2I_ERR_ARG;
     const int np = dwbar1 ? 2 : 1;
@@ -551,10 +553,10 @@ extern "C" int l2i_weights_backward2(const long long* layers, int n_layers, cons
     if (n_apply > 0) {
         if (np == 2)
             hipLaunchKernelGGL(sn_apply_kernel<2>, dim3(n_apply), dim3(256), 0, stream, layers, tab_apply, dwbar0, dwbar1, pass_uv0, pass_uv1,
-                               norms0, norms1, ws, n_layers, grads);
+                               norms0, norms1, ws, n_layers, grads, overwrite);
         else
             hipLaunchKernelGGL(sn_apply_kernel<1>, dim3(n_apply), dim3(256), 0, stream, layers, tab_apply, dwbar0, dwbar0, pass_uv0, pass_uv0,
-                               norms0, norms0, ws, n_layers, grads);
+                               norms0, norms0, ws, n_layers, grads, overwrite);
     }
     if (n_dot > 0 && hipMemsetAsync(ws, 0, sizeof(float) * L2I_WS_R * np * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     return l2i_check_launch();
@@ -564,5 +566,5 @@ extern "C" int l2i_weights_backward(const long long* layers, int n_layers, const
                                     const int* tab_apply, int n_apply, const float* params, const float* dwbar,
                                     const float* pass_uv, float* norms, float* grads, float* ws, void* stream_) {
     return l2i_weights_backward2(layers, n_layers, tab_dot, n_dot, tab_apply, n_apply, params, dwbar, pass_uv, norms, nullptr, nullptr,
-                                 nullptr, grads, ws, stream_);
+                                 nullptr, grads, ws, 0, stream_);
 }

@@ -404,8 +404,9 @@ def test_spectral_norm_backward_two_passes_in_one_launch():
 
     for n in (2, 3):
         pcs = passes(n)
-        flat.grad.zero_()
+        flat.zero_grad()   # (marks the buffer fresh: the first launch pair WRITES the weights' slices, later ones accumulate)
         arena.flush_grads()
+        assert not flat.fresh
         fused = flat.grad.clone()
         flat.grad.zero_()
         for pc in pcs:
