@@ -90,13 +90,13 @@ int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B,
                      float* scratch, long long scratch_floats, void* stream);
 /* The same launch with the weight gradient of the block's 1x1 shortcut folded in: conv2 and the shortcut of a residual block
  * receive the SAME dY (model/rcnn_discriminator_app.py:317-344), so dW_sc [Co, sc_ldw] += alpha * dYfull^T . sc_x
- * (sc_x [B, Ho, Wo, sc_Ci] T, no upsampling) becomes ceil(sc_Ci / 128) more column tiles of this launch that stage the same dY
+ * (sc_x [B, Ho >> sc_up2, Wo >> sc_up2, sc_Ci] T, read at (y >> sc_up2, x >> sc_up2)) becomes ceil(sc_Ci / 128) more column tiles of this launch that stage the same dY
  * steps; sc_dbias (optional) receives the same bias sum as dbias. Launches that cannot carry it (f32 operands, the
  * general-geometry kernel, L2I_SC_WGRAD=0) run the shortcut as a separate launch: same result. */
 int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                         int Co, int KH, int up2, int pool2, int ldw, float alpha, const int* nimg, float* dbias,
-                        float* scratch, long long scratch_floats, const void* sc_x, float* sc_dw, int sc_Ci, int sc_ldw,
-                        float* sc_dbias, void* stream);
+                        float* scratch, long long scratch_floats, const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2,
+                        int sc_ldw, float* sc_dbias, void* stream);
 /* Tuning hook: co-resident workgroups a weight-gradient launch is sized for (0 = derive from the tile: default). */
 int l2i_set_wgrad_blocks(int n);
 /* Debug aid: co-resident workgroups per CU for conv instantiation `which` with lds_bytes of dynamic LDS. */

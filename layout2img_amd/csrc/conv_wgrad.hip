@@ -35,11 +35,11 @@ struct WgradArgs {
                                   // wgrad_reduce_kernel adds the splits into dw -- instead of one f32 atomic per element and split
     // Folded 1x1 shortcut (l2i_conv2d_wgrad_sc): a residual block's conv2 and its shortcut receive the SAME dY, so the
     // shortcut's weight gradient dW_sc = dY^T x_sc is tiles_k - tiles_k_main more column tiles of this launch: they stage the
-    // same dY steps and read x_sc [B, Ho, Wo, sc_Ci] (centre tap, no upsampling) instead of im2col(x). null sc_x: none.
+    // same dY steps and read x_sc (centre tap; optionally nearest-upsampled, sc_up2) instead of im2col(x). null sc_x: none.
     const void* sc_x;
     float* sc_dw;                 // f32 [Co, sc_ldw]
     float* dbias2;                // optional: the shortcut's bias gradient (= this layer's: the same sum over dY)
-    int sc_Ci, sc_ldw, tiles_k_main;
+    int sc_Ci, sc_ldw, sc_up2, tiles_k_main;   // sc_up2: the shortcut reads x_sc [B, Ho/2, Wo/2, sc_Ci] at (y >> 1, x >> 1) (generator blocks)
     unsigned sc_x_bytes;
 };
 
@@ -299,8 +299,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
     const bool is_sc = tile_k >= p.tiles_k_main;   // (workgroup-uniform)
     const int co0 = tile_co * BMO, kc0 = (is_sc ? tile_k - p.tiles_k_main : tile_k) * BNK;
     const int pad = p.KH >> 1;
-    const int Ci_ = is_sc ? p.sc_Ci : p.Ci, K_ = is_sc ? p.sc_Ci : p.K, up2_ = is_sc ? 0 : p.up2;
-    const int Hi_ = is_sc ? p.Ho : p.Hi, Wi_ = is_sc ? p.Wo : p.Wi;
+    const int Ci_ = is_sc ? p.sc_Ci : p.Ci, K_ = is_sc ? p.sc_Ci : p.K, up2_ = is_sc ? p.sc_up2 : p.up2;
+    const int Hi_ = is_sc ? (p.Ho >> p.sc_up2) : p.Hi, Wi_ = is_sc ? (p.Wo >> p.sc_up2) : p.Wi;
+    const bool sc_gen = is_sc && p.sc_up2;   // an upsampled shortcut inside the constant-offset kernel: its tiles decode their pixels per lane
     const int Hd = p.Ho >> p.pool2, Wd = p.Wo >> p.pool2;
     int m_begin, m_end;
     wgrad_range(p, split, m_begin, m_end);
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
             const int x = m & (p.Wo - 1), y = (m >> lgW) & (p.Ho - 1);
             const int yy = y + b_ky - pad, xx = x + b_kx - pad;
             const bool in = b_on && (unsigned)yy < (unsigned)p.Ho && (unsigned)xx < (unsigned)p.Wo;
-            if constexpr (FAST) {
+            if (FAST && !sc_gen) {
                 L2I_DMA16_S(rs_xs, in ? b_base[q] : OOB, (unsigned)mstep * ci2, dst);
             } else {
                 const int b = m >> (lgW + lgH);
@@ -718,17 +719,18 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
         static const int sc_env = getenv("L2I_SC_WGRAD") ? atoi(getenv("L2I_SC_WGRAD")) : 1;
         const bool whole64 = (a.B * a.Ho * a.Wo) % 64 == 0 && ((!a.pool2 && !a.up2) || (a.Ho * a.Wo) % 64 == 0);
         const bool can = sc_env && sizeof(T) == 2 && pow2 && whole64 && a.KH == 3 && a.sc_Ci % EPG == 0 && g_wgrad_nw2 != 1 &&
+                         (!a.sc_up2 || (!(a.Ho & 1) && !(a.Wo & 1))) &&
                          !(getenv("L2I_WGRAD_NW8") && atoi(getenv("L2I_WGRAD_NW8"))) && !(getenv("L2I_WGRAD_DEEP") && atoi(getenv("L2I_WGRAD_DEEP")));
         if (!can) {
             WgradArgs s = a;
-            s.x = a.sc_x; s.dw = a.sc_dw; s.Ci = a.sc_Ci; s.Hi = a.Ho; s.Wi = a.Wo; s.KH = 1; s.up2 = 0; s.ldw = a.sc_ldw;
+            s.x = a.sc_x; s.dw = a.sc_dw; s.Ci = a.sc_Ci; s.Hi = a.Ho >> a.sc_up2; s.Wi = a.Wo >> a.sc_up2; s.KH = 1; s.up2 = a.sc_up2; s.ldw = a.sc_ldw;
             s.dbias = a.dbias2; s.dbias2 = nullptr; s.sc_x = nullptr; s.sc_dw = nullptr;
             const int rc = launch_wgrad<T>(s, stream, scratch, scratch_floats);
             if (rc != L2I_OK) return rc;
             a.sc_x = nullptr; a.sc_dw = nullptr; a.dbias2 = nullptr;
         } else {
             a.tiles_k += (a.sc_Ci + 127) / 128;
-            const size_t sb = (size_t)a.B * a.Ho * a.Wo * a.sc_Ci * sizeof(T);
+            const size_t sb = (size_t)a.B * (a.Ho >> a.sc_up2) * (a.Wo >> a.sc_up2) * a.sc_Ci * sizeof(T);
             if (sb >= 0x80000000ull) return L2I_ERR_ARG;
             a.sc_x_bytes = (unsigned)sb;
         }
@@ -844,19 +846,19 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
 extern "C" int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
                                    int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
                                    const int* nimg, float* dbias, float* scratch, long long scratch_floats,
-                                   const void* sc_x, float* sc_dw, int sc_Ci, int sc_ldw, float* sc_dbias, void* stream);
+                                   const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2, int sc_ldw, float* sc_dbias, void* stream);
 
 extern "C" int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
                                 int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
                                 const int* nimg, float* dbias, float* scratch, long long scratch_floats, void* stream) {
     return l2i_conv2d_wgrad_sc(x, dy, dw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, ldw, alpha, nimg, dbias, scratch, scratch_floats,
-                               nullptr, nullptr, 0, 0, nullptr, stream);
+                               nullptr, nullptr, 0, 0, 0, nullptr, stream);
 }
 
 extern "C" int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
                                    int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
                                    const int* nimg, float* dbias, float* scratch, long long scratch_floats,
-                                   const void* sc_x, float* sc_dw, int sc_Ci, int sc_ldw, float* sc_dbias, void* stream) {
+                                   const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2, int sc_ldw, float* sc_dbias, void* stream) {
     if (!x || !dy || !dw) return L2I_ERR_ARG;
     if (sc_x && (!sc_dw || sc_Ci <= 0 || sc_ldw < sc_Ci)) return L2I_ERR_ARG;
     if (nimg && (Ho * Wo) % 64) return L2I_ERR_ARG;
@@ -869,7 +871,7 @@ extern "C" int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int
 #endif
     a.nimg = nimg;
     a.dbias = dbias;
-    a.sc_x = sc_x; a.sc_dw = sc_x ? sc_dw : nullptr; a.dbias2 = sc_x ? sc_dbias : nullptr; a.sc_Ci = sc_Ci; a.sc_ldw = sc_ldw;
+    a.sc_x = sc_x; a.sc_dw = sc_x ? sc_dw : nullptr; a.dbias2 = sc_x ? sc_dbias : nullptr; a.sc_Ci = sc_Ci; a.sc_ldw = sc_ldw; a.sc_up2 = sc_up2 ? 1 : 0;
     a.sc_x_bytes = 0; a.tiles_k_main = 0;
     a.x = x; a.dy = dy; a.dw = dw;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;

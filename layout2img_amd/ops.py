@@ -263,10 +263,11 @@ def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0
     else:
         sx = sc["x_op"]
         _chk(sx, x_op.dtype)
-        assert sx.shape[:3] == (B, Ho, Wo)
+        su = int(bool(sc.get("up2", False)))
+        assert sx.shape[:3] == (B, Ho >> su, Wo >> su)
         _lib.call("l2i_conv2d_wgrad_sc", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
                   Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch,
-                  sx.data_ptr(), sc["dw"].data_ptr(), sx.shape[3], sc["ldw"], _p(sc["dbias"]), _stream())
+                  sx.data_ptr(), sc["dw"].data_ptr(), sx.shape[3], su, sc["ldw"], _p(sc["dbias"]), _stream())
     if end is not None:
         end.record()
 
@@ -555,16 +556,16 @@ class FusedConvFn(Function):
         if pc.need_wgrad and lazy is not None and lazy["wgrad_done"]:
             pass   # a lazy shortcut whose consumer (conv2) already computed its weight and bias gradient with its own launch
         elif pc.need_wgrad:
-            # conv2 of a block whose shortcut was handed over: the shortcut sees the same dY, so its weight gradient (no
-            # upsampling: the discriminator's blocks) becomes extra column tiles of this launch, its bias gradient the same sum
+            # conv2 of a block whose shortcut was handed over: the shortcut sees the same dY, so its weight gradient becomes
+            # extra column tiles of this launch, its bias gradient the same sum
             scw = None
             sl = getattr(ctx, "sc_lazy", None)
-            if sl is not None and SC_WGRAD and not sl["up2"] and sl["holder"].kh == 1:
+            if sl is not None and SC_WGRAD and sl["holder"].kh == 1:
                 hs = sl["holder"]
                 bgs = hs.bias.grad if hs.bias is not None else None
                 direct_s = hs.bias is None or (bgs is not None and hs.co == hs.co_p and bgs.is_contiguous() and bgs.dtype == torch.float32)
                 if direct_s and hs.co_p == h.co_p:
-                    scw = dict(x_op=sl["x_op"], dw=pc.dw_slice(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"])
+                    scw = dict(x_op=sl["x_op"], dw=pc.dw_slice(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"], up2=sl["up2"])
                     sl["wgrad_done"] = True
             wgrad_side(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
                        flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw)

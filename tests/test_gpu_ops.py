@@ -345,10 +345,11 @@ def test_weight_arena_spectral_norm(training):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("sup", [False, True], ids=["sc_same_res", "sc_upsampled"])
 @pytest.mark.parametrize("case", [(4, 16, 16, 64, 128, 128, False, None), (2, 32, 32, 128, 136, 64, True, None),
                                   (6, 8, 8, 192, 264, 256, True, 4), (3, 16, 16, 72, 64, 136, False, None),
                                   (1, 64, 64, 64, 64, 128, True, None), (5, 8, 8, 64, 128, 64, False, 2)])
-def test_conv_wgrad_folded_shortcut(case, dt):
+def test_conv_wgrad_folded_shortcut(case, dt, sup):
     """l2i_conv2d_wgrad_sc: the 3x3 weight gradient and the weight gradient of the block's 1x1 shortcut (same dY, its own
     input) from ONE launch, with both bias gradients, equal torch's -- on the scalar-step modes that fold (no pool; 2x2 pool),
     with a live-image count, and where the library runs the shortcut separately (f32 operands)."""
@@ -356,11 +357,11 @@ def test_conv_wgrad_folded_shortcut(case, dt):
     B, H, W, Ci, Co, sCi, pool2, live = case
     g = torch.Generator().manual_seed(hash(case) % 1000 + 7)
     x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
-    xs = _rt(torch.randn(B, H, W, sCi, generator=g), dt)
+    xs = _rt(torch.randn(B, H >> int(sup), W >> int(sup), sCi, generator=g), dt)   # (sup: the generator's shortcut reads the block input at half resolution)
     w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
     wsc = torch.zeros(Co, sCi, 1, 1, requires_grad=True)
     b1, b2 = torch.zeros(Co, requires_grad=True), torch.zeros(Co, requires_grad=True)
-    y = _ref_conv(x, w, b1, False, pool2) + _ref_conv(xs, wsc, b2, False, pool2)
+    y = _ref_conv(x, w, b1, False, pool2) + _ref_conv(xs, wsc, b2, sup, pool2)
     dy = _rt(torch.randn(y.shape, generator=g), dt)
     if live is not None:
         dy[live:] = 0   # (rows of dead images carry no gradient; the kernel does not read them at all)
@@ -371,7 +372,7 @@ def test_conv_wgrad_folded_shortcut(case, dt):
     dws = torch.full((Co, kps), -0.25, device=dev)
     db, dbs = torch.zeros(Co, device=dev), torch.ones(Co, device=dev)
     nimg = torch.tensor([live], dtype=torch.int32, device=dev) if live is not None else None
-    sc = dict(x_op=xs.to(dev, dt), dw=dws, ldw=kps, dbias=dbs, flops=0.0)
+    sc = dict(x_op=xs.to(dev, dt), dw=dws, ldw=kps, dbias=dbs, flops=0.0, up2=sup)
     ops.wgrad_raw(x.to(dev, dt), dy.to(dev, dt), dw, kp, Co, 3, pool2=pool2, alpha=0.25 if pool2 else 1.0, nimg=nimg, dbias=db, sc=sc)
     ref = w.grad.permute(0, 2, 3, 1).reshape(Co, kp)
     refs = wsc.grad.reshape(Co, sCi)
