@@ -6,13 +6,17 @@ train_context_app_v2.py:148-189 with the VGG term omitted -- its weights cannot 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 At N = 1 the iteration is captured once as a HIP graph and replayed (GanTrainer.capture); --no-graph runs eagerly.
+Every timed step is the same thing (a replay, or an eager iteration); the latents z are drawn per iteration as the
+reference does. The roofline leg's instrumented eager iteration runs behind the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline     -- the implicit-GEMM conv kernel (forward + data-gradient launches): algorithmic FLOPs
                   (2*M*N*K of the unpadded layer shapes) / launch time measured with HIP events on the
-                  launching stream inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+                  launching stream (one eager iteration directly behind the timed region), against the 2.5 PFLOP/s dense
+                  bf16 MFMA peak;
   cpu_baseline -- the oracle (pure-PyTorch restatement of the reference, oracle/model.py) timed on this
-                  host's cores on a bounded sample (batch 2) of the same workload.
+                  host's cores on a bounded sample (batch 4) of the same workload;
+  f32_mode     -- the same iteration with exact-f32 operands (the mode that meets the L-inf < 1e-3 image bar), secondary.
 """
 import argparse
 import json
@@ -35,7 +39,7 @@ def cpu_baseline(netG, netD, size, seconds_budget=20.0):
     sd_g = O.make_trainable({k: v.detach().float().cpu() for k, v in netG.state_dict().items()})
     sd_d = O.make_trainable({k: v.detach().float().cpu() for k, v in netD.state_dict().items()})
     tr = O.OracleTrainer(sd_g, sd_d)
-    b = 4
+    b = 4   # (the GPU line runs batch 32: the oracle's CPU iteration is timed on a bounded sample, batch 4)
     real, label, bbox, z, z_im = make_batch(b, size, "coco", seed=99, device="cpu")
     tr.step(real, label, bbox, z, z_im)  # warm-up
     t0, n = time.time(), 0
@@ -43,8 +47,11 @@ def cpu_baseline(netG, netD, size, seconds_budget=20.0):
         tr.step(real, label, bbox, z, z_im)
         n += 1
     dt = time.time() - t0
-    return dict(value=b * n / dt, unit="images/sec", cores=threads, kind="port",
+    return dict(value=b * n / dt, unit="images/sec", cores=threads, kind="port", batch=b,
                 sample=f"{n} training iterations at batch {b}, {size}x{size}, fp32, oracle/model.py OracleTrainer (VGG term omitted)")
+
+
+TRAFFIC_FILE = "r04_conv_traffic.json"   # PMC passes of this round (tools/perf/traffic2.sh); absent -> roofline.traffic is null
 
 
 RESULT_CHANGING_ENV = ("L2I_CONV_NOEPI", "L2I_WGRAD_NOEPI")   # ablation switches (results are wrong; -DL2I_ABLATIONS builds only)
@@ -114,6 +121,28 @@ def g_forward_figures(netG, args, z, bbox, z_im, label, op_dtype):
     return out
 
 
+def f32_mode_figures(args, dev, real, label, bbox, steps=4):
+    """images/s of the same iteration with exact-f32 MFMA operands (157.3 TFLOP/s peak), fresh networks, eager."""
+    import layout2img_amd as L
+    torch.manual_seed(4321)
+    g = L.ResnetGenerator128_context(num_classes=184).finalize(dev, torch.float32)
+    d = L.CombineDiscriminator128_app(num_classes=184).finalize(dev, torch.float32)
+    g.train(), d.train()
+    tr = L.GanTrainer(g, d)
+    for _ in range(2):
+        tr.step(real, label, bbox, None, None)
+    tr.flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(real, label, bbox, None, None)
+    tr.flush()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(images_per_sec=round(args.batch * steps / dt, 1), ms_per_step=round(1e3 * dt / steps, 2), steps=steps, launch="eager",
+                dtype="f32", image_linf_vs_reference="9.4e-6 (tests/test_gpu_models.py, bar 1e-3)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +159,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-g-forward", action="store_true", help="skip the secondary generator-forward measurement (profiling runs)")
+    ap.add_argument("--no-f32-mode", action="store_true", help="skip the secondary exact-f32 operand-mode measurement")
     ap.add_argument("--no-graph", action="store_true", help="run every iteration eagerly (default: replay a captured HIP graph at N=1)")
     args = ap.parse_args()
     refuse_wrong_result_switches()
@@ -185,28 +215,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The iteration is ~1700 launches and costs the host about as long as the GPU (37 vs 38 ms): at N = 1 the whole
-    # iteration (both forwards, both backwards, both Adam steps) is captured once as a HIP graph and replayed. The last
-    # timed iteration always runs eagerly so that HIP events can bracket the conv launches inside the timed region.
+    # The iteration is ~800 launches and costs the host nearly as long as the GPU: at N = 1 the whole iteration (both
+    # forwards, both backwards, both Adam steps, and the draw of the latents z, which the reference draws per iteration --
+    # train_context_app_v2.py:165) is captured once as a HIP graph and replayed. Every timed step is a replay; the roofline
+    # leg's HIP-event-instrumented eager iteration runs AFTER the clock is read (round 3 ran it as the last timed step and
+    # under-reported the steady state by ~8 % at --steps 20).
     graphed = False
     if (world == 1 or os.environ.get("L2I_DDP_GRAPH", "0") == "1") and not args.no_graph:   # (N > 1: opt-in, see GanTrainer.capture)
         try:
-            graphed = trainer.capture(real, label, bbox, z)
+            graphed = trainer.capture(real, label, bbox, None)
         except Exception as e:   # stay on the eager path
             print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-    step = (lambda: trainer.step_graphed(real, label, bbox, z)) if graphed else (lambda: trainer.step(real, label, bbox, z, None))
+    step = (lambda: trainer.step_graphed(real, label, bbox, None)) if graphed else (lambda: trainer.step(real, label, bbox, None, None))
     for _ in range(args.warmup):
         step()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == args.steps - 1 and rank == 0 and not args.no_kernel_timer:
-            ops.TIMER = ops.KernelTimer()  # HIP-event timing of the conv launches of the last timed step (eager)
-            ov, trainer.overlap = trainer.overlap, False   # one stream: a launch is timed while it owns the GPU
-            trainer.step(real, label, bbox, z, None)
-            trainer.overlap = ov
-        else:
-            step()
+        step()
     trainer.flush()   # (data parallel: the last iteration's deferred generator all-reduce + Adam belong to the timed region)
     sync()
     elapsed = time.perf_counter() - t0
@@ -214,6 +240,22 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
+    if not args.no_kernel_timer:
+        # roofline leg: ONE eager iteration on one stream with HIP events on every conv / weight-gradient dispatch, right behind
+        # the timed region (same process, same batch, same weights' shapes); a first eager iteration warms the allocator.
+        # (data parallel: every rank runs the two iterations -- they carry collectives -- rank 0 instruments its own)
+        ov, trainer.overlap = trainer.overlap, False   # one stream: a launch is timed while it owns the GPU
+        trainer.step(real, label, bbox, None, None)
+        trainer.flush()
+        torch.cuda.synchronize()
+        if rank == 0:
+            ops.TIMER = ops.KernelTimer()
+        trainer.step(real, label, bbox, None, None)
+        trainer.flush()
+        torch.cuda.synchronize()
+        trainer.overlap = ov
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         roof = None
@@ -225,14 +267,15 @@ def main():
             # rocprofv3 --pmc passes of this same command (tools/perf/traffic2.sh), committed under profiles/ with the commit
             # they were taken at; labelled as not measured in this run. null when no file of THIS round exists.
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r03_conv_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
             if op_dtype == torch.bfloat16 and args.size == 128 and args.layout == "coco" and not args.vgg and os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 traffic = round(tj["conv(fwd+dgrad)"]["traffic_bytes_per_launch"])
-                traffic_src = {"file": "profiles/r03_conv_traffic.json", "measured_in_run": False, "commit": tj.get("commit"),
+                traffic_src = {"file": "profiles/" + TRAFFIC_FILE, "measured_in_run": False, "commit": tj.get("commit"),
                                "method": "rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE; separate passes"}
             roof = dict(bound="mfma", kernel="l2i_conv2d_fwd launches (conv_halo2/3_kernel + conv_igemm_kernel), forward and data-gradient",
-                        timing="HIP events attached to each dispatch (hipExtLaunchKernelGGL) on the launching stream, inside the timed region",
+                        timing="HIP events attached to each dispatch (hipExtLaunchKernelGGL) on the launching stream, over one eager "
+                               "iteration run directly behind the timed region (same process and batch; the timed steps are graph replays)",
                         achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
                         traffic_unit="HBM bytes per launch", traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=round(s["bytes"] / s["launches"]),
@@ -243,6 +286,7 @@ def main():
             if w and w["launches"]:
                 roof["wgrad_tflops"] = round(w["work"] / (w["ms"] * 1e-3) / 1e12, 2)
                 roof["wgrad_frac"] = round(w["work"] / (w["ms"] * 1e-3) / 1e12 / peak, 4)
+                roof["wgrad_launches_per_step"] = w["launches"]
             ops.TIMER.close()
             ops.TIMER = None
         # the eager iteration (python + autograd enqueue every launch): what layout2img_amd.train falls back to when it cannot
@@ -250,11 +294,11 @@ def main():
         eager = None
         if world == 1 and graphed:
             for _ in range(2):
-                trainer.step(real, label, bbox, z, None)
+                trainer.step(real, label, bbox, None, None)
             trainer.flush(); sync()
             te, ne = time.perf_counter(), 5
             for _ in range(ne):
-                trainer.step(real, label, bbox, z, None)
+                trainer.step(real, label, bbox, None, None)
             trainer.flush(); sync()
             te = time.perf_counter() - te
             eager = dict(images_per_sec=round(args.batch * ne / te, 1), ms_per_step=round(1e3 * te / ne, 3), steps=ne)
@@ -264,6 +308,11 @@ def main():
         g_fwd = None
         if world == 1 and not args.no_g_forward:
             g_fwd = g_forward_figures(netG, args, z, bbox, z_im, label, op_dtype)
+        # the exact-f32 operand mode (the mode that meets the north star's L-inf < 1e-3 image bar: 9.4e-6 measured) on the same
+        # workload, timed eagerly on a few iterations: a secondary figure, never `value`
+        f32_mode = None
+        if world == 1 and args.dtype == "bf16" and not args.no_f32_mode and args.size == 128 and args.layout == "coco" and not args.vgg:
+            f32_mode = f32_mode_figures(args, dev, real, label, bbox)
         cpu = None
         if not args.no_cpu_baseline and world == 1 and args.size == 128 and args.layout == "coco":
             cpu = cpu_baseline(netG, netD, args.size)
@@ -282,14 +331,13 @@ def main():
                                    + ("VGG19 perceptual term included (random-init VGG)" if args.vgg else "VGG loss term omitted")
                                    + ", random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "launch": ("HIP graph replay, D(real) on a side stream (last timed step eager on one stream, with HIP events)"
-                                  if graphed else "eager")},
+                       "launch": ("HIP graph replay of the whole iteration incl. the draw of z (every timed step)" if graphed else "eager")},
             "roofline": roof, "env": l2i_env(),
-            "cpu_baseline": cpu, "g_forward": g_fwd, "eager": eager,
+            "cpu_baseline": cpu, "g_forward": g_fwd, "eager": eager, "f32_mode": f32_mode,
             "g_forward_images_per_sec": None if g_fwd is None else g_fwd["images_per_sec"],
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():   # (world > 1, or the forced one-rank group of L2I_FORCE_COLLECTIVES=1)
         dist.barrier()
         dist.destroy_process_group()
 

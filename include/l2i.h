@@ -64,6 +64,19 @@ int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias, const flo
                       float* ws, const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi,
                       int sc_Wi, int sc_Ci, int sc_up2, int sc_Kpad, void* stream);
 
+/* DUAL launch of the same convolution: the B images are TWO passes of B/2 images each that share every tensor argument but
+ * the weight pack -- the discriminator's D(real) and D(fake) of one optimiser step (train_context_app_v2.py:158,167) are two
+ * forward passes over the same layer shapes, but the reference's spectral_norm hook runs a power iteration per pass
+ * (model/rcnn_discriminator_app.py:10-15), so each pass has its own W / sigma. Images [0, B/2) are multiplied with w (sc_w),
+ * images [B/2, B) with w_b (sc_w_b): one launch with twice the tiles instead of two. `nimg` counts the live leading images of
+ * EACH half. w_b == NULL: exactly l2i_conv2d_fwd_sc. Needs B even, no `stats`, and (B/2) * Ho a multiple of the tile's pixel
+ * rows ((B/2) * Ho * min(Wo, 16) % 256 == 0 always suffices); L2I_ERR_ARG otherwise (the caller issues two launches). */
+int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bias, const float* res, const void* relu_mask,
+                        float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
+                        int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats,
+                        float* ws, const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi,
+                        int sc_Wi, int sc_Ci, int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, void* stream);
+
 /* Per-launch timing of the two MFMA entry points (bench.py's roofline leg). l2i_timing(1): from now on every kernel
  * launched by l2i_conv2d_fwd (class 0) / l2i_conv2d_wgrad (class 1) carries a start / stop HIP event pair attached to
  * its dispatch (hipExtLaunchKernelGGL: the kernel's own begin / end on the stream it runs on); l2i_timing_read
@@ -97,6 +110,14 @@ int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int dtype, int
                         int Co, int KH, int up2, int pool2, int ldw, float alpha, const int* nimg, float* dbias,
                         float* scratch, long long scratch_floats, const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2,
                         int sc_ldw, float* sc_dbias, void* stream);
+/* DUAL form (see l2i_conv2d_fwd_dual): the weight gradient of images [0, B/2) is added to dw (sc_dw), that of images [B/2, B)
+ * to dw_b (sc_dw_b) -- each pass keeps its own accumulator because the spectral-norm backward corrects each with its own
+ * u, v, sigma (l2i_weights_backward2). Both halves add their bias gradient to dbias / sc_dbias. `nimg` counts the live images of
+ * EACH half. dw_b == NULL: exactly l2i_conv2d_wgrad_sc. Needs B even and (B/2) * Ho * Wo % 64 == 0, else L2I_ERR_ARG. */
+int l2i_conv2d_wgrad_dual(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
+                          int Co, int KH, int up2, int pool2, int ldw, float alpha, const int* nimg, float* dbias,
+                          float* scratch, long long scratch_floats, const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2,
+                          int sc_ldw, float* sc_dbias, float* dw_b, float* sc_dw_b, void* stream);
 /* Tuning hook: co-resident workgroups a weight-gradient launch is sized for (0 = derive from the tile: default). */
 int l2i_set_wgrad_blocks(int n);
 /* Debug aid: co-resident workgroups per CU for conv instantiation `which` with lds_bytes of dynamic LDS. */

@@ -408,6 +408,18 @@ class PassCtx:
     def sigma(self, h):
         return self.norms[4 * h.layer_id + 2]
 
+    # (single pass: no second set of packs / accumulators -- see DualPass)
+    dual = False
+
+    def fwd_pack_b(self, h):
+        return None
+
+    def dgrad_pack_b(self, h):
+        return None
+
+    def dw_slice_b(self, h):
+        return None
+
     def group_fwd_pack(self, g):
         return self.packed[g.fwd_off:g.fwd_off + g.npad * g.kpad]
 
@@ -416,3 +428,36 @@ class PassCtx:
 
     def group_dw_slice(self, g):
         return self.dw()[g.dw_off:g.dw_off + g.n_total * g.kp]
+
+
+class DualPass:
+    """Two passes of one network run as ONE batch: images [0, b) belong to pass `a`, images [b, 2b) to pass `b` (the
+    discriminator step's D(real) and D(fake), reference train_context_app_v2.py:158,167). The reference's spectral_norm hook
+    iterates once per pass, so each pass has its own W / sigma packs and its own dWbar accumulator (the sigma-correction of
+    the spectral-norm backward differs per pass); every conv / data-gradient / weight-gradient launch takes both
+    (l2i_conv2d_fwd_dual, l2i_conv2d_wgrad_dual) and processes twice the tiles. Quacks like a PassCtx for ops.fused_conv;
+    the heads, which are not convolutions, take `.a` / `.b` for their half of the rows."""
+    dual = True
+
+    def __init__(self, a: PassCtx, b: PassCtx):
+        assert a.arena is b.arena and a.training == b.training and a.need_wgrad == b.need_wgrad
+        self.a, self.b = a, b
+        self.arena, self.training, self.need_wgrad = a.arena, a.training, a.need_wgrad
+
+    def fwd_pack(self, h):
+        return self.a.fwd_pack(h)
+
+    def dgrad_pack(self, h):
+        return self.a.dgrad_pack(h)
+
+    def dw_slice(self, h):
+        return self.a.dw_slice(h)
+
+    def fwd_pack_b(self, h):
+        return self.b.fwd_pack(h)
+
+    def dgrad_pack_b(self, h):
+        return self.b.dgrad_pack(h)
+
+    def dw_slice_b(self, h):
+        return self.b.dw_slice(h)

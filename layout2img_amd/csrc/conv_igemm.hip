@@ -29,6 +29,7 @@ L2I_TRACE_DEFINE(conv)   // wave-level timestamps of the last launch (-DL2I_TRAC
 struct ScArgs {
     const void* x;       // T [B, Hi, Wi, Ci], read at (y >> up2, x >> up2) of the launch's pre-pool output grid; null = none
     const void* w;       // T [Npad, Kpad] forward pack of the 1x1 weight
+    const void* w_b;     // dual launch (ConvArgs::w_b): the shortcut's pack of the second half of the images
     const float* bias;   // [Co] or null
     float* out;          // f32, shape of out: where the shortcut goes when it cannot be folded (split-K, generic kernel): it then runs as its own launch and is read back as `res`
     int Ci, Hi, Wi, up2, Kpad, stages;
@@ -38,6 +39,12 @@ struct ScArgs {
 struct ConvArgs {
     const void* x;      // T  [B, Hi, Wi, Ci]
     const void* w;      // T  [Npad, Kpad], K order (ky, kx, ci)
+    const void* w_b;    // DUAL launch (l2i_conv2d_fwd_dual), or null: images [B/2, B) are multiplied with THIS pack. The two passes of
+                        // the discriminator step (D(real), D(fake): reference train_context_app_v2.py:158,167) run as one batch of 2b
+                        // images, but each pass has its own power iteration, i.e. its own W / sigma (model/rcnn_discriminator_app.py
+                        // spectral_norm hooks) -- one launch, twice the tiles, two packs.
+    int half_rows;      // dual: (B/2) * Ho, the first GEMM row-of-pixels of the second half (a multiple of every tile's PH); with
+                        // `nimg` the live-image count then applies to EACH half (rows [0, n Ho) and [half_rows, half_rows + n Ho)). 0: single
     const float* bias;  // [Co] or null
     const float* res;   // f32, shape of out, or null
     float* out;         // f32 [B, Hout, Wout, Co] or null
@@ -512,7 +519,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((160 * 1024) / (NS * (BM + BN) * (HK 
     const int tile_r = fastdiv(tile_m, p.mg_tc), tile_c = tile_m - tile_r * p.tiles_c;
     const int n0 = tile_n * BN;
     const int rows_total = p.B * p.Ho;
-    const int rows_live = p.nimg ? min(rows_total, *p.nimg * p.Ho) : rows_total;   // (scalar load)
+    const bool second = p.half_rows > 0 && tile_r * p.PH >= p.half_rows;   // dual launch: this tile's images use the second pack
+    // live rows of this tile's half end at rows_live (the count applies to each half of a dual launch)
+    const int rows_live = p.nimg ? min(p.half_rows > 0 ? p.half_rows : rows_total, *p.nimg * p.Ho) + (second ? p.half_rows : 0) : rows_total;   // (scalar load)
     const bool tile_dead = !p.lin && tile_r * p.PH >= rows_live;   // every row belongs to a dead image: no reduction, zeros out
     const int pad = p.KH >> 1;
 
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((160 * 1024) / (NS * (BM + BN) * (HK 
         ++ks;
         if (++tap == 9) { tap = 0; cb += bk; }
     };
-    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
+    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(second ? p.w_b : p.w, p.w_bytes);
     const unsigned smem_addr = lds_addr_of(smem);
     // (iterator state is passed by value: captured-by-reference counters ended up in scratch memory, and scratch
     // loads count on vmcnt just like the DMA)
@@ -718,11 +727,11 @@ __global__ __launch_bounds__(WM* WN * 64, ((160 * 1024) / (NS * (BM + BN) * (HK 
 // accumulators. Two stages when the kernel's LDS allocation holds them (p.sc_stages), else one.
 template <int BM, int BN, int TM, int TN, int THREADS = 256>
 __device__ __forceinline__ void conv_sc_tail(const ConvArgs& p, ScArgsPtr sc, f32x16_t (&acc)[TM][TN], char* smem, unsigned smem_addr, int tid, int lane,
-                                             int wv, int wrow, int wcol, int tile_r, int tile_c, int n0, int rows_total) {
+                                             int wv, int wrow, int wcol, int tile_r, int tile_c, int n0, int rows_total, bool second) {
     constexpr int RPP = THREADS / 8, AP = BM / RPP, BPS = BN / RPP;   // the workgroup stages RPP rows x 128 bytes per pass
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile geometry");
     constexpr unsigned ASZ = BM * 128u, STG = (BM + BN) * 128u, OOB = 0x80000000u;
-    const u32x4_t rx = make_rsrc(sc->x, sc->x_bytes), rw = make_rsrc(sc->w, sc->w_bytes);
+    const u32x4_t rx = make_rsrc(sc->x, sc->x_bytes), rw = make_rsrc(second ? sc->w_b : sc->w, sc->w_bytes);
     const int sc_Hi = sc->Hi, sc_Wi = sc->Wi, sc_Ci = sc->Ci, sc_up2 = sc->up2, sc_Kpad = sc->Kpad;
     const int lrow = tid >> 3, hh = lane >> 5;
     unsigned aoff[AP], boff[BPS];
@@ -825,9 +834,10 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void 
     const int tile_r = fastdiv(tile_m, p.mg_tc), tile_c = tile_m - tile_r * p.tiles_c;
     const int n0 = tile_n * BN;
     const int rows_total = p.B * p.Ho;
-    const int rows_live = p.nimg ? min(rows_total, *p.nimg * p.Ho) : rows_total;   // (scalar load)
+    const bool second = p.half_rows > 0 && tile_r * p.PH >= p.half_rows;   // dual launch (ConvArgs::w_b): the second half's pack
+    const int rows_live = p.nimg ? min(p.half_rows > 0 ? p.half_rows : rows_total, *p.nimg * p.Ho) + (second ? p.half_rows : 0) : rows_total;   // (scalar load)
     const bool tile_dead = tile_r * p.PH >= rows_live;   // every row belongs to a dead image: no reduction, zeros out
-    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
+    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(second ? p.w_b : p.w, p.w_bytes);
     const unsigned smem_addr = lds_addr_of(smem);
     const unsigned halo_bytes = (unsigned)p.halo_pieces * 1024u;
     const unsigned ring_off = (H1 ? 1u : 2u) * halo_bytes;
@@ -1035,7 +1045,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void 
     if constexpr (SC) {
         const ScArgsPtr sc = late_sc();
         if (sc->x && !tile_dead)
-            conv_sc_tail<BM, BN, TM, TN, THREADS>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, wcol, tile_r, tile_c, n0, rows_total);
+            conv_sc_tail<BM, BN, TM, TN, THREADS>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, wcol, tile_r, tile_c, n0, rows_total, second);
     }
     L2I_TR(2);
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
@@ -1083,9 +1093,10 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_halo3_kernel(ConvA
     const int tile_r = fastdiv(tile_m, p.mg_tc), tile_c = tile_m - tile_r * p.tiles_c;
     const int n0 = tile_n * BN;
     const int rows_total = p.B * p.Ho;
-    const int rows_live = p.nimg ? min(rows_total, *p.nimg * p.Ho) : rows_total;
+    const bool second = p.half_rows > 0 && tile_r * p.PH >= p.half_rows;   // dual launch (ConvArgs::w_b): the second half's pack
+    const int rows_live = p.nimg ? min(p.half_rows > 0 ? p.half_rows : rows_total, *p.nimg * p.Ho) + (second ? p.half_rows : 0) : rows_total;
     const bool tile_dead = tile_r * p.PH >= rows_live;
-    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
+    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(second ? p.w_b : p.w, p.w_bytes);
     const unsigned smem_addr = lds_addr_of(smem);
     const unsigned halo_bytes = (unsigned)p.halo_pieces * 1024u;
     const unsigned ring_off = halo_bytes, zero_off = halo_bytes + 2u * BSTAGE;   // [halo][ring x 2][256 zero bytes]
@@ -1352,7 +1363,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_halo3_kernel(ConvA
 #undef H3_RD
     if constexpr (SC) {
         const ScArgsPtr sc = late_sc();
-        if (sc->x && !tile_dead) conv_sc_tail<256, BN, TM, TN, 256>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, 0, tile_r, tile_c, n0, rows_total);
+        if (sc->x && !tile_dead) conv_sc_tail<256, BN, TM, TN, 256>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, 0, tile_r, tile_c, n0, rows_total, second);
     }
     L2I_TR(2);
     if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
@@ -1383,6 +1394,7 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     a.nks = a.chunk_major ? 9 * ((a.Ci + BK - 1) / BK) : a.Kpad / BK;
     a.PH = BM / a.PW;
     if (!a.lin && (a.PH & 1)) return L2I_ERR_ARG;
+    if (a.half_rows && (a.lin || a.half_rows % a.PH)) return L2I_ERR_ARG;   // dual launch: no tile may straddle the two halves
     const int rows = a.B * a.Ho;
     a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
     a.tiles_n = (a.Co + BN - 1) / BN;
@@ -1427,14 +1439,14 @@ static int sc_unfold(ConvArgs& a, hipStream_t stream) {
     if (!a.sc.x) return L2I_OK;
     if (!a.sc.out || a.res) return L2I_ERR_ARG;
     ConvArgs s = a;
-    s.x = a.sc.x; s.w = a.sc.w; s.bias = a.sc.bias; s.res = nullptr; s.relu_mask = nullptr;
+    s.x = a.sc.x; s.w = a.sc.w; s.w_b = a.sc.w_b; s.bias = a.sc.bias; s.res = nullptr; s.relu_mask = nullptr;
     s.out = a.sc.out; s.out_op = nullptr; s.out_op_raw = nullptr; s.stat_ws = nullptr;
     s.Hi = a.sc.Hi; s.Wi = a.sc.Wi; s.Ci = a.sc.Ci; s.KH = 1; s.up2 = a.sc.up2; s.Kpad = a.sc.Kpad; s.relu_op = 0;
-    s.sc.x = nullptr; s.sc.w = nullptr; s.sc.bias = nullptr; s.sc.out = nullptr;
+    s.sc.x = nullptr; s.sc.w = nullptr; s.sc.w_b = nullptr; s.sc.bias = nullptr; s.sc.out = nullptr;
     s.SUBH = 1; s.P = 1;
     const int rc = launch_conv<T>(s, stream);
     a.res = a.sc.out;
-    a.sc.x = nullptr; a.sc.w = nullptr; a.sc.bias = nullptr;
+    a.sc.x = nullptr; a.sc.w = nullptr; a.sc.w_b = nullptr; a.sc.bias = nullptr;
     return rc;
 }
 
@@ -1449,6 +1461,7 @@ static void sc_plan(ConvArgs& a, size_t& lds, int BM, int BN) {
 template <int BM, int BN, int WM, int WN, int NSB, bool PIPE, bool H1 = false, int ABL = 0, bool CAN_SC = false>   // CAN_SC: the folding twin of this tile is compiled
 static int launch_halo2(ConvArgs a, hipStream_t stream) {
     a.PH = BM / a.PW;
+    if (a.half_rows % a.PH) return L2I_ERR_ARG;   // dual launch: no tile may straddle the two halves
     a.PHs = a.PH < a.Ho ? a.PH : a.Ho;
     a.sub_shift = ilog2(a.PHs);
     const int nsp = a.PH / a.PHs;
@@ -1513,6 +1526,7 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     if (a.Ci % 64 || a.Wo < 4 || (a.up2 && a.Wo < 8)) return -100;
     if (force_splits == 0) force_splits = g_force_splits;
     a.PH = 256 / a.PW;
+    if (a.half_rows % a.PH) return L2I_ERR_ARG;   // dual launch: no tile may straddle the two halves
     a.PHs = a.PH < a.Ho ? a.PH : a.Ho;
     a.sub_shift = ilog2(a.PHs);
     const int nsp = a.PH / a.PHs;
@@ -1761,18 +1775,18 @@ extern "C" int l2i_timing_read(int cls, double* total_ms, int* launches) {
     return L2I_OK;
 }
 
-extern "C" int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias, const float* res,
-                                 const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
-                                 int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
-                                 const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
-                                 int sc_up2, int sc_Kpad, void* stream);
+extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bias, const float* res,
+                                   const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                                   int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
+                                   const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
+                                   int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, void* stream);
 
 extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float* res,
                               const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                               int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
                               void* stream) {
-    return l2i_conv2d_fwd_sc(x, w, bias, res, relu_mask, out, out_op, out_op_raw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu_op,
-                             Kpad, alpha, nimg, stats, ws, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, stream);
+    return l2i_conv2d_fwd_dual(x, w, bias, res, relu_mask, out, out_op, out_op_raw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu_op,
+                               Kpad, alpha, nimg, stats, ws, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias, const float* res,
@@ -1780,7 +1794,22 @@ extern "C" int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias
                                  int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
                                  const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
                                  int sc_up2, int sc_Kpad, void* stream) {
+    return l2i_conv2d_fwd_dual(x, w, bias, res, relu_mask, out, out_op, out_op_raw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu_op,
+                               Kpad, alpha, nimg, stats, ws, sc_x, sc_w, sc_bias, sc_out, sc_Hi, sc_Wi, sc_Ci, sc_up2, sc_Kpad, nullptr, nullptr, stream);
+}
+
+// Dual launch: w_b (and sc_w_b with a folded shortcut) non-null -> the B images are two passes of B/2 images each that share
+// every tensor argument but the weight packs: images [0, B/2) use w (sc_w), images [B/2, B) use w_b (sc_w_b); `nimg` then counts
+// the live leading images of EACH half. B must be even and (B/2) * Ho a multiple of the tile's pixel rows (L2I_ERR_ARG otherwise:
+// the caller then issues the two halves as two launches).
+extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bias, const float* res,
+                                   const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                                   int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
+                                   const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
+                                   int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, void* stream) {
     if (!x || !w || (!out && !out_op && !out_op_raw)) return L2I_ERR_ARG;
+    if (w_b && ((B & 1) || stats || (sc_x && !sc_w_b))) return L2I_ERR_ARG;
+    if (!w_b && sc_w_b) return L2I_ERR_ARG;
     if (sc_x) {   // folded shortcut: 1x1 on the (optionally nearest-upsampled) pre-pool grid of this launch; its result stands in for `res`
         if (!sc_w || !sc_out || res || relu_mask || sc_Ci <= 0 || sc_Ci % 8 || sc_Kpad < sc_Ci) return L2I_ERR_ARG;
         if (sc_Hi << (sc_up2 ? 1 : 0) != Ho || sc_Wi << (sc_up2 ? 1 : 0) != Wo) return L2I_ERR_ARG;
@@ -1804,6 +1833,7 @@ extern "C" int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias
     const int epi_mode = g_epi_mode >= 0 ? g_epi_mode : epi_env;
     a.epi_lds = epi_mode == 2 || (epi_mode == 1 && (relu_mask != nullptr || out_op != nullptr || out_op_raw != nullptr));
     a.nimg = nimg;
+    a.w_b = w_b; a.half_rows = w_b ? (B / 2) * Ho : 0;
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out; a.out_op = out_op; a.out_op_raw = out_op_raw; a.relu_mask = relu_mask;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.relu_op = relu_op ? 1 : 0;
@@ -1812,6 +1842,7 @@ extern "C" int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias
     static const int sc_fold_env = getenv("L2I_SC_FOLD") ? atoi(getenv("L2I_SC_FOLD")) : 1;
     g_no_sc_fold = !sc_fold_env;
     const size_t esz = dtype == 0 ? 4 : 2;
+    a.sc.w_b = (sc_x && w_b) ? sc_w_b : nullptr;
     a.sc.x = sc_x; a.sc.w = sc_x ? sc_w : nullptr; a.sc.bias = sc_x ? sc_bias : nullptr; a.sc.out = sc_out;
     a.sc.Hi = sc_Hi; a.sc.Wi = sc_Wi; a.sc.Ci = sc_Ci; a.sc.up2 = sc_up2 ? 1 : 0; a.sc.Kpad = sc_Kpad; a.sc.stages = 1;
     a.sc.x_bytes = sc_x ? (unsigned)((size_t)B * sc_Hi * sc_Wi * sc_Ci * esz) : 0;

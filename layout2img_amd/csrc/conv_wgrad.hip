@@ -41,20 +41,32 @@ struct WgradArgs {
     float* dbias2;                // optional: the shortcut's bias gradient (= this layer's: the same sum over dY)
     int sc_Ci, sc_ldw, sc_up2, tiles_k_main;   // sc_up2: the shortcut reads x_sc [B, Ho/2, Wo/2, sc_Ci] at (y >> 1, x >> 1) (generator blocks)
     unsigned sc_x_bytes;
+    // DUAL launch (l2i_conv2d_wgrad_dual): the B images are two passes of B/2 images (D(real) and D(fake) of the discriminator step,
+    // reference train_context_app_v2.py:158,167) whose weight gradients go to different accumulators -- each pass has its own
+    // W / sigma and therefore its own sigma-correction in the spectral-norm backward. Splits [0, splits/2) reduce the pixels of the
+    // first half into dw (sc_dw), splits [splits/2, splits) those of the second half into dw_b (sc_dw_b); `nimg` counts the live
+    // images of EACH half. null dw_b: single.
+    float* dw_b;
+    float* sc_dw_b;
 };
 
 // The reduction range [m_begin, m_end) of one split. With a device-side image count the live pixels are divided over
 // the launch's `splits` again on the device (whole 64-pixel steps), so every split still does an equal share.
 __device__ __forceinline__ void wgrad_range(const WgradArgs& p, int split, int& m_begin, int& m_end) {
-    int M = p.M, Mper = p.Mper;
+    int M = p.M, Mper = p.Mper, nsp = p.splits, base = 0;
+    if (p.dw_b) {   // dual: this split's half of the images (p.M, p.Mper are per half then)
+        nsp >>= 1;
+        if (split >= nsp) { split -= nsp; base = p.M; }
+    }
     if (p.nimg) {
         M = min(M, *p.nimg * p.Ho * p.Wo);
         const int steps = (M + (1 << p.lgbk) - 1) >> p.lgbk;
-        Mper = ((steps + p.splits - 1) / p.splits) << p.lgbk;
+        Mper = ((steps + nsp - 1) / nsp) << p.lgbk;
     }
-    m_begin = split * Mper;
-    m_end = min(M, m_begin + Mper);
+    m_begin = base + split * Mper;
+    m_end = min(base + M, m_begin + Mper);
 }
+__device__ __forceinline__ bool wgrad_second(const WgradArgs& p, int split) { return p.dw_b && split >= (p.splits >> 1); }
 
 template <typename T> struct Tr;
 template <> struct Tr<bf16_t> {
@@ -216,10 +228,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         for (int j = 0; j < TN; ++j) {
             const int col = kc0 + wcol + j * 32 + c;
             if (col >= p.K) continue;
+            float* dwp = wgrad_second(p, split) ? p.dw_b : p.dw;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = co0 + wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < p.Co) atomicAdd(p.dw + (size_t)row * p.ldw + col, p.alpha * acc[i][j][e]);
+                if (row < p.Co) atomicAdd(dwp + (size_t)row * p.ldw + col, p.alpha * acc[i][j][e]);
             }
         }
 }
@@ -617,7 +630,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
         for (int j = 0; j < TN; ++j) {
             const int col = kc0 + wcol + j * 32 + c;
             if (col >= K_) continue;
-            float* dw_ = is_sc ? p.sc_dw : p.dw;
+            const bool sec_ = wgrad_second(p, split);
+            float* dw_ = is_sc ? (sec_ ? p.sc_dw_b : p.sc_dw) : (sec_ ? p.dw_b : p.dw);
             const int ldw_ = is_sc ? p.sc_ldw : p.ldw;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -635,7 +649,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 // nw2: the two-wave kernel's geometry (waves side by side, TM = BMO / 32), else four waves as 2 x 2 (TM = BMO / 64).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int BMO, int tiles_k,
                                                            int ntiles, int splits, int Co, int K, int ldw, float alpha, int nw2, int sper,
-                                                           int tiles_k_main, float* __restrict__ dw2, int K2, int ldw2) {
+                                                           int tiles_k_main, float* __restrict__ dw2, int K2, int ldw2,
+                                                           float* __restrict__ dw_b, float* __restrict__ dw2_b) {
     // blockIdx.y = group of `sper` consecutive splits: layers with few tiles and many splits (the 64-channel layers at
     // 128 x 128: 5 tiles x 153 splits) otherwise run on 40 workgroups, each thread walking 153 partial tiles one dependent
     // load after the other (18 us of a 69-us weight gradient). Groups combine with f32 atomics (gridDim.y > 1 only).
@@ -645,6 +660,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (tile >= ntiles) return;
     int tile_k = tile % tiles_k;
     const int tile_co = tile / tiles_k;
+    // dual launch (gridDim.z == 2): the second half of the splits belongs to the second pass's accumulators
+    const int hs = splits / (int)gridDim.z, s_off = (int)blockIdx.z * hs;
+    if (blockIdx.z) { dw = dw_b; dw2 = dw2_b; }
     if (tile_k >= tiles_k_main) {   // column tiles of the folded shortcut: their own gradient buffer
         tile_k -= tiles_k_main;
         dw = dw2; K = K2; ldw = ldw2;
@@ -657,8 +675,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const size_t tsz4 = (size_t)BMO * 32;
     const float4* src = reinterpret_cast<const float4*>(part) + (size_t)tile * splits * tsz4 + f;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = blockIdx.y * sper;
-    const int s_end = min(splits, s + sper);
+    int s = s_off + blockIdx.y * sper;
+    const int s_end = min(s_off + hs, s + sper);
     for (; s + 4 <= s_end; s += 4) {
         const float4 v0 = src[(size_t)s * tsz4], v1 = src[(size_t)(s + 1) * tsz4];
         const float4 v2 = src[(size_t)(s + 2) * tsz4], v3 = src[(size_t)(s + 3) * tsz4];
@@ -725,9 +743,10 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             WgradArgs s = a;
             s.x = a.sc_x; s.dw = a.sc_dw; s.Ci = a.sc_Ci; s.Hi = a.Ho >> a.sc_up2; s.Wi = a.Wo >> a.sc_up2; s.KH = 1; s.up2 = a.sc_up2; s.ldw = a.sc_ldw;
             s.dbias = a.dbias2; s.dbias2 = nullptr; s.sc_x = nullptr; s.sc_dw = nullptr;
+            s.dw_b = a.sc_dw_b; s.sc_dw_b = nullptr;
             const int rc = launch_wgrad<T>(s, stream, scratch, scratch_floats);
             if (rc != L2I_OK) return rc;
-            a.sc_x = nullptr; a.sc_dw = nullptr; a.dbias2 = nullptr;
+            a.sc_x = nullptr; a.sc_dw = nullptr; a.dbias2 = nullptr; a.sc_dw_b = nullptr;
         } else {
             a.tiles_k += (a.sc_Ci + 127) / 128;
             const size_t sb = (size_t)a.B * (a.Ho >> a.sc_up2) * (a.Wo >> a.sc_up2) * a.sc_Ci * sizeof(T);
@@ -769,6 +788,18 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
     int per = (steps + splits - 1) / splits;
     a.Mper = per * SBK;
     a.splits = (a.M + a.Mper - 1) / a.Mper;
+    const bool dual = a.dw_b != nullptr;
+    if (dual) {   // the same number of workgroups, half of them per pass; every split stays inside its half (WgradArgs::dw_b)
+        const int Mh = a.M / 2;
+        if ((a.B & 1) || Mh % SBK || (a.sc_x && !a.sc_dw_b)) return L2I_ERR_ARG;
+        int hs = (a.splits + 1) / 2;
+        const int steps_h = Mh / SBK;
+        per = (steps_h + hs - 1) / hs;
+        a.Mper = per * SBK;
+        hs = (Mh + a.Mper - 1) / a.Mper;
+        a.splits = 2 * hs;
+        a.M = Mh;   // (per half from here on: wgrad_range)
+    }
     const int nblk = tiles * a.splits;
     {
         const size_t xb = (size_t)a.B * a.Hi * a.Wi * a.Ci * sizeof(T);
@@ -779,7 +810,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
     a.part = nullptr;
     if (sizeof(T) == 2 && pow2) {  // bf16: LDS-DMA + transposing-read kernel
         static const int use_part = getenv("L2I_WGRAD_PART") ? atoi(getenv("L2I_WGRAD_PART")) : 1;   // (0: atomics, A/B)
-        if (use_part && scratch && a.splits > 1 && (long long)nblk * BMO * 128 <= scratch_floats) a.part = scratch;
+        if (use_part && scratch && (a.splits > 1 || dual) && (long long)nblk * BMO * 128 <= scratch_floats) a.part = scratch;
         int lgW = 0, lgH = 0;
         while ((1 << lgW) < a.Wo) ++lgW;
         while ((1 << lgH) < a.Ho) ++lgH;
@@ -822,16 +853,17 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             const long long nthr = (long long)tiles * BMO * 32;
             const unsigned nbx = (unsigned)((nthr + 255) / 256);
             // split groups: enough workgroups to fill the chip (>= ~512), at least 8 splits per group
+            const int hsp = dual ? a.splits / 2 : a.splits;   // splits per accumulator (dual: gridDim.z = 2 halves)
             int sg = 1;
-            if (nbx < 512 && a.splits > 8) {
+            if (nbx * (dual ? 2u : 1u) < 512 && hsp > 8) {
                 sg = (int)((512 + nbx - 1) / nbx);
-                if (sg > (a.splits + 7) / 8) sg = (a.splits + 7) / 8;
+                if (sg > (hsp + 7) / 8) sg = (hsp + 7) / 8;
             }
-            const int sper = (a.splits + sg - 1) / sg;
-            sg = (a.splits + sper - 1) / sper;
-            L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
+            const int sper = (hsp + sg - 1) / sg;
+            sg = (hsp + sper - 1) / sper;
+            L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg, dual ? 2u : 1u), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
                        a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, (int)(nw2 && !nw8 && BMO == 128), sper,
-                       a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw);
+                       a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b);
         }
         return l2i_check_launch();
     }
@@ -843,23 +875,38 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
     return l2i_check_launch();
 }
 
-extern "C" int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
-                                   int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
-                                   const int* nimg, float* dbias, float* scratch, long long scratch_floats,
-                                   const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2, int sc_ldw, float* sc_dbias, void* stream);
+extern "C" int l2i_conv2d_wgrad_dual(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
+                                     int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
+                                     const int* nimg, float* dbias, float* scratch, long long scratch_floats,
+                                     const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2, int sc_ldw, float* sc_dbias,
+                                     float* dw_b, float* sc_dw_b, void* stream);
 
 extern "C" int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
                                 int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
                                 const int* nimg, float* dbias, float* scratch, long long scratch_floats, void* stream) {
-    return l2i_conv2d_wgrad_sc(x, dy, dw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, ldw, alpha, nimg, dbias, scratch, scratch_floats,
-                               nullptr, nullptr, 0, 0, 0, nullptr, stream);
+    return l2i_conv2d_wgrad_dual(x, dy, dw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, ldw, alpha, nimg, dbias, scratch, scratch_floats,
+                                 nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
                                    int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
                                    const int* nimg, float* dbias, float* scratch, long long scratch_floats,
                                    const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2, int sc_ldw, float* sc_dbias, void* stream) {
+    return l2i_conv2d_wgrad_dual(x, dy, dw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, ldw, alpha, nimg, dbias, scratch, scratch_floats,
+                                 sc_x, sc_dw, sc_Ci, sc_up2, sc_ldw, sc_dbias, nullptr, nullptr, stream);
+}
+
+// Dual launch: dw_b non-null -> the B images are two passes of B/2 images; the first half's gradient is added to dw (sc_dw), the
+// second half's to dw_b (sc_dw_b); both bias gradients go to dbias (a bias has no spectral norm: one sum). `nimg` counts the live
+// leading images of EACH half. (B/2) * Ho * Wo must be a whole number of the kernel's pixel steps (64), else L2I_ERR_ARG: the
+// caller then issues two launches.
+extern "C" int l2i_conv2d_wgrad_dual(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
+                                     int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
+                                     const int* nimg, float* dbias, float* scratch, long long scratch_floats,
+                                     const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2, int sc_ldw, float* sc_dbias,
+                                     float* dw_b, float* sc_dw_b, void* stream) {
     if (!x || !dy || !dw) return L2I_ERR_ARG;
+    if (!dw_b && sc_dw_b) return L2I_ERR_ARG;
     if (sc_x && (!sc_dw || sc_Ci <= 0 || sc_ldw < sc_Ci)) return L2I_ERR_ARG;
     if (nimg && (Ho * Wo) % 64) return L2I_ERR_ARG;
     WgradArgs a;
@@ -873,6 +920,7 @@ extern "C" int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int
     a.dbias = dbias;
     a.sc_x = sc_x; a.sc_dw = sc_x ? sc_dw : nullptr; a.dbias2 = sc_x ? sc_dbias : nullptr; a.sc_Ci = sc_Ci; a.sc_ldw = sc_ldw; a.sc_up2 = sc_up2 ? 1 : 0;
     a.sc_x_bytes = 0; a.tiles_k_main = 0;
+    a.dw_b = dw_b; a.sc_dw_b = (sc_x && dw_b) ? sc_dw_b : nullptr;
     a.x = x; a.dy = dy; a.dw = dw;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.ldw = ldw; a.alpha = alpha;

@@ -665,53 +665,80 @@ extern "C" int l2i_psp_stages_bwd(const float* pooled, const float* const* W, co
 // ResnetDiscriminator128_app.forward (:131-146) without the host-synchronising nonzero(): the R = b*o rows are COMPACTED
 // on the device -- real ROIs first in the reference's output order (large ROIs, then small ones, original order within
 // each), padding rows (label 0) behind them -- i.e. a stable sort by key = 2 [label == 0] + [small] (two_scale) that the
-// host side used to do with ~26 torch launches incl. a radix sort. One workgroup of 1024 threads, R <= 1024.
+// host side used to do with ~26 torch launches incl. a radix sort. One workgroup of 1024 threads walks the rows in chunks of
+// 1024 (any R: Visual Genome layouts at a per-GPU batch above 33 have more than 1024 rows): a first sweep counts the rows
+// of each key, a second one places them (chunk order = original order within a key).
 __global__ __launch_bounds__(1024) void roi_layout_kernel(const float* __restrict__ bbox, const long long* __restrict__ label, float size,
                                                           int two_scale, int o, int R, float* __restrict__ rois, long long* __restrict__ y,
                                                           int* __restrict__ valid, int* __restrict__ count) {
     __shared__ int wtot[4][16];
-    const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
-    float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    long long lab = 0;
-    int key = -1;
-    if (i < R) {
+    __shared__ int total[4], base[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    auto row_key = [&](int i, float (&r)[5], long long& lab) {
         const float* bb = bbox + (size_t)i * 4;
         r[0] = (float)(i / o);
         r[1] = bb[0] * size; r[2] = bb[1] * size; r[3] = (bb[0] + bb[2]) * size; r[4] = (bb[1] + bb[3]) * size;
         lab = label[i];
-        key = (lab != 0 ? 0 : 2) + ((two_scale && (r[3] - r[1]) < 64.f && (r[4] - r[2]) < 64.f) ? 1 : 0);
-    }
-    int before[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned long long m = __ballot(key == k);
-        before[k] = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wtot[k][wave] = __popcll(m);
-    }
+        return (lab != 0 ? 0 : 2) + ((two_scale && (r[3] - r[1]) < 64.f && (r[4] - r[2]) < 64.f) ? 1 : 0);
+    };
+    if (t < 4) { total[t] = 0; base[t] = 0; }
     __syncthreads();
-    if (i < R) {
-        int pos = 0;
+    if (R > 1024) {   // (one chunk: the totals come out of the placement sweep's own ballots)
+        int mine[4] = {0, 0, 0, 0};
+        for (int i = t; i < R; i += 1024) {
+            float r[5];
+            long long lab;
+            ++mine[row_key(i, r, lab)];
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            int tot = 0, mine = 0;
-            for (int w_ = 0; w_ < 16; ++w_) { if (w_ < wave) mine += wtot[k][w_]; tot += wtot[k][w_]; }
-            if (k < key) pos += tot;
-            else if (k == key) pos += mine + before[k];
+            int v = mine[k];
+            for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+            if (lane == 0 && v) atomicAdd(&total[k], v);
         }
-        float* d = rois + (size_t)pos * 5;
-        d[0] = r[0]; d[1] = r[1]; d[2] = r[2]; d[3] = r[3]; d[4] = r[4];
-        y[pos] = lab;
-        valid[pos] = lab != 0 ? 1 : 0;
+        __syncthreads();
     }
-    if (i == 0) {
-        int c = 0;
-        for (int w_ = 0; w_ < 16; ++w_) c += wtot[0][w_] + wtot[1][w_];
-        count[0] = c;
+    for (int c0 = 0; c0 < R; c0 += 1024) {
+        const int i = c0 + t;
+        float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        long long lab = 0;
+        const int key = i < R ? row_key(i, r, lab) : -1;
+        int before[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long m = __ballot(key == k);
+            before[k] = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wtot[k][wave] = __popcll(m);
+        }
+        __syncthreads();
+        if (R <= 1024 && t < 4) {
+            int tot = 0;
+            for (int w_ = 0; w_ < 16; ++w_) tot += wtot[t][w_];
+            total[t] = tot;
+        }
+        if (R <= 1024) __syncthreads();
+        if (i < R) {
+            int pos = base[key] + before[key];
+            for (int w_ = 0; w_ < wave; ++w_) pos += wtot[key][w_];
+            for (int k = 0; k < key; ++k) pos += total[k];
+            float* d = rois + (size_t)pos * 5;
+            d[0] = r[0]; d[1] = r[1]; d[2] = r[2]; d[3] = r[3]; d[4] = r[4];
+            y[pos] = lab;
+            valid[pos] = lab != 0 ? 1 : 0;
+        }
+        __syncthreads();
+        if (t < 4) {
+            int tot = 0;
+            for (int w_ = 0; w_ < 16; ++w_) tot += wtot[t][w_];
+            base[t] += tot;
+        }
+        __syncthreads();
     }
+    if (t == 0) count[0] = total[0] + total[1];
 }
 extern "C" int l2i_roi_layout(const float* bbox, const long long* label, float size, int two_scale, int o, int R, float* rois, long long* y,
                               int* valid, int* count, void* stream) {
-    if (!bbox || !label || !rois || !y || !valid || !count || R < 1 || R > 1024 || o < 1) return L2I_ERR_ARG;
+    if (!bbox || !label || !rois || !y || !valid || !count || R < 1 || o < 1) return L2I_ERR_ARG;
     hipLaunchKernelGGL(roi_layout_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, bbox, label, size, two_scale, o, R, rois, y, valid, count);
     return l2i_check_launch();
 }

@@ -12,8 +12,20 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .arena import FlatParams, GemmWeight, WeightArena
+from .arena import DualPass, FlatParams, GemmWeight, WeightArena
 from .ops import RELU, arena_weight, fused_conv
+
+
+def _passes(pc):
+    """The pass contexts the heads run under: one, or the two of a dual pass (rows [0, n) belong to the first)."""
+    return (pc.a, pc.b) if pc.dual else (pc,)
+
+
+def _rows(t, pc):
+    """t's rows per pass: the tensor itself, or its two halves (one concatenation backward, ops.split_halves)."""
+    if not pc.dual:
+        return (t,)
+    return ops.split_halves(t) if t.requires_grad else (t[:t.shape[0] // 2], t[t.shape[0] // 2:])
 
 
 def _conv(ci, co, k, uses=1):
@@ -96,7 +108,8 @@ class ResnetDiscriminator128_app(nn.Module):
         x = self.block4(x2, pc, emit=both)
         x = self.block5(x, pc, emit=("relu",))
         x = self.block6(x, pc)
-        out_im = ops.proj_head(x, self.l7, pc)                               # l7(sum_hw relu(x))
+        P = _passes(pc)
+        out_im = [ops.proj_head(xk, self.l7, p) for xk, p in zip(_rows(x, pc), P)]            # l7(sum_hw relu(x))
 
         feat_s = self.block_obj4(self.block_obj3(x1, pc, emit=both), pc, use=0)   # reference order :136-141
         feat_l = self.block_obj4(x2, pc, use=1)
@@ -105,16 +118,20 @@ class ResnetDiscriminator128_app(nn.Module):
         # appearance head (reference :148-157): Gram of the ROI features + class embedding
         a = self.app_conv(obj, pc, nimg=nimg)                             # (R, 8, 8, C) pre-ReLU
         s2 = a.shape[3]
-        wa = arena_weight(self.app, pc)                                   # (1, 2C)
-        # w1 . sum_rows(Gram) / C with Gram = F F^T / C, F = relu(a): only this contraction of the (R,C,C) Gram
-        # matrices reaches the output, so they are never formed (ops.GramHeadFn / csrc/misc.hip); the class-embedding
-        # half of the head, l_y_app(y) . w2 + bias, is ops.emb_dot
-        gram_term = ops.gram_head(a, wa[0, :s2].contiguous())
-        out_app = gram_term + ops.emb_dot(self.l_y_app, y, self.app, s2, pc)
-
         # projection head (reference :160-166): l_obj(f) + sum(l_y(y) * f), f = sum_hw relu(block_obj5(obj))
-        out_obj = ops.proj_head(self.block_obj5(obj, pc, nimg=nimg), self.l_obj, pc, emb=self.l_y, y=y)
-        return out_im, out_obj, out_app
+        f5 = self.block_obj5(obj, pc, nimg=nimg)
+        out_app, out_obj = [], []
+        for ak, fk, yk, p in zip(_rows(a, pc), _rows(f5, pc), _rows(y, pc), P):
+            wa = arena_weight(self.app, p)                                # (1, 2C)
+            # w1 . sum_rows(Gram) / C with Gram = F F^T / C, F = relu(a): only this contraction of the (R,C,C) Gram
+            # matrices reaches the output, so they are never formed (ops.GramHeadFn / csrc/misc.hip); the class-embedding
+            # half of the head, l_y_app(y) . w2 + bias, is ops.emb_dot
+            gram_term = ops.gram_head(ak.contiguous(), wa[0, :s2].contiguous())
+            out_app.append(gram_term + ops.emb_dot(self.l_y_app, yk, self.app, s2, p))
+            out_obj.append(ops.proj_head(fk, self.l_obj, p, emb=self.l_y, y=yk))
+        if pc.dual:   # ((d_img, d_obj, d_app) of the first pass, the same of the second)
+            return tuple((out_im[k], out_obj[k], out_app[k]) for k in range(2))
+        return out_im[0], out_obj[0], out_app[0]
 
 
 class CombineDiscriminator128_app(nn.Module):
@@ -169,6 +186,27 @@ class CombineDiscriminator128_app(nn.Module):
         d_img, d_obj, d_app = self.obD(x, y, rois, valid, pc, nimg=count)
         return d_img, d_obj, d_app, valid, rois
 
+    def forward_dual(self, images_a, images_b, bbox, label, pcs=None, layout=None, need_wgrad=True):
+        """TWO passes over the same layout as one batch of 2b images -- the discriminator step's D(real) and D(fake)
+        (reference train_context_app_v2.py:158,167): -> (outs_a, outs_b, valid, rois), outs_k = forward_padded's outputs of pass
+        k. Each pass keeps what the reference gives it: its own power iteration, W / sigma packs and weight-gradient
+        accumulator (arena.DualPass; pcs = the two prepared pass contexts, first pass first, else prepared here in that
+        order); every convolution, data-gradient and weight-gradient launch processes both passes' tiles at once."""
+        if not (images_a.is_cuda and images_b.is_cuda):
+            raise RuntimeError("layout2img_amd discriminators run on the GPU HIP path only")
+        if images_a.shape != images_b.shape:
+            raise RuntimeError("forward_dual: the two passes must have the same batch shape")
+        b = images_a.shape[0]
+        rois, y, valid, count, x = self._prepare(torch.cat((images_a, images_b)), bbox, label, layout)
+        R = rois.shape[0]
+        rois2, y2, valid2 = torch.cat((rois, rois)), torch.cat((y, y)), torch.cat((valid, valid))
+        rois2[R:, 0] += b                                                # the second pass's images follow the first's
+        if pcs is None:
+            pcs = (self.arena.prepare(training=self.training, need_wgrad=need_wgrad),
+                   self.arena.prepare(training=self.training, need_wgrad=need_wgrad))
+        outs_a, outs_b = self.obD(x, y2, rois2, valid2, DualPass(*pcs), nimg=count)
+        return outs_a, outs_b, valid, rois
+
     def obD_arena(self):
         return self.arena
 
@@ -206,10 +244,14 @@ class ResnetDiscriminator64(nn.Module):
         x1 = self.block3(x, pc, emit=both)
         x = self.block4(x1, pc, emit=both)
         x = self.block5(x, pc)
-        out_im = ops.proj_head(x, self.l_im, pc, scale=1.0 / (x.shape[1] * x.shape[2]))    # MEAN pooling (:117)
+        P = _passes(pc)
+        out_im = [ops.proj_head(xk, self.l_im, p, scale=1.0 / (x.shape[1] * x.shape[2])) for xk, p in zip(_rows(x, pc), P)]    # MEAN pooling (:117)
         obj = ops.roi_align(x1, None, rois, valid, 8, 1.0 / 2.0, 1.0, 1e30, 0)
-        out_obj = ops.proj_head(self.block_obj4(obj, pc, nimg=nimg), self.l_obj, pc, emb=self.l_y, y=y)
-        return out_im, out_obj
+        f4 = self.block_obj4(obj, pc, nimg=nimg)
+        out_obj = [ops.proj_head(fk, self.l_obj, p, emb=self.l_y, y=yk) for fk, yk, p in zip(_rows(f4, pc), _rows(y, pc), P)]
+        if pc.dual:
+            return tuple((out_im[k], out_obj[k]) for k in range(2))
+        return out_im[0], out_obj[0]
 
 
 class CombineDiscriminator64(CombineDiscriminator128_app):

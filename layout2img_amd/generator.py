@@ -266,24 +266,6 @@ class ResBlock(nn.Module):
         return out, m
 
 
-def box_relational_embedding(f_g, dim_g=64, wave_len=1000.0):
-    """reference model/resnet_generator_app_v2.py:17-76 (xywh boxes read as corner boxes, as there)."""
-    B = f_g.size(0)
-    x_min, y_min, x_max, y_max = torch.chunk(f_g, 4, dim=-1)
-    cx, cy = (x_min + x_max) * 0.5, (y_min + y_max) * 0.5
-    w, h = (x_max - x_min) + 1.0, (y_max - y_min) + 1.0
-    dx = torch.log(torch.clamp(torch.abs((cx - cx.view(B, 1, -1)) / w), min=1e-3))
-    dy = torch.log(torch.clamp(torch.abs((cy - cy.view(B, 1, -1)) / h), min=1e-3))
-    dw = torch.log(w / w.view(B, 1, -1))
-    dh = torch.log(h / h.view(B, 1, -1))
-    pos = torch.stack((dx, dy, dw, dh), dim=-1)  # (B,O,O,4)
-    feat_range = torch.arange(dim_g / 8, device=f_g.device)
-    dim_mat = 1.0 / torch.pow(float(wave_len), feat_range / (dim_g / 8))   # (scalar base: no host-to-device copy, graph-capturable)
-    mul = (100.0 * pos).unsqueeze(-1) * dim_mat.view(1, 1, 1, 1, -1)
-    mul = mul.reshape(B, pos.size(1), pos.size(2), -1)
-    return torch.cat((torch.sin(mul), torch.cos(mul)), -1)
-
-
 class BoxMultiHeadedAttention(nn.Module):
     """reference model/resnet_generator_app_v2.py:123-214 (h = 1, dropout 0). `geometry=False` gives the
     VG variant whose logits ignore the box geometry (model/resnet_generator_vg.py:115)."""
@@ -319,33 +301,6 @@ def _view_keep_sink(t, B, O):
     v = t.view(B, O, -1)
     v._l2i_sink = t._l2i_sink
     return v
-
-
-def masks_to_layout(boxes, masks, H):
-    """reference utils/bilinear.py:137-192: box-relative grid_sample of (b,o,M,M) masks onto HxH."""
-    b, o, _ = boxes.shape
-    M = masks.size(2)
-    bx = boxes.reshape(b * o, 4, 1, 1)
-    x0, y0, ww, hh = bx[:, 0], bx[:, 1], bx[:, 2], bx[:, 3]
-    X = torch.linspace(0, 1, steps=H, device=boxes.device).view(1, 1, H)
-    Y = torch.linspace(0, 1, steps=H, device=boxes.device).view(1, H, 1)
-    X = ((X - x0) / ww).expand(b * o, H, H)
-    Y = ((Y - y0) / hh).expand(b * o, H, H)
-    grid = torch.stack([X, Y], dim=3).mul(2).sub(1)
-    return F.grid_sample(masks.reshape(b * o, 1, M, M), grid, mode="bilinear", align_corners=False).view(b, o, H, H)
-
-
-def bbox_mask(bbox, H, W):
-    """reference model/resnet_generator_app_v2.py:697-721: hard rectangle indicator."""
-    b, o, _ = bbox.shape
-    N = b * o
-    bb = bbox.float().reshape(N, 4)
-    x0, y0, ww, hh = bb[:, 0:1], bb[:, 1:2], bb[:, 2:3], bb[:, 3:4]
-    X = (torch.linspace(0, 1, steps=W, device=bbox.device).view(1, W) - x0) / ww
-    Y = (torch.linspace(0, 1, steps=H, device=bbox.device).view(1, H) - y0) / hh
-    xo = ((X < 0) | (X > 1)).view(N, 1, W).expand(N, H, W)
-    yo = ((Y < 0) | (Y > 1)).view(N, H, 1).expand(N, H, W)
-    return (1.0 - (xo | yo).float()).view(b, o, H, W)
 
 
 class MaskRegressNetv2(nn.Module):
@@ -394,12 +349,15 @@ class MaskRegressNetv2(nn.Module):
 def _with_zero_pool(fwd):
     """Run a forward inside a zero-pool step of its own when the caller (GanTrainer.step) has not opened one: the forward's
     ~30 small accumulation targets (batch statistics, ...) then come out of ONE pre-zeroed slab instead of one fill launch
-    each (sampling, the generator-forward benchmark)."""
+    each (sampling, the generator-forward benchmark). Only without an autograd tape: slices of the slab (batch statistics)
+    are saved for backward, and the NEXT stand-alone forward re-zeroes the slab -- two forwards alive before one backward
+    (f1 = G(z1); f2 = G(z2); loss(f1, f2).backward()) would hand the first graph zeroed statistics. With gradients enabled
+    a stand-alone forward therefore takes its buffers from torch.zeros as before."""
     import functools
 
     @functools.wraps(fwd)
     def run(self, z, *a, **k):
-        if ops.POOL.active or not z.is_cuda:
+        if ops.POOL.active or not z.is_cuda or torch.is_grad_enabled():
             return fwd(self, z, *a, **k)
         with ops.POOL.step(z.device, nfloats=2 << 20):
             return fwd(self, z, *a, **k)

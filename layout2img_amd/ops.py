@@ -150,9 +150,18 @@ LIVE_IMAGE_FRACTION = 1.0   # bench.py: real ROIs / ROI slots of its batch, so t
                             # count (`nimg`) are credited with the work on live rows only
 
 
+def dual_conv_ok(B, Ho, Wo):
+    """A dual launch (two weight packs, images [0, B/2) and [B/2, B)) needs every tile inside one half: tiles are at most 256
+    pixels = whole rows of min(Wo, 16) pixels. Otherwise conv_raw / wgrad_raw issue the halves as two launches."""
+    return B % 2 == 0 and ((B // 2) * Ho * min(Wo, 16)) % 256 == 0
+
+
 def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, up2=False, pool2=False, alpha=1.0,
-             want_f32=True, want_op=False, relu_op=False, want_raw=False, flops=None, nimg=None, stats=False, sc=None):
+             want_f32=True, want_op=False, relu_op=False, want_raw=False, flops=None, nimg=None, stats=False, sc=None,
+             wpack_b=None, _outs=None):
     """out = alpha*pool?(conv(up?(x))) + bias, masked, + res.  x_op (B,Hi,Wi,Ci) operand dtype.
+    wpack_b: DUAL launch (arena.DualPass) -- images [B/2, B) are multiplied with this pack (and sc["wpack_b"]), `nimg` counts
+    the live images of each half (l2i_conv2d_fwd_dual).
     nimg: 1-element int32 device tensor = number of leading images that are live (the rest come out as zeros).
     sc: a residual block's 1x1 shortcut to fold into this launch (l2i_conv2d_fwd_sc) -- dict(x_op, wpack, kpad, bias, up2,
     out, flops): the launch adds conv1x1(sc.x_op) + sc.bias on its pre-pool grid instead of reading a residual.
@@ -163,9 +172,24 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
     Ho, Wo = (2 * Hi, 2 * Wi) if up2 else (Hi, Wi)
     Hq, Wq = (Ho // 2, Wo // 2) if pool2 else (Ho, Wo)
     dev = x_op.device
-    out = torch.empty((B, Hq, Wq, co), dtype=torch.float32, device=dev) if want_f32 else None
-    out_op = torch.empty((B, Hq, Wq, co), dtype=x_op.dtype, device=dev) if want_op else None
-    out_raw = torch.empty((B, Hq, Wq, co), dtype=x_op.dtype, device=dev) if want_raw else None
+    if _outs is not None:   # (the halves of a dual call that cannot run as one launch: views of the caller's result tensors)
+        out, out_op, out_raw = _outs
+    else:
+        out = torch.empty((B, Hq, Wq, co), dtype=torch.float32, device=dev) if want_f32 else None
+        out_op = torch.empty((B, Hq, Wq, co), dtype=x_op.dtype, device=dev) if want_op else None
+        out_raw = torch.empty((B, Hq, Wq, co), dtype=x_op.dtype, device=dev) if want_raw else None
+    if wpack_b is not None and not dual_conv_ok(B, Ho, Wo):
+        assert not stats and B % 2 == 0
+        hb = B // 2
+        for k, wp in enumerate((wpack, wpack_b)):
+            sl = slice(k * hb, (k + 1) * hb)
+            sck = None if sc is None else dict(sc, x_op=sc["x_op"][sl], out=sc["out"][sl], wpack=sc["wpack_b"] if k else sc["wpack"],
+                                               wpack_b=None, flops=0.5 * sc["flops"])
+            conv_raw(x_op[sl], wp, kpad, co, kh, bias=bias, res=None if res is None else res[sl],
+                     relu_mask=None if relu_mask is None else relu_mask[sl], up2=up2, pool2=pool2, alpha=alpha, want_f32=want_f32,
+                     want_op=want_op, relu_op=relu_op, want_raw=want_raw, flops=None if flops is None else 0.5 * flops, nimg=nimg, sc=sck,
+                     _outs=tuple(None if t is None else t[sl] for t in (out, out_op, out_raw)))
+        return out, out_op, out_raw
     if res is not None:
         _chk(res, torch.float32)
         assert res.shape == (B, Hq, Wq, co), (res.shape, (B, Hq, Wq, co))
@@ -179,24 +203,31 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
             4 * (want_f32 + (res is not None)) + esz * (want_op + want_raw + (relu_mask is not None)))
         live = LIVE_IMAGE_FRACTION if nimg is not None else 1.0
         fl = flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci
+        if wpack_b is not None:
+            nbytes += wpack_b.numel() * esz
         if sc is not None:   # the folded shortcut's work and operands belong to this launch
             fl += sc["flops"]
-            nbytes += (sc["x_op"].numel() + sc["wpack"].numel()) * esz
+            nbytes += (sc["x_op"].numel() + sc["wpack"].numel() * (2 if wpack_b is not None else 1)) * esz
         end = TIMER.time("conv_igemm", live * fl, live * nbytes)
     st = _zeros((2, 1, co), dev) if (stats and out is not None and co <= 1024) else None
-    if sc is None:
+    if sc is None and wpack_b is None:
         _lib.call("l2i_conv2d_fwd", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
                   _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
                   float(alpha), _p(nimg), _p(st), _ws(dev) if st is not None else None, _stream())
+    elif sc is None:
+        _lib.call("l2i_conv2d_fwd_dual", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
+                  _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
+                  float(alpha), _p(nimg), None, None, None, None, None, None, 0, 0, 0, 0, 0, wpack_b.data_ptr(), None, _stream())
     else:
         sx = sc["x_op"]
         _chk(sx, x_op.dtype)
         assert res is None and relu_mask is None and sc["out"].shape == (B, Hq, Wq, co) and sx.shape[0] == B
-        _lib.call("l2i_conv2d_fwd_sc", x_op.data_ptr(), wpack.data_ptr(), _p(bias), None, None, _p(out), _p(out_op),
+        assert (wpack_b is None) == (sc.get("wpack_b") is None)
+        _lib.call("l2i_conv2d_fwd_dual", x_op.data_ptr(), wpack.data_ptr(), _p(bias), None, None, _p(out), _p(out_op),
                   _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
                   float(alpha), _p(nimg), _p(st), _ws(dev) if st is not None else None,
                   sx.data_ptr(), sc["wpack"].data_ptr(), _p(sc["bias"]), sc["out"].data_ptr(), sx.shape[1], sx.shape[2], sx.shape[3],
-                  int(sc["up2"]), sc["kpad"], _stream())
+                  int(sc["up2"]), sc["kpad"], _p(wpack_b), _p(sc.get("wpack_b")), _stream())
     if st is not None:
         out._l2i_stats = (st[0], st[1], out._version)
     if end is not None:
@@ -241,33 +272,54 @@ def wgrad_side(x_op, dy_op, dw, *args, **kw):
         wgrad_raw(x_op, dy_op, dw, *args, **kw)
     x_op.record_stream(side)
     dy_op.record_stream(side)
+    sc = kw.get("sc")
+    if sc is not None:   # the folded shortcut's operand and gradient targets are read / written by the same side-stream launch
+        for t in (sc.get("x_op"), sc.get("dw"), sc.get("dw_b"), sc.get("dbias")):
+            if t is not None:
+                t.record_stream(side)
 
 
-def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None, nimg=None, dbias=None, sc=None):
+def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None, nimg=None, dbias=None, sc=None, dw_b=None):
     """dbias: optional (co,) f32 tensor the bias gradient is atomically added to (summed from the staged dY tiles).
+    dw_b: DUAL launch (arena.DualPass) -- the gradient of images [B/2, B) goes to this accumulator (and sc["dw_b"]); `nimg` counts
+    the live images of each half (l2i_conv2d_wgrad_dual).
     sc: a block's 1x1 shortcut that received the same dY -- dict(x_op (B, Ho, Wo, Ci_sc), dw, ldw, dbias, flops): its weight (and
     bias) gradient become extra column tiles of this launch (l2i_conv2d_wgrad_sc)."""
     _chk(x_op)
     _chk(dy_op, x_op.dtype)
     B, Hi, Wi, Ci = x_op.shape
     Ho, Wo = (2 * Hi, 2 * Wi) if up2 else (Hi, Wi)
+    if dw_b is not None and (B % 2 or ((B // 2) * Ho * Wo) % 64):   # halves that are not whole pixel steps: two launches
+        hb = B // 2
+        assert B % 2 == 0
+        for k, d in enumerate((dw, dw_b)):
+            sl = slice(k * hb, (k + 1) * hb)
+            sck = None if sc is None else dict(sc, x_op=sc["x_op"][sl], dw=sc["dw_b"] if k else sc["dw"], dw_b=None, flops=0.5 * sc["flops"])
+            wgrad_raw(x_op[sl], dy_op[sl], d, ldw, co, kh, up2=up2, pool2=pool2, alpha=alpha, flops=None if flops is None else 0.5 * flops,
+                      nimg=nimg, dbias=dbias, sc=sck)
+        return
     end = None
     if TIMER is not None:
         live = LIVE_IMAGE_FRACTION if nimg is not None else 1.0
         fl = flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci
         end = TIMER.time("conv_wgrad", live * (fl + (sc["flops"] if sc is not None else 0.0)))
     scratch, nscratch = _lib.wgrad_scratch(x_op.device)
-    if sc is None:
+    if sc is None and dw_b is None:
         _lib.call("l2i_conv2d_wgrad", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
                   Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch, _stream())
+    elif sc is None:
+        _lib.call("l2i_conv2d_wgrad_dual", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
+                  Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch,
+                  None, None, 0, 0, 0, None, dw_b.data_ptr(), None, _stream())
     else:
         sx = sc["x_op"]
         _chk(sx, x_op.dtype)
         su = int(bool(sc.get("up2", False)))
         assert sx.shape[:3] == (B, Ho >> su, Wo >> su)
-        _lib.call("l2i_conv2d_wgrad_sc", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
+        assert (dw_b is None) == (sc.get("dw_b") is None)
+        _lib.call("l2i_conv2d_wgrad_dual", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
                   Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch,
-                  sx.data_ptr(), sc["dw"].data_ptr(), sx.shape[3], su, sc["ldw"], _p(sc["dbias"]), _stream())
+                  sx.data_ptr(), sc["dw"].data_ptr(), sx.shape[3], su, sc["ldw"], _p(sc["dbias"]), _p(dw_b), _p(sc.get("dw_b")), _stream())
     if end is not None:
         end.record()
 
@@ -497,14 +549,14 @@ class FusedConvFn(Function):
             assert holder.kh == 1 and res is None and not emit and not op_out and pro.kind not in ("norm",)
             Hq, Wq = (Ho // 2, Wo // 2) if pool2 else (Ho, Wo)
             out = torch.empty((B, Hq, Wq, holder.co_p), dtype=torch.float32, device=x.device)
-            out._l2i_lazy_sc = dict(x_op=x_op, wpack=pc.fwd_pack(holder), kpad=holder.kpad, bias=bias_p, up2=bool(up2),
+            out._l2i_lazy_sc = dict(x_op=x_op, wpack=pc.fwd_pack(holder), wpack_b=pc.fwd_pack_b(holder), kpad=holder.kpad, bias=bias_p, up2=bool(up2),
                                     pool2=bool(pool2), nimg=nimg, flops=flops, ver=out._version, holder=holder, wgrad_done=False)
             ctx.lazy = out._l2i_lazy_sc   # (shared with the consumer: its backward may compute this node's weight gradient, see below)
         else:
         # `op_out`: the ONLY reader of the result is a pre-activation conv -- the epilogue writes relu(result) in the operand
         # dtype and nothing else; that tensor is the autograd edge (its gradient arrives, and is used, in the operand dtype)
             out, o_relu, o_raw = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p,
-                                          res=None if sc is not None else res, sc=sc,
+                                          res=None if sc is not None else res, sc=sc, wpack_b=pc.fwd_pack_b(holder),
                                           up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops, nimg=nimg,
                                           want_f32=not op_out, want_op=op_out or "relu" in emit, relu_op=True,
                                           want_raw="raw" in emit, stats="stats" in emit and not op_out)
@@ -565,10 +617,10 @@ class FusedConvFn(Function):
                 bgs = hs.bias.grad if hs.bias is not None else None
                 direct_s = hs.bias is None or (bgs is not None and hs.co == hs.co_p and bgs.is_contiguous() and bgs.dtype == torch.float32)
                 if direct_s and hs.co_p == h.co_p:
-                    scw = dict(x_op=sl["x_op"], dw=pc.dw_slice(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"], up2=sl["up2"])
+                    scw = dict(x_op=sl["x_op"], dw=pc.dw_slice(hs), dw_b=pc.dw_slice_b(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"], up2=sl["up2"])
                     sl["wgrad_done"] = True
             wgrad_side(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
-                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw)
+                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw, dw_b=pc.dw_slice_b(h))
         dx = d_mask = d_w = d_b = None
         if need_x or need_mod:
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
@@ -580,7 +632,7 @@ class FusedConvFn(Function):
             joined = ctx.join[0].take() if ctx.join is not None and ctx.join[1] == "take" and need_x else None
             dxo, _, dx_op = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
                                      pool2=ctx.up2, alpha=alpha, flops=ctx.flops, nimg=ctx.nimg, want_raw=emit_raw,
-                                     want_f32=not op_in, res=joined if pro.kind != "norm" else None)
+                                     want_f32=not op_in, res=joined if pro.kind != "norm" else None, wpack_b=pc.dgrad_pack_b(h))
             if op_in:
                 dxo = dx_op
             elif emit_raw:
@@ -790,6 +842,34 @@ class ArenaWeightFn(Function):
 
 def arena_weight(holder, pc):
     return ArenaWeightFn.apply(holder.w, holder, pc)
+
+
+class SplitHalvesFn(Function):
+    """(2n, ...) -> (x[:n], x[n:]) as two autograd edges whose gradients come back as ONE concatenation (plain slicing
+    would materialise two zero-filled full-size gradients and add them). The per-pass heads of a dual discriminator pass
+    (arena.DualPass) read their half of the trunk's rows through this."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n = x.shape[0] // 2
+        ctx.meta = (x.shape, x.dtype, x.device)
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        shape, dtype, dev = ctx.meta
+        n = shape[0] // 2
+        if ga is None and gb is None:
+            return None
+        half = (n,) + tuple(shape[1:])
+        ga = torch.zeros(half, dtype=dtype, device=dev) if ga is None else ga
+        gb = torch.zeros(half, dtype=dtype, device=dev) if gb is None else gb
+        return torch.cat((ga, gb))
+
+
+def split_halves(x):
+    assert x.shape[0] % 2 == 0
+    return SplitHalvesFn.apply(x)
 
 
 # ----------------------------------------------------------------------------- ROIAlign
@@ -1367,6 +1447,8 @@ class LatentFn(Function):
     def forward(ctx, z, emb, y, ld, op_dtype):
         z, emb = _chk(z.contiguous(), torch.float32), _chk(emb, torch.float32)
         y = y.contiguous()
+        if y.dtype != torch.int64:   # (the kernel reads long long labels)
+            y = y.to(torch.int64)
         rows, Z, E = y.numel(), z.shape[-1], emb.shape[1]
         dev = z.device
         out = torch.empty((rows, 1, 1, ld), dtype=torch.float32, device=dev)

@@ -16,6 +16,18 @@ import torch
 import torch.distributed as dist
 
 
+# L2I_FORCE_COLLECTIVES=1: a ONE-rank process group still runs every collective of the data-parallel iteration (SyncBN
+# statistics, valid-ROI count, flat-gradient all-reduces on their own group, parameter broadcasts) instead of
+# short-circuiting them -- on a one-GPU box this is the only way the RCCL communicator streams, the deferred generator
+# step and graph capture with collectives inside (L2I_DDP_GRAPH=1) ever execute. Results equal the short-circuited path.
+FORCE = os.environ.get("L2I_FORCE_COLLECTIVES", "0") == "1"
+
+
+def active():
+    """True when the iteration must issue its collectives: more than one rank, or the forced one-rank group."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
+
+
 def init_from_env(backend=None):
     """Initialise the process group from torchrun's environment. Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -26,7 +38,7 @@ def init_from_env(backend=None):
     backend = os.environ.get("L2I_DIST_BACKEND", backend)
     if "L2I_FORCE_DEVICE" in os.environ:
         local = int(os.environ["L2I_FORCE_DEVICE"])
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -51,7 +63,7 @@ def grad_group():
     main stream would wait for all of it -- no overlap. Created collectively (every rank calls this at the same point:
     GanTrainer.__init__); None at world size 1."""
     global _GRAD_GROUP
-    if world_size() == 1:
+    if not active():
         return None
     if _GRAD_GROUP is None:
         _GRAD_GROUP = dist.new_group()
@@ -61,7 +73,7 @@ def grad_group():
 def allreduce_flat_(flat_grad, chunk_bytes=64 << 20, async_op=False, group=None):
     """SUM all-reduce of a flat buffer in large contiguous chunks (in place). Returns work handles.
     group: the process group to run on (grad_group() for gradient exchanges that should overlap other collectives)."""
-    if world_size() == 1:
+    if not active():
         return []
     n = flat_grad.numel()
     step = max(1, chunk_bytes // flat_grad.element_size())
@@ -79,7 +91,7 @@ def sync_bn_stats(a, b, count):
     Forward: (sum, sqsum, count) -> returns global count. Backward: (s1, s2, None) -> returns None.
     """
     ws = world_size()
-    if ws == 1:
+    if not active():
         return count
     adjacent = (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.device == b.device and
                 a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and
@@ -97,11 +109,11 @@ def sync_bn_stats(a, b, count):
 
 def global_count(local_count_tensor):
     """All-reduce a 1-element f32 device tensor holding a row count (stays on the device)."""
-    if world_size() > 1:
+    if active():
         dist.all_reduce(local_count_tensor, op=dist.ReduceOp.SUM)
     return local_count_tensor
 
 
 def broadcast_flat_(flat, src=0):
-    if world_size() > 1:
+    if active():
         dist.broadcast(flat, src=src)

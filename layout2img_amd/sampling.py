@@ -32,24 +32,38 @@ def _opt_state(o):
     return dict(state=out, t=int(o.t_dev.item()), lr=o.lr, betas=tuple(o.betas), eps=o.eps)   # (the device-side count: graph replays advance only that one)
 
 
-def _load_opt_state(o, st):
+def _load_opt_state(o, st, restore_hyper=False):
+    """restore_hyper: also take lr / betas / eps from the file (default: keep the optimizer's own, i.e. the command line's
+    --g_lr / --d_lr win on resume). Files of earlier revisions (flat moments 'm' / 'v' / 't') load when the flat layout still
+    matches."""
     flat = o.net.flat
-    names = {n for n, _ in flat._params}
-    if set(st["state"]) != names:
-        raise RuntimeError("optimizer checkpoint does not match this network: "
-                           f"{len(names - set(st['state']))} parameters missing, {len(set(st['state']) - names)} unknown")
-    with torch.no_grad():
-        o.m.zero_(), o.v.zero_()
-        for name, p in flat._params:
-            off, k = flat.offsets[name], p.numel()
-            m, v = st["state"][name]
-            if tuple(m.shape) != tuple(p.shape):
-                raise RuntimeError(f"optimizer checkpoint: {name} has shape {tuple(m.shape)}, the model {tuple(p.shape)}")
-            o.m[off:off + k].copy_(m.reshape(-1))
-            o.v[off:off + k].copy_(v.reshape(-1))
+    if "state" not in st and "m" in st and "v" in st:   # legacy: the flat moment buffers themselves
+        m, v = st["m"], st["v"]
+        if m.numel() != o.m.numel() or v.numel() != o.v.numel():
+            raise RuntimeError("optimizer checkpoint in the legacy flat format does not match this network's flat parameter "
+                               f"layout ({m.numel()} vs {o.m.numel()} floats): re-save it with the current revision")
+        with torch.no_grad():
+            o.m.copy_(m.reshape(-1)), o.v.copy_(v.reshape(-1))
+    else:
+        if "state" not in st:
+            raise RuntimeError(f"optimizer checkpoint has neither 'state' nor legacy 'm' / 'v' entries (keys: {sorted(st)})")
+        names = {n for n, _ in flat._params}
+        if set(st["state"]) != names:
+            raise RuntimeError("optimizer checkpoint does not match this network: "
+                               f"{len(names - set(st['state']))} parameters missing, {len(set(st['state']) - names)} unknown")
+        with torch.no_grad():
+            o.m.zero_(), o.v.zero_()
+            for name, p in flat._params:
+                off, k = flat.offsets[name], p.numel()
+                m, v = st["state"][name]
+                if tuple(m.shape) != tuple(p.shape):
+                    raise RuntimeError(f"optimizer checkpoint: {name} has shape {tuple(m.shape)}, the model {tuple(p.shape)}")
+                o.m[off:off + k].copy_(m.reshape(-1))
+                o.v[off:off + k].copy_(v.reshape(-1))
     o.t = int(st["t"])
     o.t_dev.fill_(o.t)
-    o.lr, o.betas, o.eps = float(st["lr"]), tuple(st["betas"]), float(st["eps"])
+    if restore_hyper and "lr" in st:
+        o.lr, o.betas, o.eps = float(st["lr"]), tuple(st["betas"]), float(st["eps"])
 
 
 def load_reference_checkpoint(net, state, prefix="module."):
@@ -96,9 +110,10 @@ def save_checkpoint(out_path, epoch, netG, netD, g_opt=None, d_opt=None, prefix=
     return paths
 
 
-def load_checkpoint(out_path, epoch, netG, netD, g_opt=None, d_opt=None, prefix="module."):
+def load_checkpoint(out_path, epoch, netG, netD, g_opt=None, d_opt=None, prefix="module.", restore_hyper=False):
     """Resume (train_context_app_v2.py:71-105): strip the prefix, keep the keys the models have, load; restore the Adam
-    state when `opt_<epoch>.pth` exists. Returns the epoch to continue from."""
+    state (moments, step count) when `opt_<epoch>.pth` exists -- lr / betas / eps stay the optimizers' own (the command
+    line's) unless restore_hyper. Returns the epoch to continue from."""
     d = os.path.join(out_path, "model")
     for name, net in (("G", netG), ("D", netD)):
         load_reference_checkpoint(net, os.path.join(d, f"{name}_{epoch}.pth"), prefix)
@@ -106,7 +121,7 @@ def load_checkpoint(out_path, epoch, netG, netD, g_opt=None, d_opt=None, prefix=
     if g_opt is not None and d_opt is not None and os.path.exists(p):
         st = torch.load(p, map_location="cpu")
         for k, o in (("G", g_opt), ("D", d_opt)):
-            _load_opt_state(o, st[k])   # per parameter name; lr / betas / eps restored too
+            _load_opt_state(o, st[k], restore_hyper)   # per parameter name
     return epoch
 
 

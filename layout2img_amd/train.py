@@ -75,19 +75,24 @@ def main(argv=None):
     # batch: shapes are fixed, drop_last) as a HIP graph and replayed with each batch copied into the graph's static inputs
     # (GanTrainer.capture / step_graphed -- what bench.py times). The latents z are drawn per iteration and passed in, as the
     # eager step would draw them. Data parallel runs stay eager (collectives are not captured).
-    graphed = False
+    graphed = tried = False
     z_dim, n_obj = trainer.z_dim, None
 
     def run(real, label, bbox):
-        nonlocal graphed, n_obj
+        nonlocal graphed, tried, n_obj
         b, o = label.shape[0], label.shape[1]
         z = torch.randn(b, o, z_dim, device=real.device)
         z_im = torch.randn(b, 128, device=real.device)
         if world == 1 and not args.no_graph:
-            if not graphed:
+            if not tried:   # ONE attempt: a failed capture falls back to the eager loop for the rest of the run
                 from layout2img_amd.trainer import restore_state, snapshot_state
+                tried = True
                 st = snapshot_state(trainer)       # the capture runs warm-up iterations on this batch: undo them, the
-                graphed = trainer.capture(real, label, bbox, z, z_im)
+                try:
+                    graphed = trainer.capture(real, label, bbox, z, z_im)
+                except Exception as e:
+                    print(f"[train] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", flush=True)
+                    graphed = False
                 restore_state(trainer, st)         # first REPLAY is the first training iteration
                 n_obj = (b, o)
             if graphed and (b, o) == n_obj:

@@ -63,21 +63,31 @@ class GanTrainer:
         self.g_opt, self.d_opt = FlatAdam(netG, g_lr), FlatAdam(netD, d_lr)
         self.l_obj, self.l_app, self.l_img, self.z_dim = lamb_obj, lamb_app, lamb_img, z_dim
         self.world = parallel.world_size()
+        self.dp = parallel.active()   # collectives are issued (world > 1, or the forced one-rank group: parallel.FORCE)
         # D(real) on a side stream next to G's forward (L2I_OVERLAP=0 turns it off)
         self.overlap = os.environ.get("L2I_OVERLAP", "1") != "0"
         self._side = None
+        # D(real) and D(fake) of the discriminator step as ONE batch of 2b images (CombineDiscriminator.forward_dual): every
+        # conv / data-gradient / weight-gradient launch of the D step then has twice the tiles (at b = 32 a single pass is ONE
+        # round of workgroups per launch, so prologue, K loop and epilogue add up instead of overlapping), with each pass's own
+        # spectral-norm iteration, packs and gradient accumulator as in the reference. Measured (round 4, 128x128, b = 32, same
+        # box): 52 conv launches fewer per iteration, conv fraction of the MFMA peak 0.300 -> 0.324, kernel time of the iteration
+        # 22.9 -> 21.7 ms under the profiler -- but the two-pass form runs D(real) on a side stream next to G's forward and next to
+        # D(fake)'s backward, which hides ~2 ms of kernel time that the one-batch form (it needs G's output before it can start)
+        # cannot hide: 20.5 ms against 21.4 ms per iteration, replayed or eager. OFF by default; L2I_DUAL_D=1 / `dual_d = True`.
+        self.dual_d = os.environ.get("L2I_DUAL_D", "0") != "0"
         # Data parallel: G's gradient all-reduce (163 MB) is launched at the end of an iteration and waited for -- together
         # with G's Adam step -- only when the NEXT iteration needs G's weights, i.e. after that iteration's D(real) pass
         # has been enqueued on the side stream: the collective overlaps D(real). (D's all-reduce has nothing independent
         # next to it: the G step reads D's updated weights at once.) flush() completes a pending step; L2I_DEFER_G=0: off.
         # (one GPU: off by default -- L2I_DEFER_G=1 turns it on there too: G's spectral-norm backward + Adam then run next to the
         #  following iteration's D(real) pass instead of at the end of their own iteration)
-        self.defer_g = self.overlap and os.environ.get("L2I_DEFER_G", "1" if self.world > 1 else "0") != "0"
+        self.defer_g = self.overlap and os.environ.get("L2I_DEFER_G", "1" if self.dp else "0") != "0"
         self._pending_g = False
         # whoever reads the generator's parameters from outside the loop (sampling.sample, checkpoints) completes a deferred
         # step first: the hook rides on the network
         netG._l2i_flush = self.flush
-        if self.world > 1:
+        if self.dp:
             self.g_opt.group = self.d_opt.group = parallel.grad_group()
             netG.sync = parallel.sync_bn_stats
             parallel.broadcast_flat_(netG.flat.data)
@@ -101,7 +111,7 @@ class GanTrainer:
             self._pending_g = False
 
     def _counts(self, valid, b):
-        if self.world == 1:
+        if not self.dp:
             return None, None
         n_roi = parallel.global_count(valid.sum().float().view(1))
         n_img = torch.full((1,), float(b * self.world), device=valid.device)
@@ -131,7 +141,27 @@ class GanTrainer:
         valid = layout[2]
         # ---- D step (reference :156-174)
         netD.zero_grad()
-        if self.overlap:
+        if self.dual_d:
+            # both passes' power iterations + weight packs need only D's weights: on the side stream, next to G's forward
+            cur = torch.cuda.current_stream()
+            if self.overlap:
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    pcs = (netD.arena.prepare(training=netD.training, need_wgrad=True),    # reference order: real first (:158), then fake (:167)
+                           netD.arena.prepare(training=netD.training, need_wgrad=True))
+            else:
+                pcs = None
+            n_roi, n_img = self._counts(valid, b)
+            self.flush()
+            fake = netG(z, bbox, z_im=z_im, y=y)
+            if self.overlap:
+                cur.wait_stream(self._side)
+            outs_r, outs_f, _, _ = netD.forward_dual(real, fake.detach(), bbox, y, pcs=pcs, layout=layout)
+            d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
+            d_loss_fake = self._d_terms(outs_f, valid, 1, n_roi, n_img)
+        elif self.overlap:
             # D(real) does not depend on the generator: it runs on a side stream next to G's forward (and, through
             # autograd's stream bookkeeping, its backward runs next to D(fake)'s). D has no batch norm, so the side
             # stream carries no collective.
@@ -151,18 +181,19 @@ class GanTrainer:
             self.flush()   # the previous iteration's G all-reduce + Adam: behind D(real)'s launches, in front of G's forward
             fake = netG(z, bbox, z_im=z_im, y=y)
             cur.wait_stream(self._side)
+            *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y, pc=pc_fake, layout=layout)
+            d_loss_fake = self._d_terms(outs_f, valid, 1, n_roi, n_img)
         else:
             self.flush()
-            pc_fake = None
             *outs_r, _, _ = netD.forward_padded(real, bbox, y, layout=layout)
             n_roi, n_img = self._counts(valid, b)
             d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
             fake = netG(z, bbox, z_im=z_im, y=y)
-        *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y, pc=pc_fake, layout=layout)
-        d_loss_fake = self._d_terms(outs_f, valid, 1, n_roi, n_img)
+            *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y, layout=layout)
+            d_loss_fake = self._d_terms(outs_f, valid, 1, n_roi, n_img)
         d_loss = d_loss_real + d_loss_fake
         d_loss.backward()
-        if self.overlap:
+        if self.overlap and not self.dual_d:
             # D(real)'s backward ran on the side stream; what it wrote outside autograd's view (weight-gradient
             # accumulators, direct bias-gradient atomics) and the pack buffers it read must be ordered before the
             # optimizer step on this stream explicitly (capture-safe: one event).
@@ -194,8 +225,10 @@ class GanTrainer:
     # host time as the GPU takes (measured 37 ms vs 38 ms), so a captured graph removes the host from the loop.
     def capture(self, real, label, bbox, z, z_im=None):
         """Capture one iteration on static copies of the inputs (shapes are fixed: the padded-ROI form has no host
-        syncs). Returns True on success; afterwards `step_graphed` copies new inputs in and replays."""
-        if self.world > 1:
+        syncs). Returns True on success; afterwards `step_graphed` copies new inputs in and replays.
+        z = None: the latents are drawn INSIDE the captured iteration (torch's graph-safe generator advances its Philox
+        offset per replay), as the reference draws them per iteration (train_context_app_v2.py:165)."""
+        if self.dp:
             # Data parallel: the iteration's collectives (SyncBN statistics, ROI count, flat-gradient all-reduces) are RCCL
             # calls on communicator streams that fork from / join the capture stream, which torch can capture into the graph
             # like any other stream dependency -- but this path has never run on a multi-GPU node (none was available to
@@ -205,6 +238,11 @@ class GanTrainer:
             import torch.distributed as dist
             if os.environ.get("L2I_DDP_GRAPH", "0") != "1" or dist.get_backend() != "nccl":
                 return False
+            # A replayed iteration must be self-contained: the deferred generator step (all-reduce launched in one iteration,
+            # waited for in the next, through work handles that would belong to the capture) is an eager-mode overlap. In the
+            # graph the generator's all-reduce, its wait and its Adam step stay inside their own iteration.
+            self.flush()
+            self.defer_g = False
         if ops.TIMER is not None:
             raise RuntimeError("capture with the kernel timer on")
         self._static = [None if t is None else t.detach().clone() for t in (real, label, bbox, z, z_im)]
@@ -228,7 +266,9 @@ class GanTrainer:
             net.arena.free_packs = []
         graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph, stream=side):
+            # (data parallel: RCCL's watchdog thread polls its own events while this thread captures; in the default "global"
+            #  capture mode any other thread's event query invalidates the capture -- hipErrorStreamCaptureInvalidated, measured)
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if self.dp else "global"):
                 self._graph_out = self.step(*self._static)
         except Exception:
             self._graph = None
@@ -240,7 +280,9 @@ class GanTrainer:
         return True
 
     def step_graphed(self, real, label, bbox, z, z_im=None):
-        for dst, src in zip(self._static, (real, label, bbox, z, z_im)):
+        for name, dst, src in zip(("real", "label", "bbox", "z", "z_im"), self._static, (real, label, bbox, z, z_im)):
+            if (dst is None) != (src is None):
+                raise RuntimeError(f"step_graphed: `{name}` was {'drawn inside' if dst is None else 'an input of'} the captured iteration")
             if dst is not None and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self._graph.replay()
@@ -267,6 +309,9 @@ def restore_state(tr, st):
             for b, v in zip(n.buffers(), bufs):
                 b.copy_(v)
             n.arena.drop_pending()
+            n.flat.fresh = False   # (whatever the undone iterations left in the gradient buffers: the next zero_grad() resets it)
+        tr._pending_g = False      # a deferred generator step of the undone iterations is dropped with them
+        tr.g_opt._works = tr.d_opt._works = None
         for o, (m, v, t, td) in zip((tr.g_opt, tr.d_opt), st["opt"]):
             o.m.copy_(m), o.v.copy_(v), o.t_dev.copy_(td)
             o.t = t

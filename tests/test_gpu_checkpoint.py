@@ -49,6 +49,22 @@ def test_save_resume_round_trip(tmp_path):
     assert torch.equal(g2.flat.data, g.flat.data) and torch.equal(d2.flat.data, d.flat.data)
     assert torch.equal(g2.arena.sn_flat.data, g.arena.sn_flat.data)
     assert tr2.g_opt.t == tr.g_opt.t == 2 and int(tr2.d_opt.t_dev) == 2
+    # resume keeps the command line's learning rate unless asked to restore the file's; files of earlier revisions (flat
+    # moments m / v / t) still load; anything else is a clear error
+    from layout2img_amd.sampling import _load_opt_state, _opt_state
+    tr3 = L.GanTrainer(g2, d2, g_lr=3e-4)
+    st = _opt_state(tr.g_opt)
+    _load_opt_state(tr3.g_opt, st)
+    assert tr3.g_opt.lr == 3e-4 and torch.equal(tr3.g_opt.m, tr.g_opt.m)
+    _load_opt_state(tr3.g_opt, st, restore_hyper=True)
+    assert tr3.g_opt.lr == tr.g_opt.lr
+    tr3.g_opt.m.zero_()
+    _load_opt_state(tr3.g_opt, dict(m=tr.g_opt.m.cpu(), v=tr.g_opt.v.cpu(), t=2))
+    assert torch.equal(tr3.g_opt.m, tr.g_opt.m) and tr3.g_opt.t == 2
+    with pytest.raises(RuntimeError, match="legacy flat format"):
+        _load_opt_state(tr3.g_opt, dict(m=torch.zeros(8), v=torch.zeros(8), t=1))
+    with pytest.raises(RuntimeError, match="neither"):
+        _load_opt_state(tr3.g_opt, dict(t=1))
     real, label, bbox, z, z_im = batch
     g.eval(), g2.eval()
     with torch.no_grad():

@@ -147,3 +147,72 @@ def test_two_rank_gradients_equal_single_process_at_128(dt_name):
         err = float((multi[k] - b).norm() / b.norm())
         assert err < 2.5 * floor + 1e-5, (k, err, floor)
         assert err < (5e-3 if dt_name == "float32" else 8e-2), (k, err)   # (and an absolute ceiling, far below a broken exchange)
+
+
+def _run_forced(rank, port, out, force, graph):
+    """One rank on cuda:0. force: L2I_FORCE_COLLECTIVES=1 -> a one-rank RCCL ("nccl") process group whose collectives all run
+    (SyncBN statistics, ROI count, flat-gradient all-reduces on their own group, the deferred generator step); graph: the
+    iteration is additionally captured with the collectives inside (L2I_DDP_GRAPH=1) and replayed."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      L2I_FORCE_COLLECTIVES="1" if force else "0", L2I_DDP_GRAPH="1" if graph else "0")
+    import torch.distributed as dist
+    from layout2img_amd import parallel
+    from layout2img_amd.trainer import restore_state, snapshot_state
+    calls = {"n": 0}
+    if force:
+        parallel.init_from_env()
+        assert parallel.FORCE and parallel.active() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        real_all_reduce = dist.all_reduce
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return real_all_reduce(*a, **k)
+        dist.all_reduce = counting
+    else:
+        assert not parallel.active()
+    torch.cuda.set_device(0)
+    g, d, tr = _build()
+    assert tr.dp == force and tr.defer_g == force
+    args = [t.to(DEV) for t in _batch()]
+    if graph:
+        st = snapshot_state(tr)
+        assert tr.capture(*args)          # two warm-up iterations + the capture, collectives recorded on the capture stream
+        restore_state(tr, st)
+        for _ in range(2):
+            r = tr.step_graphed(*args)
+    else:
+        for _ in range(2):
+            r = tr.step(*args)
+    assert tr._pending_g == (force and not graph)   # (a captured iteration keeps its generator step inside the graph)
+    tr.flush()
+    torch.cuda.synchronize()
+    out["g"] = g.flat.data.detach().cpu()
+    out["d"] = d.flat.data.detach().cpu()
+    out["d_loss"], out["g_loss"] = float(r["d_loss"]), float(r["g_loss"])
+    out["bn_mean"] = g.res5.b2.batch_norm2d.running_mean.detach().cpu()
+    out["collectives"] = calls["n"]
+    if force:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_forced_one_rank_collectives_over_rccl(graph):
+    """RCCL carries the data-parallel iteration on the one test GPU: with L2I_FORCE_COLLECTIVES=1 a ONE-rank "nccl" group stops
+    short-circuiting (parallel.active), so the SyncBN / ROI-count / gradient all-reduces, the gradient group of its own, the
+    deferred generator step and -- graph=True -- capture + replay with the collectives inside (L2I_DDP_GRAPH=1) all execute
+    on RCCL communicator streams. A SUM over one rank is the identity: losses, parameters and synchronised statistics must
+    equal the short-circuited single-process run (same bar as the two-rank test above)."""
+    mgr = mp.Manager()
+    plain, forced = mgr.dict(), mgr.dict()
+    mp.spawn(_run_forced, args=(_free_port(), plain, False, False), nprocs=1, join=True)
+    mp.spawn(_run_forced, args=(_free_port(), forced, True, graph), nprocs=1, join=True)
+    assert plain["collectives"] == 0 and forced["collectives"] >= 20, forced["collectives"]   # (per eager iteration: ~30 SyncBN pairs + count + gradients)
+    assert abs(forced["d_loss"] - plain["d_loss"]) < 2e-4 * abs(plain["d_loss"]) + 1e-5
+    assert abs(forced["g_loss"] - plain["g_loss"]) < 2e-4 * abs(plain["g_loss"]) + 1e-5
+    assert torch.allclose(forced["bn_mean"], plain["bn_mean"], atol=2e-3)
+    for k in ("g", "d"):
+        a, b = forced[k], plain[k]
+        frac = float(((a - b).abs() < 1e-4).float().mean())
+        assert frac > 0.97, (k, frac)
+        assert float((a - b).abs().max()) <= 2e-3

@@ -1,6 +1,6 @@
-"""The layout-side kernels (csrc/layout.hip) against the chains of torch ops they replace -- the same compositions the
-oracle uses (oracle/model.py: box_relational_embedding, masks_to_layout, bbox_mask, LayerNorm, PSP stages), forward
-and backward, through the C ABI."""
+"""The layout-side kernels (csrc/layout.hip) through the C ABI, forward and backward: box geometry, mask layout and box
+indicator against the oracle's own functions (oracle/model.py: box_relational_embedding, masks_to_layout, bbox_mask -- run on the
+CPU, they are the pinned restatement of the reference), the rest against the chains of torch ops they replace."""
 import math
 
 import pytest
@@ -24,36 +24,53 @@ def _boxes(b, o, g):
 
 
 def test_box_geometry_matches_the_torch_chain():
-    from layout2img_amd import ops, generator as G
+    from layout2img_amd import ops
+    from oracle import model as O
     g = torch.Generator().manual_seed(0)
     b, o = 5, 8
-    bbox = _boxes(b, o, g).to(_dev())
-    lin = torch.nn.Linear(64, 1).to(_dev())
-    ref = F.relu(lin(G.box_relational_embedding(bbox).view(-1, 64))).view(b, o, o)
-    gout = torch.randn(b, o, o, generator=g).to(_dev())
+    bbox = _boxes(b, o, g)
+    lin = torch.nn.Linear(64, 1)
+    ref = F.relu(lin(O.box_relational_embedding(bbox).view(-1, 64))).view(b, o, o)   # the oracle's function, on the CPU
+    gout = torch.randn(b, o, o, generator=g)
     rw, rb = torch.autograd.grad(ref, (lin.weight, lin.bias), gout)
-    out = ops.box_geometry(bbox, lin.weight, lin.bias)
-    dw, db = torch.autograd.grad(out, (lin.weight, lin.bias), gout)
-    assert float((out - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
-    assert float((dw - rw).abs().max()) < 1e-4 * max(1.0, float(rw.abs().max()))
-    assert float((db - rb).abs().max()) < 1e-4 * max(1.0, float(rb.abs().max()))
+    ref = ref.detach()
+    dlin = torch.nn.Linear(64, 1).to(_dev())
+    dlin.load_state_dict(lin.state_dict())
+    out = ops.box_geometry(bbox.to(_dev()), dlin.weight, dlin.bias)
+    dw, db = torch.autograd.grad(out, (dlin.weight, dlin.bias), gout.to(_dev()))
+    # (sin / cos of arguments up to ~700 rad: the device's f32 argument reduction differs from the host's in the last bits)
+    assert float((out.cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((dw.cpu() - rw).abs().max()) < 5e-4 * max(1.0, float(rw.abs().max()))
+    assert float((db.cpu() - rb).abs().max()) < 5e-4 * max(1.0, float(rb.abs().max()))
 
 
 @pytest.mark.parametrize("o", [8, 31])
 def test_layout_masks_match_grid_sample_and_bbox_mask(o):
-    from layout2img_amd import ops, generator as G
+    from layout2img_amd import ops
+    from oracle import model as O
     g = torch.Generator().manual_seed(1)
     b, M, H = 3, 16, 64
-    bbox = _boxes(b, o, g).to(_dev())
-    m = torch.randn(b * o, M, M, 8, generator=g).to(_dev()).requires_grad_(True)
-    ref = G.masks_to_layout(bbox, torch.sigmoid(m[..., 0]).view(b, o, M, M), H)
-    gout = torch.randn(b, o, H, H, generator=g).to(_dev())
-    (rm,) = torch.autograd.grad(ref, m, gout)
-    out, boxm = ops.layout_masks(m, bbox, H, True)
-    (dm,) = torch.autograd.grad(out, m, gout)
-    assert float((out - ref).abs().max()) < 2e-6
-    assert torch.equal(boxm, G.bbox_mask(bbox, H, H))
-    assert float((dm - rm).abs().max()) < 1e-5 * max(1.0, float(rm.abs().max()))
+    bbox = _boxes(b, o, g)
+    m0 = torch.randn(b * o, M, M, 8, generator=g)
+    mc = m0.clone().requires_grad_(True)
+    ref = O.masks_to_layout(bbox, torch.sigmoid(mc[..., 0]).view(b, o, M, M), H)   # the oracle's functions, on the CPU
+    gout = torch.randn(b, o, H, H, generator=g)
+    (rm,) = torch.autograd.grad(ref, mc, gout)
+    ref = ref.detach()
+    m = m0.to(_dev()).requires_grad_(True)
+    out, boxm = ops.layout_masks(m, bbox.to(_dev()), H, True)
+    (dm,) = torch.autograd.grad(out, m, gout.to(_dev()))
+    assert float((out.cpu() - ref).abs().max()) < 5e-6
+    # the rectangle indicator is exact except where a pixel centre sits ON a box edge to within one rounding of (lin - x0) / w
+    want = O.bbox_mask(bbox, H, H)
+    diff = boxm.cpu() != want
+    if bool(diff.any()):
+        lin = torch.linspace(0, 1, steps=H)
+        X = (lin.view(1, 1, 1, H) - bbox[..., 0].view(b, o, 1, 1)) / bbox[..., 2].view(b, o, 1, 1)
+        Y = (lin.view(1, 1, H, 1) - bbox[..., 1].view(b, o, 1, 1)) / bbox[..., 3].view(b, o, 1, 1)
+        edge = (torch.minimum(X.abs(), (X - 1).abs()) < 1e-6) | (torch.minimum(Y.abs(), (Y - 1).abs()) < 1e-6)
+        assert bool(edge.expand_as(diff)[diff].all()) and int(diff.sum()) <= 4
+    assert float((dm.cpu() - rm).abs().max()) < 1e-5 * max(1.0, float(rm.abs().max()))
     assert float(dm[..., 1:].abs().max()) == 0.0
 
 
@@ -164,7 +181,7 @@ def test_psp_stages(training):
 
 
 @pytest.mark.parametrize("two_scale", [True, False])
-@pytest.mark.parametrize("shape", [(32, 8), (32, 31), (3, 5)])
+@pytest.mark.parametrize("shape", [(32, 8), (32, 31), (3, 5), (40, 31), (129, 8)])   # the last two: more than 1024 rows
 def test_roi_layout_is_the_reference_order(shape, two_scale):
     """the compacted ROI rows against the torch composition the host side used (stable argsort of the same key)"""
     from layout2img_amd import ops

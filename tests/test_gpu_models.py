@@ -182,7 +182,7 @@ _LOOP_BARS = {
 }
 
 
-def _loop_vs_reference(kind, dt):
+def _loop_vs_reference(kind, dt, dual=False):
     import layout2img_amd as L
     vg = kind == "vg"
     f32 = dt == torch.float32
@@ -191,6 +191,7 @@ def _loop_vs_reference(kind, dt):
     d = _build_d(load_fixture("d_vg.npz" if vg else "d_coco.npz"), 54 if vg else 32, dt, num_classes=179 if vg else 184)
     g.train(), d.train()
     tr = L.GanTrainer(g, d)
+    tr.dual_d = dual   # D(real) + D(fake) of the D step as one batch (GanTrainer.dual_d, CombineDiscriminator.forward_dual)
     bars = _LOOP_BARS[(kind, f32)]
     for it in range(2):
         mk = recipe.make_inputs_vg(2, 31, 179, 300 + it) if vg else recipe.make_inputs(2, 8, 184, 200 + it)
@@ -216,6 +217,13 @@ def test_train_loop_vs_reference(dt):
     """Two iterations of the training loop (reference train_context_app_v2.py:148-189, VGG term omitted) against the losses,
     images and parameter sums captured from the reference loop -- f32 operands and the bf16 operands of the headline."""
     _loop_vs_reference("coco", dt)
+
+
+@pytest.mark.parametrize("kind", ["coco", "vg"])
+def test_train_loop_vs_reference_with_the_dual_discriminator_step(kind):
+    """The same goldens with D(real) and D(fake) of the discriminator step run as ONE batch (two weight packs and two gradient
+    accumulators per launch, l2i_conv2d_fwd_dual / l2i_conv2d_wgrad_dual): same losses, images and parameter sums, same bars."""
+    _loop_vs_reference(kind, torch.float32, dual=True)
 
 
 def test_full_size_step_properties():
@@ -409,6 +417,7 @@ def _grads_after_one_iteration(dt, mode, b=32, seed=5):
         if hasattr(m, "dropout_p"):
             m.dropout_p = 0.0   # (the graph replays its own Philox offsets: draws differ from an eager run's)
     tr = L.GanTrainer(g, d)
+    tr.dual_d = mode == "dual"
     real, label, bbox, z, z_im = make_batch(b, 128, "coco", seed=3, device=DEV)
     if mode == "graph":
         st = snapshot_state(tr)
@@ -444,5 +453,18 @@ def test_graph_replay_gradients_match_eager_at_full_size(dt):
     eager = _grads_after_one_iteration(dt, "eager")
     graph = _grads_after_one_iteration(dt, "graph")
     whole, med = _grad_errors(graph, eager)
+    assert whole < (2.5e-4 if f32 else 8.7e-3), whole
+    assert med < (9e-4 if f32 else 1.7e-2), med
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_dual_discriminator_step_gradients_match_two_passes_at_full_size(dt):
+    """128x128, b = 32: the discriminator step as ONE batch of 64 images (every D-step conv / data-gradient / weight-gradient
+    launch dual: two packs, two accumulators, the ROI heads' live-row count per half) gives the two-pass iteration's gradients
+    of both networks -- same floor and bars as graph vs eager above."""
+    f32 = dt == torch.float32
+    eager = _grads_after_one_iteration(dt, "eager")
+    dual = _grads_after_one_iteration(dt, "dual")
+    whole, med = _grad_errors(dual, eager)
     assert whole < (2.5e-4 if f32 else 8.7e-3), whole
     assert med < (9e-4 if f32 else 1.7e-2), med

@@ -20,8 +20,6 @@ def wrap(obj, name, tag):
 
 for cls in (G.BoxMultiHeadedAttention, G.MaskRegressNetv2, G.PSPModule, G.ConvMaskHead, G.ResBlock):
     wrap(cls, "forward", cls.__name__)
-for n in ("bbox_mask", "masks_to_layout", "box_relational_embedding"):
-    wrap(G, n, n)
 for n in ("_stage_mask", "_project_isla", "_latent"):
     wrap(G.ResnetGenerator128_context, n, n)
 
