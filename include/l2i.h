@@ -227,6 +227,14 @@ int l2i_adam_step(float* p, const float* g, float* m, float* v, long long n, flo
 /* f32 stream -> T operand copies (raw and/or ReLU'd). */
 int l2i_cast_op(const float* x, void* raw, void* act, long long n, int dtype, void* stream);
 
+/* Split operand of the forward-only "bf16x3" precision mode: x [rows][C] f32 (ReLU'd first when relu != 0) -> out3 [rows][3 C]
+ * bf16 = [hi | lo | hi], hi = bf16(x), lo = bf16(x - hi). With the weight packs of l2i_weights_prepare(dtype = 3) -- every
+ * forward pack [w_hi | w_hi | w_lo] per tap -- l2i_conv2d_fwd over 3 C input channels accumulates x_hi w_hi + x_lo w_hi + x_hi w_lo:
+ * the convolution of the reference's nn.Conv2d / nn.Linear (model/resnet_generator_app_v2.py:633-639) to ~2^-16 relative instead
+ * of bf16's 2^-8, at MFMA speed / 3 (generator image L_inf vs the reference 8e-5 in emulation, tools/parity/bf16_layer_promotion.py;
+ * bar 1e-3). C % 8 == 0. */
+int l2i_split_cast(const float* x, void* out3, long long rows, int C, int relu, void* stream);
+
 /* ReLU backward on f32 streams: out = g*[mask>0] (+ add). */
 int l2i_relu_bwd(const float* g, const float* mask, const float* add, float* out, long long n, void* stream);
 

@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libl2i_hip.so")
 
 F32, BF16 = 0, 1
+BF16X3 = 3   # l2i_weights_prepare only: bf16 with split (hi + lo) forward packs, the forward-only "bf16x3" precision mode
 
 _p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
@@ -42,6 +43,7 @@ SIGNATURES = {
     "l2i_l1_fwd_bwd": [_p, _p, _ll, _f, _p, _p, _p],
     "l2i_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p, _p],
     "l2i_cast_op": [_p, _p, _p, _ll, _i, _p],
+    "l2i_split_cast": [_p, _p, _ll, _i, _i, _p],
     "l2i_set_wgrad_blocks": [_i],
     "l2i_debug_occupancy": [_i, _i],
     "l2i_resize_bilinear": [_p, _p, _ll, _i, _i, _i, _i, _p],

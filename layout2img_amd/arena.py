@@ -215,11 +215,17 @@ class GemmGroup:
 
 
 class WeightArena:
-    def __init__(self, net: nn.Module, flat: FlatParams, device, op_dtype):
+    def __init__(self, net: nn.Module, flat: FlatParams, device, op_dtype, split=False):
+        """split: the forward-only "bf16x3" precision mode -- bf16 operands carried as hi + lo: every forward pack is laid out
+        [w_hi | w_hi | w_lo] per tap (three Ci_p-wide blocks, csrc/weights.hip sn_pack_body SPLIT) for operands
+        [x_hi | x_lo | x_hi] (ops.split_cast); the convolution kernels are unchanged and see 3 Ci_p input channels."""
         self.flat = flat
         self.device = device
         self.op_dtype = op_dtype
-        self.dtype_code = _lib.BF16 if op_dtype == torch.bfloat16 else _lib.F32
+        self.split = bool(split)
+        if self.split and op_dtype != torch.bfloat16:
+            raise ValueError("split operands are a bf16 mode")
+        self.dtype_code = (_lib.BF16X3 if self.split else _lib.BF16) if op_dtype == torch.bfloat16 else _lib.F32
         bk = 64 if op_dtype == torch.bfloat16 else 32
         holders = [m for m in net.modules() if isinstance(m, GemmWeight)]
         self.holders = holders
@@ -255,7 +261,7 @@ class WeightArena:
         for i, (h, use) in enumerate(rows):
             taps = h.kh * h.kh
             kt = h.ci * taps
-            kp = taps * h.ci_p
+            kp = taps * h.ci_p * (3 if self.split else 1)   # (split: forward K = taps x [hi | hi | lo] blocks)
             kpad, npad = _round_up(kp, bk), _round_up(h.co_p, 128)
             kp_d = taps * h.co_p
             kpad_d, npad_d = _round_up(kp_d, bk), _round_up(h.ci_p, 128)

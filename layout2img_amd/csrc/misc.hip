@@ -156,6 +156,39 @@ extern "C" int l2i_cast_op(const float* x, void* raw, void* act, long long n, in
     return l2i_check_launch();
 }
 
+// Split operand of the "bf16x3" forward mode: x [rows][C] f32 (optionally ReLU'd) -> out [rows][3 C] bf16 = [hi | lo | hi] with
+// hi = bf16(x), lo = bf16(x - hi). Against a weight pack laid out [w_hi | w_hi | w_lo] per tap (sn_pack_body SPLIT) the convolution
+// kernels accumulate x_hi w_hi + x_lo w_hi + x_hi w_lo. C % 8 == 0; one thread per 8 channels.
+__global__ __launch_bounds__(256) void split_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long long n8, int C8, int relu) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const long long row = i / C8;
+        const int c8 = (int)(i - row * C8);
+        const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (relu) v[j] = fmaxf(v[j], 0.f);
+            lo[j] = v[j] - bf2f(f2bf(v[j]));
+        }
+        uint4 hi4, lo4;
+        hi4.x = f2bf2(v[0], v[1]); hi4.y = f2bf2(v[2], v[3]); hi4.z = f2bf2(v[4], v[5]); hi4.w = f2bf2(v[6], v[7]);
+        lo4.x = f2bf2(lo[0], lo[1]); lo4.y = f2bf2(lo[2], lo[3]); lo4.z = f2bf2(lo[4], lo[5]); lo4.w = f2bf2(lo[6], lo[7]);
+        bf16_t* d = out + (row * 3 * C8 + c8) * 8;
+        *reinterpret_cast<uint4*>(d) = hi4;
+        *reinterpret_cast<uint4*>(d + (long long)C8 * 8) = lo4;
+        *reinterpret_cast<uint4*>(d + (long long)C8 * 16) = hi4;
+    }
+}
+extern "C" int l2i_split_cast(const float* x, void* out3, long long rows, int C, int relu, void* stream) {
+    if (!x || !out3 || rows <= 0 || C <= 0 || C % 8) return L2I_ERR_ARG;
+    const long long n8 = rows * (C / 8);
+    long long nblk = (n8 + 255) / 256;
+    if (nblk > 8192) nblk = 8192;
+    hipLaunchKernelGGL(split_cast_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out3, n8, C / 8, relu);
+    return l2i_check_launch();
+}
+
 // dx = g * [mask > 0] (+ add)   -- ReLU backward on f32 streams (mask: f32 pre- or post-activation values)
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ mask,
                                                        const float* __restrict__ add, float* __restrict__ out, long long n4) {

@@ -219,7 +219,12 @@ __device__ __forceinline__ void store8t(T* dst, const T (&v)[8]) {   // 8 alread
 
 // (TAPS is a template parameter: with the tap count a run-time value every index computation of the tile loops was an
 //  emulated integer division -- the kernel ran at 35 % of the HBM rate, profiles/r02_hbm_kernels.json)
-template <typename T, int TAPS>
+// SPLIT (bf16 only; dtype code 3 of l2i_weights_prepare, "bf16x3"): the FORWARD pack holds every weight as hi + lo, both bf16
+// (hi = bf16(w), lo = bf16(w - hi): w to 16 significant bits), as three Ci_p-wide blocks [hi | hi | lo] per tap. Against an
+// operand whose channels are [x_hi | x_lo | x_hi] (l2i_split_cast) the unchanged convolution kernels then accumulate
+// x_hi w_hi + x_lo w_hi + x_hi w_lo in f32 -- the product to ~2^-16 relative instead of bf16's 2^-8, at three times the MFMA
+// work: the forward-only precision mode that meets the image bar of 1e-3 at MFMA speed. The data-gradient pack is unchanged.
+template <typename T, int TAPS, bool SPLIT = false>
 __device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, const int* __restrict__ e, int layer,
                                              const float* __restrict__ params, const float* __restrict__ norms,
                                              T* __restrict__ packed, int training, T* tile) {
@@ -227,6 +232,7 @@ __device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, co
     constexpr int taps = TAPS;
     constexpr int TCI = TAPS == 1 ? 256 : 32;
     constexpr int RUN = TCI * TAPS, RUNP = RUN + 2;
+    T* tile_lo = tile + PK_TCO * RUNP;   // (SPLIT: the low halves, same layout)
     const int co0 = e[1] * PK_TCO, ci0 = e[2] * TCI;
     const int nco = min(PK_TCO, Co - co0), nrun = min(TCI, Ci - ci0) * taps;   // valid rows / valid floats per row (may be <= 0)
     const float inv = 1.f / layer_sigma(L, norms, layer, training);
@@ -258,7 +264,9 @@ __device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, co
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int jj = j + q, cil = jj / taps, tap = jj - cil * taps;
-                    tile[row * RUNP + tap * TCI + cil] = OpT<T>::from(vv[q]);
+                    const T hi = OpT<T>::from(vv[q]);
+                    tile[row * RUNP + tap * TCI + cil] = hi;
+                    if constexpr (SPLIT) tile_lo[row * RUNP + tap * TCI + cil] = OpT<T>::from(vv[q] - OpT<T>::to(hi));
                 }
             }
         }
@@ -269,7 +277,9 @@ __device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, co
             float v = 0.f;
             if (row < nco && j < nrun) v = W[((size_t)(co0 + row) * Ci + ci0) * taps + j] * inv;
             const int cil = j / taps, tap = j - cil * taps;
-            tile[row * RUNP + tap * TCI + cil] = OpT<T>::from(v);
+            const T hi = OpT<T>::from(v);
+            tile[row * RUNP + tap * TCI + cil] = hi;
+            if constexpr (SPLIT) tile_lo[row * RUNP + tap * TCI + cil] = OpT<T>::from(v - OpT<T>::to(hi));
         }
     }
     __syncthreads();
@@ -286,7 +296,16 @@ __device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, co
             T v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = tile[row * RUNP + tap * TCI + 8 * c8 + j];
-            store8t<T>(dst + (size_t)co * Kpad + tap * Ci_p + ci, v);
+            if constexpr (SPLIT) {
+                T* d3 = dst + (size_t)co * Kpad + tap * 3 * Ci_p + ci;
+                store8t<T>(d3, v);
+                store8t<T>(d3 + Ci_p, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile_lo[row * RUNP + tap * TCI + 8 * c8 + j];
+                store8t<T>(d3 + 2 * Ci_p, v);
+            } else {
+                store8t<T>(dst + (size_t)co * Kpad + tap * Ci_p + ci, v);
+            }
         }
     }
     // dgrad pack (taps flipped)
@@ -306,7 +325,7 @@ __device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, co
     }
 }
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                       const float* __restrict__ params, const float* __restrict__ norms,
                                                       T* __restrict__ packed, int training) {
@@ -315,8 +334,8 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restric
     const int* e = table + 3 * blockIdx.x;
     const int layer = e[0];
     const long long* L = layers + L2I_LSTRIDE * layer;
-    if ((int)LF(5) == 3) sn_pack_body<T, 9>(L, e, layer, params, norms, packed, training, tile);
-    else sn_pack_body<T, 1>(L, e, layer, params, norms, packed, training, tile);
+    if ((int)LF(5) == 3) sn_pack_body<T, 9, SPLIT>(L, e, layer, params, norms, packed, training, tile);
+    else sn_pack_body<T, 1, SPLIT>(L, e, layer, params, norms, packed, training, tile);
 }
 
 // ---------------------------------------------------------------- phase 3b: sigma, normalised u / v
@@ -497,7 +516,7 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
                                    float* norms, void* packed, int dtype, int training, int clear, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!layers || !params || !packed || !norms) return L2I_ERR_ARG;
-    if (dtype != 0 && dtype != 1) return L2I_ERR_ARG;
+    if (dtype != 0 && dtype != 1 && dtype != 3) return L2I_ERR_ARG;   // 3: bf16 with split (hi + lo) forward packs, see sn_pack_body
     if (clear) {  // first round of a pass
         const long long gap = pass_uv - norms;   // adjacent buffers (layout2img_amd/arena.py PassCtx): one memset for both
         if (uv_len > 0 && gap >= 4LL * n_layers && gap <= 4LL * n_layers + 64) {
@@ -527,7 +546,15 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
         if (dtype == 0)
             hipLaunchKernelGGL(sn_pack_kernel<float>, dim3(n_pack), dim3(256), lds, stream, layers, tab_pack, params, norms,
                                (float*)packed, training);
-        else
+        else if (dtype == 3) {
+            static bool ready3 = false;
+            if (!ready3) {
+                (void)hipFuncSetAttribute((const void*)sn_pack_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
+                ready3 = true;
+            }
+            hipLaunchKernelGGL((sn_pack_kernel<bf16_t, true>), dim3(n_pack), dim3(256), 2 * lds, stream, layers, tab_pack, params, norms,
+                               (bf16_t*)packed, training);
+        } else
             hipLaunchKernelGGL(sn_pack_kernel<bf16_t>, dim3(n_pack), dim3(256), lds, stream, layers, tab_pack, params, norms,
                                (bf16_t*)packed, training);
     }

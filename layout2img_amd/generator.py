@@ -192,7 +192,7 @@ class PSPModule(nn.Module):
         if bn_training and not getattr(self.stages[0][2], "_nbt_shared", False):
             for st in self.stages:
                 st[2].num_batches_tracked += 1
-        cat = ops.psp_expand(feats, ys, taps, pc.arena.op_dtype, j)                           # (B,H,W,4*100+C), operand dtype
+        cat = ops.psp_expand(feats, ys, taps, torch.float32 if pc.arena.split else pc.arena.op_dtype, j)                           # (B,H,W,4*100+C), operand dtype
         conv, bn = self.bottleneck
         h = fused_conv(cat, conv, pc, emit=("stats",) if self.training else ())
         spec, w, b = bn.spec(self.training, sync, conv.co_p)
@@ -368,6 +368,12 @@ class _GeneratorBase(nn.Module):
     """Shared plumbing: flat parameters, weight arena, SyncBN hook, state_dict layout."""
 
     def finalize(self, device, op_dtype=torch.bfloat16):
+        """op_dtype: torch.bfloat16 (MFMA operands in bf16: the throughput mode), torch.float32 (exact-f32 MFMA), or "bf16x3" --
+        bf16 operands carried as hi + lo with three MFMA products per pair (arena split; forward-only: sampling and the parity of
+        the forward against the reference to the 1e-3 image bar at MFMA speed)."""
+        split = op_dtype == "bf16x3"
+        if split:
+            op_dtype = torch.bfloat16
         self.op_dtype = op_dtype
         # the 2 x (number of ISLA layers) projections Linear(num_w -> C) (model/norm_module.py:158-159) all read the same
         # object latents: they run as ONE grouped GEMM per pass (arena.GemmGroup / ops.GroupedLinearFn)
@@ -377,7 +383,7 @@ class _GeneratorBase(nn.Module):
         for l in self.context.linears[:3]:   # q, k, v projections of the context attention read the same rows: one GEMM
             l.group = "qkv"
         self.flat = FlatParams(self, device)
-        self.arena = WeightArena(self, self.flat, device, op_dtype)
+        self.arena = WeightArena(self, self.flat, device, op_dtype, split=split)
         self.sync = None  # set by parallel.attach_sync_bn for world_size > 1
         # every batch-norm layer of the network runs in every forward: their num_batches_tracked counters live in one
         # tensor (each buffer a 0-dim view of it) and a training forward bumps them with ONE launch (_bump_nbt)

@@ -108,6 +108,15 @@ def cast_op(x, op_dtype, raw=True, act=False):
     return r, a
 
 
+def split_cast(x, relu=False):
+    """f32 stream (..., C) -> the split bf16 operand (..., 3 C) = [hi | lo | hi] of the forward-only "bf16x3" mode (arena split)."""
+    _chk(x, torch.float32)
+    C = x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (3 * C,), dtype=torch.bfloat16, device=x.device)
+    _lib.call("l2i_split_cast", x.data_ptr(), out.data_ptr(), x.numel() // C, C, int(relu), _stream())
+    return out
+
+
 class KernelTimer:
     """Timing of the individual conv / weight-gradient launches of an eager iteration (bench.py's roofline leg): the
     algorithmic work of every launch is accumulated here, the durations come from HIP events the library attaches to
@@ -501,11 +510,21 @@ class FusedConvFn(Function):
     def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None,
                 emit=(), dx_raw=False, join=None, op_out=False, lazy_sc=False):
         opd = pc.arena.op_dtype
-        _chk(x, opd if pro.kind in ("op", "opraw") else torch.float32)
+        _chk(x, opd if (pro.kind in ("op", "opraw") and not pc.arena.split) else torch.float32)
         B, H, W, C = x.shape
         assert C == holder.ci_p, (C, holder.ci_p, holder.kind)
         stats = None
-        if pro.kind in ("op", "opraw"):   # x IS the operand: the ReLU'd result of the producing conv's epilogue (`op_out`),
+        split = pc.arena.split
+        if split:   # forward-only "bf16x3" mode: every operand is made from an f32 tensor as [hi | lo | hi] (no epilogue copies)
+            if pro.kind == "norm":
+                sums, sq, count, sstride = _norm_stats(x, pro)
+                xf, _ = norm_fwd_raw(x, sums, sq, count, sstride, pro, mask, wproj, bproj, torch.float32)
+                x_op = split_cast(xf)
+            else:
+                x_op = split_cast(x if x.dtype == torch.float32 else x.float(), relu=pro.kind in ("relu", "op"))
+            emit = tuple(e for e in emit if e == "stats")
+            assert not op_out and not lazy_sc and (res is None or getattr(res, "_l2i_lazy_sc", None) is None)
+        elif pro.kind in ("op", "opraw"):   # x IS the operand: the ReLU'd result of the producing conv's epilogue (`op_out`),
             x_op = x                      # or a tensor produced in the operand dtype (ops.psp_expand) -- no f32 stream
         elif pro.kind == "norm":
             sums, sq, count, sstride = _norm_stats(x, pro)
@@ -688,6 +707,10 @@ def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None,
     allows epilogue copies the launch then writes only relu(result) in the operand dtype and returns that tensor (the f32
     stream of the result and of its gradient are never written); otherwise this is emit=("relu",)."""
     pro = prologue if prologue is not None else _CAST
+    if pc.arena.split:
+        if torch.is_grad_enabled():
+            raise RuntimeError('the split-operand ("bf16x3") precision mode is forward-only: run it under torch.no_grad()')
+        relu_op_out, lazy_sc = False, False
     if getattr(x, "_l2i_relu_op", False):
         if pro is not RELU:
             raise RuntimeError("a relu_op_out result can only feed a ReLU-prologue fused_conv")
@@ -772,9 +795,12 @@ class GroupedLinearFn(Function):
         ctx.set_materialize_grads(False)
         opd = pc.arena.op_dtype
         rows = x.shape[0]
-        x_op = _sibling(x, "raw", opd)
-        if x_op is None:
-            x_op, _ = cast_op(x, opd, raw=True, act=False)
+        if pc.arena.split:
+            x_op = split_cast(x)
+        else:
+            x_op = _sibling(x, "raw", opd)
+            if x_op is None:
+                x_op, _ = cast_op(x, opd, raw=True, act=False)
         flat = pc.arena.flat
         b0 = flat.offset_of(group.members[0].bias)
         bias = flat.data[b0:b0 + group.n_total]
@@ -814,6 +840,8 @@ class GroupedLinearFn(Function):
 
 def grouped_linear(x, group, pc):
     """-> list of (rows, C_i) outputs, one per group member, each carrying its gradient-sink coordinates."""
+    if pc.arena.split and torch.is_grad_enabled():
+        raise RuntimeError('the split-operand ("bf16x3") precision mode is forward-only: run it under torch.no_grad()')
     sink = GradSink(x.shape[0], group.n_total, x.device)
     outs = GroupedLinearFn.apply(x, group, pc, sink)
     for o, t in zip(group.offsets, outs):

@@ -110,6 +110,37 @@ def test_generator_coco_vs_reference(dt):
         assert maxdiff(oe, fx["out_eval"]) < (1e-3 if f32 else 1e-1)
 
 
+@pytest.mark.parametrize("kind", ["coco", "vg"])
+def test_generator_forward_bf16x3_meets_the_image_bar(kind):
+    """The forward-only split-operand mode (finalize(dev, "bf16x3"): bf16 operands carried as hi + lo, three MFMA products per
+    pair, f32 accumulation) against the reference's outputs: the north star's image bar L_inf < 1e-3 -- which plain bf16
+    operands miss by 60x (6.3e-2) -- at MFMA speed, train-mode forward twice (batch statistics, running statistics) and eval."""
+    coco = kind == "coco"
+    fx = load_fixture("g_coco.npz" if coco else "g_vg.npz")
+    g = _build_g(fx, 11 if coco else 12, "bf16x3", kind=kind)
+    assert g.arena.split and g.arena.op_dtype == torch.bfloat16
+    inp = {k: v.to(DEV) for k, v in fixture_inputs(fx).items()}
+    g.train()
+    with pytest.raises(RuntimeError, match="forward-only"):
+        g(inp["z"], inp["bbox"], inp["z_im"], inp["y"])
+    g.load_state_dict(fixture_state(fx, 11 if coco else 12))   # (whatever the refused call touched: start from the recipe state again)
+    with torch.no_grad():
+        taps = {}
+        out1 = g(inp["z"], inp["bbox"], inp["z_im"], inp["y"], **({"taps": taps} if coco else {}))
+        e1 = maxdiff(out1, fx["out_train1"])
+        if coco:
+            for name, a, b in (("w", taps["w"], fx["tap_w"]), ("bmask", taps["bmask"], fx["tap_bmask"]),
+                               ("pre_tanh", taps["pre_tanh"].permute(0, 3, 1, 2), fx["tap_pre_tanh"])):
+                d, sc = maxdiff(a, b), float(np.abs(b).max())
+                assert d < 2e-4 * sc, (name, d, sc)
+        out2 = g(inp["z"], inp["bbox"], inp["z_im"], inp["y"])
+        e2 = maxdiff(out2[:, :, ::2, ::2], fx["out_train2_sub"])
+        g.eval()
+        e3 = maxdiff(g(inp["z"], inp["bbox"], inp["z_im"], inp["y"]), fx["out_eval"])
+    print(f"bf16x3 {kind}: image L_inf train1 {e1:.2e} train2 {e2:.2e} eval {e3:.2e}")
+    assert max(e1, e2, e3) < 1e-3, (e1, e2, e3)   # measured: see DESIGN.md section 2 (emulation on the CPU: 8e-5)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_generator_vg_vs_reference(dt):
     fx = load_fixture("g_vg.npz")

@@ -237,6 +237,38 @@ def test_conv_folded_shortcut(case, cfg, epi):
         assert float((s1.cpu().view(-1)[:Co] - ref.sum(dim=(0, 1, 2))).abs().max()) < 1e-3 * float(ref.abs().sum(dim=(0, 1, 2)).max())
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 72, 3, False, False), (1, 32, 32, 128, 136, 3, False, True), (2, 8, 8, 104, 64, 3, True, False),
+                                  (5, 1, 1, 312, 72, 1, False, False), (2, 16, 16, 40, 104, 1, False, False), (2, 4, 4, 1024, 256, 3, False, False)])
+def test_split_operand_conv_is_f32_accurate(case):
+    """The "bf16x3" forward mode's arithmetic: operands [x_hi | x_lo | x_hi] (l2i_split_cast, with and without the ReLU) against a
+    pack [w_hi | w_hi | w_lo] through the UNCHANGED bf16 convolution kernels equal the f32 convolution of the un-rounded operands
+    to ~1e-5 relative -- plain bf16 operands are at 4e-3 on the same data."""
+    from layout2img_amd import ops
+    B, H, W, Ci, Co, KH, up2, pool2 = case
+    g = torch.Generator().manual_seed(Ci + Co)
+    x = torch.randn(B, H, W, Ci, generator=g)
+    w = torch.randn(Co, Ci, KH, KH, generator=g) / math.sqrt(Ci * KH * KH)
+    bias = torch.randn(Co, generator=g)
+    hi = lambda t: t.to(torch.bfloat16).float()
+    w_hi = hi(w)
+    w_lo = hi(w - w_hi)
+    k = KH * KH * 3 * Ci
+    kpad, npad = (k + 63) // 64 * 64, (Co + 127) // 128 * 128
+    pack = torch.zeros(npad, kpad)
+    pack[:Co, :k] = torch.cat((w_hi, w_hi, w_lo), dim=1).permute(0, 2, 3, 1).reshape(Co, k)   # per tap: [hi | hi | lo] over the input channels
+    for relu in (False, True):
+        x3 = ops.split_cast(x.to(_dev()), relu=relu)
+        xr = torch.relu(x) if relu else x
+        assert x3.shape == (B, H, W, 3 * Ci) and torch.equal(x3[..., :Ci].float().cpu(), hi(xr)) and torch.equal(x3[..., 2 * Ci:], x3[..., :Ci])
+        assert float((x3[..., :Ci].float().cpu() + x3[..., Ci:2 * Ci].float().cpu() - xr).abs().max()) < 2e-5 * float(xr.abs().max())
+        out, _, _ = ops.conv_raw(x3, pack.to(_dev(), torch.bfloat16), kpad, Co, KH, bias=bias.to(_dev()), up2=up2, pool2=pool2,
+                                 alpha=0.25 if pool2 else 1.0)
+        ref = _ref_conv(xr, w, bias, up2, pool2)
+        err = float((out.cpu() - ref).abs().max()) / float(ref.abs().max())
+        plain = float((_ref_conv(hi(xr), w_hi, bias, up2, pool2) - ref).abs().max()) / float(ref.abs().max())
+        assert err < 3e-5 and err < 0.05 * plain, (err, plain)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_conv_relu_mask(dt, epi):
     from layout2img_amd import ops
