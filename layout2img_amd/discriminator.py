@@ -62,8 +62,11 @@ class ResBlock(nn.Module):
         if self.learnable_sc:
             self.c_sc = _conv(in_ch, out_ch, 1, uses)
 
-    def forward(self, x, pc, use=0, nimg=None, emit=()):
-        """`use`: index of this application within the forward pass (each application of a spectral-normed
+    def forward(self, x, pc, use=0, nimg=None, emit=(), sole_reader=False):
+        """`sole_reader`: x is the result of another block's conv2 and this block is its ONLY reader -- the data-gradient launch
+        of conv1 (which also takes the shortcut branch's gradient as its residual: the complete dx) then writes the operand
+        copy of dx that the producing conv2's backward needs, instead of a separate cast pass over the f32 gradient.
+        `use`: index of this application within the forward pass (each application of a spectral-normed
         module runs its own power iteration in the reference). `nimg`: device count of live leading images (ROI heads).
         `emit`: operand copies of the block's result its consumers will read ("relu" / "raw"), written by conv2's
         epilogue. Inside the block conv1's epilogue writes conv2's ReLU'd operand and conv2's data-gradient launch
@@ -72,7 +75,7 @@ class ResBlock(nn.Module):
         if self.learnable_sc:
             ops.precast(x, pc.arena.op_dtype)   # conv1 reads relu(x), the shortcut reads x: one cast launch for both (if not emitted upstream)
         j = ops.GradJoin()   # dx of the shortcut branch enters conv1's data-gradient epilogue instead of a separate add
-        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, relu_op_out=True, join=(j, "take"))
+        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, relu_op_out=True, join=(j, "take"), dx_raw=sole_reader)
         sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg, join=(j, "give"), lazy_sc=True) if self.learnable_sc else x
         return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample, nimg=nimg, emit=emit,
                           dx_raw=True, join=None if self.learnable_sc else (j, "give_res"))
@@ -103,15 +106,15 @@ class ResnetDiscriminator128_app(nn.Module):
         number of valid rows when they are compacted to the front (the ROI heads then skip the rest)."""
         both = ("relu", "raw")   # what a following block with a learnable shortcut reads
         x = self.block1(x, pc, emit=both)
-        x1 = self.block2(x, pc, emit=both)
+        x1 = self.block2(x, pc, emit=both, sole_reader=True)
         x2 = self.block3(x1, pc, emit=both)
         x = self.block4(x2, pc, emit=both)
-        x = self.block5(x, pc, emit=("relu",))
-        x = self.block6(x, pc)
+        x = self.block5(x, pc, emit=("relu",), sole_reader=True)
+        x = self.block6(x, pc, sole_reader=True)
         P = _passes(pc)
         out_im = [ops.proj_head(xk, self.l7, p) for xk, p in zip(_rows(x, pc), P)]            # l7(sum_hw relu(x))
 
-        feat_s = self.block_obj4(self.block_obj3(x1, pc, emit=both), pc, use=0)   # reference order :136-141
+        feat_s = self.block_obj4(self.block_obj3(x1, pc, emit=both), pc, use=0, sole_reader=True)   # reference order :136-141
         feat_l = self.block_obj4(x2, pc, use=1)
         obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0)  # (R,8,8,C)
 
@@ -145,9 +148,13 @@ class CombineDiscriminator128_app(nn.Module):
         self.obD = ResnetDiscriminator128_app(num_classes=num_classes, input_dim=3)
 
     def finalize(self, device, op_dtype=torch.bfloat16):
+        """op_dtype: torch.bfloat16 | torch.float32 | "bf16x3" (forward-only split operands, see the generators' finalize)."""
+        split = op_dtype == "bf16x3"
+        if split:
+            op_dtype = torch.bfloat16
         self.op_dtype = op_dtype
         self.flat = FlatParams(self, device)
-        self.arena = WeightArena(self, self.flat, device, op_dtype)
+        self.arena = WeightArena(self, self.flat, device, op_dtype, split=split)
         return self
 
     def zero_grad(self, set_to_none=False):

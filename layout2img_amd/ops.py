@@ -868,7 +868,16 @@ class ArenaWeightFn(Function):
         return None, None, None
 
 
+def _wbar_f32(holder, pc):
+    """W / sigma of a layer in f32 straight from the parameter and the pass's sigma: what the heads read in the forward-only
+    split-operand mode, whose packs hold hi | hi | lo blocks (no gradient: that mode runs under no_grad)."""
+    w = holder.w.detach().reshape(holder.co, -1)
+    return w / pc.sigma(holder) if holder.sn else w
+
+
 def arena_weight(holder, pc):
+    if pc.arena.split:
+        return _wbar_f32(holder, pc)
     return ArenaWeightFn.apply(holder.w, holder, pc)
 
 
@@ -1173,6 +1182,14 @@ class ProjHeadFn(Function):
 
 def proj_head(x, linear, pc, emb=None, y=None, scale=1.0):
     """x (R,H,W,C) pre-ReLU block output; linear: GemmWeight Linear(C -> 1) (+ bias); emb: GemmWeight embedding (K, C), y (R,)."""
+    if pc.arena.split:   # forward-only precision mode: the head in f32 torch ops on W / sigma (reference :127-129, 160-166)
+        f = torch.relu(x).sum(dim=(1, 2)) * scale
+        out = f @ _wbar_f32(linear, pc)[0]
+        if linear.bias is not None:
+            out = out + linear.bias.detach()
+        if emb is not None:
+            out = out + (f * _wbar_f32(emb, pc)[y]).sum(dim=1)
+        return out.view(-1, 1)
     return ProjHeadFn.apply(x.contiguous(), linear.bias, y, linear, emb, pc, scale)
 
 
@@ -1207,6 +1224,9 @@ class EmbDotFn(Function):
 
 
 def emb_dot(emb, y, linear, off, pc):
+    if pc.arena.split:
+        out = (_wbar_f32(emb, pc)[y] * _wbar_f32(linear, pc)[0, off:off + emb.ci]).sum(dim=1)
+        return (out + linear.bias.detach() if linear.bias is not None else out).view(-1, 1)
     return EmbDotFn.apply(linear.bias, y, emb, linear, off, pc)
 
 

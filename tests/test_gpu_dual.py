@@ -202,15 +202,17 @@ def test_forward_dual_equals_two_padded_passes(size, b, dt):
         return [t.detach().clone() for t in list(oa) + list(ob)], net.flat.grad.clone(), ra.grad.clone(), fa.grad.clone(), net.arena.sn_flat.data.clone()
 
     o1, g1, ra1, fa1, sn1 = run(False)
-    o0, g0, ra0, fa0, _ = run(False)    # the two-pass form a second time: its run-to-run distance calibrates the bars (split-K and
-    o2, g2, ra2, fa2, sn2 = run(True)   # weight-gradient sums are atomics; a pre-activation at ~0 may land on the other side of its gate)
+    o2, g2, ra2, fa2, sn2 = run(True)
     assert float((sn1 - sn2).abs().max()) < 1e-5   # the same two power iterations, in the same order (their sums are atomics: not bit-identical)
-    rel = 2e-4 if dt == torch.float32 else 2e-2
-    for a_, b_ in zip(o1, o2):
+    f32 = dt == torch.float32
+    for a_, b_ in zip(o1, o2):   # forward: every output of both passes (a wrong pack would show as ~1e-3: the two sigmas differ by that much)
         assert a_.shape == b_.shape
-        assert float((a_ - b_).abs().max()) <= rel * max(1.0, float(a_.abs().max()))
-    base = 3e-4 if dt == torch.float32 else 1.5e-2
-    for name, a_, b_, c_ in (("parameters", g1, g2, g0), ("first pass's images", ra1, ra2, ra0), ("second pass's images", fa1, fa2, fa0)):
-        floor = max(float((a_ - c_).norm() / a_.norm()), base)
-        err = float((a_ - b_).norm() / a_.norm())
-        assert err < 3.0 * floor, (name, err, floor)
+        assert float((a_ - b_).abs().max()) <= (2e-5 if f32 else 2e-2) * max(1.0, float(a_.abs().max()))
+    # backward: the forwards agree to ~1e-6, but a pre-activation within that distance of 0 lands on the other side of its ReLU
+    # gate in one of the two runs and changes that IMAGE's gradient by ~1e-3 (tools/parity/dual_debug.py: the discrepancy moves
+    # between images and configurations from run to run) -- hence per image: most images tight, every image loose
+    assert float((g1 - g2).norm() / g1.norm()) < (1e-3 if f32 else 1e-2)
+    for name, a_, b_ in (("first pass's images", ra1, ra2), ("second pass's images", fa1, fa2)):
+        per = ((a_ - b_).flatten(1).norm(dim=1) / a_.flatten(1).norm(dim=1)).cpu()
+        assert float(per.sort().values[(len(per) - 1) // 2]) < (1e-4 if f32 else 6e-2), (name, per.tolist())   # (lower median)
+        assert float(per.max()) < (2e-2 if f32 else 3e-1), (name, per.tolist())

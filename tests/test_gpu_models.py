@@ -199,6 +199,28 @@ def test_discriminator_vs_reference(dt):
         assert maxdiff(e, fx[f"eval_{k}"]) < rel * max(1.0, float(np.abs(fx[f"eval_{k}"]).max())), k
 
 
+def test_discriminator_forward_bf16x3_at_the_f32_bar():
+    """The forward-only split-operand mode on the discriminator (finalize(dev, "bf16x3")): train-mode forward twice and eval
+    against the reference's outputs at the exact-f32 mode's bar (2e-4 relative; plain bf16 operands need 3e-2)."""
+    fx = load_fixture("d_coco.npz")
+    d = _build_d(fx, 21, "bf16x3")
+    inp = {k: v.to(DEV) for k, v in fixture_inputs(fx).items()}
+    d.train()
+    with pytest.raises(RuntimeError, match="forward-only"):
+        d(inp["real"], inp["bbox"], inp["y"].unsqueeze(-1))
+    d.load_state_dict(fixture_state(fx, 21))
+    with torch.no_grad():
+        o1 = d(inp["real"], inp["bbox"], inp["y"].unsqueeze(-1))
+        o2 = d(inp["real"], inp["bbox"], inp["y"].unsqueeze(-1))
+        d.eval()
+        oe = d(inp["real"], inp["bbox"], inp["y"].unsqueeze(-1))
+    for outs, tag in ((o1, "train1"), (o2, "train2"), (oe, "eval")):
+        for t, k in zip(outs, ("img", "obj", "app")):
+            ref = fx[f"{tag}_{k}"]
+            assert tuple(t.shape) == ref.shape
+            assert maxdiff(t, ref) < 2e-4 * max(1.0, float(np.abs(ref).max())), (tag, k, maxdiff(t, ref), float(np.abs(ref).max()))
+
+
 # Bars of the loop tests: (loss relative error, image L_inf) per iteration, and the parameter-sum slack in units of "every
 # element of the tensor moved by 2 lr". f32: as in rounds 1-2. bf16: 1.5 x the LARGEST value of four runs of
 # tools/parity/measure_bars.py on MI355X boxes -- the run-to-run spread is wide because already iteration 0's g_loss is

@@ -4,7 +4,7 @@ cd "$(dirname "$0")/../.."
 ROOT=$PWD
 mkdir -p gpurun_out
 : > gpurun_out/ab.txt
-ARGS=${AB_ARGS:---steps 40 --no-cpu-baseline --no-g-forward --no-kernel-timer}
+ARGS=${AB_ARGS:---steps 40 --no-cpu-baseline --no-g-forward --no-kernel-timer --no-f32-mode}
 for i in 1 2; do
   for side in prev new; do
     if [ $side = prev ]; then cd $ROOT/scratch/ab_prev; else cd $ROOT; fi

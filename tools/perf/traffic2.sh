@@ -5,12 +5,12 @@
 # (4) --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE (MFMA utilisation per kernel, in situ)
 # (PMC passes carry --kernel-trace only, as the guide / gpurun require). One stream (L2I_OVERLAP=0): a kernel's
 # duration and counters are those of a kernel that owns the GPU.
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TAG
 cd /tmp && export TMPDIR=/tmp
 export L2I_OVERLAP=0
 R=${GRAFT_REPO_ROOT:-/root/repo}
-CMD="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-g-forward"
+CMD="python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-g-forward --no-f32-mode"
 rm -rf /tmp/tr_stats /tmp/tr_FETCH_SIZE /tmp/tr_WRITE_SIZE
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_stats -o t -- $CMD > /tmp/tr_stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
