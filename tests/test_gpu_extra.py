@@ -64,3 +64,52 @@ def test_generator_draws_the_image_latent_when_z_im_is_none():
     assert a.shape == (2, 3, 128, 128)
     assert float((a - b).abs().max()) <= 1e-5
     assert float((a - c).abs().max()) > 1e-4   # another draw, another image
+
+
+def test_two_generator_forwards_before_one_backward():
+    """Stand-alone forwards with gradients enabled must not share the zero-pool slab: the batch statistics saved by
+    the first graph would be re-zeroed by the second forward -- f1 = G(z1); f2 = G(z2); loss(f1, f2).backward() has to give the sum
+    of the two separate backward passes."""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    g = L.ResnetGenerator64_context(num_classes=184).finalize(DEV, torch.float32)
+    for m in g.modules():
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = 0.0
+    g.train()
+    _, label, bbox, z1, z_im = make_batch(2, 64, "coco", seed=1, device=DEV)
+    z2 = torch.randn_like(z1)
+    state = {k: v.clone() for k, v in g.state_dict().items()}
+    sn = g.arena.sn_flat.data.clone()
+
+    def grads(pairs, together):
+        g.load_state_dict(state)
+        g.arena.sn_flat.data.copy_(sn)
+        g.arena.drop_pending()
+        g.zero_grad()
+        if together:
+            outs = [g(z, bbox, z_im, label) for z in pairs]
+            sum(o.square().mean() for o in outs).backward()
+        else:
+            for z in pairs:
+                g(z, bbox, z_im, label).square().mean().backward()
+        g.arena.flush_grads()
+        torch.cuda.synchronize()
+        return g.flat.grad.clone()
+    a, b = grads((z1, z2), True), grads((z1, z2), False)
+    assert float((a - b).norm() / b.norm()) < 2e-3, float((a - b).norm() / b.norm())
+
+
+def test_weight_gradient_with_the_fused_last_arriver_reduction():
+    """L2I_WGRAD_FUSE=1 (round 4, measured slower and off by default: DESIGN.md section 4.5): the workgroup that stores an output
+    tile's last partial tile reduces all of them itself (device-scope counter, sc1 stores / loads) -- same weight gradients. The
+    switch is read once per process: the weight-gradient tests run in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, L2I_WGRAD_FUSE="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_gpu_ops.py", "tests/test_gpu_dual.py", "-k",
+                        "conv_wgrad or dual_wgrad or device_side_image_count"], cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stdout[-3000:]
