@@ -76,6 +76,7 @@ class GanTrainer:
         # D(fake)'s backward, which hides ~2 ms of kernel time that the one-batch form (it needs G's output before it can start)
         # cannot hide: 20.5 ms against 21.4 ms per iteration, replayed or eager. OFF by default; L2I_DUAL_D=1 / `dual_d = True`.
         self.dual_d = os.environ.get("L2I_DUAL_D", "0") != "0"
+        self.real_bwd_early = os.environ.get("L2I_REAL_BWD_EARLY", "0") != "0"   # (two-pass form: see _step)
         # Data parallel: G's gradient all-reduce (163 MB) is launched at the end of an iteration and waited for -- together
         # with G's Adam step -- only when the NEXT iteration needs G's weights, i.e. after that iteration's D(real) pass
         # has been enqueued on the side stream: the collective overlaps D(real). (D's all-reduce has nothing independent
@@ -178,9 +179,20 @@ class GanTrainer:
                 d_loss_real = self._d_terms(outs_r, valid, 0, n_roi, n_img)
                 # the fake pass's power iteration + weight packs need only D's weights: done here, off the main stream
                 pc_fake = netD.arena.prepare(training=netD.training, need_wgrad=True)
+                if self.real_bwd_early:
+                    # D(real)'s backward needs nothing but its own forward: it starts here, on the side stream, next to G's forward
+                    # and D(fake)'s forward (small, latency-bound launches) instead of next to D(fake)'s backward (the same
+                    # chip-filling weight-gradient launches competing for the L2s). The main stream waits for the packs only.
+                    packs_ready = torch.cuda.Event()
+                    packs_ready.record(self._side)
+                    d_loss_real.backward()
+                    d_loss_real = d_loss_real.detach()
             self.flush()   # the previous iteration's G all-reduce + Adam: behind D(real)'s launches, in front of G's forward
             fake = netG(z, bbox, z_im=z_im, y=y)
-            cur.wait_stream(self._side)
+            if self.real_bwd_early:
+                cur.wait_event(packs_ready)
+            else:
+                cur.wait_stream(self._side)
             *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y, pc=pc_fake, layout=layout)
             d_loss_fake = self._d_terms(outs_f, valid, 1, n_roi, n_img)
         else:
@@ -191,8 +203,12 @@ class GanTrainer:
             fake = netG(z, bbox, z_im=z_im, y=y)
             *outs_f, _, _ = netD.forward_padded(fake.detach(), bbox, y, layout=layout)
             d_loss_fake = self._d_terms(outs_f, valid, 1, n_roi, n_img)
-        d_loss = d_loss_real + d_loss_fake
-        d_loss.backward()
+        if self.overlap and not self.dual_d and self.real_bwd_early:
+            d_loss_fake.backward()
+            d_loss = d_loss_real + d_loss_fake.detach()
+        else:
+            d_loss = d_loss_real + d_loss_fake
+            d_loss.backward()
         if self.overlap and not self.dual_d:
             # D(real)'s backward ran on the side stream; what it wrote outside autograd's view (weight-gradient
             # accumulators, direct bias-gradient atomics) and the pack buffers it read must be ordered before the

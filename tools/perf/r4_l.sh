@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+A="--no-cpu-baseline --no-g-forward --no-f32-mode --no-kernel-timer --steps 40"
+run() { python bench.py $A 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d['eager'])"; }
+for i in 1 2; do run base; L2I_REAL_BWD_EARLY=1 run early; done

@@ -35,12 +35,12 @@ def run(path, steps=3):
     def call(name, *a):
         if name == "l2i_conv2d_fwd":
             calls.append(("fwd",) + tuple(a[9:20]) + (a[22] is not None,))
-        elif name == "l2i_conv2d_fwd_sc":   # 3x3 conv with a block's 1x1 shortcut handed over (folded, or un-folded by the library)
-            calls.append(("fwd",) + tuple(a[9:20]) + (a[22] is not None, int(a[31])))
+        elif name in ("l2i_conv2d_fwd_sc", "l2i_conv2d_fwd_dual"):   # 3x3 conv with a block's 1x1 shortcut handed over (folded, or un-folded by the library)
+            calls.append(("fwd",) + tuple(a[9:20]) + ((a[22] is not None, int(a[31])) if a[25] is not None else (a[22] is not None,)))
         elif name == "l2i_conv2d_wgrad":
             calls.append(("wgr",) + tuple(a[4:14]) + (0, a[16] is not None))
-        elif name == "l2i_conv2d_wgrad_sc":   # conv2's weight gradient carrying the shortcut's (one launch; assumed folded)
-            calls.append(("wgr",) + tuple(a[4:14]) + (0, a[16] is not None, -int(a[22])))
+        elif name in ("l2i_conv2d_wgrad_sc", "l2i_conv2d_wgrad_dual"):   # conv2's weight gradient carrying the shortcut's (one launch; assumed folded)
+            calls.append(("wgr",) + tuple(a[4:14]) + ((0, a[16] is not None, -int(a[22])) if a[20] is not None else (0, a[16] is not None)))
         orig(name, *a)
     _lib.call = call
     ops._lib.call = call
