@@ -20,8 +20,6 @@ for cls, names in ((G.BoxMultiHeadedAttention, ["forward"]), (G.MaskRegressNetv2
                    (D.CombineDiscriminator128_app, ["prepare_layout", "_prepare"]), (arena.WeightArena, ["prepare", "flush_grads"])):
     for n in names:
         wrap(cls, n, cls.__name__ + "." + n)
-for n in ("bbox_mask", "masks_to_layout", "box_relational_embedding"):
-    wrap(G, n)
 for n in ("proj_head", "emb_dot", "gram_head", "roi_align", "hinge", "hinge_sum", "l1_loss", "stage_mask", "box_attention", "grouped_linear", "adam_step"):
     if hasattr(ops, n): wrap(ops, n, "ops." + n)
 wrap(G.ResnetGenerator128_context, "_stage_mask", "G._stage_mask")
