@@ -28,6 +28,9 @@ def _rows(t, pc):
     return ops.split_halves(t) if t.requires_grad else (t[:t.shape[0] // 2], t[t.shape[0] // 2:])
 
 
+JOIN_READERS = __import__("os").environ.get("L2I_JOIN_READERS", "1") != "0"   # A/B switch: two-reader tensors summed inside a data-gradient launch
+
+
 def _conv(ci, co, k, uses=1):
     return GemmWeight("conv", co, ci, k, sn=True, eps=1e-4, uses=uses)
 
@@ -62,10 +65,13 @@ class ResBlock(nn.Module):
         if self.learnable_sc:
             self.c_sc = _conv(in_ch, out_ch, 1, uses)
 
-    def forward(self, x, pc, use=0, nimg=None, emit=(), sole_reader=False):
+    def forward(self, x, pc, use=0, nimg=None, emit=(), sole_reader=False, join_in=None, join_out=None):
         """`sole_reader`: x is the result of another block's conv2 and this block is its ONLY reader -- the data-gradient launch
         of conv1 (which also takes the shortcut branch's gradient as its residual: the complete dx) then writes the operand
         copy of dx that the producing conv2's backward needs, instead of a separate cast pass over the f32 gradient.
+        `join_in` / `join_out` (ops.fused_conv): x is read by TWO blocks -- the one created later (its backward runs first) leaves
+        its complete dx in the shared GradJoin (join_out, conv1's launch), this block's shortcut launch adds it (join_in), so the sum
+        over both readers comes out of conv1's data-gradient launch (with `sole_reader` its operand copy as well).
         `use`: index of this application within the forward pass (each application of a spectral-normed
         module runs its own power iteration in the reference). `nimg`: device count of live leading images (ROI heads).
         `emit`: operand copies of the block's result its consumers will read ("relu" / "raw"), written by conv2's
@@ -75,8 +81,10 @@ class ResBlock(nn.Module):
         if self.learnable_sc:
             ops.precast(x, pc.arena.op_dtype)   # conv1 reads relu(x), the shortcut reads x: one cast launch for both (if not emitted upstream)
         j = ops.GradJoin()   # dx of the shortcut branch enters conv1's data-gradient epilogue instead of a separate add
-        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, relu_op_out=True, join=(j, "take"), dx_raw=sole_reader)
-        sc = fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg, join=(j, "give"), lazy_sc=True) if self.learnable_sc else x
+        h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, relu_op_out=True, join=(j, "take"), dx_raw=sole_reader,
+                       join_out=join_out)
+        sc = (fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg, join=(j, "give"), lazy_sc=True, join_in=join_in)
+              if self.learnable_sc else x)
         return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample, nimg=nimg, emit=emit,
                           dx_raw=True, join=None if self.learnable_sc else (j, "give_res"))
 
@@ -107,15 +115,16 @@ class ResnetDiscriminator128_app(nn.Module):
         both = ("relu", "raw")   # what a following block with a learnable shortcut reads
         x = self.block1(x, pc, emit=both)
         x1 = self.block2(x, pc, emit=both, sole_reader=True)
-        x2 = self.block3(x1, pc, emit=both)
-        x = self.block4(x2, pc, emit=both)
+        jx1, jx2 = ops.GradJoin(), ops.GradJoin()   # x1 and x2 are each read by a trunk block and by an object-path block
+        x2 = self.block3(x1, pc, emit=both, join_in=jx1, sole_reader=JOIN_READERS)
+        x = self.block4(x2, pc, emit=both, join_in=jx2, sole_reader=JOIN_READERS)
         x = self.block5(x, pc, emit=("relu",), sole_reader=True)
         x = self.block6(x, pc, sole_reader=True)
         P = _passes(pc)
         out_im = [ops.proj_head(xk, self.l7, p) for xk, p in zip(_rows(x, pc), P)]            # l7(sum_hw relu(x))
 
-        feat_s = self.block_obj4(self.block_obj3(x1, pc, emit=both), pc, use=0, sole_reader=True)   # reference order :136-141
-        feat_l = self.block_obj4(x2, pc, use=1)
+        feat_s = self.block_obj4(self.block_obj3(x1, pc, emit=both, join_out=jx1 if JOIN_READERS else None), pc, use=0, sole_reader=True)   # reference order :136-141
+        feat_l = self.block_obj4(x2, pc, use=1, join_out=jx2 if JOIN_READERS else None)
         obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0)  # (R,8,8,C)
 
         # appearance head (reference :148-157): Gram of the ROI features + class embedding

@@ -508,7 +508,7 @@ class FusedConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None,
-                emit=(), dx_raw=False, join=None, op_out=False, lazy_sc=False):
+                emit=(), dx_raw=False, join=None, op_out=False, lazy_sc=False, join_in=None, join_out=None):
         opd = pc.arena.op_dtype
         _chk(x, opd if (pro.kind in ("op", "opraw") and not pc.arena.split) else torch.float32)
         B, H, W, C = x.shape
@@ -585,6 +585,7 @@ class FusedConvFn(Function):
                 _attach(out, raw=o_raw, relu=o_relu)
         ctx.op_out = op_out
         ctx.flops, ctx.nimg, ctx.dx_raw, ctx.join = flops, nimg, dx_raw, join
+        ctx.join_in, ctx.join_out = join_in, join_out
         sw, sb = getattr(wproj, "_l2i_sink", None), getattr(bproj, "_l2i_sink", None)
         ctx.sink = (sw[0], sw[1], sb[1]) if sw is not None and sb is not None and sw[0] is sb[0] else None
         ctx.holder, ctx.pc, ctx.pro, ctx.up2, ctx.pool2, ctx.stats = holder, pc, pro, up2, pool2, stats
@@ -649,6 +650,8 @@ class FusedConvFn(Function):
             op_in = pro.kind in ("op", "opraw")   # the input edge is an operand tensor: its gradient is the operand copy alone
             emit_raw = op_in or (ctx.dx_raw and pro.kind != "norm" and not small)   # (the norm backward rewrites dxo: its copy would be stale)
             joined = ctx.join[0].take() if ctx.join is not None and ctx.join[1] == "take" and need_x else None
+            if joined is None and ctx.join_in is not None and need_x and pro.kind != "norm":
+                joined = ctx.join_in.take()   # the complete gradient another reader of x left for this launch's free residual slot
             dxo, _, dx_op = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
                                      pool2=ctx.up2, alpha=alpha, flops=ctx.flops, nimg=ctx.nimg, want_raw=emit_raw,
                                      want_f32=not op_in, res=joined if pro.kind != "norm" else None, wpack_b=pc.dgrad_pack_b(h))
@@ -665,10 +668,12 @@ class FusedConvFn(Function):
                 dx = dxo
             if ctx.join is not None and ctx.join[1] == "give":
                 dx = ctx.join[0].give(dx)
+            if ctx.join_out is not None and dx is not None:
+                dx = ctx.join_out.give(dx)
         d_res = dy if ctx.has_res else None
         if d_res is not None and ctx.join is not None and ctx.join[1] == "give_res":
             d_res = ctx.join[0].give(d_res)
-        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None, None, None
+        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _attach(t, raw=None, relu=None):
@@ -698,8 +703,11 @@ def precast(x, op_dtype):
 
 
 def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False, nimg=None,
-               emit=(), dx_raw=False, join=None, relu_op_out=False, lazy_sc=False):
-    """emit: operand copies of the result to write in the epilogue ("relu", "raw") for the layers that read it next.
+               emit=(), dx_raw=False, join=None, relu_op_out=False, lazy_sc=False, join_in=None, join_out=None):
+    """join_in / join_out: a GradJoin shared with ANOTHER reader of x (a tensor read by two blocks): the reader whose backward runs
+    first (the one created later) leaves its complete dx there (join_out), the other one's launch with a free residual slot (a
+    block's 1x1 shortcut) adds it in its data-gradient epilogue (join_in) -- no autograd accumulation pass over the two gradients.
+    emit: operand copies of the result to write in the epilogue ("relu", "raw") for the layers that read it next.
     dx_raw: x is read by this layer ONLY and was produced by another fused_conv -- the data-gradient launch then also
     writes the operand copy of dx that the producer's backward needs (no separate cast pass over dx).
     join: (GradJoin, "give" | "take" | "give_res") -- see GradJoin.
@@ -725,7 +733,7 @@ def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None,
         if res is not None or pool2 or ((B * Ho * Wo + 127) // 128) * ((holder.co_p + 127) // 128) < 192 or not OP_EDGES:
             relu_op_out, emit = False, tuple(emit) + ("relu",)
     out = FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg, tuple(emit), dx_raw, join,
-                            relu_op_out, bool(lazy_sc) and SC_FOLD)
+                            relu_op_out, bool(lazy_sc) and SC_FOLD, join_in, join_out)
     if relu_op_out:
         out._l2i_relu_op = True
     return out

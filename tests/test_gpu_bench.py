@@ -33,3 +33,28 @@ def test_bench_refuses_wrong_result_switches():
     env = dict(os.environ, L2I_CONV_NOEPI="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode != 0 and "refusing" in (p.stderr + p.stdout)
+
+
+def test_bench_default_line_carries_the_contract_fields():
+    """`python bench.py` at N = 1 (few steps): ONE JSON line with the contract's keys, the roofline object (frac = achieved / peak,
+    traffic from this round's PMC file, per-launch figures consistent with each other), the secondary legs (eager, f32_mode,
+    generator forward with its precision modes: bf16x3 within the 1e-3 image bar of the exact-f32 mode), every timed step a replay."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["dtype"] == "bf16" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert "replay" in d["config"]["launch"]
+    assert abs(d["value"] - 32 * 4 / (d["ms_per_step"] * 4e-3)) < 0.02 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["gflop_per_launch"] / r["avg_launch_us"] * 1e-3 * 1e3) < 0.02 * r["achieved"]   # GFLOP / us = PFLOP/s -> x 1e3 TFLOP/s
+    assert r["traffic"] is not None and r["traffic"] > r["algorithmic_bytes_per_launch"] and r["traffic_source"]["measured_in_run"] is False
+    assert 0.15 < r["frac"] < 0.7 and 0.1 < r["wgrad_frac"] < 0.7
+    assert d["eager"]["images_per_sec"] > 0.5 * d["value"] and d["f32_mode"]["images_per_sec"] > 0
+    pm = d["g_forward"]["precision_modes"]
+    assert pm["bf16x3"]["image_linf_vs_f32_mode"] < pm["bar"] < pm["bf16"]["image_linf_vs_f32_mode"]
+    assert pm["bf16x3"]["ms"] < pm["f32"]["ms"]
