@@ -91,8 +91,10 @@ def main(argv=None):
                 try:
                     graphed = trainer.capture(real, label, bbox, z, z_im)
                 except Exception as e:
-                    print(f"[train] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", flush=True)
-                    graphed = False
+                    # (an invalidated capture leaves the HIP runtime in a sticky error state: nothing in this process can launch
+                    #  any more -- tools/parity/capture_failure_probe.py; the eager loop needs a fresh process)
+                    raise RuntimeError(f"HIP graph capture of the training iteration failed ({type(e).__name__}: {str(e)[:200]}); "
+                                       "run again with --no_graph") from e
                 restore_state(trainer, st)         # first REPLAY is the first training iteration
                 n_obj = (b, o)
             if graphed and (b, o) == n_obj:

@@ -286,6 +286,8 @@ class GanTrainer:
             #  capture mode any other thread's event query invalidates the capture -- hipErrorStreamCaptureInvalidated, measured)
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if self.dp else "global"):
                 self._graph_out = self.step(*self._static)
+                if os.environ.get("L2I_TEST_CAPTURE_FAIL", "0") == "1":   # (tests: an illegal call invalidates the capture)
+                    torch.cuda.synchronize()
         except Exception:
             self._graph = None
             torch.cuda.synchronize()

@@ -58,3 +58,14 @@ def test_bench_default_line_carries_the_contract_fields():
     pm = d["g_forward"]["precision_modes"]
     assert pm["bf16x3"]["image_linf_vs_f32_mode"] < pm["bar"] < pm["bf16"]["image_linf_vs_f32_mode"]
     assert pm["bf16x3"]["ms"] < pm["f32"]["ms"]
+
+
+def test_bench_reruns_itself_eagerly_when_graph_capture_fails():
+    """A capture that is invalidated leaves the HIP runtime unusable for the rest of the process (tools/parity/capture_failure_probe.py),
+    so bench.py's fallback is a fresh process with --no-graph: forced here by an illegal call inside the capture."""
+    env = dict(os.environ, L2I_TEST_CAPTURE_FAIL="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
+                        "--no-g-forward", "--no-f32-mode"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    assert d["config"]["launch"] == "eager" and d["value"] > 0 and "re-running eagerly" in p.stderr

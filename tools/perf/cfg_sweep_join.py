@@ -10,7 +10,7 @@ for t in tags:
     name = "heur" if t == "heur" else f"cfg{t}"
     r = {}
     for line in open(f"{d}/shapes_{name}.txt"):
-        m = re.match(r"\s+([\d.]+)\s+x\s+(\d+)\s+([\d.]+)\s+(\(.*\))\s+(\S.*)", line)
+        m = re.match(r"\s+([\d.]+)\s+x\s*(\d+)\s+([\d.]+)\s+(?:[\d.]+\s+)?(\(.*\))\s+(\S.*)", line)   # (optional 4th column: us at 70 % of the peak)
         if m:
             key = ast.literal_eval(m.group(4))
             if key[0] == "fwd" and key[8] == 3:
