@@ -235,7 +235,7 @@ _LOOP_BARS = {
 }
 
 
-def _loop_vs_reference(kind, dt, dual=False):
+def _loop_vs_reference(kind, dt, dual=False, early=False):
     import layout2img_amd as L
     vg = kind == "vg"
     f32 = dt == torch.float32
@@ -245,6 +245,7 @@ def _loop_vs_reference(kind, dt, dual=False):
     g.train(), d.train()
     tr = L.GanTrainer(g, d)
     tr.dual_d = dual   # D(real) + D(fake) of the D step as one batch (GanTrainer.dual_d, CombineDiscriminator.forward_dual)
+    tr.real_bwd_early = early   # D(real)'s backward on the side stream right behind its forward (GanTrainer.real_bwd_early)
     bars = _LOOP_BARS[(kind, f32)]
     for it in range(2):
         mk = recipe.make_inputs_vg(2, 31, 179, 300 + it) if vg else recipe.make_inputs(2, 8, 184, 200 + it)
@@ -277,6 +278,13 @@ def test_train_loop_vs_reference_with_the_dual_discriminator_step(kind):
     """The same goldens with D(real) and D(fake) of the discriminator step run as ONE batch (two weight packs and two gradient
     accumulators per launch, l2i_conv2d_fwd_dual / l2i_conv2d_wgrad_dual): same losses, images and parameter sums, same bars."""
     _loop_vs_reference(kind, torch.float32, dual=True)
+
+
+def test_train_loop_vs_reference_with_the_early_real_backward():
+    """`GanTrainer.real_bwd_early` (L2I_REAL_BWD_EARLY=1: D(real)'s backward as its own backward call on the side stream, D(fake)'s
+    afterwards on the main stream; measured slower, off by default) against the same goldens: the two separate backward passes
+    accumulate into the same gradient buffers what one backward over the summed loss does."""
+    _loop_vs_reference("coco", torch.float32, early=True)
 
 
 def test_full_size_step_properties():
