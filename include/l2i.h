@@ -70,12 +70,17 @@ int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias, const flo
  * (model/rcnn_discriminator_app.py:10-15), so each pass has its own W / sigma. Images [0, B/2) are multiplied with w (sc_w),
  * images [B/2, B) with w_b (sc_w_b): one launch with twice the tiles instead of two. `nimg` counts the live leading images of
  * EACH half. w_b == NULL: exactly l2i_conv2d_fwd_sc. Needs B even, no `stats`, and (B/2) * Ho a multiple of the tile's pixel
- * rows ((B/2) * Ho * min(Wo, 16) % 256 == 0 always suffices); L2I_ERR_ARG otherwise (the caller issues two launches). */
+ * rows ((B/2) * Ho * min(Wo, 16) % 256 == 0 always suffices); L2I_ERR_ARG otherwise (the caller issues two launches).
+ * scratch (optional, caller-owned f32, as l2i_conv2d_wgrad's; L2I_WGRAD_SCRATCH_FLOATS suffices): with it 3x3 convolutions on 4x4 maps
+ * with >= 256 input channels (model/rcnn_discriminator_app.py:94-96 block6; bf16, no `nimg`, f32 result only) run on the
+ * weight-stationary split-K kernel -- every workgroup keeps one 64-channel chunk of the pack for 64 output channels and all
+ * pixels in LDS, stores its partial tile there, and a second kernel adds the Ci / 64 partial tiles and applies the epilogue. */
 int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bias, const float* res, const void* relu_mask,
                         float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                         int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats,
                         float* ws, const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi,
-                        int sc_Wi, int sc_Ci, int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, void* stream);
+                        int sc_Wi, int sc_Ci, int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, float* scratch,
+                        long long scratch_floats, void* stream);
 
 /* Per-launch timing of the two MFMA entry points (bench.py's roofline leg). l2i_timing(1): from now on every kernel
  * launched by l2i_conv2d_fwd (class 0) / l2i_conv2d_wgrad (class 1) carries a start / stop HIP event pair attached to

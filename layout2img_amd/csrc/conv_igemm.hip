@@ -71,6 +71,8 @@ struct ConvArgs {
     int no_epi;          // ablation builds only (-DL2I_ABLATIONS + L2I_CONV_NOEPI=1, results are wrong): skip the epilogue to measure what it costs
     int epi_lds;         // 1: coalesced epilogue through LDS (conv_epilogue_lds; default), 0: direct stores from the accumulator layout (L2I_EPI=0, A/B)
     ScArgs sc;           // folded 1x1 shortcut (see ScArgs); sc.x == null: none
+    float* scratch;      // optional caller-owned f32 scratch (l2i_conv2d_fwd_dual): partial tiles of the weight-stationary small-map kernel
+    long long scratch_floats;
 };
 
 typedef const ScArgs __attribute__((address_space(4)))* ScArgsPtr;
@@ -1586,6 +1588,190 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     return l2i_check_launch();
 }
 
+// ---------------------------------------------------------------- 4x4 maps: weight-stationary split-K (conv_wstat_kernel)
+// 3x3 convolutions on 4x4 maps (D block6, reference model/rcnn_discriminator_app.py:94-96: 1024 -> 1024 on 32 x 16 = 512 pixels)
+// are all weights: 18.9 MB of pack for 9.7 GFLOP. The generic kernel streams every weight tile through a 2-stage ring per
+// 128-pixel tile (4 tiles of pixels x 16 of channels x 8 K-splits: 226 MB through the L2s, a latency-bound K loop of 18
+// steps) and combines the splits with 16.8 MB of f32 atomics: 40-45 us per launch at 0.09 of the MFMA peak. Here a workgroup
+// owns ONE 64-channel chunk of the reduction for 64 output channels and ALL (up to 512) pixels: its 72 KB slice of the pack
+// (9 taps x 64 x 64) and the compact 64 KB input halo of its chunk (32 images x 16 pixels x 64 channels; taps outside an
+// image read a zero row) are DMA'd into LDS once, 288 MFMAs per wave run from LDS without a barrier, and the 512 x 64
+// partial tile is STORED (register order, 16 bytes per lane) to the caller's scratch; conv_wstat_reduce_kernel adds the
+// Ci / 64 partial tiles and applies the epilogue (alpha, bias, ReLU mask, residual). Every weight element is read by exactly
+// one workgroup per 512 pixels. bf16, KH = 3, Ho = Wo = 4, no up / pool, Ci % 64 == 0.
+struct WstatArgs {
+    const void* x; const void* w;
+    float* part;
+    int B, Ci, Co, Kpad, tiles_n, nsplit;
+    unsigned x_bytes, w_bytes;
+};
+#define WS_HALO (512 * 128)
+#define WS_ZERO 256
+#define WS_LDS (WS_HALO + WS_ZERO + 9 * 64 * 128)
+__global__ __launch_bounds__(256, 1) void conv_wstat_kernel(WstatArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr unsigned OOB = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    int bid = blockIdx.x;
+    const int tn = bid % p.tiles_n; bid /= p.tiles_n;
+    const int split = bid % p.nsplit;
+    const int tm = bid / p.nsplit;
+    const int n0 = tn * 64, c0 = split * 64, img0 = tm * 32;
+    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
+    const unsigned smem_addr = lds_addr_of(smem);
+    if (tid < WS_ZERO / 16) *reinterpret_cast<uint4*>(smem + WS_HALO + tid * 16) = make_uint4(0, 0, 0, 0);
+    // ---- DMA: the halo (64 wave-instructions of 8 rows x 128 bytes) and the pack slice (72), source-side swizzled
+    {
+        const int r8 = lane >> 3, pch = lane & 7;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (wv * 16 + q) * 8 + r8;                 // pixel of the tile: image row >> 4, pixel row & 15
+            const int img = img0 + (row >> 4);
+            const int lch = pch ^ ig2_swz(row);
+            const unsigned off = img < p.B ? (unsigned)(((img * 16 + (row & 15)) * p.Ci + c0 + lch * 8) * 2) : OOB;
+            buf_load_lds16(rsrc_x, off, smem_addr + (unsigned)((wv * 16 + q) * 1024));
+        }
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {   // tap-major: instructions 2t, 2t + 1 of every wave are tap t's rows, so tap t can start early
+            const int tap = q >> 1, n = (wv * 2 + (q & 1)) * 8 + r8;
+            const int lch = pch ^ ig2_swz(n);
+            const unsigned off = (unsigned)((((n0 + n) * p.Kpad) + tap * p.Ci + c0 + lch * 8) * 2);
+            buf_load_lds16(rsrc_w, off, smem_addr + (unsigned)(WS_HALO + WS_ZERO + (tap * 64 + (wv * 2 + (q & 1)) * 8) * 128));
+        }
+    }
+    // ---- fragment addresses: A = this lane's pixel of each of the wave's four 32-pixel tiles, for each tap
+    constexpr int TM = 4, TN = 2;
+    const int hh = lane >> 5;
+    unsigned a_addr[TM][9];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pl = wave * 128 + i * 32 + (lane & 31);
+        const int y = (pl >> 2) & 3, x = pl & 3;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            const int row = (pl & ~15) + yy * 4 + xx;
+            const bool in = yy >= 0 && yy < 4 && xx >= 0 && xx < 4;
+            a_addr[i][tap] = in ? (unsigned)(row * 128 + ((hh ^ ig2_swz(row)) << 4)) : (unsigned)(WS_HALO + (hh << 4));
+        }
+    }
+    unsigned b_addr[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = j * 32 + (lane & 31);
+        b_addr[j] = (unsigned)(WS_HALO + WS_ZERO + n * 128 + ((hh ^ ig2_swz(n)) << 4));
+    }
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // (waiting per tap -- the pack rows are issued tap-major -- and starting the MFMAs under the rest of the DMA was measured:
+    //  17.5 against 17.0 us per launch; the kernel's time is its 128 KB partial-tile store and the HBM read of its pack slice)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int k0 = 0; k0 < 4; k0 += 2) {
+            bf16x8_t fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[kk][i] = *reinterpret_cast<const bf16x8_t*>(smem + (a_addr[i][tap] ^ (unsigned)((k0 + kk) << 5)));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[kk][j] = *reinterpret_cast<const bf16x8_t*>(smem + ((b_addr[j] ^ (unsigned)((k0 + kk) << 5)) + (unsigned)(tap * 8192)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[kk][j]),   // weights first: transposed tile
+                            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[kk][i]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- partial tile in register order: float4 f = (((wave * TM + i) * TN + j) * 4 + g) * 64 + lane
+    float4* t = reinterpret_cast<float4*>(p.part) + ((size_t)(tm * p.tiles_n + tn) * p.nsplit + split) * 8192 + wave * (TM * TN * 4 * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                t[((i * TN + j) * 4 + g) * 64] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+}
+
+// out = mask(alpha * sum over the splits + bias) + res for the partial tiles above; one thread per float4 of a tile.
+__global__ __launch_bounds__(256) void conv_wstat_reduce_kernel(const float* __restrict__ part, ConvArgs p, int tiles_n, int nsplit) {
+    const int tile = blockIdx.x >> 5, f = ((blockIdx.x & 31) << 8) + threadIdx.x;
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    const float4* src = reinterpret_cast<const float4*>(part) + (size_t)tile * nsplit * 8192 + f;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {
+        const float4 v0 = src[(size_t)s * 8192], v1 = src[(size_t)(s + 1) * 8192], v2 = src[(size_t)(s + 2) * 8192], v3 = src[(size_t)(s + 3) * 8192];
+        a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+        a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < nsplit; ++s) {
+        const float4 v0 = src[(size_t)s * 8192];
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    }
+    const int lane = f & 63, g = (f >> 6) & 3, j = (f >> 8) & 1, wi = f >> 9, i = wi & 3, w = wi >> 2;
+    const int pix = tm * 512 + w * 128 + i * 32 + (lane & 31);
+    const int ch = tn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+    if (pix >= p.B * 16 || ch >= p.Co) return;
+    float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+    if (p.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    const size_t off = (size_t)pix * p.Co + ch;
+    if (p.relu_mask) {
+        float mk[4];
+        Op4<bf16_t>::load(reinterpret_cast<const bf16_t*>(p.relu_mask) + off, mk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (!(mk[e] > 0.f)) v[e] = 0.f;
+    }
+    if (p.res) {
+        const float4 r4 = *reinterpret_cast<const float4*>(p.res + off);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+    *reinterpret_cast<float4*>(p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// Returns -100 when the launch is not covered (the caller falls through to the other kernels).
+static int launch_wstat(ConvArgs& a, hipStream_t stream) {
+    static const int on = getenv("L2I_WSTAT") ? atoi(getenv("L2I_WSTAT")) : 1;
+    if (!on || a.KH != 3 || a.Ho != 4 || a.Wo != 4 || a.up2 || a.pool2 || a.Ci % 64 || a.Ci < 256 || a.Co % 4 || a.nimg || a.half_rows || a.sc.x ||
+        !a.out || a.out_op || a.out_op_raw || a.stat_ws || !a.scratch)
+        return -100;
+    WstatArgs w;
+    w.x = a.x; w.w = a.w; w.part = a.scratch;
+    w.B = a.B; w.Ci = a.Ci; w.Co = a.Co; w.Kpad = a.Kpad;
+    w.tiles_n = (a.Co + 63) / 64; w.nsplit = a.Ci / 64;
+    w.x_bytes = a.x_bytes; w.w_bytes = a.w_bytes;
+    const int tiles_m = (a.B * 16 + 511) / 512, tiles = tiles_m * w.tiles_n;
+    if ((long long)tiles * w.nsplit * 32768 > a.scratch_floats) return -100;
+    static bool ready = false;
+    if (!ready) {
+        (void)hipFuncSetAttribute((const void*)conv_wstat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
+        ready = true;
+    }
+    L2I_LAUNCH(0, conv_wstat_kernel, dim3(tiles * w.nsplit), dim3(256), WS_LDS, stream, w);
+    L2I_LAUNCH(0, conv_wstat_reduce_kernel, dim3(tiles * 32), dim3(256), 0, stream, (const float*)a.scratch, a, w.tiles_n, w.nsplit);
+    return l2i_check_launch();
+}
+
 static int g_conv_cfg_override = -1;  // tuning hook (l2i_set_conv_config): -1 = heuristic
 static int g_epi_mode = -1;           // forced epilogue form (tests / tuning), -1 = default
 extern "C" int l2i_set_conv_config(int cfg) {
@@ -1646,6 +1832,10 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     // (profiles/r02_small_map_ab.txt): 4 -> 8 layers 870 -> 657 us and 240 -> 193 us on conv_halo3; the 4x4 maps of D
     // block6 are FASTER on the generic split-K kernel there (570 vs 666 us) although slower back to back -> default 1.
     static const int no_small = getenv("L2I_NO_SMALL_HALO") ? atoi(getenv("L2I_NO_SMALL_HALO")) : 1;
+    if (sizeof(T) == 2 && g_conv_cfg_override < 0 && g_generic_cfg < 0) {   // 4x4 maps: the weight-stationary split-K kernel (needs the caller's scratch)
+        const int rc = launch_wstat(a, stream);
+        if (rc != -100) return rc;
+    }
     const bool small_map = a.Wo < 8 || (a.up2 && a.Wo < 16);   // 4-wide maps, 4 -> 8 upsampling: only conv_halo3's compact halo covers them
     if (sizeof(T) == 2 && a.KH == 3 && a.Ci >= 64 && !a.lin && a.Wo >= 4 && !(a.up2 && a.Wo < 8) && a.Ho >= 2 &&
         (!small_map || (a.Ci % 64 == 0 && a.Ci >= 256 && !((no_small & 1) && a.Wo < 8) && !((no_small & 2) && a.up2))) &&
@@ -1779,14 +1969,14 @@ extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bi
                                    const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                                    int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
                                    const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
-                                   int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, void* stream);
+                                   int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, float* scratch, long long scratch_floats, void* stream);
 
 extern "C" int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float* res,
                               const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                               int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
                               void* stream) {
     return l2i_conv2d_fwd_dual(x, w, bias, res, relu_mask, out, out_op, out_op_raw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu_op,
-                               Kpad, alpha, nimg, stats, ws, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, stream);
+                               Kpad, alpha, nimg, stats, ws, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias, const float* res,
@@ -1795,7 +1985,7 @@ extern "C" int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias
                                  const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
                                  int sc_up2, int sc_Kpad, void* stream) {
     return l2i_conv2d_fwd_dual(x, w, bias, res, relu_mask, out, out_op, out_op_raw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu_op,
-                               Kpad, alpha, nimg, stats, ws, sc_x, sc_w, sc_bias, sc_out, sc_Hi, sc_Wi, sc_Ci, sc_up2, sc_Kpad, nullptr, nullptr, stream);
+                               Kpad, alpha, nimg, stats, ws, sc_x, sc_w, sc_bias, sc_out, sc_Hi, sc_Wi, sc_Ci, sc_up2, sc_Kpad, nullptr, nullptr, nullptr, 0, stream);
 }
 
 // Dual launch: w_b (and sc_w_b with a folded shortcut) non-null -> the B images are two passes of B/2 images each that share
@@ -1806,7 +1996,7 @@ extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bi
                                    const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                                    int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
                                    const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
-                                   int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, void* stream) {
+                                   int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, float* scratch, long long scratch_floats, void* stream) {
     if (!x || !w || (!out && !out_op && !out_op_raw)) return L2I_ERR_ARG;
     if (w_b && ((B & 1) || stats || (sc_x && !sc_w_b))) return L2I_ERR_ARG;
     if (!w_b && sc_w_b) return L2I_ERR_ARG;
@@ -1834,6 +2024,7 @@ extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bi
     a.epi_lds = epi_mode == 2 || (epi_mode == 1 && (relu_mask != nullptr || out_op != nullptr || out_op_raw != nullptr));
     a.nimg = nimg;
     a.w_b = w_b; a.half_rows = w_b ? (B / 2) * Ho : 0;
+    a.scratch = scratch; a.scratch_floats = scratch ? scratch_floats : 0;
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out; a.out_op = out_op; a.out_op_raw = out_op_raw; a.relu_mask = relu_mask;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.relu_op = relu_op ? 1 : 0;

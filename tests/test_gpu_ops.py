@@ -269,6 +269,30 @@ def test_split_operand_conv_is_f32_accurate(case):
         assert err < 3e-5 and err < 0.05 * plain, (err, plain)
 
 
+@pytest.mark.parametrize("case", [(32, 1024, 1024), (3, 256, 264), (40, 512, 128), (33, 320, 72), (64, 1024, 512)])
+def test_conv_small_map_weight_stationary(case):
+    """3x3 convolutions on 4x4 maps with >= 256 input channels (D block6, reference model/rcnn_discriminator_app.py:94-96) run on
+    conv_wstat_kernel (one 64-channel chunk of the pack per workgroup, all pixels, partial tiles through the stream's scratch) +
+    conv_wstat_reduce_kernel (splits, alpha, bias, ReLU mask, residual): forward form and data-gradient form (mask + residual)
+    against the f32 convolution, incl. more than 32 images (two pixel tiles), a ragged last tile and Co that is not a multiple of 64."""
+    from layout2img_amd import ops
+    B, Ci, Co = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(B + Ci + Co)
+    x = _rt(torch.randn(B, 4, 4, Ci, generator=g), dt)
+    w = _rt(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9), dt)
+    bias = torch.randn(Co, generator=g)
+    ref = _ref_conv(x, w, bias, False, False)
+    mask = _rt(torch.randn(ref.shape, generator=g), dt)
+    res = torch.randn(ref.shape, generator=g)
+    pack, kpad = _pack(w, 64)
+    out, _, _ = ops.conv_raw(x.to(_dev(), dt), pack.to(_dev(), dt), kpad, Co, 3, bias=bias.to(_dev()))
+    assert float((out.cpu() - ref).abs().max()) < 3e-5 * float(ref.abs().max())
+    out2, _, _ = ops.conv_raw(x.to(_dev(), dt), pack.to(_dev(), dt), kpad, Co, 3, relu_mask=mask.to(_dev(), dt), res=res.to(_dev()), alpha=0.5)
+    expect = 0.5 * _ref_conv(x, w, None, False, False) * (mask > 0).float() + res
+    assert float((out2.cpu() - expect).abs().max()) < 3e-5 * float(expect.abs().max())
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_conv_relu_mask(dt, epi):
     from layout2img_amd import ops

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_ops.py tests/test_gpu_dual.py -x -q -k "wgrad or device_side" 2>&1 | tail -2
+A="--no-cpu-baseline --no-g-forward --no-f32-mode --steps 40"
+run() { python bench.py $A 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$1', d['value'], d['ms_per_step'], r['frac'], r['wgrad_frac'])"; }
+for i in 1 2; do (cd scratch/ab_prev && run prev); run new; done

@@ -64,7 +64,13 @@ def join(path, trace, out=None):
     calls, steps, live = meta["calls"], meta["steps"], meta["live"]
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    conv = [r for r in rows if r["Kernel_Name"].startswith(("void conv_", "conv_"))]
+    conv = [r for r in rows if r["Kernel_Name"].startswith(("void conv_", "conv_")) and "conv_wstat_reduce" not in r["Kernel_Name"]]
+    # (the small-map kernel's reduce launch follows its main kernel: its time is added to it)
+    red = {}
+    allc = [r for r in rows if r["Kernel_Name"].startswith(("void conv_", "conv_"))]
+    for a_, b_ in zip(allc, allc[1:]):
+        if "conv_wstat_reduce" in b_["Kernel_Name"]:
+            red[id(a_)] = int(b_["End_Timestamp"]) - int(b_["Start_Timestamp"])
     # a hand-over call is ONE kernel when the shortcut was folded, TWO (generic 1x1, then the 3x3) when the library un-folded it
     def pair(i, k):
         return len(calls[i]) == 14 and "conv_igemm" in conv[k]["Kernel_Name"] and k + 1 < len(conv) and "conv_halo" in conv[k + 1]["Kernel_Name"]
@@ -87,7 +93,7 @@ def join(path, trace, out=None):
     k = 0
     for i, c in enumerate(calls):
         r = conv[k]
-        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) + red.get(id(r), 0)) / 1e3
         k += 1
         sc_ci = 0
         if len(c) == 14:
