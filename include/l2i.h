@@ -118,11 +118,14 @@ int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int dtype, int
 /* DUAL form (see l2i_conv2d_fwd_dual): the weight gradient of images [0, B/2) is added to dw (sc_dw), that of images [B/2, B)
  * to dw_b (sc_dw_b) -- each pass keeps its own accumulator because the spectral-norm backward corrects each with its own
  * u, v, sigma (l2i_weights_backward2). Both halves add their bias gradient to dbias / sc_dbias. `nimg` counts the live images of
- * EACH half. dw_b == NULL: exactly l2i_conv2d_wgrad_sc. Needs B even and (B/2) * Ho * Wo % 64 == 0, else L2I_ERR_ARG. */
+ * EACH half. dw_b == NULL: exactly l2i_conv2d_wgrad_sc. Needs B even and (B/2) * Ho * Wo % 64 == 0, else L2I_ERR_ARG.
+ * overwrite != 0: the caller guarantees that this launch is the only writer of the dW slices it touches since they were zeroed
+ * (the trainer issues one weight-gradient launch per layer application and pass): the result is STORED -- no f32 atomics where an
+ * output tile has a single split, no read-modify-write when the splits are reduced. 0: dW += as everywhere else. */
 int l2i_conv2d_wgrad_dual(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                           int Co, int KH, int up2, int pool2, int ldw, float alpha, const int* nimg, float* dbias,
                           float* scratch, long long scratch_floats, const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2,
-                          int sc_ldw, float* sc_dbias, float* dw_b, float* sc_dw_b, void* stream);
+                          int sc_ldw, float* sc_dbias, float* dw_b, float* sc_dw_b, int overwrite, void* stream);
 /* Tuning hook: co-resident workgroups a weight-gradient launch is sized for (0 = derive from the tile: default). */
 int l2i_set_wgrad_blocks(int n);
 /* Debug aid: co-resident workgroups per CU for conv instantiation `which` with lds_bytes of dynamic LDS. */

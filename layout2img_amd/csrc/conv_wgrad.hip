@@ -52,6 +52,9 @@ struct WgradArgs {
     // tile (a device-scope counter per tile and accumulator) adds all of the tile's partial tiles into dw itself -- no
     // wgrad_reduce_kernel launch behind the main kernel. null: the separate reduce kernel.
     unsigned* fuse_cnt;
+    int overwrite;    // caller's promise: this launch is the ONLY writer of the dW slices it touches since they were zeroed (one weight-
+                      // gradient launch per layer application and pass) -- the result is then STORED: no f32 atomics where a tile has one
+                      // split, no read-modify-write in the reduce kernel. 0: dW += (the ABI's default semantics)
     int nw2_layout;   // (the register-order decode of the partial tiles: as wgrad_reduce_kernel's nw2)
 };
 
@@ -254,7 +257,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = co0 + wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < p.Co) atomicAdd(dwp + (size_t)row * p.ldw + col, p.alpha * acc[i][j][e]);
+                if (row >= p.Co) continue;
+                if (p.overwrite && p.splits == 1) dwp[(size_t)row * p.ldw + col] = p.alpha * acc[i][j][e];
+                else atomicAdd(dwp + (size_t)row * p.ldw + col, p.alpha * acc[i][j][e]);
             }
         }
 }
@@ -716,7 +721,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = co0 + wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < p.Co) atomicAdd(dw_ + (size_t)row * ldw_ + col, p.alpha * acc[i][j][e]);
+                if (row >= p.Co) continue;
+                if (p.overwrite && p.splits == 1) dw_[(size_t)row * ldw_ + col] = p.alpha * acc[i][j][e];   // the tile's only writer: a store (128-byte runs per half-wave)
+                else atomicAdd(dw_ + (size_t)row * ldw_ + col, p.alpha * acc[i][j][e]);
             }
         }
 }
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int BMO, int tiles_k,
                                                            int ntiles, int splits, int Co, int K, int ldw, float alpha, int nw2, int sper,
                                                            int tiles_k_main, float* __restrict__ dw2, int K2, int ldw2,
-                                                           float* __restrict__ dw_b, float* __restrict__ dw2_b) {
+                                                           float* __restrict__ dw_b, float* __restrict__ dw2_b, int overwrite) {
     // blockIdx.y = group of `sper` consecutive splits: layers with few tiles and many splits (the 64-channel layers at
     // 128 x 128: 5 tiles x 153 splits) otherwise run on 40 workgroups, each thread walking 153 partial tiles one dependent
     // load after the other (18 us of a 69-us weight gradient). Groups combine with f32 atomics (gridDim.y > 1 only).
@@ -774,6 +781,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         if (row0 + 1 < Co) atomicAdd(d + ldw, alpha * a.y);
         if (row0 + 2 < Co) atomicAdd(d + 2 * (size_t)ldw, alpha * a.z);
         if (row0 + 3 < Co) atomicAdd(d + 3 * (size_t)ldw, alpha * a.w);
+        return;
+    }
+    if (overwrite) {   // (WgradArgs::overwrite: nothing else has written this slice since it was zeroed)
+        if (row0 < Co) d[0] = alpha * a.x;
+        if (row0 + 1 < Co) d[ldw] = alpha * a.y;
+        if (row0 + 2 < Co) d[2 * (size_t)ldw] = alpha * a.z;
+        if (row0 + 3 < Co) d[3 * (size_t)ldw] = alpha * a.w;
         return;
     }
     if (row0 < Co) d[0] += alpha * a.x;
@@ -957,7 +971,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             sg = (hsp + sper - 1) / sper;
             L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg, dual ? 2u : 1u), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
                        a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, (int)(nw2 && !nw8 && BMO == 128), sper,
-                       a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b);
+                       a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite);
         }
         return l2i_check_launch();
     }
@@ -973,13 +987,13 @@ extern "C" int l2i_conv2d_wgrad_dual(const void* x, const void* dy, float* dw, i
                                      int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
                                      const int* nimg, float* dbias, float* scratch, long long scratch_floats,
                                      const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2, int sc_ldw, float* sc_dbias,
-                                     float* dw_b, float* sc_dw_b, void* stream);
+                                     float* dw_b, float* sc_dw_b, int overwrite, void* stream);
 
 extern "C" int l2i_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
                                 int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
                                 const int* nimg, float* dbias, float* scratch, long long scratch_floats, void* stream) {
     return l2i_conv2d_wgrad_dual(x, dy, dw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, ldw, alpha, nimg, dbias, scratch, scratch_floats,
-                                 nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, stream);
+                                 nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int dtype, int B, int Hi, int Wi, int Ci,
@@ -987,7 +1001,7 @@ extern "C" int l2i_conv2d_wgrad_sc(const void* x, const void* dy, float* dw, int
                                    const int* nimg, float* dbias, float* scratch, long long scratch_floats,
                                    const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2, int sc_ldw, float* sc_dbias, void* stream) {
     return l2i_conv2d_wgrad_dual(x, dy, dw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, ldw, alpha, nimg, dbias, scratch, scratch_floats,
-                                 sc_x, sc_dw, sc_Ci, sc_up2, sc_ldw, sc_dbias, nullptr, nullptr, stream);
+                                 sc_x, sc_dw, sc_Ci, sc_up2, sc_ldw, sc_dbias, nullptr, nullptr, 0, stream);
 }
 
 // Dual launch: dw_b non-null -> the B images are two passes of B/2 images; the first half's gradient is added to dw (sc_dw), the
@@ -998,7 +1012,7 @@ extern "C" int l2i_conv2d_wgrad_dual(const void* x, const void* dy, float* dw, i
                                      int Ho, int Wo, int Co, int KH, int up2, int pool2, int ldw, float alpha,
                                      const int* nimg, float* dbias, float* scratch, long long scratch_floats,
                                      const void* sc_x, float* sc_dw, int sc_Ci, int sc_up2, int sc_ldw, float* sc_dbias,
-                                     float* dw_b, float* sc_dw_b, void* stream) {
+                                     float* dw_b, float* sc_dw_b, int overwrite, void* stream) {
     if (!x || !dy || !dw) return L2I_ERR_ARG;
     if (!dw_b && sc_dw_b) return L2I_ERR_ARG;
     if (sc_x && (!sc_dw || sc_Ci <= 0 || sc_ldw < sc_Ci)) return L2I_ERR_ARG;
@@ -1015,7 +1029,7 @@ extern "C" int l2i_conv2d_wgrad_dual(const void* x, const void* dy, float* dw, i
     a.sc_x = sc_x; a.sc_dw = sc_x ? sc_dw : nullptr; a.dbias2 = sc_x ? sc_dbias : nullptr; a.sc_Ci = sc_Ci; a.sc_ldw = sc_ldw; a.sc_up2 = sc_up2 ? 1 : 0;
     a.sc_x_bytes = 0; a.tiles_k_main = 0;
     a.dw_b = dw_b; a.sc_dw_b = (sc_x && dw_b) ? sc_dw_b : nullptr;
-    a.fuse_cnt = nullptr; a.nw2_layout = 0;
+    a.fuse_cnt = nullptr; a.nw2_layout = 0; a.overwrite = overwrite ? 1 : 0;
     a.x = x; a.dy = dy; a.dw = dw;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.ldw = ldw; a.alpha = alpha;

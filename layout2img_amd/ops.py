@@ -294,8 +294,11 @@ def wgrad_side(x_op, dy_op, dw, *args, **kw):
                 t.record_stream(side)
 
 
-def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None, nimg=None, dbias=None, sc=None, dw_b=None):
-    """dbias: optional (co,) f32 tensor the bias gradient is atomically added to (summed from the staged dY tiles).
+def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0, flops=None, nimg=None, dbias=None, sc=None, dw_b=None,
+              overwrite=False):
+    """overwrite: this launch is the only writer of its dW slices since they were zeroed (FusedConvFn: one launch per layer application
+    and pass) -- the library stores the result instead of accumulating (no atomics on single-split tiles, no read in the reduce).
+    dbias: optional (co,) f32 tensor the bias gradient is atomically added to (summed from the staged dY tiles).
     dw_b: DUAL launch (arena.DualPass) -- the gradient of images [B/2, B) goes to this accumulator (and sc["dw_b"]); `nimg` counts
     the live images of each half (l2i_conv2d_wgrad_dual).
     sc: a block's 1x1 shortcut that received the same dY -- dict(x_op (B, Ho, Wo, Ci_sc), dw, ldw, dbias, flops): its weight (and
@@ -311,7 +314,7 @@ def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0
             sl = slice(k * hb, (k + 1) * hb)
             sck = None if sc is None else dict(sc, x_op=sc["x_op"][sl], dw=sc["dw_b"] if k else sc["dw"], dw_b=None, flops=0.5 * sc["flops"])
             wgrad_raw(x_op[sl], dy_op[sl], d, ldw, co, kh, up2=up2, pool2=pool2, alpha=alpha, flops=None if flops is None else 0.5 * flops,
-                      nimg=nimg, dbias=dbias, sc=sck)
+                      nimg=nimg, dbias=dbias, sc=sck, overwrite=overwrite)
         return
     end = None
     if TIMER is not None:
@@ -319,22 +322,17 @@ def wgrad_raw(x_op, dy_op, dw, ldw, co, kh, *, up2=False, pool2=False, alpha=1.0
         fl = flops if flops is not None else 2.0 * B * Ho * Wo * co * kh * kh * Ci
         end = TIMER.time("conv_wgrad", live * (fl + (sc["flops"] if sc is not None else 0.0)))
     scratch, nscratch = _lib.wgrad_scratch(x_op.device)
-    if sc is None and dw_b is None:
-        _lib.call("l2i_conv2d_wgrad", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
-                  Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch, _stream())
-    elif sc is None:
-        _lib.call("l2i_conv2d_wgrad_dual", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
-                  Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch,
-                  None, None, 0, 0, 0, None, dw_b.data_ptr(), None, _stream())
-    else:
+    sx = su = None
+    if sc is not None:
         sx = sc["x_op"]
         _chk(sx, x_op.dtype)
         su = int(bool(sc.get("up2", False)))
         assert sx.shape[:3] == (B, Ho >> su, Wo >> su)
         assert (dw_b is None) == (sc.get("dw_b") is None)
-        _lib.call("l2i_conv2d_wgrad_dual", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
-                  Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch,
-                  sx.data_ptr(), sc["dw"].data_ptr(), sx.shape[3], su, sc["ldw"], _p(sc["dbias"]), _p(dw_b), _p(sc.get("dw_b")), _stream())
+    _lib.call("l2i_conv2d_wgrad_dual", x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr(), _code(x_op.dtype), B, Hi, Wi, Ci, Ho,
+              Wo, co, kh, int(up2), int(pool2), ldw, float(alpha), _p(nimg), _p(dbias), scratch, nscratch,
+              _p(sx), None if sc is None else sc["dw"].data_ptr(), 0 if sc is None else sx.shape[3], su or 0, 0 if sc is None else sc["ldw"],
+              None if sc is None else _p(sc["dbias"]), _p(dw_b), None if sc is None else _p(sc.get("dw_b")), int(bool(overwrite)), _stream())
     if end is not None:
         end.record()
 
@@ -646,7 +644,7 @@ class FusedConvFn(Function):
                     scw = dict(x_op=sl["x_op"], dw=pc.dw_slice(hs), dw_b=pc.dw_slice_b(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"], up2=sl["up2"])
                     sl["wgrad_done"] = True
             wgrad_side(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
-                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw, dw_b=pc.dw_slice_b(h))
+                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw, dw_b=pc.dw_slice_b(h), overwrite=WGRAD_OVERWRITE)
         dx = d_mask = d_w = d_b = None
         if need_x or need_mod:
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
@@ -751,6 +749,7 @@ class _Simple(Prologue):
 
 
 _CAST, RELU, _OP, _OPRAW = _Simple("cast"), _Simple("relu"), _Simple("op"), _Simple("opraw")
+WGRAD_OVERWRITE = __import__("os").environ.get("L2I_WGRAD_OVERWRITE", "1") != "0"   # weight-gradient launches store into their (freshly zeroed, per-pass) dW slices (A/B switch)
 SC_WGRAD = __import__("os").environ.get("L2I_SC_WGRAD_PY", "1") != "0"   # conv2's weight-gradient launch also computes the handed-over shortcut's (A/B switch)
 SC_FOLD = __import__("os").environ.get("L2I_SC_LAZY", "1") != "0"   # blocks hand their 1x1 shortcut to conv2's launch (A/B switch; L2I_SC_FOLD=0 keeps the hand-over but un-folds in the library)
 OP_EDGES = __import__("os").environ.get("L2I_OP_EDGES", "1") != "0"   # operand-dtype autograd edges inside D blocks (A/B switch)
@@ -842,7 +841,7 @@ class GroupedLinearFn(Function):
             bg = pc.arena.flat.grad[ctx.b0:ctx.b0 + g.n_total]
             _, _, dy_op = channel_stats(dy, want_sq=False, cast_to=opd, accumulate_into=bg)
             dy4 = dy_op.view(rows, 1, 1, g.n_total)
-            wgrad_side(x_op, dy4, pc.group_dw_slice(g), g.kp, g.n_total, 1, flops=ctx.flops)
+            wgrad_side(x_op, dy4, pc.group_dw_slice(g), g.kp, g.n_total, 1, flops=ctx.flops, overwrite=WGRAD_OVERWRITE)
         else:
             dy4, _ = cast_op(dy.view(rows, 1, 1, g.n_total), opd, raw=True, act=False)
         if ctx.needs_input_grad[0]:

@@ -438,6 +438,32 @@ def test_conv_wgrad_folded_shortcut(case, dt, sup):
     assert float((db.cpu() - b1.grad).abs().max()) < tol(b1.grad) and float((dbs.cpu() - 1 - b2.grad).abs().max()) < tol(b2.grad)
 
 
+@pytest.mark.parametrize("case", [(32, 4, 4, 1024, 1024, 3), (32, 8, 8, 512, 1024, 3), (4, 16, 16, 64, 128, 3), (2, 64, 64, 64, 64, 3), (6, 32, 32, 64, 128, 1)])
+def test_conv_wgrad_overwrite_mode(case):
+    """`overwrite` (l2i_conv2d_wgrad_dual): the launch is the only writer of its dW slice, so the result is STORED -- whatever the slice
+    held before (NaN here) is gone, on single-split tiles (no atomics), split tiles (reduce kernel writes) and split groups alike (those
+    still accumulate: their slice must be zero, as the trainer's freshly zeroed accumulators are)."""
+    from layout2img_amd import ops
+    B, H, W, Ci, Co, KH = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(B + Ci)
+    x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    wz = torch.zeros(Co, Ci, KH, KH, requires_grad=True)
+    y = _ref_conv(x, wz, None, False, False)
+    dy = _rt(torch.randn(y.shape, generator=g), dt)
+    y.backward(dy)
+    ref = wz.grad.permute(0, 2, 3, 1).reshape(Co, -1)
+    K = KH * KH * Ci
+    for fill in (float("nan"), 0.0):
+        dw = torch.full((Co, K), fill, device=_dev())
+        ops.wgrad_raw(x.to(_dev(), dt), dy.to(_dev(), dt), dw, K, Co, KH, overwrite=True)
+        ok = bool(torch.isfinite(dw).all())
+        if fill == 0.0 or ok:   # (split groups accumulate with atomics: only a zeroed slice is defined there)
+            assert float((dw.cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max()) + 1e-5
+        if fill != fill and case[:2] in ((32, 4), (32, 8)):
+            assert ok   # the few-pixel, many-tile layers (one split per tile, or a plain reduce): stored, NaN gone
+
+
 def test_spectral_norm_backward_two_passes_in_one_launch():
     """l2i_weights_backward2: the sigma-corrections of two passes over the same weights (D(real) + D(fake),
     train_context_app_v2.py:158,167 -- each with its own u, v, sigma) applied by one launch pair equal the two single-pass
