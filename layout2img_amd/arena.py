@@ -334,6 +334,27 @@ class WeightArena:
         self.t_apply, self.n_apply = dev(t_apply, 2)
         self.pending = []
         self.free_packs = []   # zero-padded pack buffers of finished passes (see PassCtx)
+        # dW-bar accumulators (PassCtx.dw): a convolution's slice is STORED by its one weight-gradient launch per pass
+        # (ops.WGRAD_OVERWRITE), so only the slices that are accumulated into (Linear / Embedding layers: heads add with atomics,
+        # grouped projections, ArenaWeightFn) need clearing -- a few MB instead of the whole 163 / 251 MB buffer per pass.
+        self.conv_uses, acc = [], []
+        for h in holders:
+            if h.group is not None:
+                continue   # (its rows live in the group's slice)
+            for u in h.use_rows:
+                if h.kind == "conv":
+                    self.conv_uses.append(u)
+                else:
+                    acc.append((u.dw_off, u.dw_off + _round_up(h.co_p * u.kp, ALIGN)))
+        for g in self.groups.values():
+            acc.append((g.dw_off, g.dw_off + _round_up(g.n_total * g.kp, ALIGN)))
+        acc.sort()
+        self.acc_ranges = []
+        for a, b in acc:
+            if self.acc_ranges and a <= self.acc_ranges[-1][1]:
+                self.acc_ranges[-1][1] = max(self.acc_ranges[-1][1], b)
+            else:
+                self.acc_ranges.append([a, b])
 
     def prepare(self, training=True, need_wgrad=True):
         """Run the power iteration(s) (train mode) and pack all weights; returns the pass context."""
@@ -358,6 +379,8 @@ class WeightArena:
         WgradSide.join()   # weight-gradient launches run on side streams (ops.WgradSide)
         self.flat.flush_loose()
         live = [p for p in self.pending if p.dwbar is not None]
+        for p in live:
+            p.clear_unwritten()
         for i in range(0, len(live), 2):   # two passes per launch pair (D(real) + D(fake)): W and the gradient buffer are walked once
             p, q = live[i], (live[i + 1] if i + 1 < len(live) else None)
             _lib.call("l2i_weights_backward2", self.layers.data_ptr(), self.n_layers, self.t_dot.data_ptr(), self.n_dot,
@@ -399,8 +422,43 @@ class PassCtx:
 
     def dw(self):
         if self.dwbar is None:
-            self.dwbar = torch.zeros(self.arena.dw_len, dtype=torch.float32, device=self.arena.device)
+            from . import ops
+            a = self.arena
+            if not ops.WGRAD_OVERWRITE:
+                self.dwbar = torch.zeros(a.dw_len, dtype=torch.float32, device=a.device)
+            else:   # conv slices are stored by their weight-gradient launch; the accumulated-into slices are cleared here
+                self.dwbar = torch.empty(a.dw_len, dtype=torch.float32, device=a.device)
+                if os.environ.get("L2I_DW_NAN", "0") == "1":   # (tests: any slice that is neither stored nor cleared shows up as NaN gradients)
+                    self.dwbar.fill_(float("nan"))
+                for lo, hi in a.acc_ranges:
+                    self.dwbar[lo:hi].zero_()
+                self.written = set()
         return self.dwbar
+
+    def mark_written(self, h):
+        """h's dW slice has been stored by a weight-gradient launch of this pass."""
+        if self.written is not None:
+            self.written.add(h.dw_off)
+
+    written = None
+
+    def dw_acc(self, h):
+        """h's dW slice for a caller that ADDS to it (ArenaWeightFn): a convolution's slice is cleared on first use."""
+        s = self.dw_slice(h)
+        if self.written is not None and h.kind == "conv" and getattr(h, "group", None) is None and h.dw_off not in self.written:
+            s.zero_()
+            self.written.add(h.dw_off)
+        return s
+
+    def clear_unwritten(self):
+        """Before the spectral-norm backward reads the accumulator: convolutions whose weight gradient was never launched in this
+        pass (a layer off the loss's path) have an undefined slice -- their gradient is zero."""
+        if self.written is None or self.dwbar is None:
+            return
+        for u in self.arena.conv_uses:
+            if u.dw_off not in self.written:
+                self.dw_slice(u).zero_()
+        self.written = None
 
     def fwd_pack(self, h):
         return self.packed[h.fwd_off:h.fwd_off + h.npad * h.kpad]
@@ -467,3 +525,7 @@ class DualPass:
 
     def dw_slice_b(self, h):
         return self.b.dw_slice(h)
+
+    def mark_written(self, h):
+        self.a.mark_written(h)
+        self.b.mark_written(h)

@@ -699,10 +699,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
                     }
                     if (col >= K_) continue;
                     float* d = dw_ + (size_t)row0 * ldw_ + col;
-                    if (row0 < p.Co) d[0] += p.alpha * a.x;
-                    if (row0 + 1 < p.Co) d[ldw_] += p.alpha * a.y;
-                    if (row0 + 2 < p.Co) d[2 * (size_t)ldw_] += p.alpha * a.z;
-                    if (row0 + 3 < p.Co) d[3 * (size_t)ldw_] += p.alpha * a.w;
+                    const bool ow = p.overwrite != 0;   // (overwrite: the slice's previous contents do not count)
+                    if (row0 < p.Co) d[0] = (ow ? 0.f : d[0]) + p.alpha * a.x;
+                    if (row0 + 1 < p.Co) d[ldw_] = (ow ? 0.f : d[ldw_]) + p.alpha * a.y;
+                    if (row0 + 2 < p.Co) d[2 * (size_t)ldw_] = (ow ? 0.f : d[2 * (size_t)ldw_]) + p.alpha * a.z;
+                    if (row0 + 3 < p.Co) d[3 * (size_t)ldw_] = (ow ? 0.f : d[3 * (size_t)ldw_]) + p.alpha * a.w;
                 }
             }
         }
@@ -902,9 +903,32 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
         a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     }
     a.part = nullptr;
+    // overwrite + a path that still ADDS with atomics (several splits without scratch, split groups in the reduce, the f32 kernel's
+    // splits): the promise is "nothing else writes these slices", so the library may clear them itself before it accumulates
+    auto clear_targets = [&]() -> int {
+        if (!a.overwrite) return L2I_OK;
+        float* t[4] = {a.dw, a.dw_b, a.sc_x ? a.sc_dw : nullptr, a.sc_x ? a.sc_dw_b : nullptr};
+        const size_t n[4] = {(size_t)a.Co * a.ldw, (size_t)a.Co * a.ldw, (size_t)a.Co * a.sc_ldw, (size_t)a.Co * a.sc_ldw};
+        for (int i = 0; i < 4; ++i)
+            if (t[i] && hipMemsetAsync(t[i], 0, sizeof(float) * n[i], stream) != hipSuccess) return L2I_ERR_LAUNCH;
+        return L2I_OK;
+    };
     if (sizeof(T) == 2 && pow2) {  // bf16: LDS-DMA + transposing-read kernel
         static const int use_part = getenv("L2I_WGRAD_PART") ? atoi(getenv("L2I_WGRAD_PART")) : 1;   // (0: atomics, A/B)
         if (use_part && scratch && (a.splits > 1 || dual) && (long long)nblk * BMO * 128 <= scratch_floats) a.part = scratch;
+        // split groups of the reduce kernel (computed here: the groups combine with atomics, which needs cleared slices under `overwrite`)
+        int sg = 1, sper = a.splits;
+        if (a.part) {
+            const unsigned nbx_ = (unsigned)(((long long)tiles * BMO * 32 + 255) / 256);
+            const int hsp_ = dual ? a.splits / 2 : a.splits;
+            if (nbx_ * (dual ? 2u : 1u) < 512 && hsp_ > 8) {
+                sg = (int)((512 + nbx_ - 1) / nbx_);
+                if (sg > (hsp_ + 7) / 8) sg = (hsp_ + 7) / 8;
+            }
+            sper = (hsp_ + sg - 1) / sg;
+            sg = (hsp_ + sper - 1) / sper;
+        }
+        if ((a.part ? sg > 1 : a.splits > 1) && clear_targets() != L2I_OK) return L2I_ERR_LAUNCH;
         // fused reduction (last arriver per tile): the plain four-wave kernel with <= 16 splits per accumulator; its counters are a
         // slice of g_wgrad_cnt handed out round robin (launches that may be in flight together never share a slot: 2^20 slots)
         static const int fuse_env = getenv("L2I_WGRAD_FUSE") ? atoi(getenv("L2I_WGRAD_FUSE")) : 0;
@@ -961,20 +985,14 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             const long long nthr = (long long)tiles * BMO * 32;
             const unsigned nbx = (unsigned)((nthr + 255) / 256);
             // split groups: enough workgroups to fill the chip (>= ~512), at least 8 splits per group
-            const int hsp = dual ? a.splits / 2 : a.splits;   // splits per accumulator (dual: gridDim.z = 2 halves)
-            int sg = 1;
-            if (nbx * (dual ? 2u : 1u) < 512 && hsp > 8) {
-                sg = (int)((512 + nbx - 1) / nbx);
-                if (sg > (hsp + 7) / 8) sg = (hsp + 7) / 8;
-            }
-            const int sper = (hsp + sg - 1) / sg;
-            sg = (hsp + sper - 1) / sper;
+            // (sg split groups of sper splits each: computed above)
             L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg, dual ? 2u : 1u), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
                        a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, (int)(nw2 && !nw8 && BMO == 128), sper,
                        a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite);
         }
         return l2i_check_launch();
     }
+    if (a.splits > 1 && clear_targets() != L2I_OK) return L2I_ERR_LAUNCH;
     const size_t lds = (size_t)(BMO + 128) * IG_ROWB;
     if (BMO == 64)
         L2I_LAUNCH(1, (conv_wgrad_kernel<T, 64>), dim3(nblk), dim3(256), lds, stream, a);

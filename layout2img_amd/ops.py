@@ -644,7 +644,10 @@ class FusedConvFn(Function):
                     scw = dict(x_op=sl["x_op"], dw=pc.dw_slice(hs), dw_b=pc.dw_slice_b(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"], up2=sl["up2"])
                     sl["wgrad_done"] = True
             wgrad_side(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
-                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw, dw_b=pc.dw_slice_b(h), overwrite=WGRAD_OVERWRITE)
+                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw, dw_b=pc.dw_slice_b(h), overwrite=WGRAD_OVERWRITE and h.kind == "conv")
+            pc.mark_written(h)
+            if scw is not None:
+                pc.mark_written(sl["holder"])
         dx = d_mask = d_w = d_b = None
         if need_x or need_mod:
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
@@ -841,7 +844,7 @@ class GroupedLinearFn(Function):
             bg = pc.arena.flat.grad[ctx.b0:ctx.b0 + g.n_total]
             _, _, dy_op = channel_stats(dy, want_sq=False, cast_to=opd, accumulate_into=bg)
             dy4 = dy_op.view(rows, 1, 1, g.n_total)
-            wgrad_side(x_op, dy4, pc.group_dw_slice(g), g.kp, g.n_total, 1, flops=ctx.flops, overwrite=WGRAD_OVERWRITE)
+            wgrad_side(x_op, dy4, pc.group_dw_slice(g), g.kp, g.n_total, 1, flops=ctx.flops)   # (accumulates: the group's slice is cleared by PassCtx.dw)
         else:
             dy4, _ = cast_op(dy.view(rows, 1, 1, g.n_total), opd, raw=True, act=False)
         if ctx.needs_input_grad[0]:
@@ -877,7 +880,7 @@ class ArenaWeightFn(Function):
     def backward(ctx, g):
         h, pc = ctx.holder, ctx.pc
         if pc.need_wgrad:
-            pc.dw_slice(h).view(h.co_p, h.kp)[:h.co, :h.ci].add_(g)
+            pc.dw_acc(h).view(h.co_p, h.kp)[:h.co, :h.ci].add_(g)
         return None, None, None
 
 

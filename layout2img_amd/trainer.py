@@ -278,6 +278,13 @@ class GanTrainer:
                 self.step(*self._static)
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        if self.dp:
+            # The warm-up's collectives are complete, but their work handles sit in the process groups' watchdog lists until the
+            # watchdog threads' next poll (every 100 ms). A handle polled AFTER its communicator stream has joined the capture
+            # fails the event query ("operation not permitted on an event last recorded in a capturing stream") and the
+            # watchdog takes the process down -- measured: 4 of 11 runs of the one-rank RCCL test. Let the lists drain first.
+            import time
+            time.sleep(float(os.environ.get("L2I_CAPTURE_DRAIN_S", "0.5")))
         for net in (self.netG, self.netD):
             net.arena.free_packs = []
         graph = torch.cuda.CUDAGraph()
