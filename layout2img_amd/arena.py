@@ -258,6 +258,23 @@ class WeightArena:
         t_pack = [[] for _ in range(self.rounds)]
         t_fin = [[] for _ in range(self.rounds)]
         t_dot, t_apply = [], []
+        # dW-bar offsets: the slices that are ACCUMULATED into (Linear / Embedding layers, grouped projections) first and
+        # contiguous -- one clear per pass (PassCtx.dw) -- then the convolutions, whose slices are stored by their launches
+        def _kp(h):
+            return h.kh * h.kh * h.ci_p * (3 if self.split else 1)
+        dw_of = {}
+        for phase in (0, 1):
+            for i, (h, use) in enumerate(rows):
+                if (h.kind != "conv" or id(h) in member_of) != (phase == 0):
+                    continue
+                if id(h) in member_of:
+                    g, gi = member_of[id(h)]
+                    if gi == 0:   # first member: reserve the group's region
+                        g.dw_off, dw_len = dw_len, dw_len + _round_up(g.n_total * _kp(h), ALIGN)
+                    dw_of[i] = g.dw_off + g.offsets[gi] * _kp(h)
+                else:
+                    dw_of[i] = dw_len
+                    dw_len += _round_up(h.co_p * _kp(h), ALIGN)
         for i, (h, use) in enumerate(rows):
             taps = h.kh * h.kh
             kt = h.ci * taps
@@ -281,19 +298,16 @@ class WeightArena:
                     g.kpad_d, g.npad_d = _round_up(g.n_total, bk), npad_d
                     g.fwd_off, packed_len = packed_len, packed_len + g.npad * kpad
                     g.dg_off, packed_len = packed_len, packed_len + g.npad_d * g.kpad_d
-                    g.dw_off, dw_len = dw_len, dw_len + _round_up(g.n_total * kp, ALIGN)
                 off = g.offsets[gi]
                 row[8], row[9], row[10] = kpad, npad, g.fwd_off + off * kpad          # its rows of the stacked forward pack
                 row[11], row[12], row[13] = g.kpad_d, npad_d, g.dg_off + off          # its columns of the data-gradient pack (row stride = the group's K)
                 kpad_d = g.kpad_d
-                row[14] = g.dw_off + off * kp
             else:
                 row[8], row[9], row[10] = kpad, npad, packed_len
                 packed_len += npad * kpad
                 row[11], row[12], row[13] = kpad_d, npad_d, packed_len
                 packed_len += npad_d * kpad_d
-                row[14] = dw_len
-                dw_len += _round_up(h.co_p * kp, ALIGN)
+            row[14] = dw_of[i]
             row[15] = _f32_bits(h.eps)
             attrs = dict(layer_id=i, kpad=kpad, npad=npad, fwd_off=int(row[10]), kpad_d=kpad_d, npad_d=npad_d,
                          dg_off=int(row[13]), dw_off=int(row[14]), kp=kp)

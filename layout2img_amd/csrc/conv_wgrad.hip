@@ -56,7 +56,20 @@ struct WgradArgs {
                       // gradient launch per layer application and pass) -- the result is then STORED: no f32 atomics where a tile has one
                       // split, no read-modify-write in the reduce kernel. 0: dW += (the ABI's default semantics)
     int nw2_layout;   // (the register-order decode of the partial tiles: as wgrad_reduce_kernel's nw2)
+    int zero_targets; // overwrite + a reduce that combines split GROUPS with atomics: the main kernel (which writes only partial tiles to
+                      // scratch) clears the dW slices on its way in, so the reduce kernel behind it adds into zeros -- no memset launches
 };
+
+// grid-wide clear of one dW slice (n floats) by the threads of the weight-gradient kernel
+__device__ __forceinline__ void wg_zero_slice(float* __restrict__ d, long long n, long long gtid, long long gthreads) {
+    if (!d) return;
+    if ((((unsigned long long)d & 15ull) | ((unsigned long long)n & 3ull)) == 0) {
+        float4* d4 = reinterpret_cast<float4*>(d);
+        for (long long i = gtid; i < (n >> 2); i += gthreads) d4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (long long i = gtid; i < n; i += gthreads) d[i] = 0.f;
+    }
+}
 
 // Device-scope ("sc1") accesses for the partial tiles of the fused reduction: on gfx950 every XCD has its own L2, so data one
 // workgroup hands to a workgroup on another XCD must be written through and read around the L2s. With sc1 on the stores and on
@@ -333,6 +346,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     int bid = blockIdx.x;
+    if (p.zero_targets) {   // (WgradArgs::zero_targets: fire-and-forget stores, nothing in this kernel reads or writes dW)
+        const long long gtid = (long long)blockIdx.x * NT + tid, gthreads = (long long)gridDim.x * NT;
+        wg_zero_slice(p.dw, (long long)p.Co * p.ldw, gtid, gthreads);
+        wg_zero_slice(p.dw_b, (long long)p.Co * p.ldw, gtid, gthreads);
+        if (p.sc_x) {
+            wg_zero_slice(p.sc_dw, (long long)p.Co * p.sc_ldw, gtid, gthreads);
+            wg_zero_slice(p.sc_dw_b, (long long)p.Co * p.sc_ldw, gtid, gthreads);
+        }
+    }
     const int split = bid % p.splits; bid /= p.splits;
     const int tile_k = bid % p.tiles_k, tile_co = bid / p.tiles_k;
     // column tiles past tiles_k_main belong to the folded 1x1 shortcut: another source tensor, one (centre) tap, no upsampling
@@ -928,7 +950,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             sper = (hsp_ + sg - 1) / sg;
             sg = (hsp_ + sper - 1) / sper;
         }
-        if ((a.part ? sg > 1 : a.splits > 1) && clear_targets() != L2I_OK) return L2I_ERR_LAUNCH;
+        if (!a.part && a.splits > 1 && clear_targets() != L2I_OK) return L2I_ERR_LAUNCH;   // (atomics straight from the main kernel)
         // fused reduction (last arriver per tile): the plain four-wave kernel with <= 16 splits per accumulator; its counters are a
         // slice of g_wgrad_cnt handed out round robin (launches that may be in flight together never share a slot: 2^20 slots)
         static const int fuse_env = getenv("L2I_WGRAD_FUSE") ? atoi(getenv("L2I_WGRAD_FUSE")) : 0;
@@ -942,6 +964,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             a.fuse_cnt = cnt_base + cnt_next;
             cnt_next += need;
         }
+        a.zero_targets = (a.overwrite && a.part && !a.fuse_cnt && sg > 1) ? 1 : 0;   // (the reduce's split groups add with atomics)
         int lgW = 0, lgH = 0;
         while ((1 << lgW) < a.Wo) ++lgW;
         while ((1 << lgH) < a.Ho) ++lgH;
@@ -1047,7 +1070,7 @@ extern "C" int l2i_conv2d_wgrad_dual(const void* x, const void* dy, float* dw, i
     a.sc_x = sc_x; a.sc_dw = sc_x ? sc_dw : nullptr; a.dbias2 = sc_x ? sc_dbias : nullptr; a.sc_Ci = sc_Ci; a.sc_ldw = sc_ldw; a.sc_up2 = sc_up2 ? 1 : 0;
     a.sc_x_bytes = 0; a.tiles_k_main = 0;
     a.dw_b = dw_b; a.sc_dw_b = (sc_x && dw_b) ? sc_dw_b : nullptr;
-    a.fuse_cnt = nullptr; a.nw2_layout = 0; a.overwrite = overwrite ? 1 : 0;
+    a.fuse_cnt = nullptr; a.nw2_layout = 0; a.overwrite = overwrite ? 1 : 0; a.zero_targets = 0;
     a.x = x; a.dy = dy; a.dw = dw;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.ldw = ldw; a.alpha = alpha;

@@ -14,12 +14,14 @@ import csv, json
 line = json.loads(open("$R/gpurun_out/${TAG}_default_bench_line.json").read())
 tot = n = tf = nf = 0.0
 for r in csv.DictReader(open("$R/gpurun_out/${TAG}_default_kernel_stats.csv")):
-    if r["Name"].startswith(("void conv_halo", "void conv_igemm", "conv_halo", "conv_igemm")):
+    if r["Name"].startswith(("conv_wstat_reduce", "void conv_wstat_reduce")):   # second kernel of a 4x4 weight-stationary launch: its time, not a launch
+        tot += float(r["TotalDurationNs"])
+    elif r["Name"].startswith(("void conv_halo", "void conv_igemm", "conv_halo", "conv_igemm", "conv_wstat_kernel", "void conv_wstat_kernel")):
         if "<float" in r["Name"]:   # the exact-f32 instantiations: only the line's secondary f32_mode / precision_modes legs launch them
             tf += float(r["TotalDurationNs"]); nf += int(r["Calls"])
         else:
             tot += float(r["TotalDurationNs"]); n += int(r["Calls"])
-print(f"rocprofv3: {n:.0f} bf16 conv kernels (conv_halo2/3, conv_igemm<unsigned short>), average {tot / n / 1e3:.2f} us "
+print(f"rocprofv3: {n:.0f} bf16 conv launches (conv_halo2/3, conv_igemm<unsigned short>, conv_wstat + its reduce), average {tot / n / 1e3:.2f} us "
       f"[+ {nf:.0f} conv_igemm<float> kernels of the secondary f32 legs, average {tf / max(nf, 1) / 1e3:.1f} us, not part of the roofline leg]; "
       f"bench line (under the profiler): avg_launch_us {line['roofline']['avg_launch_us']}, frac {line['roofline']['frac']}, value {line['value']} images/s")
 PY

@@ -22,7 +22,7 @@ print(f"{iters} iterations: wall {(t1 - t0) / 1e6 / iters:.3f} ms/it; resident k
 cls = collections.Counter(); cnt = collections.Counter()
 def klass(n):
     n = n.split("(")[0]
-    for k, v in (("conv_halo", "conv"), ("conv_igemm", "conv"), ("conv_wgrad", "wgrad"), ("wgrad_reduce", "wgrad_reduce"), ("sn_", "spectral norm"), ("norm_", "norm"),
+    for k, v in (("conv_halo", "conv"), ("conv_igemm", "conv"), ("conv_wstat", "conv"), ("conv_wgrad", "wgrad"), ("wgrad_reduce", "wgrad_reduce"), ("sn_", "spectral norm"), ("norm_", "norm"),
                  ("channel_stats", "norm"), ("ws_fold", "norm"), ("adam", "adam"), ("cast_kernel", "cast"), ("at::native", "aten"), ("rocclr", "rocclr"), ("Cijk", "rocblas")):
         if k in n: return v
     return "other own"
