@@ -115,6 +115,37 @@ def g_forward_figures(netG, args, z, bbox, z_im, label, op_dtype):
             sample(netG, lab1, box1)
         torch.cuda.synchronize()
         out["sample_batch1_ms"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+        # the same forward at larger batches (what a sampling service would run): at b = 32 most launches are a fraction of one
+        # round of workgroups; these say what the kernels do once a launch fills the chip
+        if flop_img and op_dtype == torch.bfloat16:
+            from layout2img_amd.synthetic import make_batch
+            sweep = {}
+            for bs in (128, 256):
+                _, lab_b, box_b, z_b, zim_b = make_batch(bs, args.size, args.layout, seed=4321, device=z.device)
+                zim_b = zim_b if z_im is not None else None
+                for _ in range(2):
+                    netG(z_b, box_b, z_im=zim_b, y=lab_b)
+                torch.cuda.synchronize()
+                fwd_b, mode_b = (lambda: netG(z_b, box_b, z_im=zim_b, y=lab_b)), "eager"
+                if not args.no_graph:
+                    gb = torch.cuda.CUDAGraph()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.graph(gb, stream=side):
+                        netG(z_b, box_b, z_im=zim_b, y=lab_b)
+                    fwd_b, mode_b = gb.replay, "HIP graph replay"
+                for _ in range(2):
+                    fwd_b()
+                a.record()
+                for _ in range(10):
+                    fwd_b()
+                b.record()
+                torch.cuda.synchronize()
+                ms_b = a.elapsed_time(b) / 10
+                tf_b = flop_img * bs / (ms_b * 1e-3) / 1e12
+                sweep[str(bs)] = {"ms": round(ms_b, 3), "images_per_sec": round(bs / ms_b * 1e3, 1), "tflops": round(tf_b, 1),
+                                  "frac_of_mfma_peak": round(tf_b / 2500.0, 4), "launch": mode_b}
+                del fwd_b
+            out["batch_sweep"] = sweep
         if op_dtype == torch.bfloat16 and args.size == 128 and args.layout == "coco":
             out["precision_modes"] = precision_mode_figures(netG, args, z, bbox, z_im, label, ms)
     return out

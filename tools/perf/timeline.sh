@@ -4,3 +4,4 @@ timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o trace -- 
 T=$(find /tmp/tl -name '*kernel_trace.csv' | head -1)
 python $GRAFT_REPO_ROOT/tools/perf/timeline.py $T 4
 tail -1 /tmp/tl.log | cut -c1-120
+python $GRAFT_REPO_ROOT/tools/perf/stock_in_graph.py $T 4 > $GRAFT_REPO_ROOT/gpurun_out/stock_in_graph.txt 2>&1
