@@ -117,7 +117,7 @@ def g_forward_figures(netG, args, z, bbox, z_im, label, op_dtype):
         out["sample_batch1_ms"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
         # the same forward at larger batches (what a sampling service would run): at b = 32 most launches are a fraction of one
         # round of workgroups; these say what the kernels do once a launch fills the chip
-        if flop_img and op_dtype == torch.bfloat16:
+        if args.g_batch_sweep and flop_img and op_dtype == torch.bfloat16:
             from layout2img_amd.synthetic import make_batch
             sweep = {}
             for bs in (128, 256):
@@ -223,6 +223,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-g-forward", action="store_true", help="skip the secondary generator-forward measurement (profiling runs)")
+    ap.add_argument("--g-batch-sweep", action="store_true",
+                    help="also time the generator forward at batch 128 / 256 (g_forward.batch_sweep); off by default so that the default "
+                         "command's kernel statistics hold the batch-32 launches only")
     ap.add_argument("--no-f32-mode", action="store_true", help="skip the secondary exact-f32 operand-mode measurement")
     ap.add_argument("--no-graph", action="store_true", help="run every iteration eagerly (default: replay a captured HIP graph at N=1)")
     args = ap.parse_args()

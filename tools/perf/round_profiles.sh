@@ -6,6 +6,8 @@ TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 python bench.py > gpurun_out/${TAG}_bench_final.json 2> gpurun_out/${TAG}_bench_final.err
+python bench.py --steps 5 --no-cpu-baseline --no-f32-mode --no-kernel-timer --g-batch-sweep 2> /dev/null | tail -1 | python -c "
+import json, sys; g = json.loads(sys.stdin.read())['g_forward']; g.pop('precision_modes', None); print(json.dumps(g))" > gpurun_out/${TAG}_gfwd_batch_sweep.json
 bash tools/perf/traffic2.sh $TAG > gpurun_out/${TAG}_traffic.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/gf && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gf -o g -- python $R/tools/perf/gfwd_profile.py 10 > /tmp/gf.log 2>&1
