@@ -438,11 +438,13 @@ def test_conv_wgrad_folded_shortcut(case, dt, sup):
     assert float((db.cpu() - b1.grad).abs().max()) < tol(b1.grad) and float((dbs.cpu() - 1 - b2.grad).abs().max()) < tol(b2.grad)
 
 
-@pytest.mark.parametrize("case", [(32, 4, 4, 1024, 1024, 3), (32, 8, 8, 512, 1024, 3), (4, 16, 16, 64, 128, 3), (2, 64, 64, 64, 64, 3), (6, 32, 32, 64, 128, 1)])
+@pytest.mark.parametrize("case", [(32, 4, 4, 1024, 1024, 3), (32, 8, 8, 512, 1024, 3), (4, 16, 16, 64, 128, 3), (2, 64, 64, 64, 64, 3), (6, 32, 32, 64, 128, 1),
+                                  (8, 128, 128, 64, 64, 3)])
 def test_conv_wgrad_overwrite_mode(case):
     """`overwrite` (l2i_conv2d_wgrad_dual): the launch is the only writer of its dW slice, so the result is STORED -- whatever the slice
-    held before (NaN here) is gone, on single-split tiles (no atomics), split tiles (reduce kernel writes) and split groups alike (those
-    still accumulate: their slice must be zero, as the trainer's freshly zeroed accumulators are)."""
+    held before (NaN here) is gone: on single-split tiles (no atomics), split tiles (the reduce kernel writes) and split groups alike
+    (few tiles x many splits, the 64-channel layers: the reduce's groups add with atomics into a slice the weight-gradient kernel has
+    cleared on its way in, WgradArgs::zero_targets). The trainer's dW-bar accumulators are torch.empty (arena.PassCtx.dw)."""
     from layout2img_amd import ops
     B, H, W, Ci, Co, KH = case
     dt = torch.bfloat16
@@ -457,11 +459,15 @@ def test_conv_wgrad_overwrite_mode(case):
     for fill in (float("nan"), 0.0):
         dw = torch.full((Co, K), fill, device=_dev())
         ops.wgrad_raw(x.to(_dev(), dt), dy.to(_dev(), dt), dw, K, Co, KH, overwrite=True)
-        ok = bool(torch.isfinite(dw).all())
-        if fill == 0.0 or ok:   # (split groups accumulate with atomics: only a zeroed slice is defined there)
-            assert float((dw.cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max()) + 1e-5
-        if fill != fill and case[:2] in ((32, 4), (32, 8)):
-            assert ok   # the few-pixel, many-tile layers (one split per tile, or a plain reduce): stored, NaN gone
+        assert bool(torch.isfinite(dw).all())
+        assert float((dw.cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max()) + 1e-5
+    # without the caller's scratch the splits add with atomics straight from the main kernel: the library clears the slice itself
+    from layout2img_amd import _lib
+    xo, dyo = x.to(_dev(), dt), dy.to(_dev(), dt)
+    dw = torch.full((Co, K), float("nan"), device=_dev())
+    _lib.call("l2i_conv2d_wgrad_dual", xo.data_ptr(), dyo.data_ptr(), dw.data_ptr(), 1, B, H, W, Ci, H, W, Co, KH, 0, 0, K, 1.0, None, None,
+              None, 0, None, None, 0, 0, 0, None, None, None, 1, _lib.raw_stream())
+    assert float((dw.cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max()) + 1e-5
 
 
 def test_spectral_norm_backward_two_passes_in_one_launch():
