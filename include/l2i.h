@@ -242,6 +242,9 @@ int l2i_cast_op(const float* x, void* raw, void* act, long long n, int dtype, vo
  * of bf16's 2^-8, at MFMA speed / 3 (generator image L_inf vs the reference 8e-5 in emulation, tools/parity/bf16_layer_promotion.py;
  * bar 1e-3). C % 8 == 0. */
 int l2i_split_cast(const float* x, void* out3, long long rows, int C, int relu, void* stream);
+/* Measurement aid, no reference counterpart: stores the device wall clock (100 MHz ticks) to *slot in stream order. Launched between the
+ * phases of a captured iteration it gives the timeline of a graph replay without a profiler (tools/perf/phase_stamps.py). */
+int l2i_debug_stamp(long long* slot, void* stream);
 
 /* ReLU backward on f32 streams: out = g*[mask>0] (+ add). */
 int l2i_relu_bwd(const float* g, const float* mask, const float* add, float* out, long long n, void* stream);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "l2i_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p, _p],
     "l2i_cast_op": [_p, _p, _p, _ll, _i, _p],
     "l2i_split_cast": [_p, _p, _ll, _i, _i, _p],
+    "l2i_debug_stamp": [_p, _p],
     "l2i_set_wgrad_blocks": [_i],
     "l2i_debug_occupancy": [_i, _i],
     "l2i_resize_bilinear": [_p, _p, _ll, _i, _i, _i, _i, _p],

@@ -189,6 +189,17 @@ extern "C" int l2i_split_cast(const float* x, void* out3, long long rows, int C,
     return l2i_check_launch();
 }
 
+// Measurement aid (tools/perf/phase_stamps.py): one lane stores the device's wall clock (100 MHz) -- launched between the phases of a
+// captured iteration, the slots read back the REAL timeline of a graph replay, with no profiler attached.
+__global__ void stamp_kernel(long long* slot) {
+    if (threadIdx.x == 0) *slot = (long long)wall_clock64();
+}
+extern "C" int l2i_debug_stamp(long long* slot, void* stream) {
+    if (!slot) return L2I_ERR_ARG;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slot);
+    return l2i_check_launch();
+}
+
 // dx = g * [mask > 0] (+ add)   -- ReLU backward on f32 streams (mask: f32 pre- or post-activation values)
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ mask,
                                                        const float* __restrict__ add, float* __restrict__ out, long long n4) {

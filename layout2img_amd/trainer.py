@@ -55,7 +55,33 @@ class FlatAdam:
 _WGRAD_SIDE_G = os.environ.get("L2I_WGRAD_STREAM", "0") == "2"
 
 
+class PhaseStamps:
+    """Measurement aid (tools/perf/phase_stamps.py): GanTrainer.stamps = PhaseStamps(dev) makes _step launch a one-lane kernel that stores
+    the device wall clock at each phase boundary, in stream order -- also inside a captured graph, so the slots hold the timeline
+    of the last REPLAY, with no profiler attached. None (default): nothing is launched."""
+
+    def __init__(self, device, n=32):
+        self.buf = torch.zeros(n, dtype=torch.int64, device=device)
+        self.names = []
+
+    def mark(self, name):
+        from . import _lib
+        if name not in self.names:
+            self.names.append(name)
+        _lib.call("l2i_debug_stamp", self.buf[self.names.index(name)].data_ptr(), _lib.raw_stream())
+
+    def read_us(self):
+        t = self.buf[:len(self.names)].cpu().tolist()
+        return [(n, (v - t[0]) / 100.0) for n, v in zip(self.names, t)]   # 100 MHz ticks -> us since the first mark
+
+
 class GanTrainer:
+    stamps = None
+
+    def _mark(self, name):
+        if self.stamps is not None:
+            self.stamps.mark(name)
+
     def __init__(self, netG, netD, g_lr=1e-4, d_lr=1e-4, lamb_obj=1.0, lamb_app=1.0, lamb_img=0.1, z_dim=128, vgg=None):
         """vgg: an optional layout2img_amd.VGGLoss (finalized) -- the perceptual term of the G loss
         (train_context_app_v2.py:141,185); None leaves it out (the headline benchmark's configuration)."""
@@ -138,6 +164,7 @@ class GanTrainer:
     def _step(self, real, y, bbox, z, z_im, b):
         netG, netD = self.netG, self.netD
         # ROI rows compacted to the front in the reference's order + their device-side count: once for the three D passes
+        self._mark("start")
         layout = netD.prepare_layout(bbox, y, real.size(2), real.device)
         valid = layout[2]
         # ---- D step (reference :156-174)
@@ -188,7 +215,9 @@ class GanTrainer:
                     d_loss_real.backward()
                     d_loss_real = d_loss_real.detach()
             self.flush()   # the previous iteration's G all-reduce + Adam: behind D(real)'s launches, in front of G's forward
+            self._mark("G forward")
             fake = netG(z, bbox, z_im=z_im, y=y)
+            self._mark("D(fake) forward")
             if self.real_bwd_early:
                 cur.wait_event(packs_ready)
             else:
@@ -208,15 +237,19 @@ class GanTrainer:
             d_loss = d_loss_real + d_loss_fake.detach()
         else:
             d_loss = d_loss_real + d_loss_fake
+            self._mark("D backward (real on the side stream)")
             d_loss.backward()
+            self._mark("join side stream")
         if self.overlap and not self.dual_d:
             # D(real)'s backward ran on the side stream; what it wrote outside autograd's view (weight-gradient
             # accumulators, direct bias-gradient atomics) and the pack buffers it read must be ordered before the
             # optimizer step on this stream explicitly (capture-safe: one event).
             torch.cuda.current_stream().wait_stream(self._side)
+        self._mark("D flush + all-reduce + Adam")
         self.d_opt.step()
         # ---- G step (reference :178-189)
         netG.zero_grad()
+        self._mark("G step: D forward")
         *outs_g, _, _ = netD.forward_padded(fake, bbox, y, need_wgrad=False, layout=layout)
         g_adv = self._d_terms(outs_g, valid, 2, n_roi, n_img)
         pixel = ops.l1_loss(fake, real, 1.0 / self.world)
@@ -226,7 +259,9 @@ class GanTrainer:
             g_loss = g_loss + (feat if self.world == 1 else feat / self.world)
         if _WGRAD_SIDE_G:   # (tuning, L2I_WGRAD_STREAM=2: the generator's weight gradients on a side stream during the G step only)
             ops.WgradSide.enabled = True
+        self._mark("G step: backward through D and G")
         g_loss.backward()
+        self._mark("G flush + Adam")
         if _WGRAD_SIDE_G:
             ops.WgradSide.enabled = False
             ops.WgradSide.join()
@@ -235,6 +270,7 @@ class GanTrainer:
             self._pending_g = True
         else:
             self.g_opt.step()
+        self._mark("end")
         return {"d_loss": d_loss.detach(), "g_loss": g_loss.detach(), "pixel": pixel.detach(), "fake": fake.detach()}
 
     # ---- whole-iteration HIP graph: the iteration is ~1700 launches and the Python / autograd side costs about as much

@@ -5,3 +5,5 @@ T=$(find /tmp/tl -name '*kernel_trace.csv' | head -1)
 python $GRAFT_REPO_ROOT/tools/perf/timeline.py $T 4
 tail -1 /tmp/tl.log | cut -c1-120
 python $GRAFT_REPO_ROOT/tools/perf/stock_in_graph.py $T 4 > $GRAFT_REPO_ROOT/gpurun_out/stock_in_graph.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/perf/tiny_critical.py $T 4 > $GRAFT_REPO_ROOT/gpurun_out/tiny_critical.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/perf/blank_kernels.py $T > $GRAFT_REPO_ROOT/gpurun_out/blank_kernels.txt 2>&1
