@@ -456,6 +456,11 @@ class PassCtx:
 
     written = None
 
+    def was_written(self, h):
+        """A weight-gradient launch of this pass has already stored h's slice (a second backward over the same forward, e.g.
+        retain_graph): the next launch must ADD to it."""
+        return self.written is not None and h.dw_off in self.written
+
     def dw_acc(self, h):
         """h's dW slice for a caller that ADDS to it (ArenaWeightFn): a convolution's slice is cleared on first use."""
         s = self.dw_slice(h)
@@ -543,3 +548,10 @@ class DualPass:
     def mark_written(self, h):
         self.a.mark_written(h)
         self.b.mark_written(h)
+
+    def was_written(self, h):
+        return self.a.was_written(h) or self.b.was_written(h)
+
+    def dw_acc(self, h):
+        self.b.dw_acc(h)
+        return self.a.dw_acc(h)

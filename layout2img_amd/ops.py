@@ -643,8 +643,14 @@ class FusedConvFn(Function):
                 if direct_s and hs.co_p == h.co_p:
                     scw = dict(x_op=sl["x_op"], dw=pc.dw_slice(hs), dw_b=pc.dw_slice_b(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"], up2=sl["up2"])
                     sl["wgrad_done"] = True
+            # stored, not accumulated, when this is the slice's first launch of the pass (a second backward over the same forward adds)
+            ow = WGRAD_OVERWRITE and h.kind == "conv" and not pc.was_written(h) and (scw is None or not pc.was_written(sl["holder"]))
+            if WGRAD_OVERWRITE and h.kind == "conv" and not ow:   # (adding: a slice nothing has stored yet starts from zero)
+                pc.dw_acc(h)
+                if scw is not None:
+                    pc.dw_acc(sl["holder"])
             wgrad_side(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
-                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw, dw_b=pc.dw_slice_b(h), overwrite=WGRAD_OVERWRITE and h.kind == "conv")
+                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw, dw_b=pc.dw_slice_b(h), overwrite=ow)
             pc.mark_written(h)
             if scw is not None:
                 pc.mark_written(sl["holder"])

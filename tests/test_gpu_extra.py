@@ -101,6 +101,47 @@ def test_two_generator_forwards_before_one_backward():
     assert float((a - b).norm() / b.norm()) < 2e-3, float((a - b).norm() / b.norm())
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_two_backwards_over_one_forward_accumulate(dt):
+    """Weight-gradient launches STORE into their slice of the pass's accumulator (ops.WGRAD_OVERWRITE) -- but only the first launch of
+    a layer in a pass: a second backward over the same forward (retain_graph) must ADD, as autograd's .grad accumulation does in the
+    reference. (a + b).backward() == a.backward(retain_graph=True); b.backward()."""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    g = L.ResnetGenerator64_context(num_classes=184).finalize(DEV, dt)
+    for m in g.modules():
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = 0.0
+    g.train()
+    _, label, bbox, z, z_im = make_batch(2, 64, "coco", seed=1, device=DEV)
+    state = {k: v.clone() for k, v in g.state_dict().items()}
+    sn = g.arena.sn_flat.data.clone()
+
+    def grads(split):
+        g.load_state_dict(state)
+        g.arena.sn_flat.data.copy_(sn)
+        g.arena.drop_pending()
+        g.zero_grad()
+        out = g(z, bbox, z_im, label)
+        a, b = out[:, :, :32].square().mean(), out[:, :, 32:].abs().mean()
+        if split:
+            a.backward(retain_graph=True)
+            b.backward()
+        else:
+            (a + b).backward()
+        g.arena.flush_grads()
+        torch.cuda.synchronize()
+        return g.flat.grad.clone()
+    one, two = grads(False), grads(True)
+    assert bool(torch.isfinite(two).all())
+    rel = float((one - two).norm() / one.norm())
+    # The two variants run their own forward: split-K atomics move a pre-activation at ~0 across its ReLU gate, and in bf16 the two
+    # backwards round their dY operands separately -- measured over repeats: f32 3e-6 .. 6e-4, bf16 0.037 .. 0.051. A second backward
+    # that OVERWROTE the first one's weight gradients leaves only b's: an error of O(0.5).
+    assert rel < (5e-3 if dt == torch.float32 else 0.15), rel
+
+
 def test_weight_gradient_with_the_fused_last_arriver_reduction():
     """L2I_WGRAD_FUSE=1 (round 4, measured slower and off by default: DESIGN.md section 4.5): the workgroup that stores an output
     tile's last partial tile reduces all of them itself (device-scope counter, sc1 stores / loads) -- same weight gradients. The
