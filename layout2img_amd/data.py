@@ -231,7 +231,8 @@ def make_loader(dataset, batch_size, num_workers=2, shuffle=True, rank=0, world=
         sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle,
                                                                   seed=seed, drop_last=True)
     return torch.utils.data.DataLoader(dataset, batch_size=batch_size, drop_last=True, shuffle=shuffle and sampler is None,
-                                       sampler=sampler, num_workers=num_workers, collate_fn=_collate if getattr(dataset, "raw_images", False) else None)
+                                       sampler=sampler, num_workers=num_workers, collate_fn=_collate if getattr(dataset, "raw_images", False) else None,
+                                       pin_memory=torch.cuda.is_available())   # (pinned batches: DeviceBatcher's non_blocking copies do not stall the host)
 
 
 def _collate(batch):

@@ -25,7 +25,7 @@ def main(argv=None):
     ap.add_argument("--out_path", type=str, default="./outputs/")
     ap.add_argument("--checkpoint_epoch", type=int, default=0)
     ap.add_argument("--data_root", type=str, default=".")
-    ap.add_argument("--synthetic", type=int, default=0, help="iterations per epoch on synthetic layouts (no dataset on disk)")
+    ap.add_argument("--synthetic", type=int, default=0, help="iterations per epoch on synthetic layouts (no dataset on disk; a pool of 16 device-resident batches is cycled)")
     ap.add_argument("--vgg_weights", type=str, default="", help="torchvision vgg19 state_dict (.pth) for the perceptual loss; empty = term omitted")
     ap.add_argument("--img_size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -58,8 +58,11 @@ def main(argv=None):
     if args.checkpoint_epoch > 0:
         start = L.load_checkpoint(out_path, args.checkpoint_epoch, netG, netD, trainer.g_opt, trainer.d_opt)
     if args.synthetic:
-        batches = lambda epoch: (make_batch(args.batch_size, args.img_size, args.dataset, seed=epoch * 100003 + i * world + rank, device=dev)[:3]
-                                 for i in range(args.synthetic))
+        # a pool of synthetic batches made ONCE, on the device, and cycled through: drawing 1.5 M uniform numbers on the host and a
+        # blocking copy from pageable memory per iteration serialise host and GPU (measured: 48 ms per iteration against 19.5)
+        pool = [make_batch(args.batch_size, args.img_size, args.dataset, seed=100003 + i * world + rank, device=dev)[:3]
+                for i in range(min(args.synthetic, 16))]
+        batches = lambda epoch: (pool[(epoch * args.synthetic + i) % len(pool)] for i in range(args.synthetic))
     else:
         ds = data.get_dataset(args.dataset, args.img_size, args.data_root, raw_images=not args.host_resize)
         loader = data.make_loader(ds, args.batch_size, num_workers=args.num_workers, shuffle=True, rank=rank, world=world)
