@@ -72,6 +72,60 @@ def test_flat_params_and_arena_tables_on_cpu():
     assert net.b.use(1).fwd_off == tab[2, 10] and net.b.use(0) is net.b
 
 
+def test_dw_accumulator_layout_and_written_bookkeeping_on_cpu():
+    """The per-pass dW-bar accumulators are torch.empty (arena.PassCtx.dw): convolution slices are STORED by their first weight-gradient
+    launch of the pass, everything that is accumulated into (Linear / Embedding layers, grouped projections) sits in ONE contiguous
+    range at the front that is cleared per pass, slices never overlap, and the bookkeeping says when a launch must add instead
+    (a second backward over the same forward) and which slices nothing reached."""
+    from layout2img_amd.arena import FlatParams, GemmWeight, PassCtx, WeightArena, DualPass
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = GemmWeight("conv", 24, 16, 3, sn=True, eps=1e-4)
+            self.l1 = GemmWeight("linear", 16, 312, sn=False)
+            self.g1 = GemmWeight("linear", 8, 312, sn=True)
+            self.c2 = GemmWeight("conv", 32, 24, 3, sn=True, uses=2)
+            self.g2 = GemmWeight("linear", 16, 312, sn=True)
+            self.e = GemmWeight("embedding", 10, 8, sn=True)
+            self.g1.group = self.g2.group = "grp"
+    net = Net()
+    arena = WeightArena(net, FlatParams(net, "cpu"), "cpu", torch.bfloat16)
+    (lo, hi), = arena.acc_ranges                                  # one range, at the front
+    assert lo == 0 and hi < arena.dw_len
+    uses = [u for h in (net.c1, net.c2) for u in h.use_rows]
+    assert sorted(u.dw_off for u in arena.conv_uses) == sorted(u.dw_off for u in uses) and len(uses) == 3
+    assert all(u.dw_off >= hi for u in uses)                      # convolutions behind the accumulated-into slices
+    g = arena.groups["grp"]
+    spans = [(u.dw_off, u.dw_off + u.co_p * u.kp) for u in uses] + [(net.l1.dw_off, net.l1.dw_off + net.l1.co_p * net.l1.kp),
+                                                                    (net.e.dw_off, net.e.dw_off + net.e.co_p * net.e.kp), (g.dw_off, g.dw_off + g.n_total * g.kp)]
+    spans.sort()
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= arena.dw_len   # no overlap
+    assert net.g1.dw_off == g.dw_off and net.g2.dw_off == g.dw_off + net.g1.co_p * g.kp          # members: rows of the group's slice
+    assert all(lo <= a and b <= hi for a, b in spans if a < hi)  # every non-conv slice inside the cleared range
+
+    pc = PassCtx.__new__(PassCtx)                                 # (no device work: the bookkeeping alone)
+    pc.arena, pc.dwbar = arena, None
+    assert not pc.was_written(net.c1)                             # before the accumulator exists: first launch stores
+    pc.dwbar = torch.full((arena.dw_len,), float("nan"))
+    pc.dwbar[lo:hi] = 0
+    pc.written = set()
+    pc.mark_written(net.c1)
+    assert pc.was_written(net.c1) and not pc.was_written(net.c2) and not pc.was_written(net.c2.use(1))
+    s = pc.dw_acc(net.c2)                                         # a caller that ADDS: an unwritten conv slice starts from zero
+    assert float(s.abs().sum()) == 0.0 and pc.was_written(net.c2)
+    pc.clear_unwritten()                                          # what no launch reached (c2's second application) is zero for the spectral-norm backward
+    assert bool(torch.isfinite(pc.dw_slice(net.c2.use(1))).all()) and float(pc.dw_slice(net.c2.use(1)).abs().sum()) == 0.0
+    assert bool(torch.isnan(pc.dw_slice(net.c1)).all())           # (c1's was "stored" by its launch: left alone)
+    a, b = PassCtx.__new__(PassCtx), PassCtx.__new__(PassCtx)
+    for q in (a, b):
+        q.arena, q.training, q.need_wgrad, q.dwbar, q.written = arena, True, True, torch.zeros(arena.dw_len), set()
+    d = DualPass(a, b)
+    d.mark_written(net.c1)
+    assert a.was_written(net.c1) and b.was_written(net.c1) and d.was_written(net.c1) and not d.was_written(net.c2)
+
+
 def test_no_silent_cpu_fallback():
     import layout2img_amd as L
     from layout2img_amd import ops
