@@ -227,6 +227,9 @@ def main():
                     help="also time the generator forward at batch 128 / 256 (g_forward.batch_sweep); off by default so that the default "
                          "command's kernel statistics hold the batch-32 launches only")
     ap.add_argument("--no-f32-mode", action="store_true", help="skip the secondary exact-f32 operand-mode measurement")
+    ap.add_argument("--graph-iters", type=int, default=4,
+                    help="iterations per graph replay (N = 1 GPU): a second graph of this many consecutive iterations carries the timed steps "
+                         "(steps %% n run on the one-iteration graph); 1 = one iteration per replay")
     ap.add_argument("--no-graph", action="store_true", help="run every iteration eagerly (default: replay a captured HIP graph at N=1)")
     args = ap.parse_args()
     refuse_wrong_result_switches()
@@ -299,13 +302,27 @@ def main():
             if world > 1:
                 raise
             os.execv(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-graph"])
+    # n iterations per replay: the ~0.3 ms a graph launch costs on top of its kernels is paid once per n iterations (GanTrainer.capture_multi)
+    n_multi = args.graph_iters if (graphed and world == 1 and args.graph_iters > 1) else 1
+    if n_multi > 1:
+        try:
+            if not trainer.capture_multi([(real, label, bbox, None)] * n_multi):
+                n_multi = 1
+        except Exception as e:   # (sticky, as above: a fresh process with one iteration per replay)
+            print(f"[bench] multi-iteration capture unavailable ({type(e).__name__}: {str(e)[:200]}); re-running with --graph-iters 1", file=sys.stderr, flush=True)
+            os.execv(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--graph-iters", "1"])
     step = (lambda: trainer.step_graphed(real, label, bbox, None)) if graphed else (lambda: trainer.step(real, label, bbox, None, None))
-    for _ in range(args.warmup):
-        step()
+    multi = [(real, label, bbox, None)] * n_multi
+
+    def run_steps(k):   # EXACTLY k iterations: k // n replays of the n-iteration graph, the rest on the one-iteration graph / eagerly
+        for _ in range(k // n_multi if n_multi > 1 else 0):
+            trainer.step_graphed_multi(multi)
+        for _ in range(k % n_multi if n_multi > 1 else k):
+            step()
+    run_steps(args.warmup)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
+    run_steps(args.steps)
     trainer.flush()   # (data parallel: the last iteration's deferred generator all-reduce + Adam belong to the timed region)
     sync()
     elapsed = time.perf_counter() - t0
@@ -404,7 +421,8 @@ def main():
                                    + ("VGG19 perceptual term included (random-init VGG)" if args.vgg else "VGG loss term omitted")
                                    + ", random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "launch": ("HIP graph replay of the whole iteration incl. the draw of z (every timed step)" if graphed else "eager")},
+                       "launch": ("HIP graph replay of the whole iteration incl. the draw of z (every timed step)" if graphed else "eager"),
+                       "iterations_per_replay": n_multi},
             "roofline": roof, "env": l2i_env(),
             "cpu_baseline": cpu, "g_forward": g_fwd, "eager": eager, "f32_mode": f32_mode,
             "g_forward_images_per_sec": None if g_fwd is None else g_fwd["images_per_sec"],

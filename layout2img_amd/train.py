@@ -31,6 +31,8 @@ def main(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--host_resize", action="store_true", help="resize images in the loader workers (PIL, as the reference) instead of on the GPU")
     ap.add_argument("--num_workers", type=int, default=2)
+    ap.add_argument("--graph_iters", type=int, default=4,
+                    help="one GPU, graph mode: iterations per graph replay (the launch of a replay costs ~0.3 ms; batches are collected in groups of this many)")
     ap.add_argument("--no_graph", action="store_true", help="run every iteration eagerly (default at one GPU: replay the captured HIP graph of the iteration)")
     args = ap.parse_args(argv)
 
@@ -104,12 +106,42 @@ def main(argv=None):
                 return trainer.step_graphed(real, label, bbox, z, z_im)
         return trainer.step(real, label, bbox, z, z_im)
 
+    # graph mode: batches are collected in groups of --graph_iters and run by ONE replay of a graph of that many consecutive iterations
+    # (GanTrainer.capture_multi, captured on the first full group); what is left of an epoch runs on the one-iteration graph
+    group, multi = [], None
+
+    def run_group():
+        nonlocal multi
+        rs = None
+        if graphed and multi is None and len(group) == args.graph_iters:
+            try:
+                multi = trainer.capture_multi(group)
+            except Exception as e:
+                raise RuntimeError(f"HIP graph capture of {args.graph_iters} iterations failed ({type(e).__name__}: {str(e)[:200]}); "
+                                   "run again with --graph_iters 1") from e
+        if multi and len(group) == args.graph_iters and all((b[1].shape[0], b[1].shape[1]) == n_obj for b in group):
+            rs = trainer.step_graphed_multi(group)
+        else:
+            rs = [trainer.step_graphed(*b) if (graphed and (b[1].shape[0], b[1].shape[1]) == n_obj) else trainer.step(*b) for b in group]
+        group.clear()
+        return rs[-1]
+
+    def log(epoch, idx, r):
+        print(f"Time Elapsed: {time.time() - t0:.0f}s  Epoch[{epoch + 1}/{args.total_epoch}], Step[{idx + 1}], "
+              f"d_loss: {float(r['d_loss']):.4f}, g_loss: {float(r['g_loss']):.4f}, pixel: {float(r['pixel']):.4f}", flush=True)
+
     for epoch in range(start, args.total_epoch):
         for idx, (real, label, bbox) in enumerate(batches(epoch)):
-            r = run(real, label, bbox)
+            if graphed and args.graph_iters > 1:
+                b, o = label.shape[0], label.shape[1]
+                group.append((real, label, bbox, torch.randn(b, o, z_dim, device=real.device), torch.randn(b, 128, device=real.device)))
+                r = run_group() if (len(group) == args.graph_iters or (idx + 1) % 500 == 0) else None
+            else:
+                r = run(real, label, bbox)
             if rank == 0 and (idx + 1) % 500 == 0:   # (the only host synchronisation: logging, as :191-209)
-                print(f"Time Elapsed: {time.time() - t0:.0f}s  Epoch[{epoch + 1}/{args.total_epoch}], Step[{idx + 1}], "
-                      f"d_loss: {float(r['d_loss']):.4f}, g_loss: {float(r['g_loss']):.4f}, pixel: {float(r['pixel']):.4f}", flush=True)
+                log(epoch, idx, r)
+        if group:
+            run_group()
         trainer.flush()   # (a deferred generator step of the last iteration, data parallel) before the weights are read
         if rank == 0 and (epoch + 1) % 5 == 0:       # :215-217
             L.save_checkpoint(out_path, epoch + 1, netG, netD, trainer.g_opt, trainer.d_opt)

@@ -340,6 +340,54 @@ class GanTrainer:
         self._graph = graph
         return True
 
+    _graph = None
+    _graph_multi = None
+
+    def capture_multi(self, batches):
+        """ONE graph of len(batches) consecutive iterations (after a successful `capture`, which warmed the allocator and made the
+        per-stream workspaces). A replay costs ~0.3 ms of launch on top of the 19.4 ms of kernels; n iterations per
+        replay divide that by n (measured: 19.36 -> 19.27 ms per iteration at n = 2). batches: n tuples (real, label, bbox, z, z_im)
+        -- each iteration has its own static inputs (`step_graphed_multi` copies n new batches in); z = None draws the latents inside."""
+        if self._graph is None or self.dp:
+            return False
+        self._static_multi = [[None if t is None else t.detach().clone() for t in (tuple(b) + (None,) * 5)[:5]] for b in batches]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        torch.cuda.synchronize()
+        for net in (self.netG, self.netD):
+            net.arena.free_packs = []
+        t_host = (self.g_opt.t, self.d_opt.t)
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, stream=side):
+                self._multi_out = [self.step(*b) for b in self._static_multi]
+        except Exception:
+            self._graph_multi = None
+            torch.cuda.synchronize()
+            raise
+        self.g_opt.t, self.d_opt.t = t_host   # (nothing ran: the host-side mirrors of the step counts stay where they were)
+        for net in (self.netG, self.netD):
+            net.arena.free_packs = []
+        self._graph_multi = graph
+        return True
+
+    def step_graphed_multi(self, batches):
+        """Copies len(batches) new batches into the static inputs of the multi-iteration graph and replays it; returns the list of
+        the iterations' result dicts (static tensors, overwritten by the next replay)."""
+        if len(batches) != len(self._static_multi):
+            raise RuntimeError(f"step_graphed_multi: the graph holds {len(self._static_multi)} iterations, got {len(batches)} batches")
+        for st, b in zip(self._static_multi, batches):
+            for name, dst, src in zip(("real", "label", "bbox", "z", "z_im"), st, (tuple(b) + (None,) * 5)[:5]):
+                if (dst is None) != (src is None):
+                    raise RuntimeError(f"step_graphed_multi: `{name}` was {'drawn inside' if dst is None else 'an input of'} the captured iterations")
+                if dst is not None and dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+        self._graph_multi.replay()
+        self.g_opt.t += len(batches)
+        self.d_opt.t += len(batches)
+        return self._multi_out
+
     def step_graphed(self, real, label, bbox, z, z_im=None):
         for name, dst, src in zip(("real", "label", "bbox", "z", "z_im"), self._static, (real, label, bbox, z, z_im)):
             if (dst is None) != (src is None):

@@ -122,3 +122,39 @@ def test_training_entry_runs_and_resumes(tmp_path):
     assert tr.g_opt.t == 4 and (tmp_path / "coco" / "64" / "model" / "G_2.pth").exists()
     tr2 = train.main(common + ["--total_epoch", "3", "--checkpoint_epoch", "2"])
     assert tr2.g_opt.t == 6 and (tmp_path / "coco" / "64" / "model" / "D_3.pth").exists()
+
+
+def test_multi_iteration_graph_equals_single_replays():
+    """GanTrainer.capture_multi: ONE replay of a graph of three consecutive iterations (each with its own static batch) leaves the
+    networks, the Adam moments and step counts where three replays of the one-iteration graph leave them -- what bench.py's timed
+    steps and the training entry's batch groups run. (Bar: as the resume test -- atomically reduced sums are not order-deterministic;
+    an iteration that was skipped or fed the wrong batch moves the parameters by O(lr) = 1e-4 per step everywhere.)"""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_batch
+    from layout2img_amd.trainer import restore_state, snapshot_state
+    g, d = _nets(5)
+    tr = L.GanTrainer(g, d)
+    batches = [make_batch(4, 64, "coco", seed=11 + i, device=DEV) for i in range(3)]
+    st = snapshot_state(tr)
+    assert tr.capture(*batches[0])
+    restore_state(tr, st)
+    for b in batches:
+        r1 = tr.step_graphed(*b)
+    torch.cuda.synchronize()
+    p1 = (g.flat.data.clone(), d.flat.data.clone(), tr.g_opt.m.clone(), tr.d_opt.v.clone(), int(tr.g_opt.t_dev), tr.g_opt.t, float(r1["d_loss"]))
+    restore_state(tr, st)
+    assert tr.capture_multi(batches)
+    restore_state(tr, st)
+    rs = tr.step_graphed_multi(batches)
+    torch.cuda.synchronize()
+    assert len(rs) == 3 and int(tr.g_opt.t_dev) == p1[4] == int(st["opt"][0][3]) + 3 and tr.g_opt.t == p1[5]
+    for a, b_ in ((g.flat.data, p1[0]), (d.flat.data, p1[1])):
+        close = ((a - b_).abs() < 2.5e-4).float().mean()
+        assert float(close) > 0.98, float(close)
+        assert float((a - b_).abs().max()) < 2e-3
+    moved = float((g.flat.data - st["flat"][0]).abs().mean())
+    assert moved > 1e-4   # (three Adam steps of lr 1e-4 did move the parameters: the comparison above is not vacuous)
+    assert float((tr.g_opt.m - p1[2]).norm() / p1[2].norm()) < 5e-2 and float((tr.d_opt.v - p1[3]).norm() / p1[3].norm()) < 5e-2
+    assert abs(float(rs[-1]["d_loss"]) - p1[6]) < 2e-3 * abs(p1[6]) + 1e-4
+    with pytest.raises(RuntimeError, match="holds 3 iterations"):
+        tr.step_graphed_multi(batches[:2])
