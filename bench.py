@@ -427,10 +427,18 @@ def main():
             "cpu_baseline": cpu, "g_forward": g_fwd, "eager": eager, "f32_mode": f32_mode,
             "g_forward_images_per_sec": None if g_fwd is None else g_fwd["images_per_sec"],
         }
-        print(json.dumps(out), flush=True)
     if dist.is_initialized():   # (world > 1, or the forced one-rank group of L2I_FORCE_COLLECTIVES=1)
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C-level stdout, which is block-buffered when piped and would otherwise come out AFTER
+        # this line at exit: flush the C streams first so that the JSON line is the LAST line of rank 0's stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
