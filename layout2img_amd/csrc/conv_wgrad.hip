@@ -15,6 +15,7 @@
 // the MFMA loop are the same as the forward kernel's. The pixel reduction is
 // split over `splits` workgroups per output tile, combined by f32 atomics.
 #include <stdlib.h>
+#include <mutex>
 #include "igemm.h"
 
 L2I_TRACE_DEFINE(wgrad)
@@ -961,8 +962,13 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
         static const int fuse_env = getenv("L2I_WGRAD_FUSE") ? atoi(getenv("L2I_WGRAD_FUSE")) : 0;
         a.fuse_cnt = nullptr;
         if (fuse_env && a.part && !deep && !nw8 && !nw2 && (dual ? a.splits / 2 : a.splits) <= 16) {
+            // (experiment, measured slower, off by default -- DESIGN "dated experiments". The hand-out is serialised across host
+            //  threads; slots baked into a captured graph are NOT reserved against later eager launches after the ring wraps, so the
+            //  switch must not be combined with graph replay next to eager launches on another stream)
             static unsigned* cnt_base = nullptr;
             static unsigned cnt_next = 0;
+            static std::mutex cnt_mu;
+            std::lock_guard<std::mutex> lock(cnt_mu);
             if (!cnt_base && hipGetSymbolAddress((void**)&cnt_base, HIP_SYMBOL(g_wgrad_cnt)) != hipSuccess) return L2I_ERR_LAUNCH;
             const unsigned need = (unsigned)tiles * (dual ? 2u : 1u);
             if (cnt_next + need > L2I_WGRAD_CNT) cnt_next = 0;

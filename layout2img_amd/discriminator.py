@@ -65,13 +65,15 @@ class ResBlock(nn.Module):
         if self.learnable_sc:
             self.c_sc = _conv(in_ch, out_ch, 1, uses)
 
-    def forward(self, x, pc, use=0, nimg=None, emit=(), sole_reader=False, join_in=None, join_out=None):
+    def forward(self, x, pc, use=0, nimg=None, emit=(), sole_reader=False, join_in=None, join_out=None, join_src=None):
         """`sole_reader`: x is the result of another block's conv2 and this block is its ONLY reader -- the data-gradient launch
         of conv1 (which also takes the shortcut branch's gradient as its residual: the complete dx) then writes the operand
         copy of dx that the producing conv2's backward needs, instead of a separate cast pass over the f32 gradient.
         `join_in` / `join_out` (ops.fused_conv): x is read by TWO blocks -- the one created later (its backward runs first) leaves
         its complete dx in the shared GradJoin (join_out, conv1's launch), this block's shortcut launch adds it (join_in), so the sum
         over both readers comes out of conv1's data-gradient launch (with `sole_reader` its operand copy as well).
+        `join_src`: the GradJoin of the two readers of THIS block's result: conv2's backward adds a gradient that was parked
+        there for a launch that never ran (a loss without the image head: ops.GradJoin.leftover).
         `use`: index of this application within the forward pass (each application of a spectral-normed
         module runs its own power iteration in the reference). `nimg`: device count of live leading images (ROI heads).
         `emit`: operand copies of the block's result its consumers will read ("relu" / "raw"), written by conv2's
@@ -86,7 +88,7 @@ class ResBlock(nn.Module):
         sc = (fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg, join=(j, "give"), lazy_sc=True, join_in=join_in)
               if self.learnable_sc else x)
         return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample, nimg=nimg, emit=emit,
-                          dx_raw=True, join=None if self.learnable_sc else (j, "give_res"))
+                          dx_raw=True, join=None if self.learnable_sc else (j, "give_res"), join_src=join_src)
 
 
 class ResnetDiscriminator128_app(nn.Module):
@@ -114,9 +116,9 @@ class ResnetDiscriminator128_app(nn.Module):
         number of valid rows when they are compacted to the front (the ROI heads then skip the rest)."""
         both = ("relu", "raw")   # what a following block with a learnable shortcut reads
         x = self.block1(x, pc, emit=both)
-        x1 = self.block2(x, pc, emit=both, sole_reader=True)
         jx1, jx2 = ops.GradJoin(), ops.GradJoin()   # x1 and x2 are each read by a trunk block and by an object-path block
-        x2 = self.block3(x1, pc, emit=both, join_in=jx1, sole_reader=JOIN_READERS)
+        x1 = self.block2(x, pc, emit=both, sole_reader=True, join_src=jx1)
+        x2 = self.block3(x1, pc, emit=both, join_in=jx1, sole_reader=JOIN_READERS, join_src=jx2)
         x = self.block4(x2, pc, emit=both, join_in=jx2, sole_reader=JOIN_READERS)
         x = self.block5(x, pc, emit=("relu",), sole_reader=True)
         x = self.block6(x, pc, sole_reader=True)

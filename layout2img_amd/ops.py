@@ -482,7 +482,12 @@ class GradJoin:
     branch (whose backward runs first: autograd orders ready nodes by creation, latest first) GIVES its dx, the conv1
     branch TAKES it as the residual input of its own data-gradient epilogue (or of the norm backward's second pass) --
     instead of autograd materialising both and adding them with one more pass. If the order ever differs, both
-    branches simply return their gradients the ordinary way."""
+    branches simply return their gradients the ordinary way.
+    A join between two BLOCKS that read one tensor (fused_conv join_in / join_out) has a taker that is not always part of the
+    backward pass: with a loss over d_obj / d_app only, the trunk block whose shortcut launch would take the object path's
+    gradient never runs. The convolution that PRODUCED the tensor is the taker of last resort (fused_conv join_src): its backward
+    runs after every reader's, and adds a gradient that is still parked there to its dY -- one extra pass in that rare case,
+    never a silently dropped gradient."""
 
     def __init__(self):
         self.t, self.state = None, "open"
@@ -500,6 +505,13 @@ class GradJoin:
         self.state = "closed"
         return None
 
+    def leftover(self):
+        """The parked gradient nobody took (see the class docstring), or None."""
+        if self.state == "filled":
+            t, self.t, self.state = self.t, None, "done"
+            return t
+        return None
+
 
 class FusedConvFn(Function):
     """[prologue] -> implicit-GEMM conv/linear (+bias, +res, up2 / pool2) with f32 streams on both
@@ -512,7 +524,7 @@ class FusedConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None,
-                emit=(), dx_raw=False, join=None, op_out=False, lazy_sc=False, join_in=None, join_out=None):
+                emit=(), dx_raw=False, join=None, op_out=False, lazy_sc=False, join_in=None, join_out=None, join_src=None):
         opd = pc.arena.op_dtype
         _chk(x, opd if (pro.kind in ("op", "opraw") and not pc.arena.split) else torch.float32)
         B, H, W, C = x.shape
@@ -589,7 +601,7 @@ class FusedConvFn(Function):
                 _attach(out, raw=o_raw, relu=o_relu)
         ctx.op_out = op_out
         ctx.flops, ctx.nimg, ctx.dx_raw, ctx.join = flops, nimg, dx_raw, join
-        ctx.join_in, ctx.join_out = join_in, join_out
+        ctx.join_in, ctx.join_out, ctx.join_src = join_in, join_out, join_src
         sw, sb = getattr(wproj, "_l2i_sink", None), getattr(bproj, "_l2i_sink", None)
         ctx.sink = (sw[0], sw[1], sb[1]) if sw is not None and sb is not None and sw[0] is sb[0] else None
         ctx.holder, ctx.pc, ctx.pro, ctx.up2, ctx.pool2, ctx.stats = holder, pc, pro, up2, pool2, stats
@@ -603,6 +615,10 @@ class FusedConvFn(Function):
         h, pc, pro = ctx.holder, ctx.pc, ctx.pro
         x, x_op, mask, wproj, bproj = ctx.saved_tensors
         dy = dy.contiguous()
+        if ctx.join_src is not None:   # a reader of this result parked its gradient for a launch that never ran (GradJoin)
+            parked = ctx.join_src.leftover()
+            if parked is not None:
+                dy = dy + parked.to(dy.dtype)
         opd = pc.arena.op_dtype
         need_x = ctx.needs_input_grad[0]
         need_mod = pro.kind == "norm" and pro.mode in (0, 1)
@@ -686,7 +702,7 @@ class FusedConvFn(Function):
         d_res = dy if ctx.has_res else None
         if d_res is not None and ctx.join is not None and ctx.join[1] == "give_res":
             d_res = ctx.join[0].give(d_res)
-        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _attach(t, raw=None, relu=None):
@@ -716,8 +732,9 @@ def precast(x, op_dtype):
 
 
 def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False, nimg=None,
-               emit=(), dx_raw=False, join=None, relu_op_out=False, lazy_sc=False, join_in=None, join_out=None):
-    """join_in / join_out: a GradJoin shared with ANOTHER reader of x (a tensor read by two blocks): the reader whose backward runs
+               emit=(), dx_raw=False, join=None, relu_op_out=False, lazy_sc=False, join_in=None, join_out=None, join_src=None):
+    """join_src: the GradJoin(s) of the two readers of THIS conv's result (a tuple is accepted): see GradJoin.leftover.
+    join_in / join_out: a GradJoin shared with ANOTHER reader of x (a tensor read by two blocks): the reader whose backward runs
     first (the one created later) leaves its complete dx there (join_out), the other one's launch with a free residual slot (a
     block's 1x1 shortcut) adds it in its data-gradient epilogue (join_in) -- no autograd accumulation pass over the two gradients.
     emit: operand copies of the result to write in the epilogue ("relu", "raw") for the layers that read it next.
@@ -746,7 +763,7 @@ def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None,
         if res is not None or pool2 or ((B * Ho * Wo + 127) // 128) * ((holder.co_p + 127) // 128) < 192 or not OP_EDGES:
             relu_op_out, emit = False, tuple(emit) + ("relu",)
     out = FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg, tuple(emit), dx_raw, join,
-                            relu_op_out, bool(lazy_sc) and SC_FOLD, join_in, join_out)
+                            relu_op_out, bool(lazy_sc) and SC_FOLD, join_in, join_out, join_src)
     if relu_op_out:
         out._l2i_relu_op = True
     return out

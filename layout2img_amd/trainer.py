@@ -300,7 +300,7 @@ class GanTrainer:
         self._static = [None if t is None else t.detach().clone() for t in (real, label, bbox, z, z_im)]
         from . import _lib
         cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()   # the capture stream; also used for the warm-up, as torch.cuda.graphs asks
+        side = self._cap_stream = torch.cuda.Stream()   # the capture stream; also used for the warm-up, as torch.cuda.graphs asks
         if self.overlap and self._side is None:
             self._side = torch.cuda.Stream()
         for s_ in (side, self._side):   # reduction workspaces of both streams exist BEFORE capture (never in the graph's pool)
@@ -342,6 +342,7 @@ class GanTrainer:
 
     _graph = None
     _graph_multi = None
+    _cap_stream = None
 
     def capture_multi(self, batches):
         """ONE graph of len(batches) consecutive iterations (after a successful `capture`, which warmed the allocator and made the
@@ -352,7 +353,9 @@ class GanTrainer:
             return False
         self._static_multi = [[None if t is None else t.detach().clone() for t in (tuple(b) + (None,) * 5)[:5]] for b in batches]
         cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
+        # capture()'s stream again: its reduction workspace and weight-gradient scratch (keyed by the raw stream, _lib.workspace)
+        # exist already -- a fresh stream would allocate them INSIDE the capture, in the graph's private pool
+        side = self._cap_stream
         side.wait_stream(cur)
         torch.cuda.synchronize()
         for net in (self.netG, self.netD):

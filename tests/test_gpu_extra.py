@@ -154,3 +154,36 @@ def test_weight_gradient_with_the_fused_last_arriver_reduction():
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_gpu_ops.py", "tests/test_gpu_dual.py", "-k",
                         "conv_wgrad or dual_wgrad or device_side_image_count"], cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert p.returncode == 0, p.stdout[-3000:]
+
+
+@pytest.mark.parametrize("heads", ["obj+app", "obj", "img", "all"])
+def test_two_reader_joins_never_drop_a_gradient(heads, monkeypatch):
+    """The discriminator's x1 / x2 are each read by a trunk block and by an object-path block (reference
+    model/rcnn_discriminator_app.py:126-141); the object path's data gradient is handed to the trunk block's shortcut launch
+    through ops.GradJoin instead of an autograd add. A loss WITHOUT the image head never runs that trunk launch: the parked
+    gradient must then reach the tensor's producer all the same (GradJoin.leftover, taker of last resort) -- the flat gradient
+    buffer equals the one of the plain autograd accumulation (L2I_JOIN_READERS=0) for every subset of the heads."""
+    import layout2img_amd as L
+    from layout2img_amd import discriminator as D
+    from layout2img_amd.synthetic import make_batch
+    real, label, bbox, _, _ = make_batch(3, 128, "coco", seed=9, device=torch.device(DEV))
+    grads = {}
+    for join in (True, False):
+        monkeypatch.setattr(D, "JOIN_READERS", join)
+        torch.manual_seed(0)
+        d = L.CombineDiscriminator128_app(num_classes=184).finalize(DEV, torch.float32).train()
+        d.zero_grad()
+        d_img, d_obj, d_app = d(real, bbox, label)
+        loss = {"obj+app": d_obj.sum() + 0.5 * d_app.sum(), "obj": d_obj.sum(), "img": d_img.sum(),
+                "all": d_img.sum() + d_obj.sum() + 0.5 * d_app.sum()}[heads]
+        loss.backward()
+        d.arena.flush_grads()
+        torch.cuda.synchronize()
+        grads[join] = d.flat.grad.clone()
+    a, b = grads[True], grads[False]
+    assert float(b.norm()) > 0
+    named = dict(d.named_parameters())
+    if heads != "img":   # the trunk blocks in front of x1 / x2 receive the object path's gradient
+        assert float(named["obD.block1.conv1.weight_orig"].grad.norm()) > 0 and float(named["obD.block3.conv1.weight_orig"].grad.norm()) > 0
+    rel = float((a - b).norm() / b.norm())
+    assert rel < 2e-4, rel   # (accumulation order only: f32 operands)
