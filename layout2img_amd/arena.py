@@ -65,6 +65,12 @@ class FlatParams:
         owned = {id(q) for m in module.modules() if isinstance(m, GemmWeight) for q in m.parameters(recurse=False)}
         self._loose = [(p, offs[n]) for n, p in params if id(p) not in owned]
         self.defer_loose = True
+        self.epoch = 0   # see touch()
+
+    def touch(self):
+        """The parameters were changed by something torch's version counters cannot see (the Adam kernel writes through raw
+        pointers; a graph replay does so without any host call): WeightArena's cached eval-mode packs are stale."""
+        self.epoch += 1
 
     def offset_of(self, param):
         return self._by_id[id(param)]
@@ -236,6 +242,7 @@ class WeightArena:
         for t in sn_tensors:
             t.data = t.data.to(device)
         self.sn_flat = FlatBuffers(sn_tensors, device)
+        self._sn_tensors = sn_tensors
         state_off = {}
         k = 0
         for h in holders:
@@ -370,9 +377,62 @@ class WeightArena:
             else:
                 self.acc_ranges.append([a, b])
 
+    # ---- eval-mode pass cache (sampling, reference test_context_app_v2.py:68-77): in eval mode the spectral-norm hook does not
+    # iterate, so W / sigma and both packs depend on the parameters and u / v only -- normalising and packing all of a
+    # generator's 41 M parameters again on every forward was ~0.2 ms of each sampling call. The pass context of the last
+    # no-grad eval forward is kept and handed out again while nothing has changed: the version counters of every parameter
+    # and u / v buffer (torch-side writes: load_state_dict, .copy_, ...) plus FlatParams.epoch / sn_epoch (raw-pointer writes:
+    # the Adam kernel, graph replays, the train-mode power iteration). A stale cache is re-packed IN PLACE (same buffers), so
+    # that a HIP graph captured over it (sampling.GraphSampler) stays valid.
+    EVAL_CACHE = os.environ.get("L2I_EVAL_CACHE", "1") != "0"
+    _eval_pc = None
+    _eval_stamp = None
+    _eval_event = None
+    sn_epoch = 0
+
+    def _stamp(self):
+        v = 0
+        for _, p in self.flat._params:
+            v += p._version
+        for t in self._sn_tensors:
+            v += t._version
+        return (self.flat.epoch, self.sn_epoch, v, self.flat.data._version, self.sn_flat.data._version)
+
+    def _eval_pass(self):
+        st = self._stamp()
+        pc = self._eval_pc
+        cur = torch.cuda.current_stream()
+        if pc is not None and st == self._eval_stamp:
+            if self._eval_event is not None and self._eval_event[0] != cur.cuda_stream:
+                cur.wait_event(self._eval_event[1])   # (packed on another stream)
+            return pc
+        if torch.cuda.is_current_stream_capturing():
+            return None   # never create / refresh the cache inside a capture (its buffers would live in the graph's pool)
+        if pc is None:
+            pc = PassCtx(self, False, False)
+        self._pack(pc, False)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._eval_pc, self._eval_stamp, self._eval_event = pc, st, (cur.cuda_stream, ev)
+        return pc
+
     def prepare(self, training=True, need_wgrad=True):
         """Run the power iteration(s) (train mode) and pack all weights; returns the pass context."""
+        if not training and self.EVAL_CACHE and not torch.is_grad_enabled():
+            p = self._eval_pass()
+            if p is not None:
+                return p
         p = PassCtx(self, training, need_wgrad)
+        self._pack(p, training)
+        if training:
+            self.sn_epoch += 1   # (u / v advanced through raw pointers)
+        if need_wgrad and torch.is_grad_enabled():
+            self.pending.append(p)
+            if len(self.pending) > 8:  # forwards that were never followed by an optimiser step
+                self.pending.pop(0)
+        return p
+
+    def _pack(self, p, training):
         for r in range(self.rounds):
             (wtu, n_wtu), (wv, n_wv), (pk, n_pk), (fin, n_fin) = self.t_wtu[r], self.t_wv[r], self.t_pack[r], self.t_fin[r]
             if n_pk == 0:
@@ -381,11 +441,6 @@ class WeightArena:
                       pk.data_ptr(), n_pk, fin.data_ptr(), n_fin, self.flat.data.data_ptr(), self.sn_flat.data.data_ptr(), p.pass_uv.data_ptr(),
                       self.uv_len, p.norms.data_ptr(), p.packed.data_ptr(), self.dtype_code, 1 if training else 0,
                       1 if r == 0 else 0, _lib.raw_stream())
-        if need_wgrad and torch.is_grad_enabled():
-            self.pending.append(p)
-            if len(self.pending) > 8:  # forwards that were never followed by an optimiser step
-                self.pending.pop(0)
-        return p
 
     def flush_grads(self):
         """Apply the spectral-norm backward of every pending pass into the flat gradient buffer."""

@@ -1391,6 +1391,7 @@ def adam_step(flat, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=
     """step_dev: 1-element int32 device tensor with the step count (read on the device; graph-capturable)."""
     _lib.call("l2i_adam_step", flat.data.data_ptr(), flat.grad.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel, float(lr),
               float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _p(step_dev), _stream())
+    flat.touch()   # (the kernel writes the parameters through raw pointers: cached eval-mode packs are stale, arena.WeightArena._stamp)
 
 
 # ----------------------------------------------------------------------------- layout-side glue (csrc/layout.hip)

@@ -132,6 +132,71 @@ def truncated_normal(shape, thres=1.0, device="cpu", generator=None, dtype=torch
     return (math.sqrt(2.0) * torch.erfinv(u)).clamp_(-thres, thres).to(dtype)
 
 
+class GraphSampler:
+    """`sample` as a replayed HIP graph, one per layout shape (b, o): the eval-mode generator call of the reference's sampling
+    script (test_context_app_v2.py:68-77) is ~100 launches of which a batch of one fills a fraction of a CU each -- its
+    latency is launch overhead, not work (2.7 ms eager against 2.3 ms for a batch of 32). The captured graph holds the draw of the
+    truncated latents (torch's graph-safe Philox generator advances per replay, so every call returns a new sample) and the
+    whole forward; label / bbox are copied into static inputs. The weight packs are NOT part of the graph: they are the
+    arena's cached eval-mode pass (arena.WeightArena._eval_pass), re-packed in place -- eagerly, in front of the replay --
+    when a parameter changed, so a training step between two calls is picked up without a new capture.
+
+    s = GraphSampler(netG); img = s(label, bbox)     # img: a static tensor, overwritten by the next call of that shape
+    """
+
+    def __init__(self, netG, thres=2.0):
+        self.net, self.thres, self._graphs = netG, float(thres), {}
+        self._stream = None
+
+    @torch.no_grad()
+    def __call__(self, label, bbox, return_latents=False):
+        net = self.net
+        _flush(net)
+        dev = next(net.parameters()).device
+        b, o = label.shape[0], label.shape[1]
+        key = (b, o)
+        was_training = net.training
+        net.eval()
+        try:
+            net.arena.prepare(training=False)   # the cached eval pass: created, or re-packed in place if a parameter changed
+            ent = self._graphs.get(key)
+            if ent is None:
+                ent = self._capture(b, o, dev, label, bbox)
+                self._graphs[key] = ent
+            ent["label"].copy_(label.view(b, o), non_blocking=True)
+            ent["bbox"].copy_(bbox, non_blocking=True)
+            ent["graph"].replay()
+            return (ent["img"], ent["z"], ent["z_im"]) if return_latents else ent["img"]
+        finally:
+            net.train(was_training)
+
+    def _capture(self, b, o, dev, label, bbox):
+        net = self.net
+        ent = dict(label=label.to(dev).view(b, o).clone(), bbox=bbox.to(dev).float().clone())
+        cur = torch.cuda.current_stream()
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        side = self._stream
+        from . import _lib
+
+        def run():
+            z = truncated_normal((b, o, 128), self.thres, dev)
+            z_im = truncated_normal((b, 128), self.thres, dev)
+            return net(z, ent["bbox"], z_im=z_im, y=ent["label"]), z, z_im
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            _lib.workspace(dev)     # the stream's reduction workspace exists BEFORE the capture (never in the graph's pool)
+            for _ in range(2):      # warm-up on the capture stream, as torch.cuda.graphs asks
+                run()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            ent["img"], ent["z"], ent["z_im"] = run()
+        ent["graph"] = graph
+        return ent
+
+
 @torch.no_grad()
 def sample(netG, label, bbox, thres=2.0, generator=None, return_latents=False):
     """Eval-mode images for layouts (label (b,o) int64, bbox (b,o,4)); truncated latents as the reference draws them

@@ -387,9 +387,16 @@ class GanTrainer:
                 if dst is not None and dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
         self._graph_multi.replay()
+        self._touch()
         self.g_opt.t += len(batches)
         self.d_opt.t += len(batches)
         return self._multi_out
+
+    def _touch(self):
+        """A replay changed parameters and u / v with no host-side call: cached eval-mode packs are stale (arena._stamp)."""
+        for net in (self.netG, self.netD):
+            net.flat.touch()
+            net.arena.sn_epoch += 1
 
     def step_graphed(self, real, label, bbox, z, z_im=None):
         for name, dst, src in zip(("real", "label", "bbox", "z", "z_im"), self._static, (real, label, bbox, z, z_im)):
@@ -398,6 +405,7 @@ class GanTrainer:
             if dst is not None and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self._graph.replay()
+        self._touch()
         self.g_opt.t += 1   # (host-side mirrors of the device-side step counts the replayed Adam launches advance)
         self.d_opt.t += 1
         return self._graph_out

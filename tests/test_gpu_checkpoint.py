@@ -158,3 +158,63 @@ def test_multi_iteration_graph_equals_single_replays():
     assert abs(float(rs[-1]["d_loss"]) - p1[6]) < 2e-3 * abs(p1[6]) + 1e-4
     with pytest.raises(RuntimeError, match="holds 3 iterations"):
         tr.step_graphed_multi(batches[:2])
+
+
+def test_eval_pass_cache_and_graph_sampler_follow_parameter_updates():
+    """The eval-mode weight packs are cached by the arena (arena.WeightArena._eval_pass) and the sampling call is a replayed HIP
+    graph over that cache (sampling.GraphSampler; reference test_context_app_v2.py:68-77): (i) a second eval forward launches no
+    weight preparation; (ii) the graph's image equals the eager eval forward on the latents the graph drew, and two calls draw
+    different latents; (iii) a parameter changed by torch (an in-place op), by the Adam KERNEL (raw pointers: a training step) or by
+    load_state_dict is picked up by the next call -- without a new capture."""
+    import layout2img_amd as L
+    from layout2img_amd import _lib, arena as A
+    from layout2img_amd.sampling import GraphSampler
+    from layout2img_amd.synthetic import make_batch, make_layouts
+    g, d = _nets(3, torch.float32, size=128)
+    real, label, bbox, z, z_im = make_batch(4, 128, "coco", seed=9, device=DEV)
+    g.train()
+    with torch.no_grad():
+        for _ in range(3):
+            g(z, bbox, z_im, label)
+    lab1, box1 = make_layouts(1, "coco", seed=21, device=DEV)
+    calls = []
+    orig = _lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    A._lib.call = spy
+    try:
+        g.eval()
+        with torch.no_grad():
+            g(z[:1], box1, z_im[:1], lab1)
+            n1 = calls.count("l2i_weights_prepare")
+            g(z[:1], box1, z_im[:1], lab1)
+            assert n1 >= 1 and calls.count("l2i_weights_prepare") == n1   # (ii-th forward: the cached pass)
+    finally:
+        A._lib.call = orig
+    s = GraphSampler(g, thres=2.0)
+
+    def check(tag):
+        img, zs, zi = s(lab1, box1, return_latents=True)
+        img, zs, zi = img.clone(), zs.clone(), zi.clone()
+        with torch.no_grad():
+            ref = g(zs, box1, z_im=zi, y=lab1)
+        assert float(zs.abs().max()) <= 2.0 and float((img - ref).abs().max()) < 1e-5, (tag, float((img - ref).abs().max()))
+        return img, zs
+    g.eval()
+    img_a, z_a = check("first")
+    img_b, z_b = check("second")
+    assert len(s._graphs) == 1 and not torch.equal(z_a, z_b)
+    with torch.no_grad():
+        g.fc.weight_orig.mul_(1.25)          # torch-side write
+    check("after an in-place parameter write")
+    g.train()
+    tr = L.GanTrainer(g, d)
+    tr.step(real, label, bbox, z, z_im)     # the Adam kernel writes the flat buffer through raw pointers
+    g.eval()
+    check("after a training step")
+    sd = {k: v.detach().cpu().clone() * (0.5 if k == "res5.conv2.weight_orig" else 1.0) for k, v in g.state_dict().items()}
+    g.load_state_dict(sd)
+    check("after load_state_dict")
+    assert len(s._graphs) == 1   # never re-captured
