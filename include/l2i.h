@@ -128,7 +128,9 @@ int l2i_conv2d_wgrad_dual(const void* x, const void* dy, float* dw, int dtype, i
                           int sc_ldw, float* sc_dbias, float* dw_b, float* sc_dw_b, int overwrite, void* stream);
 /* Tuning hook: co-resident workgroups a weight-gradient launch is sized for (0 = derive from the tile: default). */
 int l2i_set_wgrad_blocks(int n);
-/* Debug aid: co-resident workgroups per CU for conv instantiation `which` with lds_bytes of dynamic LDS. */
+/* Debug aid: co-resident workgroups per CU for conv instantiation `which` with lds_bytes of dynamic LDS;
+ * which = 100: the K-split count of the last halo-kernel launch (> 1: stored partial tiles + the reduce kernel that carries the
+ * epilogue, < -1: combined by atomics, +-1: not split). */
 int l2i_debug_occupancy(int which, int lds_bytes);
 
 

@@ -73,6 +73,7 @@ struct ConvArgs {
     ScArgs sc;           // folded 1x1 shortcut (see ScArgs); sc.x == null: none
     float* scratch;      // optional caller-owned f32 scratch (l2i_conv2d_fwd_dual): partial tiles of the weight-stationary small-map kernel
     long long scratch_floats;
+    float* part;         // split-K with STORED partial tiles (conv_store_partial -> conv_split_reduce_kernel, which carries the epilogue); null: atomics
 };
 
 typedef const ScArgs __attribute__((address_space(4)))* ScArgsPtr;
@@ -157,6 +158,24 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvArgs& p, f32x16_t
                 atomicAdd(p.out + rowoff + n, v);
             }
         }
+}
+
+// Split-K by STORES: a workgroup's partial tile goes to the caller's scratch in REGISTER order -- float4 index
+// ((((tile * splits + split) * NW + wave) * TM + i) * TN + j) * 4 + g) * 64 + lane = acc[i][j][4g .. 4g + 3] -- every store
+// instruction a contiguous 1 KB, no transposition, no atomics (plain stores run at 4.5x the rate of f32 atomics on this chip,
+// DESIGN 4.1b); conv_split_reduce_kernel sums the splits in the same order and applies the WHOLE epilogue (alpha, biases, ReLU
+// mask, residual, 2x2 pool, operand copies, statistics, live-row count), so a split launch is no longer restricted to plain f32
+// results. Tiles of dead images (ROI heads) store nothing: the reduce kernel does not read them either.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_store_partial(const ConvArgs& p, f32x16_t (&acc)[TM][TN], int tile, int split, int nw, int wave, int lane) {
+    float4* t = reinterpret_cast<float4*>(p.part) + ((size_t)(tile * p.splits + split) * nw + wave) * (TM * TN * 4 * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                t[((i * TN + j) * 4 + g) * 64] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
 }
 
 template <typename T, int TM, int TN, bool SC = false>
@@ -1046,11 +1065,12 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void 
 #undef H2_READS
     if constexpr (SC) {
         const ScArgsPtr sc = late_sc();
-        if (sc->x && !tile_dead)
+        if (sc->x && !tile_dead && split == p.splits - 1)   // (a split launch: the shortcut's K-steps belong to the last split)
             conv_sc_tail<BM, BN, TM, TN, THREADS>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, wcol, tile_r, tile_c, n0, rows_total, second);
     }
     L2I_TR(2);
-    if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
+    if (p.splits > 1 && p.part) { if (!tile_dead) conv_store_partial<TM, TN>(p, acc, bid, split, NW, wave, lane); }
+    else if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
     else if (p.epi_lds) conv_epilogue_lds<T, TM, TN, (SC && TN == 1) ? 4 : 8, SC>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);   // (the folding 128x64 tile: 4 stages in flight keep it under its 168-VGPR cap without scratch)
     else conv_epilogue<T, TM, TN, SC>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
     L2I_TR(3);
@@ -1365,13 +1385,96 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_halo3_kernel(ConvA
 #undef H3_RD
     if constexpr (SC) {
         const ScArgsPtr sc = late_sc();
-        if (sc->x && !tile_dead) conv_sc_tail<256, BN, TM, TN, 256>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, 0, tile_r, tile_c, n0, rows_total, second);
+        if (sc->x && !tile_dead && split == p.splits - 1) conv_sc_tail<256, BN, TM, TN, 256>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, 0, tile_r, tile_c, n0, rows_total, second);
     }
     L2I_TR(2);
-    if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
+    if (p.splits > 1 && p.part) { if (!tile_dead) conv_store_partial<TM, TN>(p, acc, bid, split, NW, wave, lane); }
+    else if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
     else if (p.epi_lds) conv_epilogue_lds<T, TM, TN, 4, SC>(p, acc, wrow, 0, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);   // (4: the 256 x 64 tile runs three workgroups per CU on 168 VGPRs)
     else conv_epilogue<T, TM, TN, SC>(p, acc, wrow, 0, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
     L2I_TR(3);
+}
+
+// ---------------------------------------------------------------- split-K reduce that carries the epilogue
+// One workgroup per output tile, the SAME wave / lane -> element mapping as the kernel that stored the partial tiles
+// (conv_store_partial), so the sum of the splits lands in the accumulator layout and conv_epilogue_lds / conv_epilogue run
+// unchanged on it: alpha, both biases, ReLU mask, residual, 2x2 pool, operand copies, batch statistics, live-row count.
+// ConvArgs must be the FIRST kernel argument (late_sc() reads the shortcut's bias from the kernel-argument segment).
+template <int BM, int BN, int WM, int WN, bool SC>
+__global__ __launch_bounds__(WM* WN * 64) void conv_split_reduce_kernel(ConvArgs p, int nsplit) {
+    typedef bf16_t T;
+    constexpr int NW = WM * WN, TM = BM / (WM * 32), TN = BN / (WN * 32);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int bid = (p.nimg && !p.roi_remap) ? (int)blockIdx.x : xcd_remap(blockIdx.x, nblk);   // (the producers' block -> tile map: same XCD)
+    const int tile_m = fastdiv(bid, p.mg_tn), tile_n = bid - tile_m * p.tiles_n;
+    const int tile_r = fastdiv(tile_m, p.mg_tc), tile_c = tile_m - tile_r * p.tiles_c;
+    const int n0 = tile_n * BN;
+    const int rows_total = p.B * p.Ho;
+    const bool second = p.half_rows > 0 && tile_r * p.PH >= p.half_rows;
+    const int rows_live = p.nimg ? min(p.half_rows > 0 ? p.half_rows : rows_total, *p.nimg * p.Ho) + (second ? p.half_rows : 0) : rows_total;
+    const bool tile_dead = tile_r * p.PH >= rows_live;
+    const int wrow = (wave / WN) * (BM / WM), wcol = (wave % WN) * (BN / WN);
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (!tile_dead) {
+        const float4* src = reinterpret_cast<const float4*>(p.part) + ((size_t)bid * nsplit * NW + wave) * (TM * TN * 4 * 64) + lane;
+        for (int s_ = 0; s_ < nsplit; ++s_) {
+            float4 v[TM * TN * 4];
+#pragma unroll
+            for (int q = 0; q < TM * TN * 4; ++q) v[q] = src[q * 64];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 w_ = v[(i * TN + j) * 4 + g];
+                        acc[i][j][4 * g] += w_.x; acc[i][j][4 * g + 1] += w_.y; acc[i][j][4 * g + 2] += w_.z; acc[i][j][4 * g + 3] += w_.w;
+                    }
+            src += (size_t)NW * (TM * TN * 4 * 64);
+        }
+    }
+    if (p.epi_lds) conv_epilogue_lds<T, TM, TN, 8, SC>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
+    else conv_epilogue<T, TM, TN, SC>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, 0, rows_total, rows_live);
+}
+
+// Split planning for the stored-partials path: a launch whose tiles fill less than 3/4 of the resident workgroup slots
+// (`per_cu` workgroups x 256 CUs) is split along K so that tiles x splits is at most ONE full round, each split keeping at least
+// two 64-channel chunks (18 K-steps); the partial tiles must fit the caller's scratch. Returns 1 when the launch stays whole.
+static int g_last_splits = 1;   // debug aid (l2i_debug_occupancy(100, 0)): splits of the last halo launch, negative when combined by atomics
+static int g_part_mode = -1;   // L2I_CONV_PART: 0 off (atomics where the old rule splits), 1 on (default)
+static int plan_part_splits(const ConvArgs& a, int nblk, int nchunks, int per_cu, long long tile_floats) {
+    if (g_part_mode < 0) g_part_mode = getenv("L2I_CONV_PART") ? atoi(getenv("L2I_CONV_PART")) : 1;
+    if (!g_part_mode || !a.scratch || nchunks < 4) return 1;
+    if (!a.out && !a.out_op && !a.out_op_raw) return 1;
+    const int slots = per_cu * 256;
+    if (4 * nblk > 3 * slots) return 1;
+    int splits = slots / nblk;
+    if (splits > nchunks / 2) splits = nchunks / 2;
+    while (splits > 1 && (long long)nblk * splits * tile_floats > a.scratch_floats) --splits;
+    return splits < 1 ? 1 : splits;
+}
+
+template <int BM, int BN, int WM, int WN, bool SC>
+static int launch_split_reduce(const ConvArgs& a, int nblk, size_t lds, hipStream_t stream) {
+    ConvArgs r = a;
+    const int nsplit = a.splits;
+    r.splits = 1;
+    static bool ready = false;
+    if (!ready) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)conv_split_reduce_kernel<BM, BN, WM, WN, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ready = true;
+    }
+    L2I_LAUNCH(0, (conv_split_reduce_kernel<BM, BN, WM, WN, SC>), dim3(nblk), dim3(WM * WN * 64), lds, stream, r, nsplit);
+    return l2i_check_launch();
 }
 
 static int ilog2(int v) {
@@ -1488,7 +1591,12 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     a.mg_subh = fastdiv_magic(a.SUBH); a.mg_p = fastdiv_magic(a.P);
     const int nblk = a.tiles_m * a.tiles_n;
     int splits = 1;
-    if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 192 && nchunks >= 4) {
+    a.part = nullptr;
+    // stored partial tiles + a reduce kernel that carries the epilogue (any epilogue option, folded shortcut included) ...
+    const int psplits = ABL ? 1 : plan_part_splits(a, nblk, nchunks, (BM == 128 && BN == 64) ? 3 : 2, (long long)BM * BN);
+    if (psplits > 1) { splits = psplits; a.part = a.scratch; }
+    // ... else the round-1 rule: atomics into a zeroed plain f32 result
+    else if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 192 && nchunks >= 4) {
         splits = (g_split_target + nblk - 1) / nblk;
         if (splits > nchunks / 2) splits = nchunks / 2;   // >= 18 K-steps per split
         if (splits < 1) splits = 1;
@@ -1496,12 +1604,14 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     const int cper = (nchunks + splits - 1) / splits;
     a.ks_per = 9 * cper;
     a.splits = (nchunks + cper - 1) / cper;
-    if (a.sc.x && (!CAN_SC || a.splits > 1 || a.sc.Ci % 64 || g_no_sc_fold)) {
+    if (a.splits == 1) a.part = nullptr;
+    if (a.sc.x && (!CAN_SC || (a.splits > 1 && !a.part) || a.sc.Ci % 64 || g_no_sc_fold)) {
         const int rc = sc_unfold<bf16_t>(a, stream);
         if (rc != L2I_OK) return rc;
     }
+    g_last_splits = a.part ? a.splits : -a.splits;
     sc_plan(a, lds, BM, BN);
-    if (a.splits > 1) {
+    if (a.splits > 1 && !a.part) {
         const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
         if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     }
@@ -1515,10 +1625,12 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     if constexpr (CAN_SC) {
         if (a.sc.x) {
             L2I_LAUNCH(0, (conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL, true>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+            if (a.part) return launch_split_reduce<BM, BN, WM, WN, true>(a, nblk, epi, stream);
             return l2i_check_launch();
         }
     }
     L2I_LAUNCH(0, (conv_halo2_kernel<BM, BN, WM, WN, NSB, PIPE, H1, ABL>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+    if (a.part) return launch_split_reduce<BM, BN, WM, WN, false>(a, nblk, epi, stream);
     return l2i_check_launch();
 }
 
@@ -1552,22 +1664,28 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     a.mg_subh = fastdiv_magic(a.SUBH); a.mg_p = fastdiv_magic(a.P);
     const int nblk = a.tiles_m * a.tiles_n;
     int splits = 1;
-    if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 256 && nchunks >= 4) {   // fill the 512 workgroup slots (two per CU); more than 8
+    a.part = nullptr;
+    const int psplits = ABL ? 1 : plan_part_splits(a, nblk, nchunks, BN == 64 ? 3 : 2, 256LL * BN);   // (see launch_halo2)
+    if (psplits > 1) { splits = psplits; a.part = a.scratch; }
+    else if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 256 && nchunks >= 4) {   // fill the 512 workgroup slots (two per CU); more than 8
         splits = (g_split_target + nblk / 2) / nblk;                           // splits lose to their atomics (tools/perf/conv_small.py)
         if (splits > nchunks / 2) splits = nchunks / 2;   // >= 18 K-steps per split
         if (splits > 8) splits = 8;
         if (splits < 1) splits = 1;
     }
-    if (force_splits > 0 && a.out && !a.out_op && !a.out_op_raw && !a.stat_ws) splits = force_splits < nchunks ? force_splits : nchunks;
+    if (force_splits > 0 && (a.part || (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws))) splits = force_splits < nchunks ? force_splits : nchunks;
     const int cper = (nchunks + splits - 1) / splits;
     a.ks_per = 9 * cper;
     a.splits = (nchunks + cper - 1) / cper;
-    if (a.sc.x && (!CAN_SC || a.splits > 1 || a.sc.Ci % 64 || g_no_sc_fold)) {
+    if (a.splits == 1 || (long long)nblk * a.splits * 256 * BN > a.scratch_floats) a.part = nullptr;
+    if (!a.part && a.splits > 1 && !(a.out && !a.out_op && !a.out_op_raw && !a.stat_ws)) { a.splits = 1; a.ks_per = 9 * nchunks; }
+    if (a.sc.x && (!CAN_SC || (a.splits > 1 && !a.part) || a.sc.Ci % 64 || g_no_sc_fold)) {
         const int rc = sc_unfold<bf16_t>(a, stream);
         if (rc != L2I_OK) return rc;
     }
+    g_last_splits = a.part ? a.splits : -a.splits;
     sc_plan(a, lds, 256, BN);
-    if (a.splits > 1) {
+    if (a.splits > 1 && !a.part) {
         const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
         if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     }
@@ -1581,10 +1699,12 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     if constexpr (CAN_SC) {
         if (a.sc.x) {
             L2I_LAUNCH(0, (conv_halo3_kernel<BN, ABL, PF, true>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
+            if (a.part) return launch_split_reduce<256, BN, 4, 1, true>(a, nblk, epi, stream);
             return l2i_check_launch();
         }
     }
     L2I_LAUNCH(0, (conv_halo3_kernel<BN, ABL, PF>), dim3(nblk * a.splits), dim3(256), lds, stream, a);
+    if (a.part) return launch_split_reduce<256, BN, 4, 1, false>(a, nblk, epi, stream);
     return l2i_check_launch();
 }
 
@@ -2024,7 +2144,7 @@ extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bi
     a.epi_lds = epi_mode == 2 || (epi_mode == 1 && (relu_mask != nullptr || out_op != nullptr || out_op_raw != nullptr));
     a.nimg = nimg;
     a.w_b = w_b; a.half_rows = w_b ? (B / 2) * Ho : 0;
-    a.scratch = scratch; a.scratch_floats = scratch ? scratch_floats : 0;
+    a.scratch = scratch; a.scratch_floats = scratch ? scratch_floats : 0; a.part = nullptr;
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out; a.out_op = out_op; a.out_op_raw = out_op_raw; a.relu_mask = relu_mask;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.relu_op = relu_op ? 1 : 0;
@@ -2055,6 +2175,7 @@ extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bi
 extern "C" int l2i_debug_occupancy(int which, int lds_bytes) {
     int n = -1;
     hipError_t e = hipSuccess;
+    if (which == 100) return g_last_splits;   // splits of the last halo-kernel launch: > 1 stored partial tiles + reduce, < -1 atomics
     switch (which) {
         case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_igemm_kernel<bf16_t, 128, 128, 2, 2, 2, 0>, 256, lds_bytes); break;
         case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_halo2_kernel<128, 128, 2, 2, 2, false>, 256, lds_bytes); break;

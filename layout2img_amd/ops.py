@@ -219,8 +219,10 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
             nbytes += (sc["x_op"].numel() + sc["wpack"].numel() * (2 if wpack_b is not None else 1)) * esz
         end = TIMER.time("conv_igemm", live * fl, live * nbytes)
     st = _zeros((2, 1, co), dev) if (stats and out is not None and co <= 1024) else None
-    scr, nscr = _lib.wgrad_scratch(dev) if (kh == 3 and Ho == 4 and Wo == 4 and x_op.dtype == torch.bfloat16) else (None, 0)
-    if scr is not None and sc is None:   # 4x4 maps: the weight-stationary kernel needs the stream's scratch (l2i_conv2d_fwd_dual)
+    # the stream's scratch (caller-owned, shared with the weight-gradient launches of the same stream): partial tiles of the
+    # 4x4 weight-stationary kernel and of every split-K launch of the halo kernels (conv_store_partial + reduce with epilogue)
+    scr, nscr = _lib.wgrad_scratch(dev) if (kh == 3 and x_op.dtype == torch.bfloat16) else (None, 0)
+    if scr is not None and sc is None:
         _lib.call("l2i_conv2d_fwd_dual", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
                   _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
                   float(alpha), _p(nimg), _p(st), _ws(dev) if st is not None else None, None, None, None, None, 0, 0, 0, 0, 0,
@@ -242,7 +244,7 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
                   _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
                   float(alpha), _p(nimg), _p(st), _ws(dev) if st is not None else None,
                   sx.data_ptr(), sc["wpack"].data_ptr(), _p(sc["bias"]), sc["out"].data_ptr(), sx.shape[1], sx.shape[2], sx.shape[3],
-                  int(sc["up2"]), sc["kpad"], _p(wpack_b), _p(sc.get("wpack_b")), None, 0, _stream())
+                  int(sc["up2"]), sc["kpad"], _p(wpack_b), _p(sc.get("wpack_b")), scr, nscr, _stream())
     if st is not None:
         out._l2i_stats = (st[0], st[1], out._version)
     if end is not None:

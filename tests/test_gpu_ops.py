@@ -1024,3 +1024,77 @@ def test_roi_rows_are_compacted_in_reference_order():
     # large (w or h >= 64 px): (img0: 0.9x0.9), (img0: 0.5 wide = 64 px), (img1: 0.6 tall); small: img0 #0, img1 #1
     assert y.tolist()[:5] == [4, 5, 6, 3, 7] and valid.tolist() == [1, 1, 1, 1, 1, 0, 0, 0] and int(count) == 5
     assert rois[:5, 0].tolist() == [0.0, 0.0, 1.0, 0.0, 1.0]
+
+
+# (B, H, W, Ci, Co, up2, pool2, sc_Ci | None, sc_up2, live | None): under-filled grids with a long reduction
+SPLIT_CASES = [(2, 16, 16, 256, 72, False, False, None, False, None), (3, 8, 8, 512, 264, False, True, 128, False, 2),
+               (2, 16, 16, 320, 128, False, False, 64, True, None), (4, 4, 4, 256, 128, True, False, None, False, None),
+               (2, 8, 8, 1024, 136, False, False, None, False, None), (3, 16, 16, 256, 64, False, True, 128, False, None),
+               (5, 8, 8, 384, 192, False, False, None, False, 3), (1, 32, 32, 256, 64, False, False, None, False, None)]
+
+
+@pytest.mark.parametrize("cfg", [-1, 14, 15, 17, 18, 19, 29])
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv_split_k_stored_partials_carry_the_whole_epilogue(case, cfg, epi):
+    """Split-K by stores (conv_store_partial -> conv_split_reduce_kernel): a launch whose tiles fill less than 3/4 of the resident
+    workgroup slots is split along K, the partial tiles go to the stream's scratch in register order and the reduce kernel applies
+    the WHOLE epilogue -- alpha, both biases, ReLU mask, residual, 2x2 pool / upsampling, operand copies, batch statistics,
+    live-row count, folded 1x1 shortcut (its K-steps ride on the last split) -- on every halo tile shape, both epilogue forms;
+    against the torch f32 convolution (the layers of reference model/resnet_generator_app_v2.py:411-412 res1 / res2 and
+    model/rcnn_discriminator_app.py:93-94 block5 / block6 in miniature)."""
+    from layout2img_amd import ops, _lib
+    B, H, W, Ci, Co, up2, pool2, sCi, sup, live = case
+    if cfg in (17, 18, 19, 29) and Ci % 64:
+        pytest.skip("the 256-pixel tiles need Ci % 64 == 0")
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    w = _rt(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9), dt)
+    bias = torch.randn(Co, generator=g)
+    ref = _ref_conv(x, w, bias, up2, pool2)
+    dev = _dev()
+    co_p = (Co + 7) // 8 * 8
+    pad = lambda b: torch.nn.functional.pad(b, (0, co_p - Co)).to(dev)
+    pack, kpad = _pack(w, 64)
+    kw = {}
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    if sCi is not None:
+        hs, ws_ = (Ho // 2, Wo // 2) if sup else (Ho, Wo)
+        xs = _rt(torch.randn(B, hs, ws_, sCi, generator=g), dt)
+        wsc = _rt(torch.randn(Co, sCi, 1, 1, generator=g) / math.sqrt(sCi), dt)
+        bias_sc = torch.randn(Co, generator=g)
+        ref = ref + _ref_conv(xs, wsc, bias_sc, sup, pool2)
+        pack_sc, kpad_sc = _pack(wsc, 64)
+        placeholder = torch.full(ref.shape[:3] + (co_p,), float("nan"), device=dev)
+        kw["sc"] = dict(x_op=xs.to(dev, dt), wpack=pack_sc.to(dev, dt), kpad=kpad_sc, bias=pad(bias_sc), up2=sup, out=placeholder, flops=0.0)
+    else:
+        mask = _rt(torch.randn(ref.shape, generator=g), dt)
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref * (mask > 0).float() + res
+        padc = lambda t: torch.nn.functional.pad(t, (0, co_p - Co)).contiguous()
+        kw["relu_mask"], kw["res"] = padc(mask).to(dev, dt), padc(res).to(dev)
+    nimg = None
+    if live is not None:
+        nimg = torch.tensor([live], dtype=torch.int32, device=dev)
+        ref[live:] = 0
+    _lib.call("l2i_set_conv_config", cfg)
+    try:
+        out, op, raw = ops.conv_raw(x.to(dev, dt), pack.to(dev, dt), kpad, co_p, 3, bias=pad(bias), up2=up2, pool2=pool2,
+                                    alpha=0.25 if pool2 else 1.0, nimg=nimg, want_op=True, relu_op=True, want_raw=True, stats=live is None, **kw)
+        splits = _lib.load().l2i_debug_occupancy(100, 0)
+    finally:
+        _lib.call("l2i_set_conv_config", -1)
+    if cfg >= 10:   # a forced halo tile on these shapes is under-filled with >= 4 chunks: it must have taken the stored-partials path
+        assert splits > 1, splits
+    tol = 3e-5 * float(ref.abs().max())
+    o = out.cpu()[..., :Co]
+    assert float((o - ref).abs().max()) < tol
+    assert float((raw.float().cpu() - _rt(out.cpu(), dt)).abs().max()) == 0.0
+    assert float((op.float().cpu() - _rt(out.cpu().clamp_min(0), dt)).abs().max()) == 0.0
+    if sCi is not None and cfg >= 10 and sCi % 64 == 0 and cfg not in (17, 18):   # (17 / 18: the tiles without a folding twin)
+        assert bool(torch.isnan(kw["sc"]["out"]).all())   # folded on the last split: the placeholder is never written
+    if live is None:
+        s1, s2, _ = out._l2i_stats
+        od = out.double().cpu().view(-1, co_p)
+        assert float((s1.cpu().double().view(-1) - od.sum(0)).abs().max()) < 1e-5 * float(od.abs().sum(0).max()) + 1e-4
+        assert float((s2.cpu().double().view(-1) - (od * od).sum(0)).abs().max()) < 1e-5 * float((od * od).sum(0).max()) + 1e-4
