@@ -479,6 +479,19 @@ def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, 
 
 
 # ----------------------------------------------------------------------------- fused conv Function
+def _atomics_split(B, Ho, Wo, n_out, kh, k_in, op_dtype):
+    """True when the library may run this launch as split-K combined by f32 ATOMICS into a plain f32 result (small grids with a
+    long reduction on the generic kernel): such a launch cannot write operand copies or gather statistics in its epilogue. The
+    halo kernels (bf16, 3x3, >= 64 input channels, maps >= 8 wide) split by STORED partial tiles instead, and their reduce kernel
+    carries the whole epilogue (csrc conv_split_reduce_kernel): no restriction there."""
+    if ((B * Ho * Wo + 127) // 128) * ((n_out + 127) // 128) >= 192:
+        return False
+    return not (kh == 3 and op_dtype == torch.bfloat16 and k_in >= 64 and Wo >= 8 and STORED_SPLITS)   # (4-wide maps: the weight-stationary kernel)
+
+
+STORED_SPLITS = __import__("os").environ.get("L2I_CONV_PART", "1") != "0"   # (the library's switch of the same name)
+
+
 class GradJoin:
     """Joins the two gradient branches of a residual block's input inside the data-gradient launch: the shortcut
     branch (whose backward runs first: autograd orders ready nodes by creation, latest first) GIVES its dx, the conv1
@@ -570,7 +583,7 @@ class FusedConvFn(Function):
         # `emit`: operand copies of the RESULT written by this launch's epilogue for the layers that read it next
         # ("relu": ReLU'd copy for a pre-activation conv, "raw": plain copy for a shortcut conv) -- they ride on the
         # result tensor (`_sibling`) and replace separate cast launches over the f32 stream.
-        if emit and ((B * Ho * Wo + 127) // 128) * ((holder.co_p + 127) // 128) < 192:
+        if emit and _atomics_split(B, Ho, Wo, holder.co_p, holder.kh, holder.ci_p, opd):
             emit = ()   # small grids run split-K (partial sums combined by atomics): no epilogue copies there
         # `lazy_sc`: this is a residual block's 1x1 shortcut and its ONLY reader is the `res` input of the block's second 3x3
         # fused_conv: nothing is launched here; the operands ride on an unwritten placeholder of the result's shape and the
@@ -677,7 +690,7 @@ class FusedConvFn(Function):
             # data gradient: same kernel on the flipped pack; upsample <-> pool swap roles
             relu_mask = x_op if pro.kind in ("relu", "op") else None
             Bq, Hq, Wq = dy.shape[0], dy.shape[1] << int(ctx.pool2), dy.shape[2] << int(ctx.pool2)
-            small = ((Bq * Hq * Wq + 127) // 128) * ((h.ci_p + 127) // 128) < 192   # split-K grid: no epilogue copies
+            small = _atomics_split(Bq, Hq, Wq, h.ci_p, h.kh, h.co_p, opd)   # split-K grid combined by atomics: no epilogue copies
             op_in = pro.kind in ("op", "opraw")   # the input edge is an operand tensor: its gradient is the operand copy alone
             emit_raw = op_in or (ctx.dx_raw and pro.kind != "norm" and not small)   # (the norm backward rewrites dxo: its copy would be stale)
             joined = ctx.join[0].take() if ctx.join is not None and ctx.join[1] == "take" and need_x else None
@@ -762,7 +775,7 @@ def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None,
     if relu_op_out:
         B, H, W, _ = x.shape
         Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
-        if res is not None or pool2 or ((B * Ho * Wo + 127) // 128) * ((holder.co_p + 127) // 128) < 192 or not OP_EDGES:
+        if res is not None or pool2 or _atomics_split(B, Ho, Wo, holder.co_p, holder.kh, holder.ci_p, pc.arena.op_dtype) or not OP_EDGES:
             relu_op_out, emit = False, tuple(emit) + ("relu",)
     out = FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg, tuple(emit), dx_raw, join,
                             relu_op_out, bool(lazy_sc) and SC_FOLD, join_in, join_out, join_src)

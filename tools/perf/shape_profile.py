@@ -64,12 +64,13 @@ def join(path, trace, out=None):
     calls, steps, live = meta["calls"], meta["steps"], meta["live"]
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    conv = [r for r in rows if r["Kernel_Name"].startswith(("void conv_", "conv_")) and "conv_wstat_reduce" not in r["Kernel_Name"]]
-    # (the small-map kernel's reduce launch follows its main kernel: its time is added to it)
+    is_red = lambda r: "conv_wstat_reduce" in r["Kernel_Name"] or "conv_split_reduce" in r["Kernel_Name"]
+    conv = [r for r in rows if r["Kernel_Name"].startswith(("void conv_", "conv_")) and not is_red(r)]
+    # (the reduce launch of the small-map kernel / of a split-K launch follows its main kernel: its time is added to it)
     red = {}
     allc = [r for r in rows if r["Kernel_Name"].startswith(("void conv_", "conv_"))]
     for a_, b_ in zip(allc, allc[1:]):
-        if "conv_wstat_reduce" in b_["Kernel_Name"]:
+        if is_red(b_):
             red[id(a_)] = int(b_["End_Timestamp"]) - int(b_["Start_Timestamp"])
     # a hand-over call is ONE kernel when the shortcut was folded, TWO (generic 1x1, then the 3x3) when the library un-folded it
     def pair(i, k):
@@ -92,7 +93,7 @@ def join(path, trace, out=None):
     agg = collections.OrderedDict()
     k = 0
     for i, c in enumerate(calls):
-        r = conv[k]
+        r = r0 = conv[k]
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) + red.get(id(r), 0)) / 1e3
         k += 1
         sc_ci = 0
@@ -100,12 +101,12 @@ def join(path, trace, out=None):
             sc_ci = abs(c[13])
             if c[0] == "fwd" and "conv_igemm" in r["Kernel_Name"] and k < len(conv) and "conv_halo" in conv[k]["Kernel_Name"]:
                 r = conv[k]   # un-folded: the 1x1 launch, then the 3x3 -- both belong to this call
-                us += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                us += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) + red.get(id(r), 0)) / 1e3
                 k += 1
                 sc_ci = -sc_ci
             c = c[:13]
         kind, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu, limited = c
-        kern = r["Kernel_Name"].split("(")[0].replace("void ", "") + (f" +sc{sc_ci}" if sc_ci else "")
+        kern = r["Kernel_Name"].split("(")[0].replace("void ", "") + (f" +sc{sc_ci}" if sc_ci else "") + (" +split-reduce" if ((id(r0) in red or id(r) in red) and "halo" in r["Kernel_Name"]) else "")
         d = agg.setdefault((tuple(c), kern), [0, 0.0])
         d[0] += 1
         d[1] += us
@@ -116,7 +117,7 @@ def join(path, trace, out=None):
         ci = 3 if Ci == 8 and Hi >= 64 and kind == "fwd" and Co == 64 else Ci   # (the image is padded 3 -> 8 channels)
         fl = 2.0 * B * Ho * Wo * Co * ci * KH * KH * (live if limited else 1.0)
         if "+sc" in kern:
-            fl += 2.0 * B * Ho * Wo * Co * abs(int(kern.split("+sc")[1])) * (live if limited else 1.0)
+            fl += 2.0 * B * Ho * Wo * Co * abs(int(kern.split("+sc")[1].split()[0])) * (live if limited else 1.0)
         tot[kind][0] += fl * n / steps
         tot[kind][1] += us / steps
         lines.append((us / steps, n // steps, fl * n / us / 1e6, c, kern))
