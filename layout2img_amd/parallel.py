@@ -23,6 +23,47 @@ import torch.distributed as dist
 FORCE = os.environ.get("L2I_FORCE_COLLECTIVES", "0") == "1"
 
 
+class CommStats:
+    """Accounting of one iteration's collectives for bench.py's N > 1 line (`comm`): how many were issued, how many bytes the
+    flat-gradient all-reduces carried, and -- HIP events on the issuing stream around every blocking collective and around every
+    wait for an asynchronous one -- for how long that stream was held up by them (`exposed_ms`: communication that did NOT
+    overlap compute; read after a device synchronisation). Off unless bench.py switches it on for one eager iteration."""
+    on = False
+    collectives = 0
+    allreduce_bytes = 0
+    _pairs = []
+
+    @classmethod
+    def start(cls):
+        cls.on, cls.collectives, cls.allreduce_bytes, cls._pairs = True, 0, 0, []
+
+    @classmethod
+    def bracket(cls):
+        """context manager: events on the current stream around a call that makes it wait for a communicator stream"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _b():
+            if not cls.on or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+                yield
+                return
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            yield
+            b.record()
+            cls._pairs.append((a, b))
+        return _b()
+
+    @classmethod
+    def stop(cls):
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        ms = sum(a.elapsed_time(b) for a, b in cls._pairs)
+        cls.on = False
+        out = dict(collectives_per_step=cls.collectives, allreduce_bytes_per_step=cls.allreduce_bytes, comm_exposed_ms=round(ms, 3))
+        cls._pairs = []
+        return out
+
+
 def active():
     """True when the iteration must issue its collectives: more than one rank, or the forced one-rank group."""
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
@@ -79,10 +120,23 @@ def allreduce_flat_(flat_grad, chunk_bytes=64 << 20, async_op=False, group=None)
     step = max(1, chunk_bytes // flat_grad.element_size())
     works = []
     for s in range(0, n, step):
-        w = dist.all_reduce(flat_grad[s:min(n, s + step)], op=dist.ReduceOp.SUM, async_op=async_op, group=group)
+        if CommStats.on:
+            CommStats.collectives += 1
+            CommStats.allreduce_bytes += (min(n, s + step) - s) * flat_grad.element_size()
         if async_op:
-            works.append(w)
+            works.append(dist.all_reduce(flat_grad[s:min(n, s + step)], op=dist.ReduceOp.SUM, async_op=True, group=group))
+        else:
+            with CommStats.bracket():
+                dist.all_reduce(flat_grad[s:min(n, s + step)], op=dist.ReduceOp.SUM, group=group)
     return works
+
+
+def wait_all(works):
+    """The current stream waits for asynchronous collectives (their exposed time is accounted when CommStats is on)."""
+    if works:
+        with CommStats.bracket():
+            for w in works:
+                w.wait()
 
 
 def sync_bn_stats(a, b, count):
@@ -96,12 +150,16 @@ def sync_bn_stats(a, b, count):
     adjacent = (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.device == b.device and
                 a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and
                 b.storage_offset() == a.storage_offset() + a.numel())
+    if CommStats.on:
+        CommStats.collectives += 1
     if adjacent:   # the usual case: both halves of one statistics buffer -> reduce it in place, no staging copies
         both = a.new_empty(0).set_(a.untyped_storage(), a.storage_offset(), (a.numel() + b.numel(),), (1,))
-        dist.all_reduce(both, op=dist.ReduceOp.SUM)
+        with CommStats.bracket():
+            dist.all_reduce(both, op=dist.ReduceOp.SUM)
     else:
         buf = torch.cat((a.reshape(-1), b.reshape(-1)))
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        with CommStats.bracket():
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         a.copy_(buf[:a.numel()].view_as(a))
         b.copy_(buf[a.numel():].view_as(b))
     return None if count is None else count * ws
@@ -110,7 +168,10 @@ def sync_bn_stats(a, b, count):
 def global_count(local_count_tensor):
     """All-reduce a 1-element f32 device tensor holding a row count (stays on the device)."""
     if active():
-        dist.all_reduce(local_count_tensor, op=dist.ReduceOp.SUM)
+        if CommStats.on:
+            CommStats.collectives += 1
+        with CommStats.bracket():
+            dist.all_reduce(local_count_tensor, op=dist.ReduceOp.SUM)
     return local_count_tensor
 
 
