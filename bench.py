@@ -358,6 +358,17 @@ def main():
         trainer.flush()
         torch.cuda.synchronize()
         trainer.overlap = ov
+    comm = None
+    from layout2img_amd import parallel as _par
+    if _par.active():
+        # the collectives of ONE eager iteration (every rank runs it; they are collectives): how many, how many gradient bytes,
+        # and for how long the issuing stream was held up by them (HIP events around every blocking collective / every wait)
+        _par.CommStats.start()
+        trainer.step(real, label, bbox, None, None)
+        trainer.flush()
+        comm = _par.CommStats.stop()
+        comm["measured"] = "one eager iteration behind the timed region; exposed = stream time between HIP events around each blocking collective and each wait for an asynchronous one"
+        comm["grad_groups"] = {"G": netG.arena.grad_groups["n"], "D": netD.arena.grad_groups["n"]} if trainer.g_opt.chunked else None
     if world > 1:
         dist.barrier()
 
@@ -437,7 +448,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": ("HIP graph replay of the whole iteration incl. the draw of z (every timed step)" if graphed else "eager"),
                        "iterations_per_replay": n_multi},
-            "roofline": roof, "env": l2i_env(),
+            "roofline": roof, "env": l2i_env(), "comm": comm,
             "cpu_baseline": cpu, "g_forward": g_fwd, "eager": eager, "f32_mode": f32_mode,
             "g_forward_images_per_sec": None if g_fwd is None else g_fwd["images_per_sec"],
         }

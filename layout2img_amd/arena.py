@@ -351,6 +351,34 @@ class WeightArena:
         self.t_wv = [dev(t, 2) for t in t_wv]
         self.t_pack = [dev(t, 3) for t in t_pack]
         self.t_fin = [dev(t, 1) for t in t_fin]
+        # Layer GROUPS for the data-parallel gradient exchange (flush_grads(on_group=)): the rows of both backward tables are laid out
+        # group-major, a group being a contiguous range of the flat parameter buffer of ~1/NG of the weights; the spectral-norm
+        # backward then runs group by group and every finished range of the flat gradient buffer can be handed to its all-reduce
+        # while the following groups are still being corrected (trainer.FlatAdam).
+        NG = max(1, int(os.environ.get("L2I_GRAD_GROUPS", "4")))
+        by_off = sorted(range(L), key=lambda i: int(tab[i][0]))
+        total_w = sum(rows[i][0].co * rows[i][0].ci * rows[i][0].kh * rows[i][0].kh for i in by_off) or 1
+        group_of, acc_w, starts, prev_h = {}, 0, [0], None
+        for i in by_off:
+            h = rows[i][0]
+            if h is not prev_h:   # (the uses of one weight share its flat slot: they stay in one group)
+                if min(NG - 1, acc_w * NG // total_w) > len(starts) - 1:
+                    starts.append(int(tab[i][0]))
+                acc_w += h.co * h.ci * h.kh * h.kh
+                prev_h = h
+            group_of[i] = len(starts) - 1
+        ng = len(starts)
+        t_dot.sort(key=lambda r: group_of[r[0]])     # (stable: layer order inside a group is kept)
+        t_apply.sort(key=lambda r: group_of[r[0]])
+        def _bounds(t):
+            b = [0] * (ng + 1)
+            for r in t:
+                b[group_of[r[0]] + 1] += 1
+            for k in range(ng):
+                b[k + 1] += b[k]
+            return b
+        self.grad_groups = dict(n=ng, dot=_bounds(t_dot), apply=_bounds(t_apply), lo=starts, hi=starts[1:] + [flat.numel])
+        self.grad_groups["lo"][0] = 0
         self.t_dot, self.n_dot = dev(t_dot, 2)
         self.t_apply, self.n_apply = dev(t_apply, 2)
         self.pending = []
@@ -442,21 +470,33 @@ class WeightArena:
                       self.uv_len, p.norms.data_ptr(), p.packed.data_ptr(), self.dtype_code, 1 if training else 0,
                       1 if r == 0 else 0, _lib.raw_stream())
 
-    def flush_grads(self):
-        """Apply the spectral-norm backward of every pending pass into the flat gradient buffer."""
+    def flush_grads(self, on_group=None):
+        """Apply the spectral-norm backward of every pending pass into the flat gradient buffer.
+        on_group(lo, hi): called after each layer group (self.grad_groups) with the range of the flat gradient buffer that is
+        FINAL from then on -- the data-parallel trainer launches that range's all-reduce there, so that the exchange of group k
+        runs beside the correction of groups k + 1 .. (reference train_context_app_v2.py:108-110: nn.DataParallel reduces the
+        replicas' gradients inside backward). None: one launch pair over all layers."""
         from .ops import WgradSide
         WgradSide.join()   # weight-gradient launches run on side streams (ops.WgradSide)
         self.flat.flush_loose()
         live = [p for p in self.pending if p.dwbar is not None]
         for p in live:
             p.clear_unwritten()
-        for i in range(0, len(live), 2):   # two passes per launch pair (D(real) + D(fake)): W and the gradient buffer are walked once
-            p, q = live[i], (live[i + 1] if i + 1 < len(live) else None)
-            _lib.call("l2i_weights_backward2", self.layers.data_ptr(), self.n_layers, self.t_dot.data_ptr(), self.n_dot,
-                      self.t_apply.data_ptr(), self.n_apply, self.flat.data.data_ptr(), p.dwbar.data_ptr(),
-                      p.pass_uv.data_ptr(), p.norms.data_ptr(), q.dwbar.data_ptr() if q else None,
-                      q.pass_uv.data_ptr() if q else None, q.norms.data_ptr() if q else None, self.flat.grad.data_ptr(),
-                      _lib.workspace(self.device), 1 if (getattr(self.flat, "fresh", False) and i == 0) else 0, _lib.raw_stream())
+        gg = self.grad_groups
+        spans = [(0, self.n_dot, 0, self.n_apply, 0, self.flat.numel)] if on_group is None else \
+            [(gg["dot"][k], gg["dot"][k + 1], gg["apply"][k], gg["apply"][k + 1], gg["lo"][k], gg["hi"][k]) for k in range(gg["n"])]
+        fresh = bool(getattr(self.flat, "fresh", False))
+        for d0, d1, a0, a1, lo, hi in spans:
+            for i in range(0, len(live), 2):   # two passes per launch pair (D(real) + D(fake)): W and the gradient buffer are walked once
+                p, q = live[i], (live[i + 1] if i + 1 < len(live) else None)
+                if d1 > d0 or a1 > a0:
+                    _lib.call("l2i_weights_backward2", self.layers.data_ptr(), self.n_layers, self.t_dot.data_ptr() + 8 * d0, d1 - d0,
+                              self.t_apply.data_ptr() + 8 * a0, a1 - a0, self.flat.data.data_ptr(), p.dwbar.data_ptr(),
+                              p.pass_uv.data_ptr(), p.norms.data_ptr(), q.dwbar.data_ptr() if q else None,
+                              q.pass_uv.data_ptr() if q else None, q.norms.data_ptr() if q else None, self.flat.grad.data_ptr(),
+                              _lib.workspace(self.device), 1 if (fresh and i == 0) else 0, _lib.raw_stream())
+            if on_group is not None:
+                on_group(lo, hi)
         if live:
             self.flat.fresh = False
         self.pending = []

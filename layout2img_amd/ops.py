@@ -1402,10 +1402,14 @@ def l1_loss(a, b, weight=1.0):
     return L1Fn.apply(a, b, weight)
 
 
-def adam_step(flat, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=None):
-    """step_dev: 1-element int32 device tensor with the step count (read on the device; graph-capturable)."""
-    _lib.call("l2i_adam_step", flat.data.data_ptr(), flat.grad.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel, float(lr),
-              float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _p(step_dev), _stream())
+def adam_step(flat, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=None, lo=0, hi=None):
+    """step_dev: 1-element int32 device tensor with the step count (read on the device; graph-capturable).
+    lo, hi: the range of the flat buffer to update (multiples of 4 floats) -- the data-parallel trainer updates a layer group as
+    soon as its gradient all-reduce has landed (trainer.FlatAdam); default: everything."""
+    hi = flat.numel if hi is None else hi
+    assert lo % 4 == 0 and (hi - lo) % 4 == 0 and 0 <= lo < hi <= flat.numel
+    _lib.call("l2i_adam_step", flat.data.data_ptr() + 4 * lo, flat.grad.data_ptr() + 4 * lo, m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo,
+              hi - lo, float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _p(step_dev), _stream())
     flat.touch()   # (the kernel writes the parameters through raw pointers: cached eval-mode packs are stale, arena.WeightArena._stamp)
 
 

@@ -31,21 +31,33 @@ class FlatAdam:
         self.group = None   # process group of the gradient all-reduce (GanTrainer: parallel.grad_group(), its own comm stream)
 
     _works = None
+    # Data parallel: the spectral-norm backward runs in layer groups (arena.grad_groups) and each group's range of the flat
+    # gradient buffer is handed to its all-reduce the moment it is final; the Adam update of a range is launched as soon as ITS
+    # all-reduce has landed. The exchange of group k thus runs beside the correction of groups k + 1 .. and beside the Adam
+    # launches of groups .. k - 1, instead of one 251 MB all-reduce (D) fully exposed between flush and Adam. L2I_GRAD_CHUNKED=0:
+    # one flush, one all-reduce over the whole buffer, one Adam launch (the round-4 form).
+    chunked = os.environ.get("L2I_GRAD_CHUNKED", "1") != "0"
 
     def begin_step(self):
         """First half of step(): spectral-norm backward flush, then the gradient all-reduce LAUNCHED (asynchronously under
         data parallelism: the collective runs on the communicator's stream while this stream goes on)."""
-        self.net.arena.flush_grads()
-        self._works = parallel.allreduce_flat_(self.net.flat.grad, async_op=True, group=self.group)
+        flat = self.net.flat
+        if parallel.active() and self.chunked:
+            self._works = []
+            self.net.arena.flush_grads(on_group=lambda lo, hi: self._works.append(
+                (lo, hi, parallel.allreduce_flat_(flat.grad[lo:hi], async_op=True, group=self.group))))
+        else:
+            self.net.arena.flush_grads()
+            self._works = [(0, flat.numel, parallel.allreduce_flat_(flat.grad, async_op=True, group=self.group))]
 
     def finish_step(self):
-        """Second half: the current stream waits for the all-reduce, then the fused Adam launch."""
-        for w in self._works or ():
-            w.wait()
-        self._works = None
+        """Second half: per range, the current stream waits for the range's all-reduce, then its Adam launch."""
         self.t += 1
         self.t_dev += 1   # (device-side: a captured graph of the iteration replays with the right bias corrections)
-        ops.adam_step(self.net.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t, step_dev=self.t_dev)
+        for lo, hi, works in self._works or [(0, self.net.flat.numel, [])]:
+            parallel.wait_all(works)
+            ops.adam_step(self.net.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t, step_dev=self.t_dev, lo=lo, hi=hi)
+        self._works = None
 
     def step(self):
         self.begin_step()

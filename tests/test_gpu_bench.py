@@ -69,3 +69,17 @@ def test_bench_reruns_itself_eagerly_when_graph_capture_fails():
     assert p.returncode == 0, p.stderr[-3000:]
     d = _line(p.stdout)
     assert d["config"]["launch"] == "eager" and d["value"] > 0 and "re-running eagerly" in p.stderr
+
+
+def test_bench_line_accounts_for_the_collectives_of_a_data_parallel_step():
+    """`comm` (N > 1, or the forced one-rank RCCL group): collectives per iteration, gradient bytes all-reduced (the flat buffers
+    of G and D: 4 bytes x (40 853 873 + 62 696 387) parameters + padding), the stream time they held up, and the layer groups the
+    gradient exchange is chunked into (arena.grad_groups; reference train_context_app_v2.py:108-110, model/sync_batchnorm/batchnorm.py:59-125)."""
+    env = dict(os.environ, L2I_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", "--no-graph",
+                        "--no-cpu-baseline", "--no-g-forward", "--no-f32-mode"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    c = _line(p.stdout)["comm"]
+    assert c["collectives_per_step"] >= 20 and c["comm_exposed_ms"] >= 0.0
+    assert 4 * (40853873 + 62696387) <= c["allreduce_bytes_per_step"] < 4.1 * (40853873 + 62696387)
+    assert c["grad_groups"] == {"G": 4, "D": 4}

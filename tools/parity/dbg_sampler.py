@@ -1,54 +1,60 @@
+"""Debug aid: where does a replayed eval-mode generator graph diverge from the eager forward after load_state_dict?"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import layout2img_amd as L
-from layout2img_amd import _lib, arena as A
-from layout2img_amd.sampling import GraphSampler
+from layout2img_amd.sampling import truncated_normal
 from layout2img_amd.synthetic import make_batch, make_layouts
+from layout2img_amd import _lib
 DEV = "cuda:0"
 torch.manual_seed(3)
 g = L.ResnetGenerator128_context(num_classes=184).finalize(DEV, torch.float32)
-d = L.CombineDiscriminator128_app(num_classes=184).finalize(DEV, torch.float32)
 real, label, bbox, z, z_im = make_batch(4, 128, "coco", seed=9, device=DEV)
 g.train()
 with torch.no_grad():
     for _ in range(3):
         g(z, bbox, z_im, label)
 lab1, box1 = make_layouts(1, "coco", seed=21, device=DEV)
-calls = []
-orig = _lib.call
-def spy(name, *a):
-    calls.append(name)
-    return orig(name, *a)
-A._lib.call = spy
 g.eval()
-s = GraphSampler(g, thres=2.0)
-def check(tag):
-    n0 = calls.count("l2i_weights_prepare")
-    img, zs, zi = s(lab1, box1, return_latents=True)
-    n1 = calls.count("l2i_weights_prepare")
-    img, zs, zi = img.clone(), zs.clone(), zi.clone()
-    with torch.no_grad():
-        ref = g(zs, box1, z_im=zi, y=lab1)
-        ref2 = g(zs, box1, z_im=zi, y=lab1)
-    n2 = calls.count("l2i_weights_prepare")
-    print(tag, "graph-vs-eager", float((img - ref).abs().max()), "eager-vs-eager", float((ref - ref2).abs().max()), "img absmean", float(img.abs().mean()), float(ref.abs().mean()),
-          "prepare calls in sampler", n1 - n0, "in eager", n2 - n1, "stamp", g.arena._eval_stamp, flush=True)
-check("first"); check("second")
+mode = sys.argv[1] if len(sys.argv) > 1 else "cache"
+if mode == "nocache":
+    g.arena.EVAL_CACHE = False
+side = torch.cuda.Stream()
+zs, zi = truncated_normal((1, 8, 128), 2.0, DEV), truncated_normal((1, 128), 2.0, DEV)
+taps = {}
 with torch.no_grad():
-    g.fc.weight_orig.mul_(1.25)
-check("after mul_")
+    g.arena.prepare(training=False)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _lib.workspace(DEV)
+        for _ in range(2):
+            g(zs, box1, z_im=zi, y=lab1)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        img = g(zs, box1, z_im=zi, y=lab1, taps=taps)
+
+def flat_taps(t):
+    return [("w", t["w"]), ("bmask", t["bmask"])] + [(f"stage{i}", s) for i, s in enumerate(t["stages"])] + [(f"res{i}", r) for i, r in enumerate(t["res"])] + [("pre", t["pre_tanh"])]
+
+def check(tag):
+    with torch.no_grad():
+        g.arena.prepare(training=False)
+        graph.replay()
+        torch.cuda.synchronize()
+        gi = img.clone()
+        gt = [(n, t.clone()) for n, t in flat_taps(taps)]
+        et = {}
+        ref = g(zs, box1, z_im=zi, y=lab1, taps=et)
+    msg = [f"{n}:{float((a.float() - b.float()).abs().max()):.2e}/{float(b.float().abs().max()):.2e}" for (n, a), (_, b) in zip(gt, flat_taps(et))]
+    print(tag, "img", float((gi - ref).abs().max()), " ".join(msg), flush=True)
+check("first")
 sd = {k: v.detach().cpu().clone() for k, v in g.state_dict().items()}
+check("after state_dict()")
+for name in ("final.0.running_mean", "res1.b1.batch_norm2d.running_var", "fc.weight_orig", "fc.weight_u", "label_embedding.weight", "alpha1"):
+    t = dict(g.state_dict())[name]
+    t.copy_(sd[name])
+    check("after copy_ of " + name)
 g.load_state_dict(sd)
 check("after identical load_state_dict")
-g.train()
-tr = L.GanTrainer(g, d)
-tr.step(real, label, bbox, z, z_im)
-g.eval()
-check("after a training step")
-check("again")
-sd = {k: v.detach().cpu().clone() for k, v in g.state_dict().items()}
-g.load_state_dict(sd)
-check("after identical load_state_dict 2")
-torch.cuda.synchronize()
-check("again 2")
