@@ -15,15 +15,16 @@ with torch.no_grad():
     for _ in range(3):
         g(z, bbox, z_im, label)
 lab1, box1 = make_layouts(1, "coco", seed=21, device=DEV)
-g.eval()
 mode = sys.argv[1] if len(sys.argv) > 1 else "cache"
+if mode != "train":
+    g.eval()
 if mode == "nocache":
     g.arena.EVAL_CACHE = False
 side = torch.cuda.Stream()
 zs, zi = truncated_normal((1, 8, 128), 2.0, DEV), truncated_normal((1, 128), 2.0, DEV)
 taps = {}
 with torch.no_grad():
-    g.arena.prepare(training=False)
+    g.arena.prepare(training=False) if mode != 'train' else None
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         _lib.workspace(DEV)
@@ -40,7 +41,8 @@ def flat_taps(t):
 
 def check(tag):
     with torch.no_grad():
-        g.arena.prepare(training=False)
+        if mode != 'train':
+            g.arena.prepare(training=False)
         graph.replay()
         torch.cuda.synchronize()
         gi = img.clone()
@@ -50,11 +52,17 @@ def check(tag):
     msg = [f"{n}:{float((a.float() - b.float()).abs().max()):.2e}/{float(b.float().abs().max()):.2e}" for (n, a), (_, b) in zip(gt, flat_taps(et))]
     print(tag, "img", float((gi - ref).abs().max()), " ".join(msg), flush=True)
 check("first")
-sd = {k: v.detach().cpu().clone() for k, v in g.state_dict().items()}
-check("after state_dict()")
-for name in ("final.0.running_mean", "res1.b1.batch_norm2d.running_var", "fc.weight_orig", "fc.weight_u", "label_embedding.weight", "alpha1"):
-    t = dict(g.state_dict())[name]
-    t.copy_(sd[name])
-    check("after copy_ of " + name)
-g.load_state_dict(sd)
-check("after identical load_state_dict")
+check("second (nothing in between)")
+if mode == "train":
+    pass
+junk = [torch.randn(1 << 20) for _ in range(300)]   # 1.2 GB of host allocations
+del junk
+check("after host allocation churn")
+vals = list(g.state_dict().values())
+check("after state_dict() (no copies)")
+small = [v.detach().cpu() for v in vals if v.numel() < 4096]
+check(f"after D2H of {len(small)} small tensors")
+big = [v.detach().cpu() for v in vals if v.numel() >= 4096]
+check(f"after D2H of {len(big)} big tensors")
+x = torch.zeros(1 << 20, device=DEV); y_ = x.cpu()
+check("after one 4 MB D2H")
