@@ -306,7 +306,7 @@ class GanTrainer:
             # waited for in the next, through work handles that would belong to the capture) is an eager-mode overlap. In the
             # graph the generator's all-reduce, its wait and its Adam step stay inside their own iteration.
             self.flush()
-            self.defer_g = False
+            self._defer_g_eager, self.defer_g = self.defer_g, False
         if ops.TIMER is not None:
             raise RuntimeError("capture with the kernel timer on")
         self._static = [None if t is None else t.detach().clone() for t in (real, label, bbox, z, z_im)]
@@ -336,6 +336,7 @@ class GanTrainer:
         for net in (self.netG, self.netD):
             net.arena.free_packs = []
         graph = torch.cuda.CUDAGraph()
+        err = None
         try:
             # (data parallel: RCCL's watchdog thread polls its own events while this thread captures; in the default "global"
             #  capture mode any other thread's event query invalidates the capture -- hipErrorStreamCaptureInvalidated, measured)
@@ -343,12 +344,26 @@ class GanTrainer:
                 self._graph_out = self.step(*self._static)
                 if os.environ.get("L2I_TEST_CAPTURE_FAIL", "0") == "1":   # (tests: an illegal call invalidates the capture)
                     torch.cuda.synchronize()
-        except Exception:
+        except Exception as e:
+            err = e
             self._graph = None
-            torch.cuda.synchronize()
-            raise
+            if not self.dp:
+                torch.cuda.synchronize()
+                raise
         for net in (self.netG, self.netD):
             net.arena.free_packs = []   # buffers from the graph's private pool must not be handed to eager iterations
+        if self.dp:
+            # The decision to replay is COLLECTIVE: a rank that replays while another runs eagerly would issue its collectives
+            # in a different order and dead-lock the job. Every rank contributes "my capture succeeded"; MIN over the ranks.
+            import torch.distributed as dist
+            ok = torch.tensor([0.0 if err is not None else 1.0], device=real.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok) < 1.0:
+                self._graph = None
+                self.defer_g = self._defer_g_eager   # (back to the eager-mode overlap of the generator's all-reduce)
+                if err is not None:
+                    print(f"[layout2img_amd] graph capture failed on this rank ({type(err).__name__}: {str(err)[:160]}); every rank runs eagerly", flush=True)
+                return False
         self._graph = graph
         return True
 
