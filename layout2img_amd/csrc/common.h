@@ -122,6 +122,31 @@ static inline void ws_fold(float* ws, int L, int C, float* d0, float* d1, float*
     hipLaunchKernelGGL(ws_fold_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, a);
 }
 
+// ---------------------------------------------------------------- clearing a buffer from inside the library
+// NOT hipMemsetAsync: a memset node captured into a HIP graph in front of a kernel that accumulates into the same buffer with
+// atomics (split-K results, weight-gradient slices) is not ordered / executed reliably on replay with this runtime -- measured
+// (tools/parity/graph_idempotence.py): the FIRST replay of such a launch is correct (fresh graph-pool memory happens to be zero), every
+// later one adds onto stale or half-cleared contents (relative errors 0.15 ... 1e27). A kernel node is ordered like any other.
+static __global__ __launch_bounds__(256) void l2i_zero_kernel(float4* __restrict__ p4, long long n4, float* __restrict__ tail, int ntail) {
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    for (long long i = i0; i < n4; i += step) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 < ntail) tail[i0] = 0.f;
+}
+static inline hipError_t l2i_zero_async(void* p, size_t bytes, hipStream_t stream) {   // p 4-byte aligned, bytes a multiple of 4
+    if (bytes == 0) return hipSuccess;
+    if (((size_t)p & 3) || (bytes & 3)) return hipErrorInvalidValue;
+    float* f = (float*)p;
+    size_t nf = bytes / 4, head = 0;
+    while (((size_t)(f + head) & 15) && head < nf) ++head;            // floats in front of the first 16-byte boundary
+    if (head) { hipLaunchKernelGGL(l2i_zero_kernel, dim3(1), dim3(256), 0, stream, (float4*)nullptr, 0LL, f, (int)head); }
+    const size_t n4 = (nf - head) / 4, ntail = (nf - head) % 4;
+    long long nblk = (long long)((n4 + 255) / 256);
+    if (nblk > 2048) nblk = 2048;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL(l2i_zero_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, (float4*)(f + head), (long long)n4, f + head + 4 * n4, (int)ntail);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- optional per-launch timing (l2i_timing / l2i_timing_read)
 // bench.py's roofline leg needs the duration of every conv / weight-gradient launch inside a timed iteration. A pair of
 // hipEventRecord calls around a launch also brackets the launch latency (~4 us per launch, 1.2 ms per iteration over the

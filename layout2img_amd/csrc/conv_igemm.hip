@@ -1519,7 +1519,7 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     a.splits = (nks + a.ks_per - 1) / a.ks_per;
     if (a.splits > 1) {
         const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
-        if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+        if (l2i_zero_async(a.out, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     }
     static bool ready = false;
     if (!ready) {
@@ -1613,7 +1613,7 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     sc_plan(a, lds, BM, BN);
     if (a.splits > 1 && !a.part) {
         const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
-        if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+        if (l2i_zero_async(a.out, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     }
     static bool ready = false;
     if (!ready) {
@@ -1687,7 +1687,7 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     sc_plan(a, lds, 256, BN);
     if (a.splits > 1 && !a.part) {
         const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
-        if (hipMemsetAsync(a.out, 0, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+        if (l2i_zero_async(a.out, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     }
     static bool ready = false;
     if (!ready) {

@@ -938,7 +938,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
         float* t[4] = {a.dw, a.dw_b, a.sc_x ? a.sc_dw : nullptr, a.sc_x ? a.sc_dw_b : nullptr};
         const size_t n[4] = {(size_t)a.Co * a.ldw, (size_t)a.Co * a.ldw, (size_t)a.Co * a.sc_ldw, (size_t)a.Co * a.sc_ldw};
         for (int i = 0; i < 4; ++i)
-            if (t[i] && hipMemsetAsync(t[i], 0, sizeof(float) * n[i], stream) != hipSuccess) return L2I_ERR_LAUNCH;
+            if (t[i] && l2i_zero_async(t[i], sizeof(float) * n[i], stream) != hipSuccess) return L2I_ERR_LAUNCH;
         return L2I_OK;
     };
     if (sizeof(T) == 2 && pow2) {  // bf16: LDS-DMA + transposing-read kernel

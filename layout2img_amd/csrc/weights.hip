@@ -520,10 +520,10 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
     if (clear) {  // first round of a pass
         const long long gap = pass_uv - norms;   // adjacent buffers (layout2img_amd/arena.py PassCtx): one memset for both
         if (uv_len > 0 && gap >= 4LL * n_layers && gap <= 4LL * n_layers + 64) {
-            if (hipMemsetAsync(norms, 0, sizeof(float) * (size_t)(gap + uv_len), stream) != hipSuccess) return L2I_ERR_LAUNCH;
+            if (l2i_zero_async(norms, sizeof(float) * (size_t)(gap + uv_len), stream) != hipSuccess) return L2I_ERR_LAUNCH;
         } else {
-            if (hipMemsetAsync(norms, 0, sizeof(float) * 4 * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
-            if (uv_len > 0 && hipMemsetAsync(pass_uv, 0, sizeof(float) * uv_len, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+            if (l2i_zero_async(norms, sizeof(float) * 4 * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+            if (uv_len > 0 && l2i_zero_async(pass_uv, sizeof(float) * uv_len, stream) != hipSuccess) return L2I_ERR_LAUNCH;
         }
     }
     if (training && n_wtu > 0)
@@ -585,7 +585,7 @@ extern "C" int l2i_weights_backward2(const long long* layers, int n_layers, cons
             hipLaunchKernelGGL(sn_apply_kernel<1>, dim3(n_apply), dim3(256), 0, stream, layers, tab_apply, dwbar0, dwbar0, pass_uv0, pass_uv0,
                                norms0, norms0, ws, n_layers, grads, overwrite);
     }
-    if (n_dot > 0 && hipMemsetAsync(ws, 0, sizeof(float) * L2I_WS_R * np * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+    if (n_dot > 0 && l2i_zero_async(ws, sizeof(float) * L2I_WS_R * np * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     return l2i_check_launch();
 }
 

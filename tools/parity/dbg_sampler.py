@@ -39,30 +39,36 @@ with torch.no_grad():
 def flat_taps(t):
     return [("w", t["w"]), ("bmask", t["bmask"])] + [(f"stage{i}", s) for i, s in enumerate(t["stages"])] + [(f"res{i}", r) for i, r in enumerate(t["res"])] + [("pre", t["pre_tanh"])]
 
-def check(tag):
+def replay():
     with torch.no_grad():
         if mode != 'train':
             g.arena.prepare(training=False)
         graph.replay()
         torch.cuda.synchronize()
-        gi = img.clone()
-        gt = [(n, t.clone()) for n, t in flat_taps(taps)]
-        et = {}
-        ref = g(zs, box1, z_im=zi, y=lab1, taps=et)
-    msg = [f"{n}:{float((a.float() - b.float()).abs().max()):.2e}/{float(b.float().abs().max()):.2e}" for (n, a), (_, b) in zip(gt, flat_taps(et))]
-    print(tag, "img", float((gi - ref).abs().max()), " ".join(msg), flush=True)
-check("first")
-check("second (nothing in between)")
-if mode == "train":
-    pass
-junk = [torch.randn(1 << 20) for _ in range(300)]   # 1.2 GB of host allocations
-del junk
-check("after host allocation churn")
-vals = list(g.state_dict().values())
-check("after state_dict() (no copies)")
-small = [v.detach().cpu() for v in vals if v.numel() < 4096]
-check(f"after D2H of {len(small)} small tensors")
-big = [v.detach().cpu() for v in vals if v.numel() >= 4096]
-check(f"after D2H of {len(big)} big tensors")
-x = torch.zeros(1 << 20, device=DEV); y_ = x.cpu()
-check("after one 4 MB D2H")
+        return [(n, t.clone()) for n, t in flat_taps(taps)] + [("img", img.clone())]
+
+def diff(a, b):
+    return " ".join(f"{n}:{float((x.float() - y.float()).abs().max()):.1e}" for (n, x), (_, y) in zip(a, b))
+
+variant = sys.argv[2] if len(sys.argv) > 2 else "eager"
+r1 = replay()
+r2 = replay()
+print(variant, "replay2 vs replay1:", diff(r2, r1), flush=True)
+if variant == "eager":
+    with torch.no_grad():
+        g(zs, box1, z_im=zi, y=lab1)
+elif variant == "eager_taps":
+    with torch.no_grad():
+        g(zs, box1, z_im=zi, y=lab1, taps={})
+elif variant == "eager_b4":
+    with torch.no_grad():
+        g(z, bbox, z_im=z_im, y=label)
+elif variant == "alloc":
+    junk = [torch.randn(16 << 20, device=DEV) for _ in range(10)]
+    del junk
+elif variant == "alloc_small":
+    junk = [torch.full((1 << (8 + (i % 12)),), 1e30, device=DEV) for i in range(400)]
+    del junk
+torch.cuda.synchronize()
+r3 = replay()
+print(variant, "replay3 (after the variant's step) vs replay1:", diff(r3, r1), flush=True)
