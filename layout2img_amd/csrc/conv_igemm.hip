@@ -1395,6 +1395,276 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_halo3_kernel(ConvA
     L2I_TR(3);
 }
 
+// ---------------------------------------------------------------- 256 x 256 tiles, ONE workgroup of 8 waves per CU: conv_halo8_kernel
+// Round 5 experiment: the "one workgroup per CU, eight waves, deep weight pipeline" structure of the GEMM
+// guide on the convolution: tile = 256 pixels (a 16 x 16 patch, or whole images of smaller maps) x 256 output channels, waves
+// as 4 (pixels) x 2 (channels), a wave owns 64 x 128 (TM = 2, TN = 4: the per-wave step of conv_halo3_kernel<128>). Against two
+// 4-wave workgroups of 256 x 128 per CU: the halo of a chunk is staged ONCE per CU instead of twice, DOUBLE-buffered (the next
+// chunk's pieces ride on taps 0..5 of the current one: no refill stall at the chunk boundary, which the single-buffer 256-pixel
+// kernel pays once per 9 K-steps), and the weight tile of a K-step (256 rows x 128 B = 32 KB) streams through a ring whose
+// depth is a template parameter in HALF K-steps (NH half-tiles of 16 KB in flight or being read):
+//   NH = 4: [k 0..31 | k 32..63] of step s being read, both halves of step s + 1 in flight (counted vmcnt: never 0 in the loop)
+// LDS: 2 x 42 KB halo + NH x 16 KB ring + 256 zero bytes = 148.25 KB at NH = 4 -- one workgroup per CU, 256 VGPRs per wave.
+// bf16, 3x3, Ci % 64 == 0, Co % 256 == 0 for full tiles (other Co: rows past Co read zeros through the descriptor).
+template <bool SC = false, bool DEEP = false>   // DEEP: two barriers per K-step, three half-tiles of weights in flight, counted vmcnt (never 0 in the loop)
+__global__ __launch_bounds__(512, 1) void conv_halo8_kernel(ConvArgs p) {
+    typedef bf16_t T;
+    constexpr int NW = 8, TM = 2, TN = 4, BN = 256, SZ = 2;
+    constexpr int HPMAX = 6;                        // 42 halo pieces of 1 KB over 8 waves
+    constexpr unsigned OOB = 0x80000000u, HSTAGE = BN * 64u;   // a half K-step of the weight tile: 256 rows x 64 bytes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int bid = (p.nimg && !p.roi_remap) ? (int)blockIdx.x : xcd_remap(blockIdx.x, nblk);
+    const int tile_m = fastdiv(bid, p.mg_tn), tile_n = bid - tile_m * p.tiles_n;
+    const int tile_r = fastdiv(tile_m, p.mg_tc), tile_c = tile_m - tile_r * p.tiles_c;
+    const int n0 = tile_n * BN;
+    const int rows_total = p.B * p.Ho;
+    const int rows_live = p.nimg ? min(rows_total, *p.nimg * p.Ho) : rows_total;
+    const bool tile_dead = tile_r * p.PH >= rows_live;
+    const u32x4_t rsrc_x = make_rsrc(p.x, p.x_bytes), rsrc_w = make_rsrc(p.w, p.w_bytes);
+    const unsigned smem_addr = lds_addr_of(smem);
+    const unsigned halo_bytes = (unsigned)p.halo_pieces * 1024u;
+    const unsigned ring_off = 2u * halo_bytes, zero_off = ring_off + 4u * HSTAGE;   // [halo x 2][ring: 4 half-tiles][256 zero bytes]
+    const int border = p.compact ? 0 : 1;
+    const int Hh = (p.up2 ? p.PHs >> 1 : p.PHs), Wh = (p.up2 ? p.PW >> 1 : p.PW);
+
+    if (tid < 16) *reinterpret_cast<uint4*>(smem + zero_off + tid * 16) = make_uint4(0, 0, 0, 0);
+
+    // ---- halo pieces of this wave (as conv_halo3_kernel, eight waves)
+    unsigned hoff[HPMAX];
+#pragma unroll
+    for (int q = 0; q < HPMAX; ++q) {
+        const int piece = wv + NW * q;
+        const int h = piece * 8 + (lane >> 3), pch = lane & 7;
+        const int sp = fastdiv(h, p.mg_subh), rem = h - sp * p.SUBH;
+        const int hy = fastdiv(rem, p.mg_p), hx = rem - hy * p.P;
+        const int hyp = hy + 1 - border, hxp = hx + 1 - border;
+        const int gr0 = tile_r * p.PH + sp * p.PHs;
+        const int b = fastdiv(gr0, p.mg_ho), y0 = gr0 - b * p.Ho, x0 = tile_c * p.PW;
+        const int iy = (y0 >> p.up2) + hyp - 1, ix = (x0 >> p.up2) + hxp - 1;
+        const bool ok = h < p.HR && hx < p.HWd && gr0 < rows_total && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const int lch = pch ^ (((hxp >> 1) + 4 * hyp + 2 * sp) & 7);
+        hoff[q] = ok ? (unsigned)(((b * p.Hi + iy) * p.Wi + ix) * p.Ci + lch * 8) * SZ : OOB;
+    }
+    const int nq = (p.halo_pieces - wv + NW - 1) / NW;
+    // ---- weight rows of a HALF K-step: 256 rows x 64 bytes = 4 chunks of 16 bytes per row; 512 threads x 16 bytes = 128 rows per
+    // pass, two passes. Row r's chunk c is stored at chunk (c ^ ((r >> 2) & 3)) (64-byte rows: four rows per 256-byte bank row).
+    const int lrow = tid >> 2;
+    const int lchunk = (tid & 3) ^ ((lrow >> 2) & 3);
+    unsigned b_off[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) b_off[q] = (unsigned)((n0 + lrow + 128 * q) * p.Kpad + lchunk * 8) * SZ;   // (+ 64 bytes for the second half of a K-step)
+    const unsigned ring_w = smem_addr + ring_off + (unsigned)wv * 1024u;   // this wave's 16 rows x 64 bytes of a pass
+    const unsigned halo_w = smem_addr + (unsigned)wv * 1024u;
+
+    // ---- fragment addresses
+    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 128;
+    const int hh = lane >> 5;
+    unsigned a_addr[TM][9];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int py, px;
+        idx2pix(wrow + i * 32 + (lane & 31), p.hw_shift, 0, py, px);
+        const int sp = py >> p.sub_shift, pyl = py & (p.PHs - 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            int hyp, hxp;
+            if (p.up2) { hyp = ((pyl + ky - 1) >> 1) + 1; hxp = ((px + kx - 1) >> 1) + 1; }
+            else { hyp = pyl + ky; hxp = px + kx; }
+            const unsigned sl = (unsigned)((hh ^ (((hxp >> 1) + 4 * hyp + 2 * sp) & 7)) << 4);
+            const bool inside = hyp >= 1 && hyp <= Hh && hxp >= 1 && hxp <= Wh;
+            if (border || inside) a_addr[i][tap] = (unsigned)((sp * p.SUBH + (hyp - 1 + border) * p.P + (hxp - 1 + border)) * 128) + sl;
+            else a_addr[i][tap] = zero_off + (unsigned)(((hxp - 1) & 1) * 128) + sl;
+        }
+    }
+    // B fragment of k16 sub-step kk (0..3): half = kk >> 1, within the half's 64-byte rows chunk (kk & 1) * 2 + hh, swizzled
+    unsigned b_addr[2];
+    {
+        const int row = wcol + (lane & 31);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) b_addr[k2] = ring_off + (unsigned)(row * 64 + (((k2 * 2 + hh) ^ ((row >> 2) & 3)) << 4));
+    }
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nchunks = tile_dead ? 0 : (p.Ci >> 6);
+    const int ci2 = p.Ci * SZ;
+    bf16x8_t fa[2][TM], fb[2][TN];
+
+    // half-tile h of K-step (tap, cb) -> ring slot SLOT (0..3): two passes of 128 rows
+#define H8_W(TAPX, CBX, HALF, SLOT)                                                                                    \
+    {                                                                                                                  \
+        const unsigned kadd_ = (unsigned)((TAPX) * ci2 + (CBX) * SZ + (HALF) * 64);                                    \
+        H2_DMA(rsrc_w, b_off[0], kadd_, ring_w + (unsigned)(SLOT) * HSTAGE);                                            \
+        H2_DMA(rsrc_w, b_off[1], kadd_, ring_w + (unsigned)(SLOT) * HSTAGE + 8192u);                                    \
+    }
+#define H8_RD(KK, TAP, SLOT0)                                                                                          \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                              \
+            fa[(KK)&1][i_] = *reinterpret_cast<const bf16x8_t*>(smem + (a_addr[i_][TAP] ^ (unsigned)((KK) << 5)));     \
+        _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                                              \
+            fb[(KK)&1][j_] = *reinterpret_cast<const bf16x8_t*>(smem + b_addr[(KK)&1] + (unsigned)((SLOT0) + ((KK) >> 1)) * HSTAGE + j_ * 2048u); \
+    }
+#define H8_MM(KK)                                                                                                      \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)            \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                     \
+                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fb[(KK)&1][j_]),                        \
+                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[(KK)&1][i_]), acc[i_][j_], 0, 0, 0); \
+    }
+    // One K-step S (0..17 over a pair of chunks): tap = S % 9, halo buffer = S / 9, ring slots 2 (S & 1), 2 (S & 1) + 1.
+    // Top of the step: this step's two half-tiles (issued one step ago) have landed for every wave [vmcnt + barrier]; the
+    // barrier also says every wave has finished reading the other two slots (step S - 1), so the next step's halves go there.
+#define H8_STEP(S, cb_cur, cb_nxt)                                                                                     \
+    {                                                                                                                  \
+        constexpr int TAP = (S) % 9, HB = (S) / 9, SL = 2 * ((S)&1), TAP2 = (TAP + 1) % 9;                             \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) asm volatile("" : "+v"(a_addr[i_][TAP])); }              \
+        H8_RD(0, TAP, SL) H8_RD(1, TAP, SL)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H8_MM(0)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H8_W(TAP2, (TAP == 8 ? (cb_nxt) : (cb_cur)), 0, 2 - SL)                                                        \
+        H8_RD(2, TAP, SL)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H8_MM(1)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H8_W(TAP2, (TAP == 8 ? (cb_nxt) : (cb_cur)), 1, 3 - SL)                                                        \
+        if (TAP < HPMAX && TAP < nq) {   /* one piece of the NEXT chunk's halo into the other buffer */                \
+            H2_DMA(rsrc_x, hoff[TAP], (unsigned)((cb_nxt)*SZ), halo_w + (unsigned)(1 - HB) * halo_bytes + (unsigned)(NW * TAP) * 1024u); \
+        }                                                                                                              \
+        H8_RD(3, TAP, SL)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H8_MM(2)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H8_MM(3)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
+    // DEEP. Half-tiles are numbered h = 2 S + {0, 1} and live in ring slot h & 3; half h + 3 is issued the moment half h - 1 has been
+    // read by every wave (the barrier of half-phase h), i.e. THREE half-tiles are in flight while one is read -- 1.5 K-steps of
+    // latency cover instead of one -- and a wave never waits for more than it needs: in-order completion lets `s_waitcnt vmcnt(N)`
+    // with N = the DMAs issued AFTER the half about to be read (two per later half-tile, one per halo piece: all compile-time).
+    //   phase A (half 2S):     wait N_A = 4 + [tap(S-2) < 6] + [tap(S-1) < 6]; barrier; issue half 2S + 3; sub-steps 0, 1
+    //   phase B (half 2S + 1): wait N_B = 4 + [tap(S-1) < 6];                  barrier; issue half 2S + 4 + this tap's halo piece; sub-steps 2, 3
+#define H8D_STEP(S, cb_cur, cb_nxt)                                                                                    \
+    {                                                                                                                  \
+        constexpr int TAP = (S) % 9, HB = (S) / 9, SL = 2 * ((S)&1), TAP1 = (TAP + 1) % 9, TAP2 = (TAP + 2) % 9;       \
+        constexpr int HP1 = ((TAP + 8) % 9) < HPMAX ? 1 : 0, HP2 = ((TAP + 7) % 9) < HPMAX ? 1 : 0;                    \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + HP1 + HP2) : "memory");                                           \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        H8_W(TAP1, (TAP == 8 ? (cb_nxt) : (cb_cur)), 1, 3 - SL)                                                        \
+        { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) asm volatile("" : "+v"(a_addr[i_][TAP])); }              \
+        H8_RD(0, TAP, SL) H8_RD(1, TAP, SL)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H8_MM(0)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H8_MM(1)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + HP1) : "memory");                                                 \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        H8_W(TAP2, (TAP >= 7 ? (cb_nxt) : (cb_cur)), 0, SL)                                                            \
+        if (TAP < HPMAX) {   /* one piece of the NEXT chunk's halo (a wave with fewer pieces re-loads its first one: the count stays static) */ \
+            const bool own_ = TAP < nq;                                                                                \
+            H2_DMA(rsrc_x, own_ ? hoff[TAP] : hoff[0], (unsigned)((cb_nxt)*SZ),                                        \
+                   halo_w + (unsigned)(1 - HB) * halo_bytes + (unsigned)(NW * (own_ ? TAP : 0)) * 1024u);              \
+        }                                                                                                              \
+        H8_RD(2, TAP, SL) H8_RD(3, TAP, SL)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H8_MM(2)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        H8_MM(3)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
+    if (DEEP && nchunks > 0) {
+        {   // prologue: the first halo, then half-tiles 0, 1, 2 (tap 0 both halves, tap 1 first half)
+#pragma unroll
+            for (int q = 0; q < HPMAX; ++q)
+                if (q < nq) H2_DMA(rsrc_x, hoff[q], 0u, halo_w + (unsigned)(NW * q) * 1024u);
+            H8_W(0, 0, 0, 0)
+            H8_W(0, 0, 1, 1)
+            H8_W(1, 0, 0, 2)
+        }
+        const int last_cb = (nchunks - 1) * 64;
+        for (int c = 0; c < nchunks; c += 2) {
+            const int cbA = c * 64;
+            const int cbB = min(cbA + 64, last_cb), cbC = min(cbA + 128, last_cb);
+            H8D_STEP(0, cbA, cbB) H8D_STEP(1, cbA, cbB) H8D_STEP(2, cbA, cbB) H8D_STEP(3, cbA, cbB) H8D_STEP(4, cbA, cbB)
+            H8D_STEP(5, cbA, cbB) H8D_STEP(6, cbA, cbB) H8D_STEP(7, cbA, cbB) H8D_STEP(8, cbA, cbB)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+                    if (a_addr[i][tap] < zero_off) a_addr[i][tap] += halo_bytes;
+            if (c + 1 < nchunks) {
+                H8D_STEP(9, cbB, cbC) H8D_STEP(10, cbB, cbC) H8D_STEP(11, cbB, cbC) H8D_STEP(12, cbB, cbC) H8D_STEP(13, cbB, cbC)
+                H8D_STEP(14, cbB, cbC) H8D_STEP(15, cbB, cbC) H8D_STEP(16, cbB, cbC) H8D_STEP(17, cbB, cbC)
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+                    if (a_addr[i][tap] < zero_off) a_addr[i][tap] -= halo_bytes;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef H8D_STEP
+    if (!DEEP && nchunks > 0) {
+        {   // prologue: the first halo, the two half-tiles of tap 0
+#pragma unroll
+            for (int q = 0; q < HPMAX; ++q)
+                if (q < nq) H2_DMA(rsrc_x, hoff[q], 0u, halo_w + (unsigned)(NW * q) * 1024u);
+            H8_W(0, 0, 0, 0)
+            H8_W(0, 0, 1, 1)
+        }
+        const int last_cb = (nchunks - 1) * 64;
+        for (int c = 0; c < nchunks; c += 2) {
+            const int cbA = c * 64;
+            const int cbB = min(cbA + 64, last_cb), cbC = min(cbA + 128, last_cb);
+            H8_STEP(0, cbA, cbB) H8_STEP(1, cbA, cbB) H8_STEP(2, cbA, cbB) H8_STEP(3, cbA, cbB) H8_STEP(4, cbA, cbB)
+            H8_STEP(5, cbA, cbB) H8_STEP(6, cbA, cbB) H8_STEP(7, cbA, cbB) H8_STEP(8, cbA, cbB)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+                    if (a_addr[i][tap] < zero_off) a_addr[i][tap] += halo_bytes;
+            if (c + 1 < nchunks) {
+                H8_STEP(9, cbB, cbC) H8_STEP(10, cbB, cbC) H8_STEP(11, cbB, cbC) H8_STEP(12, cbB, cbC) H8_STEP(13, cbB, cbC)
+                H8_STEP(14, cbB, cbC) H8_STEP(15, cbB, cbC) H8_STEP(16, cbB, cbC) H8_STEP(17, cbB, cbC)
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+                    if (a_addr[i][tap] < zero_off) a_addr[i][tap] -= halo_bytes;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef H8_STEP
+#undef H8_MM
+#undef H8_RD
+#undef H8_W
+    if constexpr (SC) {
+        const ScArgsPtr sc = late_sc();
+        if (sc->x && !tile_dead) conv_sc_tail<256, BN, TM, TN, 512>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, wcol, tile_r, tile_c, n0, rows_total, false);
+    }
+    if (p.epi_lds) conv_epilogue_lds<T, TM, TN, 4, SC>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
+    else conv_epilogue<T, TM, TN, SC>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, 0, rows_total, rows_live);
+}
+
 // ---------------------------------------------------------------- split-K reduce that carries the epilogue
 // One workgroup per output tile, the SAME wave / lane -> element mapping as the kernel that stored the partial tiles
 // (conv_store_partial), so the sum of the splits lands in the accumulator layout and conv_epilogue_lds / conv_epilogue run
@@ -1708,6 +1978,59 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     return l2i_check_launch();
 }
 
+// conv_halo8_kernel launch (round-5 experiment; tuning configuration 40 / 41 only). Returns -100 when the shape is not covered.
+template <bool CAN_SC = false, bool DEEP = false>
+static int launch_halo8(ConvArgs a, hipStream_t stream) {
+    if (a.Ci % 64 || a.Wo < 4 || (a.up2 && a.Wo < 8) || a.half_rows) return -100;
+    a.PH = 256 / a.PW;
+    a.PHs = a.PH < a.Ho ? a.PH : a.Ho;
+    a.sub_shift = ilog2(a.PHs);
+    const int nsp = a.PH / a.PHs;
+    const int Wh = a.up2 ? a.PW / 2 : a.PW, Hh = a.up2 ? a.PHs / 2 : a.PHs;
+    a.compact = (a.PW == a.Wo && a.PHs == a.Ho) ? 1 : 0;
+    if (a.compact) { a.HWd = Wh; a.P = Wh; a.SUBH = Hh * Wh; }
+    else { a.HWd = Wh + 2; a.P = (a.HWd + 1) & ~1; a.SUBH = (Hh + 2) * a.P; }
+    if ((a.P & 1) || (a.SUBH & 1)) return -100;
+    a.HR = nsp * a.SUBH;
+    a.halo_pieces = (a.HR + 7) / 8;
+    if (a.halo_pieces > 48 || a.halo_pieces < 8) return -100;
+    size_t lds = (size_t)2 * a.halo_pieces * 1024 + (size_t)4 * 256 * 64 + 256;
+    constexpr size_t epi = (size_t)8 * 32 * (128 + 4) * 4;
+    if (lds < epi) lds = epi;
+    a.nks = 9 * (a.Ci / 64);
+    const int rows = a.B * a.Ho;
+    a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
+    a.tiles_n = (a.Co + 255) / 256;
+    a.mg_tn = fastdiv_magic(a.tiles_n); a.mg_tc = fastdiv_magic(a.tiles_c); a.mg_ho = fastdiv_magic(a.Ho);
+    a.mg_subh = fastdiv_magic(a.SUBH); a.mg_p = fastdiv_magic(a.P);
+    const int nblk = a.tiles_m * a.tiles_n;
+    a.splits = 1; a.ks_per = a.nks; a.part = nullptr;
+    g_last_splits = -1;
+    if (a.sc.x && (!CAN_SC || a.sc.Ci % 64 || g_no_sc_fold)) {
+        const int rc = sc_unfold<bf16_t>(a, stream);
+        if (rc != L2I_OK) return rc;
+    }
+    if (a.sc.x) {
+        const size_t stg = (size_t)(256 + 256) * 128;
+        if (lds < stg) lds = stg;
+        a.sc.stages = lds >= 2 * stg ? 2 : 1;
+    }
+    static bool ready = false;
+    if (!ready) {
+        (void)hipFuncSetAttribute((const void*)conv_halo8_kernel<false, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (CAN_SC) (void)hipFuncSetAttribute((const void*)conv_halo8_kernel<true, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        ready = true;
+    }
+    if constexpr (CAN_SC) {
+        if (a.sc.x) {
+            L2I_LAUNCH(0, (conv_halo8_kernel<true, DEEP>), dim3(nblk), dim3(512), lds, stream, a);
+            return l2i_check_launch();
+        }
+    }
+    L2I_LAUNCH(0, (conv_halo8_kernel<false, DEEP>), dim3(nblk), dim3(512), lds, stream, a);
+    return l2i_check_launch();
+}
+
 // ---------------------------------------------------------------- 4x4 maps: weight-stationary split-K (conv_wstat_kernel)
 // 3x3 convolutions on 4x4 maps (D block6, reference model/rcnn_discriminator_app.py:94-96: 1024 -> 1024 on 32 x 16 = 512 pixels)
 // are all weights: 18.9 MB of pack for 9.7 GFLOP. The generic kernel streams every weight tile through a 2-stage ring per
@@ -2008,6 +2331,8 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
             case 8: rc = launch_halo3<64>(a, stream); break;     // 256 x 64 tiles
             case 9: rc = launch_halo3<128, 0, true, true>(a, stream); break;   // the same with the barrier moved inside the K-step (PF)
             case 19: rc = launch_halo3<64, 0, true, true>(a, stream); break;
+            case 30: rc = launch_halo8<true, false>(a, stream); break;   // 256 x 256 tiles, eight waves, one workgroup per CU (round-5 experiment)
+            case 31: rc = launch_halo8<true, true>(a, stream); break;    // ... with three half-tiles of weights in flight and counted vmcnt
 #ifdef L2I_ABLATIONS
             case 41: rc = launch_halo3<128, 1>(a, stream); break;
             case 42: rc = launch_halo3<128, 2>(a, stream); break;

@@ -151,7 +151,7 @@ def test_conv_split_k(case, dt):
     assert float((out.cpu() - expect).abs().max()) < 3e-5 * float(expect.abs().max()) + 1e-5
 
 
-@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 29])
+@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 29, 40, 41])   # (40 / 41: conv_halo8_kernel, the 256 x 256 eight-wave tile)
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 72, 3, False, False), (1, 32, 32, 128, 136, 3, False, True),
                                   (2, 16, 16, 64, 64, 3, True, False), (9, 16, 16, 192, 128, 3, False, False),
                                   (5, 8, 8, 64, 264, 3, False, True), (1, 64, 64, 64, 8, 3, True, False),
@@ -189,7 +189,7 @@ SC_CASES = [(2, 16, 16, 64, 72, 128, False, False, None), (1, 32, 32, 128, 136, 
             (1, 64, 64, 64, 64, 128, False, True, None), (2, 16, 16, 64, 64, 72, False, False, None)]
 
 
-@pytest.mark.parametrize("cfg", [-1, 14, 15, 19, 29])
+@pytest.mark.parametrize("cfg", [-1, 14, 15, 19, 29, 40, 41])
 @pytest.mark.parametrize("case", SC_CASES)
 def test_conv_folded_shortcut(case, cfg, epi):
     """l2i_conv2d_fwd_sc: conv3x3(h) + conv1x1(x at (y >> up, x >> up)) + both biases (+ 2x2 pool of the sum) in ONE launch
@@ -230,7 +230,7 @@ def test_conv_folded_shortcut(case, cfg, epi):
     tol = 3e-5 * float(ref.abs().max())
     assert float((out.cpu()[..., :Co] - ref).abs().max()) < tol
     assert float((op.float().cpu()[..., :Co] - torch.relu(ref)).abs().max()) < 1e-2 * float(ref.abs().max())
-    if cfg >= 10:   # a forced halo tile with sc_Ci % 64 == 0 must FOLD: the placeholder is never written
+    if 10 <= cfg < 40:   # a forced halo tile with sc_Ci % 64 == 0 must FOLD: the placeholder is never written
         assert bool(torch.isnan(placeholder).all()) == (sCi % 64 == 0)
     if live is None:
         s1, s2, _ = out._l2i_stats
@@ -1098,3 +1098,46 @@ def test_conv_split_k_stored_partials_carry_the_whole_epilogue(case, cfg, epi):
         od = out.double().cpu().view(-1, co_p)
         assert float((s1.cpu().double().view(-1) - od.sum(0)).abs().max()) < 1e-5 * float(od.abs().sum(0).max()) + 1e-4
         assert float((s2.cpu().double().view(-1) - (od * od).sum(0)).abs().max()) < 1e-5 * float((od * od).sum(0).max()) + 1e-4
+
+
+@pytest.mark.parametrize("cfg", [40, 41])
+@pytest.mark.parametrize("case", [(4, 32, 32, 128, 264, False, False, None), (6, 16, 16, 192, 256, False, True, 128), (20, 8, 8, 256, 512, False, False, None),
+                                  (12, 4, 4, 256, 256, True, False, None), (3, 32, 32, 64, 512, True, True, 64), (2, 64, 64, 64, 136, False, False, None)])
+def test_conv_256x256_eight_wave_tile(case, cfg, epi):
+    """conv_halo8_kernel (round-5 experiment: one workgroup of eight waves per CU, 256 pixels x 256 channels, double-buffered halo,
+    weights in half-K-step tiles; cfg 41: three half-tiles in flight with counted vmcnt, two barriers per K-step) on bordered and
+    compact halos, upsampling, pool, ragged channel counts, odd chunk counts and with a folded shortcut -- against torch f32."""
+    from layout2img_amd import ops, _lib
+    B, H, W, Ci, Co, up2, pool2, sCi = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(77)
+    x = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    w = _rt(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9), dt)
+    bias = torch.randn(Co, generator=g)
+    ref = _ref_conv(x, w, bias, up2, pool2)
+    dev = _dev()
+    pack, kpad = _pack(w, 64)
+    kw = {}
+    if sCi is not None:
+        Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+        xs = _rt(torch.randn(B, Ho, Wo, sCi, generator=g), dt)
+        wsc = _rt(torch.randn(Co, sCi, 1, 1, generator=g) / math.sqrt(sCi), dt)
+        bias_sc = torch.randn(Co, generator=g)
+        ref = ref + _ref_conv(xs, wsc, bias_sc, False, pool2)
+        pack_sc, kpad_sc = _pack(wsc, 64)
+        kw["sc"] = dict(x_op=xs.to(dev, dt), wpack=pack_sc.to(dev, dt), kpad=kpad_sc, bias=bias_sc.to(dev), up2=False,
+                        out=torch.full(ref.shape, float("nan"), device=dev), flops=0.0)
+    else:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res
+        kw["res"] = res.to(dev)
+    _lib.call("l2i_set_conv_config", cfg)
+    try:
+        out, op, _ = ops.conv_raw(x.to(dev, dt), pack.to(dev, dt), kpad, Co, 3, bias=bias.to(dev), up2=up2, pool2=pool2,
+                                  alpha=0.25 if pool2 else 1.0, want_op=True, relu_op=True, **kw)
+    finally:
+        _lib.call("l2i_set_conv_config", -1)
+    assert float((out.cpu() - ref).abs().max()) < 3e-5 * float(ref.abs().max())
+    assert float((op.float().cpu() - _rt(out.cpu().clamp_min(0), dt)).abs().max()) == 0.0
+    if sCi is not None:
+        assert bool(torch.isnan(kw["sc"]["out"]).all())   # folded
