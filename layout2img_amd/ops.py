@@ -1410,7 +1410,9 @@ def adam_step(flat, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=
     assert lo % 4 == 0 and (hi - lo) % 4 == 0 and 0 <= lo < hi <= flat.numel
     _lib.call("l2i_adam_step", flat.data.data_ptr() + 4 * lo, flat.grad.data_ptr() + 4 * lo, m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo,
               hi - lo, float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _p(step_dev), _stream())
-    flat.touch()   # (the kernel writes the parameters through raw pointers: cached eval-mode packs are stale, arena.WeightArena._stamp)
+    touch = getattr(flat, "touch", None)   # (the kernel writes the parameters through raw pointers: cached eval-mode packs are stale,
+    if touch is not None:                  #  arena.WeightArena._stamp)
+        touch()
 
 
 # ----------------------------------------------------------------------------- layout-side glue (csrc/layout.hip)

@@ -760,7 +760,8 @@ def test_hinge_l1_adam():
         pr.grad = gr.clone()
         opt.step()
         flat.grad.copy_(gr)
-        ops.adam_step(flat, m, v, 1e-4, 0.0, 0.999, 1e-8, t)
+        ops.adam_step(flat, m, v, 1e-4, 0.0, 0.999, 1e-8, t, lo=0, hi=512)   # (two ranges: the data-parallel trainer updates layer groups
+        ops.adam_step(flat, m, v, 1e-4, 0.0, 0.999, 1e-8, t, lo=512)         #  one by one, trainer.FlatAdam)
     assert float((flat.data.cpu() - pr.detach()).abs().max()) < 1e-6
 
 
