@@ -2,7 +2,7 @@
 # usage (GPU box): bash tools/perf/default_profile.sh [tag=r03] -- the EXACT default command of the contract under rocprofv3:
 #   rocprofv3 --kernel-trace --stats -- python bench.py     -> gpurun_out/<tag>_default_kernel_stats.csv + the JSON line of that run
 # and the check that the profiler's average conv-kernel duration agrees with the line's roofline.avg_launch_us (HIP events).
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/dp
@@ -14,9 +14,9 @@ import csv, json
 line = json.loads(open("$R/gpurun_out/${TAG}_default_bench_line.json").read())
 tot = n = tf = nf = 0.0
 for r in csv.DictReader(open("$R/gpurun_out/${TAG}_default_kernel_stats.csv")):
-    if r["Name"].startswith(("conv_wstat_reduce", "void conv_wstat_reduce")):   # second kernel of a 4x4 weight-stationary launch: its time, not a launch
+    if r["Name"].startswith(("conv_wstat_reduce", "void conv_wstat_reduce", "conv_split_reduce", "void conv_split_reduce")):   # second kernel of a 4x4 weight-stationary launch: its time, not a launch
         tot += float(r["TotalDurationNs"])
-    elif r["Name"].startswith(("void conv_halo", "void conv_igemm", "conv_halo", "conv_igemm", "conv_wstat_kernel", "void conv_wstat_kernel")):
+    elif r["Name"].startswith(("void conv_halo", "void conv_igemm", "conv_halo", "conv_igemm", "conv_wstat_kernel", "void conv_wstat_kernel")):   # (a split launch = its halo kernel + conv_split_reduce: one launch)
         if "<float" in r["Name"]:   # the exact-f32 instantiations: only the line's secondary f32_mode / precision_modes legs launch them
             tf += float(r["TotalDurationNs"]); nf += int(r["Calls"])
         else:

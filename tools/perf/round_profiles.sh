@@ -2,7 +2,7 @@
 # usage (GPU box): bash tools/perf/round_profiles.sh [tag=r03]  -> everything the round's DESIGN.md numbers come from, under gpurun_out/<tag>_*
 # (copied into profiles/ afterwards): bench line, rocprofv3 kernel stats of the iteration and of the generator forward, HBM /
 # MFMA counter passes (traffic2.sh), in-situ per-layer table, launch censuses, per-wave traces of representative launches.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 python bench.py > gpurun_out/${TAG}_bench_final.json 2> gpurun_out/${TAG}_bench_final.err

@@ -5,7 +5,7 @@
 # (4) --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE (MFMA utilisation per kernel, in situ)
 # (PMC passes carry --kernel-trace only, as the guide / gpurun require). One stream (L2I_OVERLAP=0): a kernel's
 # duration and counters are those of a kernel that owns the GPU.
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TAG
 cd /tmp && export TMPDIR=/tmp
 export L2I_OVERLAP=0
@@ -44,7 +44,7 @@ def group(pred, is_launch=lambda k: True):   # is_launch: kernels that are the s
     calls = sum(v[0] for k, v in stats.items() if pred(k) and is_launch(k)); ns = sum(v[1] for k, v in stats.items() if pred(k))
     return dict(launches_profiled=n, hbm_read_bytes_per_launch=rd / max(n, 1), hbm_write_bytes_per_launch=wr / max(n, 1),
                 traffic_bytes_per_launch=(rd + wr) / max(n, 1), avg_launch_us=ns / max(calls, 1) / 1e3)
-res = {"conv(fwd+dgrad)": group(lambda k: k.startswith(("conv_halo", "conv_igemm", "conv_wstat")), lambda k: not k.startswith("conv_wstat_reduce")), "wgrad": group(lambda k: k.startswith("conv_wgrad")),
+res = {"conv(fwd+dgrad)": group(lambda k: k.startswith(("conv_halo", "conv_igemm", "conv_wstat")), lambda k: not k.startswith(("conv_wstat_reduce", "conv_split_reduce"))), "wgrad": group(lambda k: k.startswith("conv_wgrad")),
        "_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over python bench.py --steps 4 --warmup 1, L2I_OVERLAP=0; "
                 "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section); WRITE_SIZE uncalibrated; durations from a third pass without counters"}
 json.dump(res, open(R + "/gpurun_out/" + TAG + "_conv_traffic.json", "w"), indent=1)
