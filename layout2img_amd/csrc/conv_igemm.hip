@@ -2297,6 +2297,16 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // (in-situ sweep, profiles/r02_insitu_cfg_sweep.txt: the single-halo 128x128 tile also beats the double-buffered one
         //  on the long reductions now -- 210 vs 270 us on 32x32x512->256 -- so 0 is only a tuning option)
         if (a.Co > 64 && t128h >= 512) hc = 4;
+        // Round 5: with split-K by stored partial tiles (plan_part_splits) an under-filled grid no longer has to buy workgroups with
+        // SMALLER tiles: the 128x128 tile (1.0 fragment read per MFMA against 1.5 on 128x64) split along K so that tiles x splits
+        // fills its 512 slots. L2I_PART_BIG = 0: the round-4 choice (128x64, split only below 3/4 of its 768 slots). Tuning hook.
+        static const int part_big = getenv("L2I_PART_BIG") ? atoi(getenv("L2I_PART_BIG")) : 1;
+        if (part_big && hc == 5 && a.Co > 64 && a.scratch && !a.nimg && !small_map && a.Ci % 64 == 0) {
+            const int nch = a.Ci / 64;
+            long long sp = t128h > 0 ? 512 / t128h : 1;
+            if (sp > nch / 2) sp = nch / 2;
+            if (nch >= 4 && sp >= 2 && t128h * sp >= 384 && t128h * sp * 16384LL <= a.scratch_floats) hc = 4;
+        }
         // (64-wide maps with <= 128 input channels -- 9-18 K-steps per tile -- and the 104 -> 528 PSP bottleneck: 128x64 tiles,
         //  5-10 % in the sweep of profiles/r02b_insitu_cfg_sweep.txt)
         if (hc == 4 && a.Ho == 64 && a.Ci <= 128 && (a.Co <= 128 || a.Ci == 104)) hc = 5;
