@@ -2297,10 +2297,13 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // (in-situ sweep, profiles/r02_insitu_cfg_sweep.txt: the single-halo 128x128 tile also beats the double-buffered one
         //  on the long reductions now -- 210 vs 270 us on 32x32x512->256 -- so 0 is only a tuning option)
         if (a.Co > 64 && t128h >= 512) hc = 4;
-        // Round 5: with split-K by stored partial tiles (plan_part_splits) an under-filled grid no longer has to buy workgroups with
-        // SMALLER tiles: the 128x128 tile (1.0 fragment read per MFMA against 1.5 on 128x64) split along K so that tiles x splits
-        // fills its 512 slots. L2I_PART_BIG = 0: the round-4 choice (128x64, split only below 3/4 of its 768 slots). Tuning hook.
-        static const int part_big = getenv("L2I_PART_BIG") ? atoi(getenv("L2I_PART_BIG")) : 1;
+        // Round 5 experiment, OFF (L2I_PART_BIG=1 turns it on): with split-K by stored partial tiles an under-filled grid could buy its
+        // workgroups with K splits of the 128x128 tile (1.0 fragment read per MFMA against 1.5 on 128x64) instead of smaller tiles.
+        // Measured in situ (profiles/r05_ab_big_tiles.txt): every affected layer got SLOWER -- (32,16,16,512->512) 43 -> 55 us,
+        // (32,16,16,256->512) 26 -> 38, (32,32,32,256->128) 29 -> 41 -- the iteration 19.68 -> 20.03 ms: at 4-8 chunks per tile the
+        // partial-tile round trip + the reduce launch cost more than the better tile returns; splits pay only where the
+        // reduction is long AND the tiles are few (the <= 8-px maps: plan_part_splits' 3/4 rule on the tile the heuristic picked).
+        static const int part_big = getenv("L2I_PART_BIG") ? atoi(getenv("L2I_PART_BIG")) : 0;
         if (part_big && hc == 5 && a.Co > 64 && a.scratch && !a.nimg && !small_map && a.Ci % 64 == 0) {
             const int nch = a.Ci / 64;
             long long sp = t128h > 0 ? 512 / t128h : 1;
