@@ -82,6 +82,21 @@ int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bias, const f
                         int sc_Wi, int sc_Ci, int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, float* scratch,
                         long long scratch_floats, void* stream);
 
+/* Data gradient of the first 3x3 convolution of a pre-activation residual block with the data gradient of the block's 1x1 shortcut
+ * folded into the same launch (round 5; replaces the shortcut's own data-gradient launch and the residual read of its f32 result):
+ *   out = relu_mask > 0 ? alpha * conv3x3(dh, w) : 0   +   sc_alpha * conv1x1(sc_dy at (y >> sc_up2, x >> sc_up2), sc_w)   + res
+ * i.e. dx of  x -> relu -> conv1 -> ...  plus dx of  x -> c_sc -> avg_pool(2)?  (reference model/rcnn_discriminator_app.py:326,336-341;
+ * sc_up2 = 1, sc_alpha = 0.25 for a down-sampling block). dh [B,H,W,Ci] bf16 (gradient of conv1's result), w the flipped
+ * data-gradient pack of conv1 [Npad][Kpad], relu_mask [B,H,W,Co] bf16 (the block input's ReLU operand), sc_dy [B,sc_Hi,sc_Wi,sc_Ci]
+ * bf16 (gradient of the block's result), sc_w the data-gradient pack of the 1x1 weight, res optional f32 (another reader's
+ * gradient), out f32 and / or out_op_raw bf16 [B,H,W,Co]. The ReLU mask belongs to the 3x3 part only: it is applied to the
+ * accumulators before the shortcut's K-steps (conv_mask_first). sc_out (f32, shape of out, contents undefined afterwards): where
+ * the shortcut goes on launches that cannot fold (as l2i_conv2d_fwd_sc) -- same result. scratch: as l2i_conv2d_fwd_dual. bf16 only. */
+int l2i_conv2d_dgrad_sc(const void* dh, const void* w, const float* res, const void* relu_mask, float* out, void* out_op_raw,
+                        int B, int H, int W, int Ci, int Co, int Kpad, float alpha, const int* nimg,
+                        const void* sc_dy, const void* sc_w, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci, int sc_up2, int sc_Kpad,
+                        float sc_alpha, float* scratch, long long scratch_floats, void* stream);
+
 /* Per-launch timing of the two MFMA entry points (bench.py's roofline leg). l2i_timing(1): from now on every kernel
  * launched by l2i_conv2d_fwd (class 0) / l2i_conv2d_wgrad (class 1) carries a start / stop HIP event pair attached to
  * its dispatch (hipExtLaunchKernelGGL: the kernel's own begin / end on the stream it runs on); l2i_timing_read

@@ -34,6 +34,12 @@ struct ScArgs {
     float* out;          // f32, shape of out: where the shortcut goes when it cannot be folded (split-K, generic kernel): it then runs as its own launch and is read back as `res`
     int Ci, Hi, Wi, up2, Kpad, stages;
     unsigned x_bytes, w_bytes;
+    // DATA-GRADIENT fold (l2i_conv2d_dgrad_sc, round 5): the launch is conv1's data gradient of a pre-activation block and the tail is
+    // the data gradient of the block's 1x1 shortcut: dx = relu'(x) . (alpha W1^T * dh) + sc_alpha Wsc^T . dy(y >> up2, x >> up2).
+    // The ReLU mask belongs to the 3x3 part only, so it is applied to the ACCUMULATORS (with the ratio of the two alphas) before
+    // the tail's K-steps (conv_mask_first); the epilogue then scales by sc_alpha and adds bias-free residuals as usual.
+    const void* mask_first;   // T, shape of out; null: the forward fold
+    float pre_scale;          // alpha / sc_alpha
 };
 
 struct ConvArgs {
@@ -746,6 +752,36 @@ __global__ __launch_bounds__(WM* WN * 64, ((160 * 1024) / (NS * (BM + BN) * (HK 
 // the shortcut's input ([BM][64] operand rows, read at (y >> sc_up2, x >> sc_up2): nearest upsampling of the generator
 // blocks) and BN rows of the 1x1 pack in the LDS the halo and the ring no longer need, and multiplies them into the same
 // accumulators. Two stages when the kernel's LDS allocation holds them (p.sc_stages), else one.
+// ReLU mask of the 3x3 part applied in ACCUMULATOR order (see ScArgs::mask_first): lane l holds pixel (l & 31) of each 32-row
+// tile and 4 consecutive channels per register group, so a lane reads 8 bytes of the mask per group -- 32 rows apart per
+// half-wave, i.e. uncoalesced per instruction, but every byte of the tile's mask rows is used across the groups (L2 hits after
+// the first touch), once per workgroup. No pool / upsampling on these launches (conv1 of a discriminator block has neither).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_mask_first(const ConvArgs& p, ScArgsPtr sc, f32x16_t (&acc)[TM][TN], int wrow, int wcol, int lane,
+                                                int tile_r, int tile_c, int n0, int rows_total) {
+    const bf16_t* __restrict__ M = reinterpret_cast<const bf16_t*>(sc->mask_first);
+    const float s = sc->pre_scale;
+    const int m = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int py, px;
+        idx2pix(wrow + i * 32 + m, p.hw_shift, 0, py, px);
+        const int r = tile_r * p.PH + py;
+        const size_t rowoff = ((size_t)r * p.Wo + tile_c * p.PW + px) * p.Co;
+        const bool live = r < rows_total;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wcol + j * 32 + 8 * g + 4 * h;
+                float mk[4] = {0.f, 0.f, 0.f, 0.f};
+                if (live && n < p.Co) Op4<bf16_t>::load(M + rowoff + n, mk);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = mk[e] > 0.f ? acc[i][j][4 * g + e] * s : 0.f;
+            }
+    }
+}
+
 template <int BM, int BN, int TM, int TN, int THREADS = 256>
 __device__ __forceinline__ void conv_sc_tail(const ConvArgs& p, ScArgsPtr sc, f32x16_t (&acc)[TM][TN], char* smem, unsigned smem_addr, int tid, int lane,
                                              int wv, int wrow, int wcol, int tile_r, int tile_c, int n0, int rows_total, bool second) {
@@ -1065,6 +1101,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM == 128 && BN == 64) ? 3 : 2) void 
 #undef H2_READS
     if constexpr (SC) {
         const ScArgsPtr sc = late_sc();
+        if (sc->x && !tile_dead && sc->mask_first) conv_mask_first<TM, TN>(p, sc, acc, wrow, wcol, lane, tile_r, tile_c, n0, rows_total);   // (every split: the mask is linear)
         if (sc->x && !tile_dead && split == p.splits - 1)   // (a split launch: the shortcut's K-steps belong to the last split)
             conv_sc_tail<BM, BN, TM, TN, THREADS>(p, sc, acc, smem, smem_addr, tid, lane, wv, wrow, wcol, tile_r, tile_c, n0, rows_total, second);
     }
@@ -1812,9 +1849,12 @@ template <typename T> static int launch_conv(ConvArgs& a, hipStream_t stream);
 template <typename T>
 static int sc_unfold(ConvArgs& a, hipStream_t stream) {
     if (!a.sc.x) return L2I_OK;
-    if (!a.sc.out || a.res) return L2I_ERR_ARG;
+    const bool mf = a.sc.mask_first != nullptr;   // data-gradient fold: the 1x1 launch carries the caller's residual, the 3x3 launch its own alpha + mask
+    if (!a.sc.out || (a.res && !mf)) return L2I_ERR_ARG;
     ConvArgs s = a;
-    s.x = a.sc.x; s.w = a.sc.w; s.w_b = a.sc.w_b; s.bias = a.sc.bias; s.res = nullptr; s.relu_mask = nullptr;
+    s.x = a.sc.x; s.w = a.sc.w; s.w_b = a.sc.w_b; s.bias = a.sc.bias; s.res = mf ? a.res : nullptr; s.relu_mask = nullptr;
+    if (mf) { a.relu_mask = a.sc.mask_first; a.alpha = a.alpha * a.sc.pre_scale; a.sc.mask_first = nullptr; }   // (a.alpha was the tail's: s keeps it)
+    s.sc.mask_first = nullptr;
     s.out = a.sc.out; s.out_op = nullptr; s.out_op_raw = nullptr; s.stat_ws = nullptr;
     s.Hi = a.sc.Hi; s.Wi = a.sc.Wi; s.Ci = a.sc.Ci; s.KH = 1; s.up2 = a.sc.up2; s.Kpad = a.sc.Kpad; s.relu_op = 0;
     s.sc.x = nullptr; s.sc.w = nullptr; s.sc.w_b = nullptr; s.sc.bias = nullptr; s.sc.out = nullptr;
@@ -1949,7 +1989,7 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     a.splits = (nchunks + cper - 1) / cper;
     if (a.splits == 1 || (long long)nblk * a.splits * 256 * BN > a.scratch_floats) a.part = nullptr;
     if (!a.part && a.splits > 1 && !(a.out && !a.out_op && !a.out_op_raw && !a.stat_ws)) { a.splits = 1; a.ks_per = 9 * nchunks; }
-    if (a.sc.x && (!CAN_SC || (a.splits > 1 && !a.part) || a.sc.Ci % 64 || g_no_sc_fold)) {
+    if (a.sc.x && (!CAN_SC || (a.splits > 1 && !a.part) || a.sc.Ci % 64 || g_no_sc_fold || a.sc.mask_first)) {   // (mask-first folds: 128-pixel tiles only)
         const int rc = sc_unfold<bf16_t>(a, stream);
         if (rc != L2I_OK) return rc;
     }
@@ -2006,7 +2046,7 @@ static int launch_halo8(ConvArgs a, hipStream_t stream) {
     const int nblk = a.tiles_m * a.tiles_n;
     a.splits = 1; a.ks_per = a.nks; a.part = nullptr;
     g_last_splits = -1;
-    if (a.sc.x && (!CAN_SC || a.sc.Ci % 64 || g_no_sc_fold)) {
+    if (a.sc.x && (!CAN_SC || a.sc.Ci % 64 || g_no_sc_fold || a.sc.mask_first)) {
         const int rc = sc_unfold<bf16_t>(a, stream);
         if (rc != L2I_OK) return rc;
     }
@@ -2450,16 +2490,18 @@ extern "C" int l2i_conv2d_fwd_sc(const void* x, const void* w, const float* bias
 // every tensor argument but the weight packs: images [0, B/2) use w (sc_w), images [B/2, B) use w_b (sc_w_b); `nimg` then counts
 // the live leading images of EACH half. B must be even and (B/2) * Ho a multiple of the tile's pixel rows (L2I_ERR_ARG otherwise:
 // the caller then issues the two halves as two launches).
-extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bias, const float* res,
+static int conv2d_impl(const void* x, const void* w, const float* bias, const float* res,
                                    const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
                                    int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
                                    const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
-                                   int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, float* scratch, long long scratch_floats, void* stream) {
+                                   int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, float* scratch, long long scratch_floats, void* stream,
+                                   float sc_alpha, int mask_first) {
     if (!x || !w || (!out && !out_op && !out_op_raw)) return L2I_ERR_ARG;
+    if (mask_first && (!sc_x || !relu_mask || sc_bias || bias || up2 || pool2 || stats || w_b || dtype != 1 || !(sc_alpha > 0.f))) return L2I_ERR_ARG;
     if (w_b && ((B & 1) || stats || (sc_x && !sc_w_b))) return L2I_ERR_ARG;
     if (!w_b && sc_w_b) return L2I_ERR_ARG;
     if (sc_x) {   // folded shortcut: 1x1 on the (optionally nearest-upsampled) pre-pool grid of this launch; its result stands in for `res`
-        if (!sc_w || !sc_out || res || relu_mask || sc_Ci <= 0 || sc_Ci % 8 || sc_Kpad < sc_Ci) return L2I_ERR_ARG;
+        if (!sc_w || !sc_out || ((res || relu_mask) && !mask_first) || sc_Ci <= 0 || sc_Ci % 8 || sc_Kpad < sc_Ci) return L2I_ERR_ARG;
         if (sc_Hi << (sc_up2 ? 1 : 0) != Ho || sc_Wi << (sc_up2 ? 1 : 0) != Wo) return L2I_ERR_ARG;
     }
     if (stats && (!ws || !out || Co % 4 || 2LL * Co * L2I_WS_R > L2I_WS_FLOATS)) return L2I_ERR_ARG;
@@ -2494,6 +2536,11 @@ extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bi
     a.sc.w_b = (sc_x && w_b) ? sc_w_b : nullptr;
     a.sc.x = sc_x; a.sc.w = sc_x ? sc_w : nullptr; a.sc.bias = sc_x ? sc_bias : nullptr; a.sc.out = sc_out;
     a.sc.Hi = sc_Hi; a.sc.Wi = sc_Wi; a.sc.Ci = sc_Ci; a.sc.up2 = sc_up2 ? 1 : 0; a.sc.Kpad = sc_Kpad; a.sc.stages = 1;
+    a.sc.mask_first = nullptr; a.sc.pre_scale = 1.f;
+    if (mask_first) {   // data-gradient fold: the epilogue scales by the TAIL's alpha, the 3x3 accumulators are masked and pre-scaled in front of the tail
+        a.sc.mask_first = relu_mask; a.relu_mask = nullptr;
+        a.sc.pre_scale = alpha / sc_alpha; a.alpha = sc_alpha;
+    }
     a.sc.x_bytes = sc_x ? (unsigned)((size_t)B * sc_Hi * sc_Wi * sc_Ci * esz) : 0;
     a.sc.w_bytes = sc_x ? (unsigned)((size_t)((Co + 127) / 128 * 128) * sc_Kpad * esz) : 0;
     if (sc_x && ((size_t)B * sc_Hi * sc_Wi * sc_Ci * esz >= (1ull << 31))) return L2I_ERR_ARG;
@@ -2507,6 +2554,25 @@ extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bi
         rc = l2i_check_launch();
     }
     return rc;
+}
+
+extern "C" int l2i_conv2d_fwd_dual(const void* x, const void* w, const float* bias, const float* res,
+                                   const void* relu_mask, float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int KH,
+                                   int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats, float* ws,
+                                   const void* sc_x, const void* sc_w, const float* sc_bias, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci,
+                                   int sc_up2, int sc_Kpad, const void* w_b, const void* sc_w_b, float* scratch, long long scratch_floats, void* stream) {
+    return conv2d_impl(x, w, bias, res, relu_mask, out, out_op, out_op_raw, dtype, B, Hi, Wi, Ci, Ho, Wo, Co, KH, up2, pool2, relu_op, Kpad, alpha, nimg, stats, ws,
+                       sc_x, sc_w, sc_bias, sc_out, sc_Hi, sc_Wi, sc_Ci, sc_up2, sc_Kpad, w_b, sc_w_b, scratch, scratch_floats, stream, alpha, 0);
+}
+
+// Data gradient of a pre-activation residual block's first convolution WITH the data gradient of the block's 1x1 shortcut folded in
+// (reference model/rcnn_discriminator_app.py:326,336-341: x -> relu -> conv1 ... and x -> c_sc -> avg_pool): see include/l2i.h.
+extern "C" int l2i_conv2d_dgrad_sc(const void* dh, const void* w, const float* res, const void* relu_mask, float* out, void* out_op_raw,
+                                   int B, int H, int W, int Ci, int Co, int Kpad, float alpha, const int* nimg,
+                                   const void* sc_dy, const void* sc_w, float* sc_out, int sc_Hi, int sc_Wi, int sc_Ci, int sc_up2, int sc_Kpad,
+                                   float sc_alpha, float* scratch, long long scratch_floats, void* stream) {
+    return conv2d_impl(dh, w, nullptr, res, relu_mask, out, nullptr, out_op_raw, 1, B, H, W, Ci, H, W, Co, 3, 0, 0, 0, Kpad, alpha, nimg, nullptr, nullptr,
+                       sc_dy, sc_w, nullptr, sc_out, sc_Hi, sc_Wi, sc_Ci, sc_up2, sc_Kpad, nullptr, nullptr, scratch, scratch_floats, stream, sc_alpha, 1);
 }
 
 // Debug aid: co-resident workgroups per CU the runtime computes for a few instantiations (tools/perf/occupancy.py).

@@ -83,6 +83,9 @@ class ResBlock(nn.Module):
         if self.learnable_sc:
             ops.precast(x, pc.arena.op_dtype)   # conv1 reads relu(x), the shortcut reads x: one cast launch for both (if not emitted upstream)
         j = ops.GradJoin()   # dx of the shortcut branch enters conv1's data-gradient epilogue instead of a separate add
+        # ... and, round 5, is not even a launch of its own: conv1's data-gradient launch multiplies the shortcut's operands into its own
+        # accumulators behind the ReLU mask (ops.FusedConvFn.backward (a) / (b), csrc conv_mask_first + conv_sc_tail)
+        j.fold_ok = self.learnable_sc
         h = fused_conv(x, self.conv1.use(use), pc, prologue=RELU, nimg=nimg, relu_op_out=True, join=(j, "take"), dx_raw=sole_reader,
                        join_out=join_out)
         sc = (fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg, join=(j, "give"), lazy_sc=True, join_in=join_in)

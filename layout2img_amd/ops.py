@@ -235,6 +235,16 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
         _lib.call("l2i_conv2d_fwd_dual", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
                   _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
                   float(alpha), _p(nimg), None, None, None, None, None, None, 0, 0, 0, 0, 0, wpack_b.data_ptr(), None, None, 0, _stream())
+    elif sc.get("mask_first"):
+        # data gradient of a pre-activation block's conv1 with the data gradient of the block's 1x1 shortcut folded in (l2i_conv2d_dgrad_sc):
+        # out = relu_mask > 0 ? alpha * conv3x3(x_op) : 0  +  sc.alpha * conv1x1(sc.x_op at (y >> up2, x >> up2))  + res
+        sx = sc["x_op"]
+        _chk(sx, torch.bfloat16), _chk(x_op, torch.bfloat16)
+        assert kh == 3 and not up2 and not pool2 and bias is None and relu_mask is not None and not want_op and st is None and wpack_b is None
+        assert sc["out"].shape == (B, Hq, Wq, co) and sx.shape[0] == B
+        _lib.call("l2i_conv2d_dgrad_sc", x_op.data_ptr(), wpack.data_ptr(), _p(res), relu_mask.data_ptr(), _p(out), _p(out_raw), B, Hi, Wi, Ci, co, kpad,
+                  float(alpha), _p(nimg), sx.data_ptr(), sc["wpack"].data_ptr(), sc["out"].data_ptr(), sx.shape[1], sx.shape[2], sx.shape[3],
+                  int(sc["up2"]), sc["kpad"], float(sc["alpha"]), scr, nscr, _stream())
     else:
         sx = sc["x_op"]
         _chk(sx, x_op.dtype)
@@ -504,6 +514,8 @@ class GradJoin:
     runs after every reader's, and adds a gradient that is still parked there to its dY -- one extra pass in that rare case,
     never a silently dropped gradient."""
 
+    fold_ok = False   # the taker is a ReLU-prologue 3x3 conv that can fold the giver's (a 1x1 shortcut's) data gradient into its own launch
+
     def __init__(self):
         self.t, self.state = None, "open"
 
@@ -696,9 +708,25 @@ class FusedConvFn(Function):
             joined = ctx.join[0].take() if ctx.join is not None and ctx.join[1] == "take" and need_x else None
             if joined is None and ctx.join_in is not None and need_x and pro.kind != "norm":
                 joined = ctx.join_in.take()   # the complete gradient another reader of x left for this launch's free residual slot
+            # (a) this is a block's 1x1 shortcut and the block's conv1 can fold its data gradient (GradJoin.fold_ok): hand over the
+            #     OPERANDS instead of launching -- conv1's launch computes mask(alpha1 W1^T dh) + alpha W_sc^T dy (+ this node's residual)
+            if (DGRAD_FOLD and ctx.join is not None and ctx.join[1] == "give" and ctx.join[0].fold_ok and ctx.join[0].state == "open" and need_x
+                    and h.kh == 1 and pro.kind == "cast" and opd == torch.bfloat16 and not pc.arena.split and pc.dgrad_pack_b(h) is None
+                    and not ctx.up2 and h.co_p % 64 == 0 and not op_in and ctx.join_out is None):
+                ctx.join[0].give(dict(x_op=dy_op, wpack=pc.dgrad_pack(h), kpad=h.kpad_d, up2=bool(ctx.pool2), alpha=alpha, flops=ctx.flops,
+                                      res=joined, mask_first=True, nimg=ctx.nimg))
+                d_res = dy if ctx.has_res else None
+                return None, d_res, d_bias, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
+            # (b) the taker's side of (a)
+            sc_fold = None
+            if isinstance(joined, dict):
+                sc_fold, joined = joined, joined["res"]
+                if relu_mask is None or h.kh != 3 or ctx.up2 or ctx.pool2 or op_in or sc_fold["nimg"] is not ctx.nimg or pro.kind == "norm":
+                    raise RuntimeError("GradJoin.fold_ok was set on a join whose taker cannot fold the shortcut's data gradient")
+                sc_fold = dict(sc_fold, bias=None, out=torch.empty((Bq, Hq, Wq, h.ci_p), dtype=torch.float32, device=dy.device))
             dxo, _, dx_op = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
                                      pool2=ctx.up2, alpha=alpha, flops=ctx.flops, nimg=ctx.nimg, want_raw=emit_raw,
-                                     want_f32=not op_in, res=joined if pro.kind != "norm" else None, wpack_b=pc.dgrad_pack_b(h))
+                                     want_f32=not op_in, res=joined if pro.kind != "norm" else None, wpack_b=pc.dgrad_pack_b(h), sc=sc_fold)
             if op_in:
                 dxo = dx_op
             elif emit_raw:
@@ -793,6 +821,7 @@ _CAST, RELU, _OP, _OPRAW = _Simple("cast"), _Simple("relu"), _Simple("op"), _Sim
 WGRAD_OVERWRITE = __import__("os").environ.get("L2I_WGRAD_OVERWRITE", "1") != "0"   # weight-gradient launches store into their (freshly zeroed, per-pass) dW slices (A/B switch)
 SC_WGRAD = __import__("os").environ.get("L2I_SC_WGRAD_PY", "1") != "0"   # conv2's weight-gradient launch also computes the handed-over shortcut's (A/B switch)
 SC_FOLD = __import__("os").environ.get("L2I_SC_LAZY", "1") != "0"   # blocks hand their 1x1 shortcut to conv2's launch (A/B switch; L2I_SC_FOLD=0 keeps the hand-over but un-folds in the library)
+DGRAD_FOLD = __import__("os").environ.get("L2I_DGRAD_FOLD", "1") != "0"   # a D block's 1x1 shortcut data gradient rides on conv1's data-gradient launch (A/B switch)
 OP_EDGES = __import__("os").environ.get("L2I_OP_EDGES", "1") != "0"   # operand-dtype autograd edges inside D blocks (A/B switch)
 
 

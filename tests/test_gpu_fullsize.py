@@ -335,3 +335,52 @@ def test_every_weight_gradient_launch_of_the_full_size_iteration_vs_torch_f32(he
     """weight-gradient launches (l2i_conv2d_wgrad_dual): splits + reduce, stores (overwrite) into NaN-filled slices, bias
     gradients, live-row count, the shortcut's gradient as extra column tiles."""
     _run_all("wgrad", headline_launches, _replay_wgrad)
+
+
+# ----------------------------------------------------------------------------- BASELINE config 5: VG layouts (31 slots, 179 classes) at b = 32
+def _vg_batch():
+    from layout2img_amd.synthetic import make_batch
+    return make_batch(BATCH, 128, "vg", seed=SEED, device="cpu")
+
+
+@pytest.fixture(scope="module")
+def oracle_vg():
+    real, label, bbox, z, z_im = _vg_batch()
+    sd_g = fixture_state(load_fixture("g_vg_img.npz"), 53)
+    sd_d = fixture_state(load_fixture("d_vg.npz"), 54)
+    with torch.no_grad():
+        img = O.vg_generator_forward(sd_g, z, bbox, z_im, label, training=True)
+        outs = O.discriminator_forward(sd_d, real, bbox, label, training=True)
+    return img, outs
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+def test_vg_models_full_size_vs_oracle(mode, oracle_vg):
+    """context_aware_generator (reference model/resnet_generator_vg.py:639-727: attention and ISLA over 31 object slots) and the
+    discriminator on VG layouts (992 ROI slots with the `__image__` box among them) at batch 32 against the oracle."""
+    import layout2img_amd as L
+    from layout2img_amd import generator as G
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16}.get(mode, mode)
+    real, label, bbox, z, z_im = (t.to(DEV) for t in _vg_batch())
+    ref_img, ref_outs = oracle_vg
+    torch.manual_seed(0)
+    g = G.context_aware_generator(num_classes=179, output_dim=3)
+    g.load_state_dict(fixture_state(load_fixture("g_vg_img.npz"), 53))
+    g.finalize(DEV, dt).train()
+    with torch.no_grad():
+        img = g(z, bbox, z_im, label)
+    e_img = maxdiff(img, ref_img)
+    print(f"full-size VG G forward [{mode}]: image L_inf {e_img:.2e}")
+    assert e_img < (1e-1 if mode == "bf16" else 1e-3), e_img
+    del g
+    d = L.CombineDiscriminator128_app(num_classes=179)
+    d.load_state_dict(fixture_state(load_fixture("d_vg.npz"), 54))
+    d.finalize(DEV, dt).train()
+    with torch.no_grad():
+        outs = d(real, bbox, label)
+    rel = 3e-2 if mode == "bf16" else 2e-4
+    for t, ref, k in zip(outs, ref_outs, ("img", "obj", "app")):
+        assert tuple(t.shape) == tuple(ref.shape), (k, t.shape, ref.shape)
+        e, s = maxdiff(t, ref), max(1.0, float(ref.abs().max()))
+        print(f"full-size VG D forward [{mode}] {k}: {e:.2e} (scale {s:.2e}, {t.shape[0]} rows)")
+        assert e < rel * s, (k, e, s)

@@ -1142,3 +1142,50 @@ def test_conv_256x256_eight_wave_tile(case, cfg, epi):
     assert float((op.float().cpu() - _rt(out.cpu().clamp_min(0), dt)).abs().max()) == 0.0
     if sCi is not None:
         assert bool(torch.isnan(kw["sc"]["out"]).all())   # folded
+
+
+# (B, H, W, Ci = channels of dh, Co = channels of x, sc_Ci = channels of dy, shortcut pooled, live images | None)
+DGRAD_SC_CASES = [(2, 32, 32, 128, 64, 128, True, None), (3, 16, 16, 256, 128, 256, True, None), (2, 32, 32, 256, 128, 256, False, None),
+                  (5, 8, 8, 512, 256, 512, True, 3), (1, 64, 64, 64, 64, 128, True, None), (2, 16, 16, 128, 72, 192, False, None)]
+
+
+@pytest.mark.parametrize("cfg", [-1, 14, 15, 19, 29])
+@pytest.mark.parametrize("case", DGRAD_SC_CASES)
+def test_conv_dgrad_with_the_shortcut_data_gradient_folded_in(case, cfg, epi):
+    """l2i_conv2d_dgrad_sc: dx of a pre-activation discriminator block (reference model/rcnn_discriminator_app.py:326,336-341) from ONE launch:
+    relu'(x) . conv3x3(dh, W1 flipped) + sc_alpha conv1x1(dy at (y >> 1, x >> 1), Wsc^T) + another reader's gradient -- the ReLU mask applied to
+    the accumulators in front of the shortcut's K-steps on the 128-pixel tiles (folded: the placeholder stays NaN), un-folded by the library on the
+    256-pixel tiles and for channel counts that are not multiples of 64; with a live-image count; against torch f32."""
+    from layout2img_amd import ops, _lib
+    B, H, W, Ci, Co, sCi, pooled, live = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(41)
+    dh = _rt(torch.randn(B, H, W, Ci, generator=g), dt)
+    w = _rt(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9), dt)
+    hs, ws_ = (H // 2, W // 2) if pooled else (H, W)
+    dy = _rt(torch.randn(B, hs, ws_, sCi, generator=g), dt)
+    wsc = _rt(torch.randn(Co, sCi, 1, 1, generator=g) / math.sqrt(sCi), dt)
+    mask = _rt(torch.randn(B, H, W, Co, generator=g), dt)
+    res = torch.randn(B, H, W, Co, generator=g)
+    sc_alpha = 0.25 if pooled else 1.0
+    ref = _ref_conv(dh, w, None, False, False) * (mask > 0).float() + sc_alpha * _ref_conv(dy, wsc, None, pooled, False) + res
+    dev = _dev()
+    nimg = None
+    if live is not None:
+        nimg = torch.tensor([live], dtype=torch.int32, device=dev)
+        ref[live:] = 0
+    pack, kpad = _pack(w, 64)
+    pack_sc, kpad_sc = _pack(wsc, 64)
+    placeholder = torch.full((B, H, W, Co), float("nan"), device=dev)
+    sc = dict(x_op=dy.to(dev, dt), wpack=pack_sc.to(dev, dt), kpad=kpad_sc, bias=None, up2=pooled, alpha=sc_alpha, out=placeholder, flops=0.0, mask_first=True)
+    _lib.call("l2i_set_conv_config", cfg)
+    try:
+        out, _, raw = ops.conv_raw(dh.to(dev, dt), pack.to(dev, dt), kpad, Co, 3, relu_mask=mask.to(dev, dt), res=res.to(dev), nimg=nimg, sc=sc, want_raw=True)
+    finally:
+        _lib.call("l2i_set_conv_config", -1)
+    assert float((out.cpu() - ref).abs().max()) < 3e-5 * float(ref.abs().max())
+    assert float((raw.float().cpu() - _rt(out.cpu(), dt)).abs().max()) == 0.0
+    if cfg in (14, 15):   # the 128-pixel tiles fold when the shortcut's channel count is a multiple of 64
+        assert bool(torch.isnan(placeholder).all()) == (sCi % 64 == 0)
+    if cfg in (19, 29):   # the 256-pixel tiles never compile the mask-first tail: un-folded
+        assert not bool(torch.isnan(placeholder).any()) or live is not None
