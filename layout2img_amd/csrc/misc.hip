@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void stage_mask_fwd_kernel(const float* __rest
             const float top = q[0] * 0.5f + q[1] * 0.5f, bot = q[S] * 0.5f + q[S + 1] * 0.5f;
             rb = top * 0.5f + bot * 0.5f;
         }
-        const float sg = sm_sigmoid(logits[((size_t)b * H * H + p) * Cp + cls]);
+        const float sg = sm_sigmoid(Cp ? logits[((size_t)b * H * H + p) * Cp + cls] : logits[(size_t)bo * H * H + p]);   // Cp = 0: logits already gathered per object, planar [B][O][H][H] (class_logits_fwd_kernel)
         const float m = xm[(size_t)(f * h) * S + f * w];
         out[(size_t)bo * H * H + p] = rb * (1.f - a) + (sg * m) * a;
         keep[(size_t)bo * H * H + p] = sg;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void stage_mask_bwd_logits_kernel(const float*
 }
 
 static bool stage_mask_geom_ok(int B, int O, int H, int Cp, int S) {
-    if (B <= 0 || O <= 0 || H <= 0 || S <= 0 || Cp <= 0 || Cp % 4 || S % H) return false;
+    if (B <= 0 || O <= 0 || H <= 0 || S <= 0 || Cp < 0 || Cp % 4 || S % H) return false;   // (Cp = 0: planar gathered logits)
     const int f = S / H;
     return f == 1 || f % 2 == 0;
 }
@@ -462,15 +462,136 @@ extern "C" int l2i_stage_mask_fwd(const float* logits, const float* bmask, const
 extern "C" int l2i_stage_mask_bwd(const float* g, const float* keep, const float* boxm, const float* alpha, const long long* y,
                                   float* gl, float* dlogits, float* dbmask, float* dalpha, int B, int O, int H, int Cp, int S,
                                   void* stream) {
-    if (!g || !keep || !boxm || !alpha || !y || !gl || !dlogits || !dbmask || !dalpha || !stage_mask_geom_ok(B, O, H, Cp, S))
+    if (!g || !keep || !boxm || !alpha || !y || !gl || (!dlogits && Cp) || !dbmask || !dalpha || !stage_mask_geom_ok(B, O, H, Cp, S))
         return L2I_ERR_ARG;
     hipLaunchKernelGGL(stage_mask_bwd_planar_kernel, dim3(B * O), dim3(256), 0, (hipStream_t)stream, g, keep, boxm, alpha, y, gl,
                        dbmask, dalpha, O, H, S);
+    if (Cp == 0) return l2i_check_launch();   // planar logits: gl IS their gradient (no dense [B][H][H][Cp] tensor exists)
     const long long total4 = (long long)B * H * H * (Cp / 4);
     long long nblk = (total4 + 255) / 256;
     if (nblk > 16384) nblk = 16384;
     hipLaunchKernelGGL(stage_mask_bwd_logits_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, gl, y, dlogits, O,
                        H * H, Cp, total4);
+    return l2i_check_launch();
+}
+
+// ---------------------------------------------------------------- class-gathered logits of the generator's mask heads
+// reference model/resnet_generator_app_v2.py:643-651 + :465-466: every mask head ends in Conv2d(100, 184, 1) and the ONLY reader of its
+// 184-channel result is  seman = gather(m, 1, y)  -- the <= 8 channels of the image's own object classes. Computing all 184 (a 96 MB
+// f32 tensor at 64 x 64, its bias-gradient pass, a dense mostly-zero gradient, three GEMM launches each way) is work nobody reads:
+//   lg[b,o,p] = bias[y[b,o]] + sum_c a[b,p,c] W[y[b,o],c]                                   (forward: 8 x 100 MACs per pixel)
+//   da[b,p,c] = sum_o gl[b,o,p] W[y_o,c];  dW[y_o,c] += sum_p gl[b,o,p] a[b,p,c];  dbias[y_o] += sum_p gl[b,o,p]     (backward)
+// a [B][HH][Cp] f32 NHWC (Cp >= C, multiple of 4), W [classes][ldw] f32, lg / gl planar [B][O][HH], O <= 8.
+#define CL_O 8
+__global__ __launch_bounds__(256) void class_logits_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               const long long* __restrict__ y, float* __restrict__ lg, int O, int HH, int Cp, int C, int ldw) {
+    __shared__ float wt[128][CL_O];   // [channel][object]: a pixel's 8 dot products read two broadcast float4 per channel
+    __shared__ float bs[CL_O];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < 128 * CL_O; i += 256) {
+        const int c = i / CL_O, o = i % CL_O;
+        wt[c][o] = (c < C && o < O) ? w[(size_t)y[b * O + o] * ldw + c] : 0.f;
+    }
+    if (threadIdx.x < CL_O) bs[threadIdx.x] = (threadIdx.x < O && bias) ? bias[y[b * O + threadIdx.x]] : 0.f;
+    __syncthreads();
+    for (int p = blockIdx.y * 256 + threadIdx.x; p < HH; p += gridDim.y * 256) {
+        const float4* row = reinterpret_cast<const float4*>(a + ((size_t)b * HH + p) * Cp);
+        float acc[CL_O];
+#pragma unroll
+        for (int o = 0; o < CL_O; ++o) acc[o] = bs[o];
+        for (int c4 = 0; c4 < (C + 3) / 4; ++c4) {
+            const float4 v = row[c4];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 w0 = *reinterpret_cast<const float4*>(&wt[4 * c4 + k][0]), w1 = *reinterpret_cast<const float4*>(&wt[4 * c4 + k][4]);
+                acc[0] = fmaf(e[k], w0.x, acc[0]); acc[1] = fmaf(e[k], w0.y, acc[1]); acc[2] = fmaf(e[k], w0.z, acc[2]); acc[3] = fmaf(e[k], w0.w, acc[3]);
+                acc[4] = fmaf(e[k], w1.x, acc[4]); acc[5] = fmaf(e[k], w1.y, acc[5]); acc[6] = fmaf(e[k], w1.z, acc[6]); acc[7] = fmaf(e[k], w1.w, acc[7]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < CL_O; ++o)
+            if (o < O) lg[((size_t)b * O + o) * HH + p] = acc[o];
+    }
+}
+
+// backward: lanes over CHANNELS (thread = channel c of pixel phase ph), loop over the block's pixels: a and da rows are read / written
+// contiguously, the 8 gradients of a pixel are LDS broadcasts, a thread keeps its 8 x 1 column of dW in registers.
+__global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __restrict__ a, const float* __restrict__ w, const long long* __restrict__ y,
+                                                               const float* __restrict__ gl, float* __restrict__ da, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, int O, int HH, int Cp, int C, int ldw, int per) {
+    __shared__ float gs[CL_O][256];
+    __shared__ float red[CL_O][128];
+    const int b = blockIdx.x, c = threadIdx.x & 127, ph = threadIdx.x >> 7;
+    const int p0 = blockIdx.y * per, p1 = min(HH, p0 + per);
+    float wr[CL_O], acc[CL_O], gsum = 0.f;
+    int cls[CL_O];
+#pragma unroll
+    for (int o = 0; o < CL_O; ++o) {
+        cls[o] = o < O ? (int)y[b * O + o] : 0;
+        wr[o] = (o < O && c < C) ? w[(size_t)cls[o] * ldw + c] : 0.f;
+        acc[o] = 0.f;
+    }
+    for (int q0 = p0; q0 < p1; q0 += 256) {
+        const int nq = min(256, p1 - q0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < CL_O * 256; i += 256) {
+            const int o = i >> 8, q = i & 255;
+            gs[o][q] = (o < O && q < nq) ? gl[((size_t)b * O + o) * HH + q0 + q] : 0.f;
+        }
+        __syncthreads();
+        if (c < Cp)
+            for (int q = ph; q < nq; q += 2) {
+                const size_t off = ((size_t)b * HH + q0 + q) * Cp + c;
+                const float av = c < C ? a[off] : 0.f;
+                float d = 0.f;
+#pragma unroll
+                for (int o = 0; o < CL_O; ++o) {
+                    const float g_ = gs[o][q];
+                    d = fmaf(g_, wr[o], d);
+                    acc[o] = fmaf(g_, av, acc[o]);
+                }
+                da[off] = d;
+            }
+        if (threadIdx.x < CL_O) {   // bias gradient: thread o sums its object's gradients of this chunk
+            float t = 0.f;
+            for (int q = 0; q < nq; ++q) t += gs[threadIdx.x][q];
+            gsum += t;
+        }
+    }
+    __syncthreads();
+    if (ph == 1) {
+#pragma unroll
+        for (int o = 0; o < CL_O; ++o) red[o][c] = acc[o];
+    }
+    __syncthreads();
+    if (ph == 0 && c < C) {
+#pragma unroll
+        for (int o = 0; o < CL_O; ++o)
+            if (o < O) atomicAdd(dw + (size_t)cls[o] * ldw + c, acc[o] + red[o][c]);
+    }
+    if (threadIdx.x < CL_O && threadIdx.x < O && dbias) atomicAdd(dbias + (int)y[b * O + threadIdx.x], gsum);
+}
+
+extern "C" int l2i_class_logits_fwd(const float* a, const float* w, const float* bias, const long long* y, float* lg, int B, int O, int HH,
+                                    int Cp, int C, int ldw, void* stream) {
+    if (!a || !w || !y || !lg || B <= 0 || O <= 0 || O > CL_O || HH <= 0 || C <= 0 || C > 128 || Cp < C || Cp % 4 || ldw < C) return L2I_ERR_ARG;
+    int parts = (HH + 255) / 256;
+    if (parts > 16) parts = 16;
+    hipLaunchKernelGGL(class_logits_fwd_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, a, w, bias, y, lg, O, HH, Cp, C, ldw);
+    return l2i_check_launch();
+}
+
+// dw [classes][ldw] and dbias [classes] are ACCUMULATED into (atomics): the caller zeroes them.
+extern "C" int l2i_class_logits_bwd(const float* a, const float* w, const long long* y, const float* gl, float* da, float* dw, float* dbias,
+                                    int B, int O, int HH, int Cp, int C, int ldw, void* stream) {
+    if (!a || !w || !y || !gl || !da || !dw || B <= 0 || O <= 0 || O > CL_O || HH <= 0 || C <= 0 || C > 128 || Cp < C || Cp > 128 || Cp % 4 || ldw < C)
+        return L2I_ERR_ARG;
+    int parts = (HH + 255) / 256;
+    if (parts > 16) parts = 16;
+    const int per = ((HH + parts - 1) / parts + 255) / 256 * 256;
+    parts = (HH + per - 1) / per;
+    hipLaunchKernelGGL(class_logits_bwd_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, a, w, y, gl, da, dw, dbias, O, HH, Cp, C, ldw, per);
     return l2i_check_launch();
 }
 

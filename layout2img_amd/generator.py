@@ -9,6 +9,7 @@ WeightArena. Small layout-sized tensors (masks, embeddings, box geometry) are ha
 device-side torch ops.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -203,6 +204,9 @@ class PSPModule(nn.Module):
         return y
 
 
+CLASS_GATHER = os.environ.get("L2I_CLASS_GATHER", "1") != "0"   # mask heads compute only the gathered classes (A/B switch)
+
+
 class ConvMaskHead(nn.ModuleList):
     """conv_mask of the generator ResBlock (reference :643-651). Keys 0,1,3 (plain) or 0,1 (PSP)."""
 
@@ -214,16 +218,30 @@ class ConvMaskHead(nn.ModuleList):
                               GemmWeight("conv", 184, 100, 1, sn=False)])
         self.psp = psp
 
-    def forward(self, x, pc, sync):
+    def forward(self, x, pc, sync, y=None):
+        """y (b, o) int64, o <= 8: the caller will only ever gather the channels of these classes from the head's 184-channel result
+        (`seman = gather(m, 1, y)`, reference :465-466) -- the last 1x1 convolution is then evaluated for those classes alone
+        (ops.class_logits) and the result is the planar (b, o, H, W) tensor of gathered logits, tagged `_l2i_planar`. None: the dense
+        (b, H, W, 184) logits."""
+        gather = y is not None and CLASS_GATHER and y.shape[1] <= 8
         if self.psp:
-            y = self[0](x, pc, sync)
-            return fused_conv(y, self[1], pc)
-        conv, bn, _, out = self
-        h = fused_conv(x, conv, pc, emit=("stats",) if self.training else ())
-        spec, w, b = bn.spec(self.training, sync, conv.co_p)
-        m = fused_conv(h, out, pc, prologue=spec, wproj=w, bproj=b, dx_raw=True)   # (h has this one reader: its gradient's operand copy comes out of the norm backward)
-        bn.commit(conv.co_p)
-        return m
+            a = self[0](x, pc, sync)
+            if not gather:
+                return fused_conv(a, self[1], pc)
+            out = self[1]
+        else:
+            conv, bn, _, out = self
+            h = fused_conv(x, conv, pc, emit=("stats",) if self.training else ())
+            spec, w, b = bn.spec(self.training, sync, conv.co_p)
+            if not gather:
+                m = fused_conv(h, out, pc, prologue=spec, wproj=w, bproj=b, dx_raw=True)   # (h has this one reader: its gradient's operand copy comes out of the norm backward)
+                bn.commit(conv.co_p)
+                return m
+            a = ops.norm_act(h, spec, w, b)
+            bn.commit(conv.co_p)
+        lg = ops.class_logits(a, ops.arena_weight(out, pc), out.bias, y)
+        lg._l2i_planar = True
+        return lg
 
 
 class ResBlock(nn.Module):
@@ -243,9 +261,9 @@ class ResBlock(nn.Module):
         if predict_mask:
             self.conv_mask = ConvMaskHead(out_ch, psp_module)
 
-    def forward(self, x, w, mask, pc, sync, emit=()):
+    def forward(self, x, w, mask, pc, sync, emit=(), y=None):
         """emit: operand copies of the block's result written by conv2's epilogue ("raw": what the next block's shortcut
-        conv and this block's mask head read)."""
+        conv and this block's mask head read). y: the object classes (see ConvMaskHead.forward)."""
         B, H, W, C = x.shape
         O = mask.shape[1]
         up = self.upsample
@@ -262,7 +280,7 @@ class ResBlock(nn.Module):
                          dx_raw=True)   # (the block's result is normalised next: by the following block's b1 or by the final BN)
         self.b1.batch_norm2d.commit()
         self.b2.batch_norm2d.commit()
-        m = self.conv_mask(out, pc, sync) if self.predict_mask else None
+        m = self.conv_mask(out, pc, sync, y) if self.predict_mask else None
         return out, m
 
 
@@ -453,9 +471,16 @@ class ResnetGenerator128_context(_GeneratorBase):
 
     def _stage_mask(self, stage_logits, bmask, bbox_mask_, alpha, y):
         """reference :465-470: blend the regressed mask with the predicted semantic mask."""
-        B, H, W, Cp = stage_logits.shape
         b, o = y.shape
         S = bmask.shape[-1]
+        if getattr(stage_logits, "_l2i_planar", False):   # class-gathered logits (b, o, H, W) of ConvMaskHead
+            H, W = stage_logits.shape[2], stage_logits.shape[3]
+            if H == W and S % H == 0 and (S == H or (S // H) % 2 == 0):
+                return ops.stage_mask(stage_logits, bmask, bbox_mask_, alpha, y, planar=True)
+            seman = torch.sigmoid(stage_logits) * F.interpolate(bbox_mask_, size=(H, W), mode="nearest")
+            a = torch.gather(torch.sigmoid(alpha).expand(b, -1, -1), dim=1, index=y.view(b, o, 1)).unsqueeze(-1)
+            return (_resize_mask(bmask, H, W) * (1 - a) + seman * a).contiguous()
+        B, H, W, Cp = stage_logits.shape
         if H == W and Cp % 4 == 0 and alpha.numel() == Cp and S % H == 0 and (S == H or (S // H) % 2 == 0):
             return ops.stage_mask(stage_logits, bmask, bbox_mask_, alpha, y)   # the fused form of the lines below
         idx = y.view(b, 1, 1, o).expand(b, H, W, o)
@@ -479,14 +504,14 @@ class ResnetGenerator128_context(_GeneratorBase):
         if z_im is None:
             z_im = torch.randn((b, 128), device=z.device)
         x = ops.fc_to_nhwc(fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc), 16 * self.ch, self.op_dtype)
-        x, m = self.res1(x, wp, bmask, pc, self.sync, emit=("raw",))
+        x, m = self.res1(x, wp, bmask, pc, self.sync, emit=("raw",), y=y)
         stage = bmask
         stages = []
         res_out = [x]
         for blk, alpha in ((self.res2, self.alpha1), (self.res3, self.alpha2), (self.res4, self.alpha3), (self.res5, self.alpha4)):
             stage = self._stage_mask(m, bmask, bbox_mask_, alpha, y)
             stages.append(stage)
-            x, m = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",))
+            x, m = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",), y=y)
             res_out.append(x)
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
@@ -583,10 +608,10 @@ class ResnetGenerator64_context(ResnetGenerator128_context):
         if z_im is None:
             z_im = torch.randn((b, 128), device=z.device)
         x = ops.fc_to_nhwc(fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc), 16 * self.ch, self.op_dtype)
-        x, m = self.res2(x, wp, bmask, pc, self.sync, emit=("raw",))
+        x, m = self.res2(x, wp, bmask, pc, self.sync, emit=("raw",), y=y)
         for blk, alpha in ((self.res3, self.alpha1), (self.res4, self.alpha2), (self.res5, self.alpha3)):
             stage = self._stage_mask(m, bmask, bbox_mask_, alpha, y)
-            x, m = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",))
+            x, m = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",), y=y)
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
         pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba, dx_raw=True)   # (x: the last block's result, read by this layer alone)

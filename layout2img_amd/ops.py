@@ -842,7 +842,7 @@ class NormActFn(Function):
     def backward(ctx, dy):
         x, mask, wproj, bproj = ctx.saved_tensors
         sums, sq, count, sstride = ctx.stats
-        dy = dy.contiguous().clone()
+        dy = dy.contiguous() if getattr(dy, "_l2i_owned", False) else dy.contiguous().clone()   # (norm_bwd_raw overwrites dy: a gradient nobody else holds needs no copy)
         dx, d_w, d_b, d_mask = norm_bwd_raw(x, dy, sums, sq, count, sstride, ctx.spec, mask, wproj, bproj,
                                             need_mask_grad=mask is not None and ctx.needs_input_grad[1])
         return dx, d_mask, d_w, d_b, None
@@ -1191,12 +1191,19 @@ class StageMaskFn(Function):
     a = sigmoid(alpha[y])."""
 
     @staticmethod
-    def forward(ctx, logits, bmask, boxm, alpha, y):
+    def forward(ctx, logits, bmask, boxm, alpha, y, planar=False):
+        """planar: `logits` are the class-GATHERED logits (B, O, H, H) of ops.class_logits, not the dense (B, H, H, Cp) tensor."""
         for t in (logits, bmask, boxm, alpha):
             _chk(t, torch.float32)
-        B, H, W, Cp = logits.shape
         b, o, S, _ = bmask.shape
-        assert H == W and b == B and boxm.shape == bmask.shape and y.dtype == torch.int64 and alpha.numel() == Cp
+        if planar:
+            B, o_, H, W = logits.shape
+            Cp = 0
+            assert o_ == o
+        else:
+            B, H, W, Cp = logits.shape
+            assert alpha.numel() == Cp
+        assert H == W and b == B and boxm.shape == bmask.shape and y.dtype == torch.int64
         out = torch.empty((B, o, H, H), dtype=torch.float32, device=logits.device)
         keep = torch.empty((2, B, o, H, H), dtype=torch.float32, device=logits.device)
         _lib.call("l2i_stage_mask_fwd", logits.data_ptr(), bmask.data_ptr(), boxm.data_ptr(), alpha.data_ptr(), y.data_ptr(),
@@ -1212,16 +1219,53 @@ class StageMaskFn(Function):
         g = g.contiguous()
         dev = g.device
         gl = torch.empty((B, o, H, H), dtype=torch.float32, device=dev)
-        dlogits = torch.empty((B, H, H, Cp), dtype=torch.float32, device=dev)
+        dlogits = torch.empty((B, H, H, Cp), dtype=torch.float32, device=dev) if Cp else None
         dbmask = torch.empty((B, o, S, S), dtype=torch.float32, device=dev)
         dalpha = _zeros(tuple(alpha.shape), dev)
         _lib.call("l2i_stage_mask_bwd", g.data_ptr(), keep.data_ptr(), boxm.data_ptr(), alpha.data_ptr(), y.data_ptr(),
-                  gl.data_ptr(), dlogits.data_ptr(), dbmask.data_ptr(), dalpha.data_ptr(), B, o, H, Cp, S, _stream())
-        return dlogits, dbmask, None, dalpha, None
+                  gl.data_ptr(), _p(dlogits), dbmask.data_ptr(), dalpha.data_ptr(), B, o, H, Cp, S, _stream())
+        return (dlogits if Cp else gl), dbmask, None, dalpha, None, None
 
 
-def stage_mask(logits, bmask, boxm, alpha, y):
-    return StageMaskFn.apply(logits.contiguous(), bmask.contiguous(), boxm.contiguous(), alpha.contiguous(), y.contiguous())
+def stage_mask(logits, bmask, boxm, alpha, y, planar=False):
+    return StageMaskFn.apply(logits.contiguous(), bmask.contiguous(), boxm.contiguous(), alpha.contiguous(), y.contiguous(), planar)
+
+
+class ClassLogitsFn(Function):
+    """The last layer of a generator mask head, Conv2d(100, 184, 1), evaluated ONLY for the classes its single reader gathers
+    (reference model/resnet_generator_app_v2.py:643-651, 465-466: `seman = gather(m, 1, y)`): lg[b,o,p] = bias[y[b,o]] + a[b,p,:] . W[y[b,o],:]
+    -- 8 x 100 MACs per pixel instead of 184 x 100, and neither the 184-channel tensor (96 MB at 64 x 64) nor its dense, mostly-zero
+    gradient ever exists (csrc/misc.hip class_logits_*_kernel). a (B, H, W, Cp) f32; w (classes, C) f32 (ops.arena_weight); y (B, O)."""
+
+    @staticmethod
+    def forward(ctx, a, w, bias, y):
+        _chk(a, torch.float32), _chk(w, torch.float32)
+        B, H, W, Cp = a.shape
+        O, C = y.shape[1], w.shape[1]
+        lg = torch.empty((B, O, H, W), dtype=torch.float32, device=a.device)
+        _lib.call("l2i_class_logits_fwd", a.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), lg.data_ptr(), B, O, H * W, Cp, C, w.stride(0), _stream())
+        ctx.save_for_backward(a, w, y)
+        ctx.has_bias = bias is not None
+        ctx.nb = 0 if bias is None else bias.numel()
+        return lg
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w, y = ctx.saved_tensors
+        B, H, W, Cp = a.shape
+        O, C = y.shape[1], w.shape[1]
+        g = _chk(g.contiguous(), torch.float32)
+        da = torch.empty_like(a)
+        dw = torch.zeros_like(w)
+        db = torch.zeros(ctx.nb, dtype=torch.float32, device=a.device) if ctx.has_bias else None
+        _lib.call("l2i_class_logits_bwd", a.data_ptr(), w.data_ptr(), y.data_ptr(), g.data_ptr(), da.data_ptr(), dw.data_ptr(), _p(db),
+                  B, O, H * W, Cp, C, w.stride(0), _stream())
+        da._l2i_owned = True   # (fresh, handed to exactly one consumer: NormActFn.backward may overwrite it)
+        return da, dw, db, None
+
+
+def class_logits(a, w, bias, y):
+    return ClassLogitsFn.apply(a.contiguous(), w.contiguous(), bias, y.contiguous())
 
 
 class ProjHeadFn(Function):

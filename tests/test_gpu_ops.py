@@ -1189,3 +1189,38 @@ def test_conv_dgrad_with_the_shortcut_data_gradient_folded_in(case, cfg, epi):
         assert bool(torch.isnan(placeholder).all()) == (sCi % 64 == 0)
     # (19 / 29, where the heuristic honours them -- not for <= 64 output channels --: the 256-pixel tiles do not compile the mask-first tail
     #  and the library un-folds; same result either way)
+
+
+@pytest.mark.parametrize("case", [(3, 8, 16, 100, 104, True), (2, 5, 64, 100, 104, True), (4, 8, 8, 100, 104, False), (1, 8, 32, 128, 128, True)])
+def test_class_gathered_logits_equal_the_gather_of_the_dense_head(case):
+    """ops.class_logits (l2i_class_logits_fwd / _bwd): the last 1x1 convolution of a generator mask head evaluated only for the classes its
+    reader gathers (reference model/resnet_generator_app_v2.py:643-651, 465-466) equals gather(conv1x1(a), 1, y) forward and in all three
+    gradients (activations incl. zeroed pad channels, weight, bias), with repeated classes and the padding class 0 among the objects."""
+    from layout2img_amd import ops
+    B, O, H, C, Cp, has_bias = case
+    g = torch.Generator().manual_seed(B * 100 + O)
+    a = torch.randn(B, H, H, Cp, generator=g)
+    a[..., C:] = 0
+    w = torch.randn(184, C, generator=g) / math.sqrt(C)
+    bias = torch.randn(184, generator=g) if has_bias else None
+    y = torch.randint(0, 184, (B, O), generator=g)
+    y[:, -1] = y[:, 0]          # a repeated class
+    y[0, 1] = 0                 # the padding class
+    ar, wr = a.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True) if has_bias else None
+    dense = torch.einsum("bhwc,kc->bkhw", ar[..., :C], wr) + (br.view(1, -1, 1, 1) if has_bias else 0)
+    ref = torch.gather(dense, 1, y.view(B, O, 1, 1).expand(B, O, H, H))
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    dev = _dev()
+    ad, wd = a.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    bd = bias.to(dev).requires_grad_(True) if has_bias else None
+    lg = ops.class_logits(ad, wd, bd, y.to(dev))
+    assert float((lg.cpu() - ref).abs().max()) < 1e-5 * float(ref.abs().max()) + 1e-6
+    lg.backward(go.to(dev))
+    tol = lambda r: 2e-5 * float(r.abs().max()) + 1e-6
+    assert float((ad.grad.cpu()[..., :C] - ar.grad[..., :C]).abs().max()) < tol(ar.grad)
+    assert float(ad.grad.cpu()[..., C:].abs().max()) == 0.0 if Cp > C else True
+    assert float((wd.grad.cpu() - wr.grad).abs().max()) < tol(wr.grad)
+    if has_bias:
+        assert float((bd.grad.cpu() - br.grad).abs().max()) < tol(br.grad)
