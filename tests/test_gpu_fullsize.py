@@ -107,7 +107,8 @@ def test_discriminator_forward_full_size_vs_oracle(mode, oracle_d):
 def _sig_conv(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, up2=False, pool2=False, alpha=1.0,
               want_f32=True, want_op=False, relu_op=False, want_raw=False, flops=None, nimg=None, stats=False, sc=None,
               wpack_b=None, _outs=None):
-    scs = None if sc is None else (tuple(sc["x_op"].shape), int(sc["kpad"]), sc["bias"] is not None, bool(sc["up2"]))
+    scs = None if sc is None else (tuple(sc["x_op"].shape), int(sc["kpad"]), sc.get("bias") is not None, bool(sc["up2"]),
+                                   bool(sc.get("mask_first")), float(sc.get("alpha", 0.0)))
     return ("conv", tuple(x_op.shape), str(x_op.dtype), int(kpad), int(co), int(kh), bias is not None, res is not None,
             relu_mask is not None, bool(up2), bool(pool2), float(alpha), bool(want_f32), bool(want_op), bool(relu_op),
             bool(want_raw), nimg is not None, bool(stats), scs, wpack_b is not None)
@@ -196,21 +197,28 @@ def _replay_conv(sig, live_frac, seed):
     dev = DEV
     bf = torch.bfloat16
     kw = dict(up2=up2, pool2=pool2, alpha=alpha, want_f32=want_f32, want_op=want_op, relu_op=relu_op, want_raw=want_raw, stats=stats)
+    mask_first = scs is not None and scs[4]
+    if mask_first:   # the data gradient of a D block's conv1 with the shortcut's data gradient folded in: the mask belongs to the 3x3 part only
+        mask = _rt(torch.randn(ref.shape, generator=g))
+        ref = ref * (mask > 0).float()
+        kw["relu_mask"] = mask.to(dev, bf)
     if scs is not None:
-        sxs, skpad, sbias, sup = scs
+        sxs, skpad, sbias, sup, _, salpha = scs
         xsc = _rt(torch.randn(sxs, generator=g))
         wsc = _rt(torch.randn(co, sxs[3], 1, 1, generator=g) / math.sqrt(sxs[3]))
-        ref = ref + alpha * _conv_ref(xsc, wsc, sup, pool2)
+        ref = ref + (salpha if mask_first else alpha) * _conv_ref(xsc, wsc, sup, pool2)
         bsc = torch.randn(co, generator=g) if sbias else None
         if bsc is not None:
             ref = ref + bsc
         kw["sc"] = dict(x_op=xsc.to(dev, bf), wpack=_pack(wsc, skpad).to(dev, bf), kpad=skpad, bias=None if bsc is None else bsc.to(dev),
                         up2=sup, out=torch.full(ref.shape, float("nan"), device=dev), flops=0.0)
+        if mask_first:
+            kw["sc"].update(mask_first=True, alpha=salpha)
     if has_bias:
         bias = torch.randn(co, generator=g)
         ref = ref + bias
         kw["bias"] = bias.to(dev)
-    if has_mask:
+    if has_mask and not mask_first:
         mask = _rt(torch.randn(ref.shape, generator=g))
         ref = ref * (mask > 0).float()
         kw["relu_mask"] = mask.to(dev, bf)
