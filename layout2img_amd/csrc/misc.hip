@@ -515,8 +515,10 @@ __global__ __launch_bounds__(256) void class_logits_fwd_kernel(const float* __re
     }
 }
 
-// backward: lanes over CHANNELS (thread = channel c of pixel phase ph), loop over the block's pixels: a and da rows are read / written
-// contiguously, the 8 gradients of a pixel are LDS broadcasts, a thread keeps its 8 x 1 column of dW in registers.
+// backward: lanes over CHANNELS (thread = channel c of pixel phase ph), loop over the block's pixels in batches of 8 loads (the first
+// version issued one dependent load per iteration and had 8 threads sum the bias gradient serially: 64 us per launch; this form ~15):
+// a and da rows are read / written contiguously, the 8 gradients of a pixel are LDS broadcasts, a thread keeps its 8 x 1 column of dW in
+// registers; the bias gradient is summed by the threads that stage gl (one pixel each) and reduced once per block.
 __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __restrict__ a, const float* __restrict__ w, const long long* __restrict__ y,
                                                                const float* __restrict__ gl, float* __restrict__ da, float* __restrict__ dw,
                                                                float* __restrict__ dbias, int O, int HH, int Cp, int C, int ldw, int per) {
@@ -524,39 +526,45 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
     __shared__ float red[CL_O][128];
     const int b = blockIdx.x, c = threadIdx.x & 127, ph = threadIdx.x >> 7;
     const int p0 = blockIdx.y * per, p1 = min(HH, p0 + per);
-    float wr[CL_O], acc[CL_O], gsum = 0.f;
+    float wr[CL_O], acc[CL_O], gpart[CL_O];
     int cls[CL_O];
 #pragma unroll
     for (int o = 0; o < CL_O; ++o) {
         cls[o] = o < O ? (int)y[b * O + o] : 0;
         wr[o] = (o < O && c < C) ? w[(size_t)cls[o] * ldw + c] : 0.f;
-        acc[o] = 0.f;
+        acc[o] = 0.f; gpart[o] = 0.f;
     }
     for (int q0 = p0; q0 < p1; q0 += 256) {
         const int nq = min(256, p1 - q0);
         __syncthreads();
-        for (int i = threadIdx.x; i < CL_O * 256; i += 256) {
-            const int o = i >> 8, q = i & 255;
-            gs[o][q] = (o < O && q < nq) ? gl[((size_t)b * O + o) * HH + q0 + q] : 0.f;
+#pragma unroll
+        for (int o = 0; o < CL_O; ++o) {
+            const float v = (o < O && (int)threadIdx.x < nq) ? gl[((size_t)b * O + o) * HH + q0 + threadIdx.x] : 0.f;
+            gs[o][threadIdx.x] = v;
+            gpart[o] += v;
         }
         __syncthreads();
-        if (c < Cp)
-            for (int q = ph; q < nq; q += 2) {
-                const size_t off = ((size_t)b * HH + q0 + q) * Cp + c;
-                const float av = c < C ? a[off] : 0.f;
-                float d = 0.f;
+        if (c < Cp) {
+            const size_t base = ((size_t)b * HH + q0) * Cp + c;
+            for (int q = ph; q < nq; q += 16) {
+                float av[8];
 #pragma unroll
-                for (int o = 0; o < CL_O; ++o) {
-                    const float g_ = gs[o][q];
-                    d = fmaf(g_, wr[o], d);
-                    acc[o] = fmaf(g_, av, acc[o]);
+                for (int u = 0; u < 8; ++u) av[u] = (q + 2 * u < nq && c < C) ? a[base + (size_t)(q + 2 * u) * Cp] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int qq = q + 2 * u;
+                    if (qq < nq) {
+                        float d = 0.f;
+#pragma unroll
+                        for (int o = 0; o < CL_O; ++o) {
+                            const float g_ = gs[o][qq];
+                            d = fmaf(g_, wr[o], d);
+                            acc[o] = fmaf(g_, av[u], acc[o]);
+                        }
+                        da[base + (size_t)qq * Cp] = d;
+                    }
                 }
-                da[off] = d;
             }
-        if (threadIdx.x < CL_O) {   // bias gradient: thread o sums its object's gradients of this chunk
-            float t = 0.f;
-            for (int q = 0; q < nq; ++q) t += gs[threadIdx.x][q];
-            gsum += t;
         }
     }
     __syncthreads();
@@ -570,7 +578,19 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
         for (int o = 0; o < CL_O; ++o)
             if (o < O) atomicAdd(dw + (size_t)cls[o] * ldw + c, acc[o] + red[o][c]);
     }
-    if (threadIdx.x < CL_O && threadIdx.x < O && dbias) atomicAdd(dbias + (int)y[b * O + threadIdx.x], gsum);
+    if (dbias) {   // (uniform) bias gradient: wave-level sums of the staging threads' partials, then one atomic per object
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < CL_O; ++o) {
+            float v = gpart[o];
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_down(v, sh, 64);
+            if ((threadIdx.x & 63) == 0) red[o][threadIdx.x >> 6] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < CL_O && (int)threadIdx.x < O)
+            atomicAdd(dbias + cls[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
 }
 
 extern "C" int l2i_class_logits_fwd(const float* a, const float* w, const float* bias, const long long* y, float* lg, int B, int O, int HH,
@@ -587,10 +607,8 @@ extern "C" int l2i_class_logits_bwd(const float* a, const float* w, const long l
                                     int B, int O, int HH, int Cp, int C, int ldw, void* stream) {
     if (!a || !w || !y || !gl || !da || !dw || B <= 0 || O <= 0 || O > CL_O || HH <= 0 || C <= 0 || C > 128 || Cp < C || Cp > 128 || Cp % 4 || ldw < C)
         return L2I_ERR_ARG;
-    int parts = (HH + 255) / 256;
-    if (parts > 16) parts = 16;
-    const int per = ((HH + parts - 1) / parts + 255) / 256 * 256;
-    parts = (HH + per - 1) / per;
+    const int per = HH >= 2048 ? 128 : 256;   // pixels per workgroup (more, shorter workgroups on the large maps: the loop is latency-bound)
+    const int parts = (HH + per - 1) / per;
     hipLaunchKernelGGL(class_logits_bwd_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, a, w, y, gl, da, dw, dbias, O, HH, Cp, C, ldw, per);
     return l2i_check_launch();
 }

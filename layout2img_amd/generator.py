@@ -237,7 +237,7 @@ class ConvMaskHead(nn.ModuleList):
                 m = fused_conv(h, out, pc, prologue=spec, wproj=w, bproj=b, dx_raw=True)   # (h has this one reader: its gradient's operand copy comes out of the norm backward)
                 bn.commit(conv.co_p)
                 return m
-            a = ops.norm_act(h, spec, w, b)
+            a = ops.norm_act(h, spec, w, b, emit_op=pc.arena.op_dtype if pc.arena.op_dtype == torch.bfloat16 and not pc.arena.split else None)
             bn.commit(conv.co_p)
         lg = ops.class_logits(a, ops.arena_weight(out, pc), out.bias, y)
         lg._l2i_planar = True

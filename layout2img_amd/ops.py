@@ -830,11 +830,11 @@ class NormActFn(Function):
     other than a convolution follows (bilinear upsampling in the mask regressor, Dropout2d in PSP)."""
 
     @staticmethod
-    def forward(ctx, x, mask, wproj, bproj, spec):
+    def forward(ctx, x, mask, wproj, bproj, spec, emit_op=None):
         _chk(x, torch.float32)
         sums, sq, count, sstride = _norm_stats(x, spec)
         out, _ = norm_fwd_raw(x, sums, sq, count, sstride, spec, mask, wproj, bproj, torch.float32)
-        ctx.spec, ctx.stats = spec, (sums, sq, count, sstride)
+        ctx.spec, ctx.stats, ctx.emit_op = spec, (sums, sq, count, sstride), emit_op
         ctx.save_for_backward(x, mask, wproj, bproj)
         return out
 
@@ -844,12 +844,14 @@ class NormActFn(Function):
         sums, sq, count, sstride = ctx.stats
         dy = dy.contiguous() if getattr(dy, "_l2i_owned", False) else dy.contiguous().clone()   # (norm_bwd_raw overwrites dy: a gradient nobody else holds needs no copy)
         dx, d_w, d_b, d_mask = norm_bwd_raw(x, dy, sums, sq, count, sstride, ctx.spec, mask, wproj, bproj,
-                                            need_mask_grad=mask is not None and ctx.needs_input_grad[1])
-        return dx, d_mask, d_w, d_b, None
+                                            need_mask_grad=mask is not None and ctx.needs_input_grad[1], emit_op=ctx.emit_op)
+        return dx, d_mask, d_w, d_b, None, None
 
 
-def norm_act(x, spec, wproj=None, bproj=None, mask=None):
-    return NormActFn.apply(x, mask, wproj, bproj, spec)
+def norm_act(x, spec, wproj=None, bproj=None, mask=None, emit_op=None):
+    """emit_op: torch.bfloat16 when x is the result of a fused_conv read by this layer alone: the backward's second pass then also
+    writes the operand copy of dx that conv's backward needs (as fused_conv(dx_raw=True) does for a norm prologue)."""
+    return NormActFn.apply(x, mask, wproj, bproj, spec, emit_op)
 
 
 class GradSink:
