@@ -515,24 +515,28 @@ __global__ __launch_bounds__(256) void class_logits_fwd_kernel(const float* __re
     }
 }
 
-// backward: lanes over CHANNELS (thread = channel c of pixel phase ph), loop over the block's pixels in batches of 8 loads (the first
-// version issued one dependent load per iteration and had 8 threads sum the bias gradient serially: 64 us per launch; this form ~15):
-// a and da rows are read / written contiguously, the 8 gradients of a pixel are LDS broadcasts, a thread keeps its 8 x 1 column of dW in
-// registers; the bias gradient is summed by the threads that stage gl (one pixel each) and reduced once per block.
+// backward: a thread owns FOUR consecutive channels (one float4 of a pixel row: Cp / 4 <= 32 lanes per pixel, PG = 256 / (Cp / 4)
+// pixels per block iteration), loops over the block's pixels with four row loads in flight: a and da move as 16-byte accesses of whole
+// rows, the 8 gradients of a pixel are LDS broadcasts, a thread keeps its 8 x 4 block of dW in registers; the PG partial blocks are
+// combined through LDS and added with one atomic per (class, channel); the bias gradient is summed by the threads that stage gl.
+// (first version: one channel per thread, one dependent 4-byte load per iteration, 8 threads summing the bias serially: 64 us per launch.)
 __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __restrict__ a, const float* __restrict__ w, const long long* __restrict__ y,
                                                                const float* __restrict__ gl, float* __restrict__ da, float* __restrict__ dw,
                                                                float* __restrict__ dbias, int O, int HH, int Cp, int C, int ldw, int per) {
     __shared__ float gs[CL_O][256];
     __shared__ float red[CL_O][128];
-    const int b = blockIdx.x, c = threadIdx.x & 127, ph = threadIdx.x >> 7;
+    const int b = blockIdx.x, L4 = Cp >> 2, PG = 256 / L4;
+    const int c4 = threadIdx.x % L4, pg = threadIdx.x / L4, c = 4 * c4;
+    const bool act = pg < PG;
     const int p0 = blockIdx.y * per, p1 = min(HH, p0 + per);
-    float wr[CL_O], acc[CL_O], gpart[CL_O];
+    float wr[CL_O][4], acc[CL_O][4], gpart[CL_O];
     int cls[CL_O];
 #pragma unroll
     for (int o = 0; o < CL_O; ++o) {
         cls[o] = o < O ? (int)y[b * O + o] : 0;
-        wr[o] = (o < O && c < C) ? w[(size_t)cls[o] * ldw + c] : 0.f;
-        acc[o] = 0.f; gpart[o] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wr[o][k] = (o < O && c + k < C) ? w[(size_t)cls[o] * ldw + c + k] : 0.f; acc[o][k] = 0.f; }
+        gpart[o] = 0.f;
     }
     for (int q0 = p0; q0 < p1; q0 += 256) {
         const int nq = min(256, p1 - q0);
@@ -544,39 +548,47 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
             gpart[o] += v;
         }
         __syncthreads();
-        if (c < Cp) {
-            const size_t base = ((size_t)b * HH + q0) * Cp + c;
-            for (int q = ph; q < nq; q += 16) {
-                float av[8];
+        if (act) {
+            const float4* arow = reinterpret_cast<const float4*>(a + ((size_t)b * HH + q0) * Cp) + c4;
+            float4* drow = reinterpret_cast<float4*>(da + ((size_t)b * HH + q0) * Cp) + c4;
+            for (int q = pg; q < nq; q += 4 * PG) {
+                float4 av[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) av[u] = (q + 2 * u < nq && c < C) ? a[base + (size_t)(q + 2 * u) * Cp] : 0.f;
+                for (int u = 0; u < 4; ++u) av[u] = q + u * PG < nq ? arow[(size_t)(q + u * PG) * L4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int qq = q + 2 * u;
+                for (int u = 0; u < 4; ++u) {
+                    const int qq = q + u * PG;
                     if (qq < nq) {
-                        float d = 0.f;
+                        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                         for (int o = 0; o < CL_O; ++o) {
                             const float g_ = gs[o][qq];
-                            d = fmaf(g_, wr[o], d);
-                            acc[o] = fmaf(g_, av[u], acc[o]);
+                            d.x = fmaf(g_, wr[o][0], d.x); d.y = fmaf(g_, wr[o][1], d.y); d.z = fmaf(g_, wr[o][2], d.z); d.w = fmaf(g_, wr[o][3], d.w);
+                            acc[o][0] = fmaf(g_, av[u].x, acc[o][0]); acc[o][1] = fmaf(g_, av[u].y, acc[o][1]);
+                            acc[o][2] = fmaf(g_, av[u].z, acc[o][2]); acc[o][3] = fmaf(g_, av[u].w, acc[o][3]);
                         }
-                        da[base + (size_t)qq * Cp] = d;
+                        drow[(size_t)qq * L4] = d;
                     }
                 }
             }
         }
     }
+    // combine the PG pixel groups: group after group adds its block into red[o][channel] (Cp <= 128)
     __syncthreads();
-    if (ph == 1) {
+    for (int i = threadIdx.x; i < CL_O * 128; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    for (int g_ = 0; g_ < PG; ++g_) {
+        if (act && pg == g_) {
 #pragma unroll
-        for (int o = 0; o < CL_O; ++o) red[o][c] = acc[o];
+            for (int o = 0; o < CL_O; ++o)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) red[o][c + k] += acc[o][k];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (ph == 0 && c < C) {
-#pragma unroll
-        for (int o = 0; o < CL_O; ++o)
-            if (o < O) atomicAdd(dw + (size_t)cls[o] * ldw + c, acc[o] + red[o][c]);
+    for (int i = threadIdx.x; i < CL_O * 128; i += 256) {
+        const int o = i >> 7, ch = i & 127;
+        if (o < O && ch < C) atomicAdd(dw + (size_t)y[b * O + o] * ldw + ch, red[o][ch]);
     }
     if (dbias) {   // (uniform) bias gradient: wave-level sums of the staging threads' partials, then one atomic per object
         __syncthreads();
@@ -589,7 +601,7 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
         }
         __syncthreads();
         if (threadIdx.x < CL_O && (int)threadIdx.x < O)
-            atomicAdd(dbias + cls[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+            atomicAdd(dbias + y[b * O + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
     }
 }
 
