@@ -283,12 +283,14 @@ int l2i_gram_head_bwd(const float* x, const float* w, const float* s_keep, const
  * result is gather(m, 1, y) (reference model/resnet_generator_app_v2.py:643-651, 465-466), so only the <= 8 channels of the image's own
  * object classes are computed:  lg[b,o,p] = bias[y[b,o]] + sum_c a[b,p,c] w[y[b,o]][c]  (a [B][HH][Cp] f32 NHWC, w [classes][ldw] f32, y [B][O]
  * int64, lg planar [B][O][HH] f32; O <= 8, C <= 128, Cp >= C a multiple of 4). Backward: da[b,p,c] = sum_o gl[b,o,p] w[y_o][c] (every element of
- * da written, pad channels zero); dw[y_o][c] += sum_p gl a; dbias[y_o] += sum_p gl (accumulated with atomics: the caller zeroes them).
+ * da written, pad channels zero); dw[y_o][c] += sum_p gl a; dbias[y_o] += sum_p gl: first per (image, object) into tmp ([B * O][128] f32, ZEROED by the
+ * caller; the padding class 0 is carried by most images, so direct atomics on dw[0][:] serialise), then one workgroup per class (`classes` rows of dw) adds
+ * its slots' rows into dw / dbias without atomics. C <= 126.
  * l2i_stage_mask_fwd / _bwd take such planar logits with Cp = 0 (their gradient is then `gl`, dlogits may be null). */
 int l2i_class_logits_fwd(const float* a, const float* w, const float* bias, const long long* y, float* lg, int B, int O, int HH, int Cp, int C,
                          int ldw, void* stream);
-int l2i_class_logits_bwd(const float* a, const float* w, const long long* y, const float* gl, float* da, float* dw, float* dbias, int B, int O,
-                         int HH, int Cp, int C, int ldw, void* stream);
+int l2i_class_logits_bwd(const float* a, const float* w, const long long* y, const float* gl, float* da, float* dw, float* dbias, float* tmp,
+                         int classes, int B, int O, int HH, int Cp, int C, int ldw, void* stream);
 
 /* Stage-mask blend of the generator (model/resnet_generator_app_v2.py:465-470): per object
  *   out = bilinear(bmask, H) * (1 - a) + sigmoid(logits[..., y]) * nearest(boxm, H) * a,  a = sigmoid(alpha[y]).

@@ -60,7 +60,7 @@ SIGNATURES = {
     "l2i_psp_expand_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "l2i_psp_expand_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "l2i_class_logits_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "l2i_class_logits_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "l2i_class_logits_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "l2i_stage_mask_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "l2i_stage_mask_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "l2i_relu_bwd": [_p, _p, _p, _p, _ll, _p],

@@ -586,11 +586,13 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
         }
         __syncthreads();
     }
+    // per-(image, object) rows of `tmp` ([B * O][128], zeroed by the caller): at most `parts` workgroups add into one address. Adding into
+    // dw[class] directly put every image's padding slots (class 0) on the same 100 addresses: ~3000 same-address atomics = 90 us.
     for (int i = threadIdx.x; i < CL_O * 128; i += 256) {
         const int o = i >> 7, ch = i & 127;
-        if (o < O && ch < C) atomicAdd(dw + (size_t)y[b * O + o] * ldw + ch, red[o][ch]);
+        if (o < O && ch < C) atomicAdd(dw + ((size_t)b * O + o) * 128 + ch, red[o][ch]);
     }
-    if (dbias) {   // (uniform) bias gradient: wave-level sums of the staging threads' partials, then one atomic per object
+    if (dbias) {   // (uniform; column 127 of the row) bias gradient: wave-level sums of the staging threads' partials, one atomic per object
         __syncthreads();
 #pragma unroll
         for (int o = 0; o < CL_O; ++o) {
@@ -601,8 +603,19 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
         }
         __syncthreads();
         if (threadIdx.x < CL_O && (int)threadIdx.x < O)
-            atomicAdd(dbias + y[b * O + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+            atomicAdd(dw + ((size_t)b * O + threadIdx.x) * 128 + 127, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
     }
+}
+
+// second kernel: one workgroup per CLASS gathers the rows of the (image, object) slots that carry it -- no atomics, deterministic
+__global__ __launch_bounds__(128) void class_logits_bwd_finish_kernel(const float* __restrict__ tmp, const long long* __restrict__ y, float* __restrict__ dw,
+                                                                      float* __restrict__ dbias, int BO, int C, int ldw) {
+    const int k = blockIdx.x, c = threadIdx.x;
+    float v = 0.f;
+    for (int r = 0; r < BO; ++r)
+        if ((int)y[r] == k) v += tmp[(size_t)r * 128 + c];
+    if (c < C) dw[(size_t)k * ldw + c] += v;
+    if (c == 127 && dbias) dbias[k] += v;
 }
 
 extern "C" int l2i_class_logits_fwd(const float* a, const float* w, const float* bias, const long long* y, float* lg, int B, int O, int HH,
@@ -614,14 +627,17 @@ extern "C" int l2i_class_logits_fwd(const float* a, const float* w, const float*
     return l2i_check_launch();
 }
 
-// dw [classes][ldw] and dbias [classes] are ACCUMULATED into (atomics): the caller zeroes them.
+// dw [classes][ldw] and dbias [classes] are ADDED to (one workgroup per class, no atomics: deterministic). tmp: [B * O][128] f32 scratch, ZEROED by
+// the caller: the per-(image, object) rows the first kernel accumulates (column 127: the bias gradient).
 extern "C" int l2i_class_logits_bwd(const float* a, const float* w, const long long* y, const float* gl, float* da, float* dw, float* dbias,
-                                    int B, int O, int HH, int Cp, int C, int ldw, void* stream) {
-    if (!a || !w || !y || !gl || !da || !dw || B <= 0 || O <= 0 || O > CL_O || HH <= 0 || C <= 0 || C > 128 || Cp < C || Cp > 128 || Cp % 4 || ldw < C)
+                                    float* tmp, int classes, int B, int O, int HH, int Cp, int C, int ldw, void* stream) {
+    if (!a || !w || !y || !gl || !da || !dw || !tmp || classes <= 0 || B <= 0 || O <= 0 || O > CL_O || HH <= 0 || C <= 0 || C > 126 || Cp < C || Cp > 128 ||
+        Cp % 4 || ldw < C)
         return L2I_ERR_ARG;
     const int per = HH >= 2048 ? 128 : 256;   // pixels per workgroup (more, shorter workgroups on the large maps: the loop is latency-bound)
     const int parts = (HH + per - 1) / per;
-    hipLaunchKernelGGL(class_logits_bwd_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, a, w, y, gl, da, dw, dbias, O, HH, Cp, C, ldw, per);
+    hipLaunchKernelGGL(class_logits_bwd_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, a, w, y, gl, da, tmp, tmp, O, HH, Cp, C, ldw, per);
+    hipLaunchKernelGGL(class_logits_bwd_finish_kernel, dim3(classes), dim3(128), 0, (hipStream_t)stream, (const float*)tmp, y, dw, dbias, B * O, C, ldw);
     return l2i_check_launch();
 }
 
