@@ -610,10 +610,17 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
 // second kernel: one workgroup per CLASS gathers the rows of the (image, object) slots that carry it -- no atomics, deterministic
 __global__ __launch_bounds__(128) void class_logits_bwd_finish_kernel(const float* __restrict__ tmp, const long long* __restrict__ y, float* __restrict__ dw,
                                                                       float* __restrict__ dbias, int BO, int C, int ldw) {
+    __shared__ int ys[1024];
     const int k = blockIdx.x, c = threadIdx.x;
     float v = 0.f;
-    for (int r = 0; r < BO; ++r)
-        if ((int)y[r] == k) v += tmp[(size_t)r * 128 + c];
+    for (int r0 = 0; r0 < BO; r0 += 1024) {   // (the slot classes through LDS: a dependent global load per slot made this loop 35 us)
+        const int n = min(1024, BO - r0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 128) ys[i] = (int)y[r0 + i];
+        __syncthreads();
+        for (int r = 0; r < n; ++r)
+            if (ys[r] == k) v += tmp[(size_t)(r0 + r) * 128 + c];
+    }
     if (c < C) dw[(size_t)k * ldw + c] += v;
     if (c == 127 && dbias) dbias[k] += v;
 }
