@@ -607,22 +607,29 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
     }
 }
 
-// second kernel: one workgroup per CLASS gathers the rows of the (image, object) slots that carry it -- no atomics, deterministic
-__global__ __launch_bounds__(128) void class_logits_bwd_finish_kernel(const float* __restrict__ tmp, const long long* __restrict__ y, float* __restrict__ dw,
-                                                                      float* __restrict__ dbias, int BO, int C, int ldw) {
+// second kernel: one workgroup per CLASS gathers the rows of the (image, object) slots that carry it -- no atomics, fixed summation order.
+// 128 channels x 8 slot phases: the padding class is carried by ~100 slots, and a single thread walking them is 100 dependent loads (36 us measured).
+__global__ __launch_bounds__(1024) void class_logits_bwd_finish_kernel(const float* __restrict__ tmp, const long long* __restrict__ y, float* __restrict__ dw,
+                                                                       float* __restrict__ dbias, int BO, int C, int ldw) {
     __shared__ int ys[1024];
-    const int k = blockIdx.x, c = threadIdx.x;
+    __shared__ float part[8][128];
+    const int k = blockIdx.x, c = threadIdx.x & 127, ph = threadIdx.x >> 7;
     float v = 0.f;
-    for (int r0 = 0; r0 < BO; r0 += 1024) {   // (the slot classes through LDS: a dependent global load per slot made this loop 35 us)
+    for (int r0 = 0; r0 < BO; r0 += 1024) {
         const int n = min(1024, BO - r0);
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 128) ys[i] = (int)y[r0 + i];
+        if ((int)threadIdx.x < n) ys[threadIdx.x] = (int)y[r0 + threadIdx.x];
         __syncthreads();
-        for (int r = 0; r < n; ++r)
+        for (int r = ph; r < n; r += 8)
             if (ys[r] == k) v += tmp[(size_t)(r0 + r) * 128 + c];
     }
-    if (c < C) dw[(size_t)k * ldw + c] += v;
-    if (c == 127 && dbias) dbias[k] += v;
+    part[ph][c] = v;
+    __syncthreads();
+    if (ph == 0) {
+        v = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
+        if (c < C) dw[(size_t)k * ldw + c] += v;
+        if (c == 127 && dbias) dbias[k] += v;
+    }
 }
 
 extern "C" int l2i_class_logits_fwd(const float* a, const float* w, const float* bias, const long long* y, float* lg, int B, int O, int HH,
@@ -644,7 +651,7 @@ extern "C" int l2i_class_logits_bwd(const float* a, const float* w, const long l
     const int per = HH >= 2048 ? 128 : 256;   // pixels per workgroup (more, shorter workgroups on the large maps: the loop is latency-bound)
     const int parts = (HH + per - 1) / per;
     hipLaunchKernelGGL(class_logits_bwd_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, a, w, y, gl, da, tmp, tmp, O, HH, Cp, C, ldw, per);
-    hipLaunchKernelGGL(class_logits_bwd_finish_kernel, dim3(classes), dim3(128), 0, (hipStream_t)stream, (const float*)tmp, y, dw, dbias, B * O, C, ldw);
+    hipLaunchKernelGGL(class_logits_bwd_finish_kernel, dim3(classes), dim3(1024), 0, (hipStream_t)stream, (const float*)tmp, y, dw, dbias, B * O, C, ldw);
     return l2i_check_launch();
 }
 
