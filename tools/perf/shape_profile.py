@@ -44,6 +44,8 @@ def run(path, steps=3):
             calls.append(("fwd",) + tuple(a[9:20]) + (a[22] is not None,))
         elif name in ("l2i_conv2d_fwd_sc", "l2i_conv2d_fwd_dual"):   # 3x3 conv with a block's 1x1 shortcut handed over (folded, or un-folded by the library)
             calls.append(("fwd",) + tuple(a[9:20]) + ((a[22] is not None, int(a[31])) if a[25] is not None else (a[22] is not None,)))
+        elif name == "l2i_conv2d_dgrad_sc":   # conv1's data gradient of a D block with the shortcut's data gradient folded in (or un-folded by the library)
+            calls.append(("fwd", a[6], a[7], a[8], a[9], a[7], a[8], a[10], 3, 0, 0, 0, a[13] is not None, int(a[19])))
         elif name == "l2i_conv2d_wgrad":
             calls.append(("wgr",) + tuple(a[4:14]) + (0, a[16] is not None))
         elif name in ("l2i_conv2d_wgrad_sc", "l2i_conv2d_wgrad_dual"):   # conv2's weight gradient carrying the shortcut's (one launch; assumed folded)
