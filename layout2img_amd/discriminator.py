@@ -133,6 +133,8 @@ class ResnetDiscriminator128_app(nn.Module):
         obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0)  # (R,8,8,C)
 
         # appearance head (reference :148-157): Gram of the ROI features + class embedding
+        if not pc.arena.split:   # both operand copies of the ROI features in ONE launch: app_conv's conv1 reads relu(obj), block_obj5 relu(obj) and obj
+            ops.precast(obj, pc.arena.op_dtype)
         a = self.app_conv(obj, pc, nimg=nimg)                             # (R, 8, 8, C) pre-ReLU
         s2 = a.shape[3]
         # projection head (reference :160-166): l_obj(f) + sum(l_y(y) * f), f = sum_hw relu(block_obj5(obj))

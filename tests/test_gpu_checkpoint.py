@@ -218,3 +218,34 @@ def test_eval_pass_cache_and_graph_sampler_follow_parameter_updates():
     g.load_state_dict(sd)
     check("after load_state_dict")
     assert len(s._graphs) == 1   # never re-captured
+
+
+def test_three_graph_replays_equal_three_eager_iterations():
+    """The whole-iteration graph against the eager path over SEVERAL consecutive replays (round 5: replays after the first used to accumulate
+    split-K results onto uncleared buffers -- `hipMemsetAsync` nodes in front of atomics -- which a one-replay comparison cannot see): from one
+    snapshot, three replays and three eager iterations on the same batches and latents leave the parameters, the Adam moments and the last
+    losses equal up to the order of the atomically reduced sums (bars of test_multi_iteration_graph_equals_single_replays)."""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_batch
+    from layout2img_amd.trainer import restore_state, snapshot_state
+    g, d = _nets(7)
+    tr = L.GanTrainer(g, d)
+    batches = [make_batch(4, 64, "coco", seed=31 + i, device=DEV) for i in range(3)]
+    st = snapshot_state(tr)
+    assert tr.capture(*batches[0])
+    restore_state(tr, st)
+    for b in batches:
+        r_g = tr.step_graphed(*b)
+    torch.cuda.synchronize()
+    graph = (g.flat.data.clone(), d.flat.data.clone(), tr.g_opt.m.clone(), tr.d_opt.v.clone(), float(r_g["d_loss"]), float(r_g["g_loss"]))
+    restore_state(tr, st)
+    for b in batches:
+        r_e = tr.step(*b)
+    tr.flush()
+    torch.cuda.synchronize()
+    for a, b_ in ((g.flat.data, graph[0]), (d.flat.data, graph[1])):
+        close = ((a - b_).abs() < 2.5e-4).float().mean()
+        assert float(close) > 0.98, float(close)
+        assert float((a - b_).abs().max()) < 2e-3
+    assert float((tr.g_opt.m - graph[2]).norm() / graph[2].norm()) < 5e-2 and float((tr.d_opt.v - graph[3]).norm() / graph[3].norm()) < 5e-2
+    assert abs(float(r_e["d_loss"]) - graph[4]) < 2e-3 * abs(graph[4]) + 1e-4 and abs(float(r_e["g_loss"]) - graph[5]) < 5e-3 * abs(graph[5]) + 1e-3
