@@ -187,3 +187,33 @@ def test_two_reader_joins_never_drop_a_gradient(heads, monkeypatch):
         assert float(named["obD.block1.conv1.weight_orig"].grad.norm()) > 0 and float(named["obD.block3.conv1.weight_orig"].grad.norm()) > 0
     rel = float((a - b).norm() / b.norm())
     assert rel < 2e-4, rel   # (accumulation order only: f32 operands)
+
+
+@pytest.mark.parametrize("variant", ["eager", "graph", "dual", "real_bwd_early"])
+def test_training_step_with_nan_poisoned_weight_gradient_accumulators(variant, monkeypatch):
+    """The dW-bar accumulators of a pass are torch.empty: a convolution's slice is valid only because exactly one weight-gradient launch STORES
+    it (ops.WGRAD_OVERWRITE) or flush_grads clears it (arena.PassCtx.clear_unwritten). L2I_DW_NAN=1 fills the fresh accumulator with NaN, so a
+    slice that is neither stored nor cleared -- a new fused op writing outside FusedConvFn.backward, a pass context reused for two forwards --
+    poisons the parameters: two full trainer iterations in every launch variant must leave both networks finite."""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_batch
+    monkeypatch.setenv("L2I_DW_NAN", "1")
+    torch.manual_seed(0)
+    g = L.ResnetGenerator128_context(num_classes=184).finalize(DEV, torch.bfloat16)
+    d = L.CombineDiscriminator128_app(num_classes=184).finalize(DEV, torch.bfloat16)
+    tr = L.GanTrainer(g, d)
+    tr.dual_d = variant == "dual"
+    tr.real_bwd_early = variant == "real_bwd_early"
+    batch = make_batch(4, 128, "coco", seed=3, device=torch.device(DEV))
+    if variant == "graph":
+        assert tr.capture(*batch)
+        for _ in range(2):
+            r = tr.step_graphed(*batch)
+    else:
+        for _ in range(2):
+            r = tr.step(*batch)
+    tr.flush()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g.flat.data).all()) and bool(torch.isfinite(d.flat.data).all())
+    assert bool(torch.isfinite(r["d_loss"])) and bool(torch.isfinite(r["g_loss"]))
+    assert float((g.flat.grad != 0).float().mean()) > 0.5 and float((d.flat.grad != 0).float().mean()) > 0.5
