@@ -870,11 +870,19 @@ __global__ __launch_bounds__(256) void norm_mod8_kernel(NormArgs p) {
     __syncthreads();
     T* OutOp = reinterpret_cast<T*>(p.out_op);
     const int npx = min(PT, p.HW - p0);
-#pragma unroll 2
-    for (int pl = prow; pl < npx; pl += ROWS) {
-        if (!con) continue;
+    // four row loads in flight per thread (round 5: the loop was two loads deep and ran at 0.51 of the HBM rate)
+    if (con)
+    for (int pl0 = prow; pl0 < npx; pl0 += 4 * ROWS) {
+      float4 xq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+          xq[u] = pl0 + u * ROWS < npx ? *reinterpret_cast<const float4*>(p.x + ((size_t)b * p.HW + p0 + pl0 + u * ROWS) * p.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pl = pl0 + u * ROWS;
+        if (pl >= npx) break;
         const size_t off = ((size_t)b * p.HW + p0 + pl) * p.C + c;
-        const float4 xv = *reinterpret_cast<const float4*>(p.x + off);
+        const float4 xv = xq[u];
         const float4 xh = make_float4((xv.x - mean.x) * istd.x, (xv.y - mean.y) * istd.y, (xv.z - mean.z) * istd.z, (xv.w - mean.w) * istd.w);
         float4 ga = ga0, be = be0;
         if (p.mode == 0) {
@@ -901,6 +909,7 @@ __global__ __launch_bounds__(256) void norm_mod8_kernel(NormArgs p) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(OutOp) + off) = y;
             }
         }
+      }
     }
 }
 
