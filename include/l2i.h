@@ -202,12 +202,17 @@ int l2i_norm_mod_fwd(const float* x, int B, int HW, int C, const float* sums, co
  *  r = (1 - momentum) r + momentum * {mean, unbiased var}, done by the same launch.) */
 
 /* Backward, first pass: dxhat = dy*[y>0]*gamma (may alias dy); s1 += sum dxhat, s2 += sum dxhat*xhat;
- * dwproj/dbproj += ; dmask += (all pre-zeroed by the caller). dy_keep: scratch of dy's size, needed when O > 8. */
+ * dwproj/dbproj += ; dmask += (all pre-zeroed by the caller). dy_keep: scratch of dy's size, needed when O > 8.
+ * part / part_floats (optional, mode 0 with O <= 8): scratch the workgroups park their partial dwproj / dbproj rows in (at
+ * most 512 workgroups x 16 x 128 floats = 4 MiB; contents need not be initialised); a second small launch on the same
+ * stream (the one that folds ws) adds them into dwproj / dbproj. Without it: atomics from every workgroup.
+ * dmask_fresh = 1: dmask is uninitialised memory and receives the result (= instead of +=; it is written with plain stores
+ * where one workgroup owns a pixel's mask gradient, cleared by the library first otherwise). */
 int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW, int C, const float* sums, const float* sqsums,
                        float count, float eps, int stat_stride, const float* mask, int O, const float* wproj,
                        const float* bproj, long long pstride_b, long long pstride_o, int mode, int relu, float* dxhat,
                        float* s1, float* s2, float* dwproj, float* dbproj, float* dmask, float* dy_keep, float* ws,
-                       void* stream);
+                       float* part, long long part_floats, int dmask_fresh, void* stream);
 
 /* Backward, second pass: dx (+)= invstd * (dxhat - s1/count - xhat*s2/count).
  * dx_op_bf16 (optional, [rows][C] bf16): also receives the bf16 operand copy of the final dx -- what the backward of the

@@ -102,8 +102,8 @@ __device__ __forceinline__ float* ws_replica(float* ws, int r, int L) { return w
 
 // value i = row k (= i / C) x channel: added to dst[k][i % C]
 struct WsFoldArgs { float* ws; float* dst[4]; int L, C; };
-static __global__ __launch_bounds__(256) void ws_fold_kernel(WsFoldArgs p) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ws_fold_body(const WsFoldArgs& p, int block) {
+    const int i = block * 256 + threadIdx.x;
     if (i >= p.L) return;
     float* q = p.ws + i;
     float v[L2I_WS_R];
@@ -116,6 +116,7 @@ static __global__ __launch_bounds__(256) void ws_fold_kernel(WsFoldArgs p) {
     float* d = p.dst[k];
     if (d) atomicAdd(d + (i - k * p.C), t);   // (atomic: two passes of one network may fold into the same gradient from two streams)
 }
+static __global__ __launch_bounds__(256) void ws_fold_kernel(WsFoldArgs p) { ws_fold_body(p, blockIdx.x); }
 static inline void ws_fold(float* ws, int L, int C, float* d0, float* d1, float* d2, float* d3, hipStream_t stream) {
     WsFoldArgs a;
     a.ws = ws; a.dst[0] = d0; a.dst[1] = d1; a.dst[2] = d2; a.dst[3] = d3; a.L = L; a.C = C;

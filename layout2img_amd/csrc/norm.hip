@@ -131,10 +131,12 @@ struct NormArgs {
     float* s1; float* s2;  // bwd: [G][C]
     float* dwproj; float* dbproj; float* dmask;
     float* ws;             // bwd: replicated workspace for the per-channel totals (common.h) or null
+    float* part;           // bwd, <= 8 objects: per-workgroup partial dW / dB rows, summed by norm_a8_finish_kernel (no atomics) -- or null
     float* run_mean; float* run_var; float momentum;   // fwd, train mode: running statistics updated in the same launch (or null)
     long long pstride_b, pstride_o;
     int B, HW, C, O, mode, relu, stat_stride;
     float count, eps;
+    int dmask_store;       // bwd, <= 8 objects, C within one channel chunk: dmask = (plain stores) instead of += (atomics)
 };
 
 __device__ __forceinline__ float4 f4mad(float a, float4 b, float4 c) {
@@ -750,12 +752,49 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_a8_kernel(NormArgs p, int nse
                 const float t0 = ma.x * partl[0 * NB_PX + pl] + ma.y * partl[1 * NB_PX + pl] + ma.z * partl[2 * NB_PX + pl] +
                                  ma.w * partl[3 * NB_PX + pl] + mb.x * partl[4 * NB_PX + pl] + mb.y * partl[5 * NB_PX + pl] +
                                  mb.z * partl[6 * NB_PX + pl] + mb.w * partl[7 * NB_PX + pl];
-                atomicAdd(p.dmask + ((size_t)b * O + o) * p.HW + px, (partl[i] - t0) * sinv[pl]);
+                float* dm = p.dmask + ((size_t)b * O + o) * p.HW + px;
+                const float v = (partl[i] - t0) * sinv[pl];
+                if (p.dmask_store) *dm = v;   // one channel chunk: this thread is the only writer (4 M atomics of the 128^2 layer = 10 us)
+                else atomicAdd(dm, v);
             }
         }
     }
 
-    // ---- per-object gradients: sum the PR pixel-row partials through LDS (dW, then dB), one atomic per value per workgroup
+    // ---- per-object gradients: sum the PR pixel-row partials through LDS (dW, then dB). With p.part the workgroup's 2 x 8 x CC
+    // sums go to its own rows of `part` with plain stores and norm_a8_finish_kernel, the launch behind this one, adds the nseg
+    // partial rows of an (image, channel chunk) into dW / dB: 2048 atomics per workgroup (1 M per launch) cost 5-11 us of a
+    // 18-57 us launch (tools/perf/norm_shapes.py, round 5; a last-arriver sum inside this kernel needs an agent-scope release
+    // per workgroup: 26 -> 71 us). One segment per image: plain read-modify-write here. Without p.part: atomics.
+    if (p.part) {
+        float4* mine = reinterpret_cast<float4*>(p.part) + ((size_t)(b * tiles_c + tc) * nseg + seg) * (2 * 8 * CV);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+#pragma unroll
+            for (int o = 0; o < 8; ++o) red[(prow * 8 + o) * CV + cv] = pass == 0 ? adw[o] : adb[o];
+            __syncthreads();
+            if (tid < 8 * CV) {   // 8 objects x CV float4 values per pass
+                const int i = tid;
+                const int o = i / CV, lc = i - o * CV;
+                float4 a = red[o * CV + lc];
+#pragma unroll
+                for (int r = 1; r < PR; ++r) {
+                    const float4 t = red[(r * 8 + o) * CV + lc];
+                    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+                }
+                if (nseg == 1) {
+                    if (o < O && 4 * lc < cc) {
+                        float4* dst = reinterpret_cast<float4*>((pass == 0 ? p.dwproj : p.dbproj) + (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + c0 + 4 * lc);
+                        float4 d = *dst;
+                        d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+                        *dst = d;
+                    }
+                } else {
+                    mine[pass * 8 * CV + i] = a;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
@@ -773,6 +812,7 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_a8_kernel(NormArgs p, int nse
             float* dst = (pass == 0 ? p.dwproj : p.dbproj) + (size_t)b * p.pstride_b + (size_t)o * p.pstride_o + c0 + 4 * lc;
             atomicAdd(dst + 0, a.x); atomicAdd(dst + 1, a.y); atomicAdd(dst + 2, a.z); atomicAdd(dst + 3, a.w);
         }
+    }
     }
     // ---- per-channel sums s1, s2
     __syncthreads();
@@ -793,6 +833,34 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_a8_kernel(NormArgs p, int nse
         else dst = (k == 0 ? p.s1 : p.s2) + (size_t)b * p.stat_stride + cch;
         atomicAdd(dst + 0, a.x); atomicAdd(dst + 1, a.y); atomicAdd(dst + 2, a.z); atomicAdd(dst + 3, a.w);
     }
+}
+
+// Behind norm_bwd_a8_kernel on the same stream: blocks [0, nfold) fold the replicated s1 / s2 workspace (ws_fold_kernel's job),
+// the others add the nseg partial dW / dB rows of every (image, channel chunk) into dwproj / dbproj (float4 per thread).
+__global__ __launch_bounds__(256) void norm_a8_finish_kernel(WsFoldArgs f, int nfold, const float4* __restrict__ part, float* dw, float* db,
+                                                             int B, int tiles_c, int nseg, int CV, int C, int O, long long psb, long long pso) {
+    if ((int)blockIdx.x < nfold) { ws_fold_body(f, blockIdx.x); return; }
+    const int idx = (blockIdx.x - nfold) * 256 + threadIdx.x;
+    const int row = 16 * CV;   // float4 values per partial row: [2 passes][8 objects][CV]
+    const int r = idx % row, bt = idx / row;
+    if (bt >= B * tiles_c) return;
+    const int lc = r % CV, o = (r / CV) % 8, pass = r / (8 * CV);
+    const int tc = bt % tiles_c, b = bt / tiles_c;
+    const int c = tc * 4 * CV + 4 * lc;
+    if (o >= O || c >= C) return;
+    const float4* src = part + (size_t)bt * nseg * row + r;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < nseg; s0 += 8) {   // eight partial rows in flight
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = s0 + u < nseg ? src[(size_t)(s0 + u) * row] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w; }
+    }
+    float4* dst = reinterpret_cast<float4*>((pass == 0 ? dw : db) + (size_t)b * psb + (size_t)o * pso + c);
+    float4 d = *dst;
+    d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+    *dst = d;
 }
 
 static size_t norm_bwd_lds(const NormArgs& a) {
@@ -963,7 +1031,7 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
                                   const float* sqsums, float count, float eps, int stat_stride, const float* mask, int O,
                                   const float* wproj, const float* bproj, long long pstride_b, long long pstride_o,
                                   int mode, int relu, float* dxhat, float* s1, float* s2, float* dwproj, float* dbproj,
-                                  float* dmask, float* dy_keep, float* ws, void* stream) {
+                                  float* dmask, float* dy_keep, float* ws, float* part, long long part_floats, int dmask_fresh, void* stream) {
     NormArgs a = {};
     a.x = x; a.dy = dy; a.B = B; a.HW = HW; a.C = C; a.sums = sums; a.sqsums = sqsums; a.count = count; a.eps = eps;
     a.stat_stride = stat_stride; a.mask = mask; a.O = O; a.wproj = wproj; a.bproj = bproj;
@@ -984,13 +1052,29 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
     const int seg_pixels = ((subtiles + nseg - 1) / nseg) * NB_PX;
     nseg = (HW + seg_pixels - 1) / seg_pixels;
     a.ws = (stat_stride == 0 && B * nseg > 32) ? ws : nullptr;   // batch statistics shared by many workgroups
+    // <= 8 objects: dW / dB through per-workgroup partial rows (16 x 64 or 16 x 128 floats each) when the caller lends scratch
+    const bool vec_ok = mode == 0 && dwproj && dbproj && ((uintptr_t)dwproj % 16 == 0) && ((uintptr_t)dbproj % 16 == 0) && pstride_b % 4 == 0 && pstride_o % 4 == 0;
+    int fin_ns = 0, fin_tc = 0, fin_cv = 0;
+    auto lend = [&](int ns, int tc, int cc) {
+        a.part = nullptr;
+        static const bool off = getenv("L2I_NORM_PART") && atoi(getenv("L2I_NORM_PART")) == 0;
+        if (off || !vec_ok || !part) return;
+        if (ns > 1 && (long long)B * tc * ns * 16 * cc > part_floats) return;
+        a.part = part;
+        if (ns > 1) { fin_ns = ns; fin_tc = tc; fin_cv = cc / 4; }
+    };
     static bool ready = false;
     if (!ready) {   // up to 31 objects: ~72 KB of dynamic LDS
         (void)hipFuncSetAttribute((const void*)norm_bwd_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         ready = true;
     }
     static const bool no_a8 = getenv("L2I_NORM_A8") && atoi(getenv("L2I_NORM_A8")) == 0;   // tuning: the LDS version for every layer
-    if (mode == 0 && O <= 8 && !no_a8) {   // COCO layouts: the register-resident version
+    const bool a8 = mode == 0 && O <= 8 && !no_a8;
+    if (dmask && dmask_fresh) {   // the caller's dmask is uninitialised: overwrite it where one workgroup owns a pixel, else clear it first
+        if (a8 && C <= NM_CC) a.dmask_store = 1;
+        else if (l2i_zero_async(dmask, sizeof(float) * (size_t)B * O * HW, (hipStream_t)stream) != hipSuccess) return L2I_ERR_LAUNCH;
+    }
+    if (a8) {   // COCO layouts: the register-resident version
         const size_t lds8 = sizeof(float) * (8 * NB_PX + NB_PX + 8 * NB_PX) + 32 * 1024 + 16;
         if (C <= 64) {
             const int t64 = (C + 63) / 64;
@@ -1000,14 +1084,23 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
             const int sp = ((subtiles + ns - 1) / ns) * NB_PX;
             ns = (HW + sp - 1) / sp;
             a.ws = (stat_stride == 0 && B * ns > 32) ? ws : nullptr;
+            lend(ns, t64, 64);
             hipLaunchKernelGGL(norm_bwd_a8_kernel<16>, dim3(B * ns * t64), dim3(256), lds8, (hipStream_t)stream, a, ns, sp);
         } else {
+            lend(nseg, tiles_c, 128);
             hipLaunchKernelGGL(norm_bwd_a8_kernel<32>, dim3(B * nseg * tiles_c), dim3(256), lds8, (hipStream_t)stream, a, nseg, seg_pixels);
         }
     } else
     hipLaunchKernelGGL(norm_bwd_a_kernel, dim3(B * nseg * tiles_c), dim3(256), norm_bwd_lds(a), (hipStream_t)stream, a, nseg,
                        seg_pixels);
-    if (a.ws) ws_fold(a.ws, (mode == 1 ? 4 : 2) * C, C, s1, s2, dwproj, dbproj, (hipStream_t)stream);
+    if (fin_ns) {   // one launch: the workspace fold (if any) and the sum of the partial rows
+        WsFoldArgs f = {};
+        f.ws = a.ws; f.dst[0] = s1; f.dst[1] = s2; f.L = 2 * C; f.C = C;
+        const int nfold = a.ws ? (2 * C + 255) / 256 : 0;
+        const int nfin = (int)(((long long)B * fin_tc * 16 * fin_cv + 255) / 256);
+        hipLaunchKernelGGL(norm_a8_finish_kernel, dim3(nfold + nfin), dim3(256), 0, (hipStream_t)stream, f, nfold, (const float4*)part, dwproj,
+                           dbproj, B, fin_tc, fin_ns, fin_cv, C, O, pstride_b, pstride_o);
+    } else if (a.ws) ws_fold(a.ws, (mode == 1 ? 4 : 2) * C, C, s1, s2, dwproj, dbproj, (hipStream_t)stream);
     return l2i_check_launch();
 }
 

@@ -465,14 +465,15 @@ def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, 
                 wproj, bproj = wproj.contiguous(), bproj.contiguous()
                 psb, pso = O * C, C
             dw, db = _zeros(wproj.shape, dev), _zeros(bproj.shape, dev)
-        dm = torch.zeros_like(mask) if need_mask_grad else None
+        dm = torch.empty_like(mask) if need_mask_grad else None   # (dmask_fresh: written, or cleared first, by the launch)
     elif spec.mode == 1:
         dw, db = _zeros(wproj.shape, dev), _zeros(bproj.shape, dev)
     keep = None
+    part, npart = _lib.wgrad_scratch(dev) if (spec.mode == 0 and O <= 8) else (None, 0)   # partial dW / dB rows (no atomics)
     _lib.call("l2i_norm_mod_bwd_a", x.data_ptr(), dy.data_ptr(), B, H * W, C, sums.data_ptr(), sq.data_ptr(), float(count),
               float(spec.eps), stat_stride, _p(mask), O, _p(wproj), _p(bproj), psb, pso, spec.mode, int(spec.relu),
               dy.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(dw), _p(db), _p(dm), _p(keep),
-              _ws(dev) if C <= 1024 else None, _stream())
+              _ws(dev) if C <= 1024 else None, part, npart, 1, _stream())
     frozen = (not spec.training) and spec.running is not None and not spec.instance
     if frozen:
         raise RuntimeError("backward through eval-mode batch norm is not part of the hot path")

@@ -765,6 +765,36 @@ def test_hinge_l1_adam():
     assert float((flat.data.cpu() - pr.detach()).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("case", [(32, 4, 1024, 8), (4, 16, 256, 8), (2, 32, 128, 7), (2, 32, 64, 8), (3, 8, 136, 5), (1, 64, 64, 8), (40, 8, 256, 3)])
+def test_isla_backward_register_resident_shapes(case):
+    """ISLA norm + ReLU with at most 8 objects (norm_bwd_a8_kernel): projection gradients through per-workgroup partial rows and
+    the last-arriver sum (one pixel segment per image: plain read-modify-write; several: partials + arrival counter), mask
+    gradient without atomics when one channel chunk covers C -- against torch autograd on the reference formula
+    (model/norm_module.py:163-186). Run twice on the same scratch: the counters are left all-zero."""
+    from layout2img_amd import ops
+    B, H, C, O_ = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, H, H, C, generator=g) * 1.5 + 0.3
+    mask = torch.rand(B, O_, H, H, generator=g) * (torch.rand(B, O_, H, H, generator=g) > 0.3)
+    wproj, bproj = torch.randn(B, O_, C, generator=g) * 0.3, torch.randn(B, O_, C, generator=g) * 0.3
+    go = torch.randn(B, H, H, C, generator=g)
+    xr, mr, wr, br = [t.clone().requires_grad_(True) for t in (x, mask, wproj, bproj)]
+    xh = F.batch_norm(xr.permute(0, 3, 1, 2), None, None, None, None, True, 0.1, 1e-5)
+    den = mr.sum(1, keepdim=True) + 1e-6
+    ref = F.relu((torch.einsum("bohw,boc->bchw", mr, wr) / den + 1) * xh + torch.einsum("bohw,boc->bchw", mr, br) / den).permute(0, 2, 3, 1)
+    ref.backward(go)
+    dev = _dev()
+    for rep in range(2):
+        xg, mg, wg, bg = [t.to(dev).requires_grad_(True) for t in (x, mask, wproj, bproj)]
+        out = ops.norm_act(xg, ops.NormSpec(0), wg, bg, mask=mg)
+        out.backward(go.to(dev))
+        torch.cuda.synchronize()
+        assert float((out.detach().cpu() - ref.detach()).abs().max()) < 5e-5
+        for a_, b_, name in ((xg, xr, "dx"), (mg, mr, "dmask"), (wg, wr, "dwproj"), (bg, br, "dbproj")):
+            d, sc = float((a_.grad.cpu() - b_.grad).abs().max()), float(b_.grad.abs().max())
+            assert d < 2e-4 * sc, (name, rep, d, sc)
+
+
 def test_norm_act_standalone():
     from layout2img_amd import ops
     g = torch.Generator().manual_seed(8)
