@@ -336,15 +336,18 @@ int l2i_emb_dot_bwd(const void* emb, int emb_stride, const long long* y, const v
  *   x-bin of each stage (device array)
  *  pool_fwd:   pooled[b,k,c] = sum_{y,x} wy[k,y] wx[xq[k],x] feats[b,y,x,c]     feats [B][H][H][C] f32, pooled [B][NB][C];
  *              rows: scratch [B][H][NQ][C] f32
- *  pool_bwd:   dfeats[b,p,c] = add[b,p,c] + sum_t aw[p,t] dpooled[b,aidx[p,t],c]            (add may be NULL)
+ *  pool_bwd:   dfeats[b,p,c] = add[b,p,c] + add2[b,p,c] + cat[b,p,cat_off+c] + sum_t aw[p,t] dpooled[b,aidx[p,t],c]
+ *              add, add2 (f32 [B][HW][C]) and cat (rows of cat_w elements of cat_dtype: the gradient of expand_fwd's result, read
+ *              in place instead of expand_bwd's dfeats copy) may each be NULL; dfeats_op (optional): bf16 copy of dfeats
  *  expand_fwd: cat[b,p,:] = [sum_t uw[p,s,t] y[b,uidx[p,s,t],:] for s] ++ feats[b,p,:]     y [B][NB][F], cat [B][HW][NS*F+C]
  *              of `dtype`
  *  expand_bwd: g = d cat (dtype) -> dy[b,k,j] = sum_{y,x} wy[k,y] wx[xq[k],x] g[b,y,x,s(k)*F+j], dfeats [B][HW][C] =
- *              g[..., NS*F:]; rows: scratch [B][H][NQ][F] f32 */
+ *              g[..., NS*F:] (NULL: not written); rows: scratch [B][H][NQ][F] f32 */
 int l2i_psp_pool_fwd(const float* feats, const float* wx, const float* wy, const int* xq, float* pooled, float* rows, int B, int H,
                      int C, int NB, int NQ, void* stream);
-int l2i_psp_pool_bwd(const float* dpooled, const int* aidx, const float* aw, int TA, const float* add, float* dfeats, int B,
-                     int HW, int C, int NB, void* stream);
+int l2i_psp_pool_bwd(const float* dpooled, const int* aidx, const float* aw, int TA, const float* add, const float* add2,
+                     const void* cat, int cat_w, int cat_off, int cat_dtype, float* dfeats, void* dfeats_op, int B, int HW, int C,
+                     int NB, void* stream);
 int l2i_psp_expand_fwd(const float* feats, const float* y, const int* uidx, const float* uw, void* cat, int B, int HW, int C,
                        int F, int NB, int n_stages, int dtype, void* stream);
 int l2i_psp_expand_bwd(const void* g, const float* wx, const float* wy, const int* xq, const int* qoff, float* dy, float* dfeats,

@@ -56,7 +56,7 @@ SIGNATURES = {
     "l2i_emb_dot_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "l2i_emb_dot_bwd": [_p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p],
     "l2i_psp_pool_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "l2i_psp_pool_bwd": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p],
+    "l2i_psp_pool_bwd": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "l2i_psp_expand_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "l2i_psp_expand_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "l2i_class_logits_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

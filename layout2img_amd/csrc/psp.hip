@@ -91,11 +91,15 @@ __global__ __launch_bounds__(256) void psp_rows_reduce_kernel(const float* __res
     out[(size_t)b * NB * D + i] = acc;
 }
 
-// ---------------------------------------------------------------- dfeats[b,p,c] = add[b,p,c] + sum_t aw[p,t] dpooled[b, aidx[p,t], c]
-template <int TA>
+// ---------------------------------------------------------------- dfeats[b,p,c] = add[b,p,c] + add2[b,p,c] + cat[b,p,off+c] + sum_t aw[p,t] dpooled[b, aidx[p,t], c]
+// add / add2: f32 gradients other readers of feats left for this launch (either may be null); cat: the gradient of the concat
+// tensor (T_, rows of `cat_w` elements), whose last C columns are the concat branch's part of dfeats -- read here instead of
+// being copied out to an f32 tensor first. dop (optional): bf16 operand copy of the result.
+template <int TA, typename T_>
 __global__ __launch_bounds__(256) void psp_pool_bwd_kernel(const float* __restrict__ dpooled, const int* __restrict__ aidx,
                                                            const float* __restrict__ aw, const float* __restrict__ add,
-                                                           float* __restrict__ dfeats, int HW, int C, int NB) {
+                                                           const float* __restrict__ add2, const T_* __restrict__ cat, int cat_w, int cat_off,
+                                                           float* __restrict__ dfeats, bf16_t* __restrict__ dop, int HW, int C, int NB) {
     extern __shared__ float sm[];                     // dP [NB][C] | taps [PSP_CH][TA]
     float* dP = sm;
     int2* taps = reinterpret_cast<int2*>(sm + NB * C);
@@ -108,6 +112,15 @@ __global__ __launch_bounds__(256) void psp_pool_bwd_kernel(const float* __restri
         const int pl = t0 / c4n, cq = t0 - pl * c4n;
         const size_t o = ((size_t)b * HW + p0 + pl) * C + 4 * cq;
         float4 acc = add ? *reinterpret_cast<const float4*>(add + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (add2) {
+            const float4 a2 = *reinterpret_cast<const float4*>(add2 + o);
+            acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w;
+        }
+        if (cat) {
+            float v[4];
+            Op4<T_>::load(cat + ((size_t)b * HW + p0 + pl) * cat_w + cat_off + 4 * cq, v);
+            acc.x += v[0]; acc.y += v[1]; acc.z += v[2]; acc.w += v[3];
+        }
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
             const int2 tp = taps[pl * TA + t];
@@ -116,6 +129,10 @@ __global__ __launch_bounds__(256) void psp_pool_bwd_kernel(const float* __restri
             acc.x = fmaf(w, d.x, acc.x); acc.y = fmaf(w, d.y, acc.y); acc.z = fmaf(w, d.z, acc.z); acc.w = fmaf(w, d.w, acc.w);
         }
         *reinterpret_cast<float4*>(dfeats + o) = acc;
+        if (dop) {
+            const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+            Op4<bf16_t>::store(dop + o, v);
+        }
     }
 }
 
@@ -192,6 +209,7 @@ __global__ __launch_bounds__(256) void psp_expand_rows_kernel(const T_* __restri
         }
     }
     const int c4n = C >> 2;
+    if (dfeats)   // (null: l2i_psp_pool_bwd reads these columns of g itself)
     for (int t = threadIdx.x; t < W * c4n; t += 256) {
         const int x = t / c4n, c = 4 * (t - x * c4n);
         float v[4];
@@ -216,18 +234,21 @@ extern "C" int l2i_psp_pool_fwd(const float* feats, const float* wx, const float
     return l2i_check_launch();
 }
 
-extern "C" int l2i_psp_pool_bwd(const float* dpooled, const int* aidx, const float* aw, int TA, const float* add, float* dfeats,
-                                int B, int HW, int C, int NB, void* stream) {
+extern "C" int l2i_psp_pool_bwd(const float* dpooled, const int* aidx, const float* aw, int TA, const float* add, const float* add2,
+                                const void* cat, int cat_w, int cat_off, int cat_dtype, float* dfeats, void* dfeats_op, int B, int HW, int C,
+                                int NB, void* stream) {
     if (!dpooled || !aidx || !aw || !dfeats || !psp_ok(B, HW, C, 0, NB)) return L2I_ERR_ARG;
+    if (cat && (cat_w < cat_off + C || cat_off % 4 || cat_w % 4 || (cat_dtype != 0 && cat_dtype != 1))) return L2I_ERR_ARG;
     const size_t lds = sizeof(float) * (size_t)NB * C + sizeof(int2) * (size_t)PSP_CH * TA;
     if (lds > 64 * 1024) return L2I_ERR_ARG;
     const dim3 grid(HW / PSP_CH, B);
-    if (TA == 12)
-        hipLaunchKernelGGL(psp_pool_bwd_kernel<12>, grid, dim3(256), lds, (hipStream_t)stream, dpooled, aidx, aw, add, dfeats, HW, C, NB);
-    else if (TA == 16)
-        hipLaunchKernelGGL(psp_pool_bwd_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, dpooled, aidx, aw, add, dfeats, HW, C, NB);
-    else
-        return L2I_ERR_ARG;
+#define PSP_PB(TA_, TT) hipLaunchKernelGGL((psp_pool_bwd_kernel<TA_, TT>), grid, dim3(256), lds, (hipStream_t)stream, dpooled, aidx, aw, add, add2, \
+                                           (const TT*)cat, cat_w, cat_off, dfeats, (bf16_t*)dfeats_op, HW, C, NB)
+    const bool b16 = cat && cat_dtype == 1;
+    if (TA == 12) { if (b16) PSP_PB(12, bf16_t); else PSP_PB(12, float); }
+    else if (TA == 16) { if (b16) PSP_PB(16, bf16_t); else PSP_PB(16, float); }
+    else return L2I_ERR_ARG;
+#undef PSP_PB
     return l2i_check_launch();
 }
 
@@ -251,7 +272,7 @@ extern "C" int l2i_psp_expand_fwd(const float* feats, const float* y, const int*
 extern "C" int l2i_psp_expand_bwd(const void* g, const float* wxt, const float* wy, const int* xq, const int* qoff, float* dy,
                                   float* dfeats, float* rows, int B, int H, int C, int F, int NB, int NQ, int n_stages, int dtype,
                                   void* stream) {
-    if (!g || !wxt || !wy || !xq || !qoff || !dy || !dfeats || !rows || H <= 0 || H > PSP_MAXW || NQ <= 0 || NQ > PSP_MAXQ ||
+    if (!g || !wxt || !wy || !xq || !qoff || !dy || !rows || H <= 0 || H > PSP_MAXW || NQ <= 0 || NQ > PSP_MAXQ ||
         n_stages <= 0 || n_stages > 8 || !psp_ok(B, H * H, C, F, NB) || F == 0)
         return L2I_ERR_ARG;
     const dim3 grid(H, B);

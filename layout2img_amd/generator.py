@@ -180,14 +180,14 @@ class PSPModule(nn.Module):
 
     SIZES = (1, 2, 3, 6)
 
-    def forward(self, feats, pc, sync):
-        """feats (B,H,W,C) f32. Each stage is AdaptiveAvgPool(s) -> 1x1 conv -> BatchNorm2d -> ReLU -> bilinear
+    def forward(self, feats, pc, sync, join_in=None):
+        """join_in: see ConvMaskHead.forward (taken by the pooling branch's backward launch). feats (B,H,W,C) f32. Each stage is AdaptiveAvgPool(s) -> 1x1 conv -> BatchNorm2d -> ReLU -> bilinear
         (align_corners=True) back to HxW; the two resamplings are fixed sparse linear maps over the pixels (psp_taps) applied
         by csrc/psp.hip for all stages at once, the per-stage conv / BN / ReLU between them is one launch (csrc/layout.hip)."""
         B, H, W, C = feats.shape
         taps = psp_taps(H, self.SIZES, feats.device)
         j = ops.GradJoin()   # d feats: the concat branch's part enters the pooling branch's backward launch
-        pooled = ops.psp_pool(feats, taps, j)                                                  # (B, 50, C)
+        pooled = ops.psp_pool(feats, taps, j, join_in, pc.arena.op_dtype if (join_in is not None and not pc.arena.split) else None)   # (B, 50, C)
         bn_training = self.stages[0][2].training   # (the stage norms' own mode: they are plain nn.BatchNorm2d and may be frozen separately)
         ys = ops.psp_stages(pooled, [st[1] for st in self.stages], [st[2] for st in self.stages], self.SIZES, bn_training)   # (B, 50, F)
         if bn_training and not getattr(self.stages[0][2], "_nbt_shared", False):
@@ -204,6 +204,7 @@ class PSPModule(nn.Module):
         return y
 
 
+JOIN_HEADS = os.environ.get("L2I_JOIN_HEADS", "1") != "0"   # A/B switch: a block result's two gradients (next block, mask head) summed in the head's data-gradient launch
 CLASS_GATHER = os.environ.get("L2I_CLASS_GATHER", "1") != "0"   # mask heads compute only the gathered classes (A/B switch)
 
 
@@ -218,20 +219,23 @@ class ConvMaskHead(nn.ModuleList):
                               GemmWeight("conv", 184, 100, 1, sn=False)])
         self.psp = psp
 
-    def forward(self, x, pc, sync, y=None):
-        """y (b, o) int64, o <= 8: the caller will only ever gather the channels of these classes from the head's 184-channel result
+    def forward(self, x, pc, sync, y=None, join_in=None):
+        """join_in (ops.GradJoin): x is also read by the NEXT block, whose backward runs first and leaves its complete
+        gradient there; this head's 3x3 data-gradient launch (PSP head: the pooling branch's backward launch) adds it and writes the
+        operand copy of the sum.
+        y (b, o) int64, o <= 8: the caller will only ever gather the channels of these classes from the head's 184-channel result
         (`seman = gather(m, 1, y)`, reference :465-466) -- the last 1x1 convolution is then evaluated for those classes alone
         (ops.class_logits) and the result is the planar (b, o, H, W) tensor of gathered logits, tagged `_l2i_planar`. None: the dense
         (b, H, W, 184) logits."""
         gather = y is not None and CLASS_GATHER and y.shape[1] <= 8
         if self.psp:
-            a = self[0](x, pc, sync)
+            a = self[0](x, pc, sync, join_in)
             if not gather:
                 return fused_conv(a, self[1], pc)
             out = self[1]
         else:
             conv, bn, _, out = self
-            h = fused_conv(x, conv, pc, emit=("stats",) if self.training else ())
+            h = fused_conv(x, conv, pc, emit=("stats",) if self.training else (), join_in=join_in, dx_raw=join_in is not None)
             spec, w, b = bn.spec(self.training, sync, conv.co_p)
             if not gather:
                 m = fused_conv(h, out, pc, prologue=spec, wproj=w, bproj=b, dx_raw=True)   # (h has this one reader: its gradient's operand copy comes out of the norm backward)
@@ -261,27 +265,32 @@ class ResBlock(nn.Module):
         if predict_mask:
             self.conv_mask = ConvMaskHead(out_ch, psp_module)
 
-    def forward(self, x, w, mask, pc, sync, emit=(), y=None):
+    def forward(self, x, w, mask, pc, sync, emit=(), y=None, join_x=None, join_next=False):
         """emit: operand copies of the block's result written by conv2's epilogue ("raw": what the next block's shortcut
-        conv and this block's mask head read). y: the object classes (see ConvMaskHead.forward)."""
+        conv and this block's mask head read). y: the object classes (see ConvMaskHead.forward).
+        join_x: the GradJoin of x's two readers (this block and the previous block's mask head): conv1's backward leaves the block's
+        complete dx there for the mask head's data-gradient launch. join_next: create that join for THIS block's result (returned as
+        the third value): given to the next block, taken by this block's mask head, conv2 the taker of last resort."""
         B, H, W, C = x.shape
         O = mask.shape[1]
         up = self.upsample
         gw1, gb1 = self.b1.project(w, pc, B, O)
         j = ops.GradJoin()   # the shortcut's dx is accumulated by the second pass of b1's backward instead of a separate add
         h = fused_conv(x, self.conv1, pc, prologue=self.b1.spec(self.training, sync), mask=_resize_mask(mask, H, W).contiguous(),
-                       wproj=gw1, bproj=gb1, up2=up, join=(j, "take"),
+                       wproj=gw1, bproj=gb1, up2=up, join=(j, "take"), join_out=join_x,
                        emit=("stats",) if self.training else ())   # b2's batch statistics come out of this epilogue
         H2, W2 = h.shape[1], h.shape[2]
         sc = fused_conv(x, self.c_sc, pc, up2=up, join=(j, "give"), lazy_sc=True) if self.learnable_sc else x
         gw2, gb2 = self.b2.project(w, pc, B, O)
+        jn = ops.GradJoin() if (join_next and JOIN_HEADS and self.predict_mask and torch.is_grad_enabled()) else None
         out = fused_conv(h, self.conv2, pc, prologue=self.b2.spec(self.training, sync),
                          mask=_resize_mask(mask, H2, W2).contiguous(), wproj=gw2, bproj=gb2, res=sc, emit=tuple(emit) + (("stats",) if self.training else ()),
-                         dx_raw=True)   # (the block's result is normalised next: by the following block's b1 or by the final BN)
+                         dx_raw=True,   # (the block's result is normalised next: by the following block's b1 or by the final BN)
+                         join_src=jn)
         self.b1.batch_norm2d.commit()
         self.b2.batch_norm2d.commit()
-        m = self.conv_mask(out, pc, sync, y) if self.predict_mask else None
-        return out, m
+        m = self.conv_mask(out, pc, sync, y, join_in=jn) if self.predict_mask else None
+        return (out, m, jn) if join_next else (out, m)
 
 
 class BoxMultiHeadedAttention(nn.Module):
@@ -504,14 +513,14 @@ class ResnetGenerator128_context(_GeneratorBase):
         if z_im is None:
             z_im = torch.randn((b, 128), device=z.device)
         x = ops.fc_to_nhwc(fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc), 16 * self.ch, self.op_dtype)
-        x, m = self.res1(x, wp, bmask, pc, self.sync, emit=("raw",), y=y)
+        x, m, jx = self.res1(x, wp, bmask, pc, self.sync, emit=("raw",), y=y, join_next=True)
         stage = bmask
         stages = []
         res_out = [x]
         for blk, alpha in ((self.res2, self.alpha1), (self.res3, self.alpha2), (self.res4, self.alpha3), (self.res5, self.alpha4)):
             stage = self._stage_mask(m, bmask, bbox_mask_, alpha, y)
             stages.append(stage)
-            x, m = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",), y=y)
+            x, m, jx = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",), y=y, join_x=jx, join_next=True)
             res_out.append(x)
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
@@ -608,10 +617,10 @@ class ResnetGenerator64_context(ResnetGenerator128_context):
         if z_im is None:
             z_im = torch.randn((b, 128), device=z.device)
         x = ops.fc_to_nhwc(fused_conv(z_im.reshape(b, 1, 1, -1).contiguous(), self.fc, pc), 16 * self.ch, self.op_dtype)
-        x, m = self.res2(x, wp, bmask, pc, self.sync, emit=("raw",), y=y)
+        x, m, jx = self.res2(x, wp, bmask, pc, self.sync, emit=("raw",), y=y, join_next=True)
         for blk, alpha in ((self.res3, self.alpha1), (self.res4, self.alpha2), (self.res5, self.alpha3)):
             stage = self._stage_mask(m, bmask, bbox_mask_, alpha, y)
-            x, m = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",), y=y)
+            x, m, jx = blk(x, wp, stage, pc, self.sync, emit=() if blk is self.res5 else ("raw",), y=y, join_x=jx, join_next=True)
         bn, _, conv, _ = self.final
         spec, wa, ba = bn.spec(self.training, self.sync)
         pre = fused_conv(x, conv, pc, prologue=spec, wproj=wa, bproj=ba, dx_raw=True)   # (x: the last block's result, read by this layer alone)

@@ -1366,7 +1366,7 @@ class PspPoolFn(Function):
     feature map (csrc/psp.hip; taps = generator.psp_taps). Backward adds the gradient the concat branch left in `join`."""
 
     @staticmethod
-    def forward(ctx, feats, taps, join):
+    def forward(ctx, feats, taps, join, join_x=None, emit_op=None):
         _chk(feats, torch.float32)
         B, H, W, C = feats.shape
         NB, NQ = taps["nb"], taps["nq"]
@@ -1375,7 +1375,7 @@ class PspPoolFn(Function):
         rows = torch.empty((B, H, NQ, C), dtype=torch.float32, device=feats.device)
         _lib.call("l2i_psp_pool_fwd", feats.data_ptr(), taps["pwx"].data_ptr(), taps["pwy"].data_ptr(), taps["xq"].data_ptr(),
                   pooled.data_ptr(), rows.data_ptr(), B, H, C, NB, NQ, _stream())
-        ctx.shape, ctx.join, ctx.taps = (B, H, W, C), join, taps
+        ctx.shape, ctx.join, ctx.taps, ctx.join_x, ctx.emit_op = (B, H, W, C), join, taps, join_x, emit_op
         return pooled
 
     @staticmethod
@@ -1384,14 +1384,27 @@ class PspPoolFn(Function):
         B, H, W, C = ctx.shape
         g = g.contiguous()
         add = ctx.join.take() if ctx.join is not None else None
+        cat, cat_w, cat_off, cat_dt = None, 0, 0, 0
+        if isinstance(add, dict):   # the concat branch handed over the gradient of the concat tensor itself (PspExpandFn.backward)
+            cat, cat_w, cat_off, cat_dt, add = add["g"], add["width"], add["off"], _code(add["g"].dtype), None
+        add2 = ctx.join_x.take() if ctx.join_x is not None else None   # another reader of feats (the next block) left its gradient
         dfeats = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
-        _lib.call("l2i_psp_pool_bwd", g.data_ptr(), taps["aidx"].data_ptr(), taps["aw"].data_ptr(), taps["aidx"].shape[1], _p(add),
-                  dfeats.data_ptr(), B, H * W, C, taps["nb"], _stream())
-        return dfeats, None, None
+        # the operand copy of the sum, when this is the complete gradient of feats (what the producing conv's backward reads)
+        dop = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=g.device) if (ctx.emit_op is torch.bfloat16 and add2 is not None) else None
+        _lib.call("l2i_psp_pool_bwd", g.data_ptr(), taps["aidx"].data_ptr(), taps["aw"].data_ptr(), taps["aidx"].shape[1], _p(add), _p(add2),
+                  _p(cat), cat_w, cat_off, cat_dt, dfeats.data_ptr(), _p(dop), B, H * W, C, taps["nb"], _stream())
+        if dop is not None:
+            _attach(dfeats, raw=dop)
+        return dfeats, None, None, None, None
 
 
-def psp_pool(feats, taps, join=None):
-    return PspPoolFn.apply(feats.contiguous(), taps, join)
+def psp_pool(feats, taps, join=None, join_x=None, emit_op=None):
+    """join: shared with psp_expand (the concat branch's part of d feats enters this launch); join_x: a GradJoin another reader of
+    feats (created later) leaves its complete gradient in; emit_op: torch.bfloat16 to attach the operand copy of the joined sum."""
+    return PspPoolFn.apply(feats.contiguous(), taps, join, join_x, emit_op)
+
+
+PSP_HANDOVER = __import__("os").environ.get("L2I_PSP_HANDOVER", "1") != "0"   # A/B switch (see PspExpandFn.backward)
 
 
 class PspExpandFn(Function):
@@ -1416,12 +1429,17 @@ class PspExpandFn(Function):
         B, H, W, C, NB, F_, ns, op_dtype, join, taps = ctx.meta
         g = _chk(g.contiguous(), op_dtype)
         dy = torch.empty((B, NB, F_), dtype=torch.float32, device=g.device)
-        dfeats = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
+        # d feats = the last C columns of g: when the pooling branch's backward is going to run (it takes from `join`; it runs
+        # whenever this one did, the stage outputs y descend from its result) it reads them from g in place -- no f32 copy here
+        hand = join is not None and join.state == "open" and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and PSP_HANDOVER
+        dfeats = None if hand else torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
         rows = torch.empty((B, H, taps["nq"], F_), dtype=torch.float32, device=g.device)
         _lib.call("l2i_psp_expand_bwd", g.data_ptr(), taps["uwx"].data_ptr(), taps["uwy"].data_ptr(), taps["xq"].data_ptr(),
-                  taps["qoff"].data_ptr(), dy.data_ptr(), dfeats.data_ptr(), rows.data_ptr(), B, H, C, F_, NB, taps["nq"], ns,
+                  taps["qoff"].data_ptr(), dy.data_ptr(), _p(dfeats), rows.data_ptr(), B, H, C, F_, NB, taps["nq"], ns,
                   _code(op_dtype), _stream())
-        if join is not None:
+        if hand:
+            join.give(dict(g=g, width=ns * F_ + C, off=ns * F_))
+        elif join is not None:
             dfeats = join.give(dfeats)
         return dfeats, dy, None, None, None
 

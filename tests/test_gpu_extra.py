@@ -189,6 +189,45 @@ def test_two_reader_joins_never_drop_a_gradient(heads, monkeypatch):
     assert rel < 2e-4, rel   # (accumulation order only: f32 operands)
 
 
+@pytest.mark.parametrize("size,loss_kind", [(128, "image"), (128, "image+tap"), (64, "image")])
+def test_generator_block_results_join_their_two_gradients(size, loss_kind, monkeypatch):
+    """A generator block's result is read by the next block and by the block's own mask head (reference
+    model/resnet_generator_app_v2.py:438-470, 628-678): the next block's conv1 backward leaves its complete dx in an
+    ops.GradJoin, the mask head's 3x3 data-gradient launch adds it in its epilogue (and writes the operand copy of the sum)
+    instead of an autograd add + cast. The flat gradient equals the plain autograd accumulation (generator.JOIN_HEADS = False);
+    "image+tap": a loss that also reads a block result directly (a third gradient into the same tensor)."""
+    import layout2img_amd as L
+    from layout2img_amd import generator as G
+    from layout2img_amd.synthetic import make_batch
+    real, label, bbox, z, z_im = make_batch(3, size, "coco", seed=5, device=torch.device(DEV))
+    grads = {}
+    for run, join in (("on", True), ("off", False), ("off2", False)):
+        monkeypatch.setattr(G, "JOIN_HEADS", join)
+        torch.manual_seed(0)
+        g = (L.ResnetGenerator128_context if size == 128 else L.ResnetGenerator64_context)(num_classes=184).finalize(DEV, torch.float32).train()
+        for m in g.modules():
+            if hasattr(m, "dropout_p"):
+                m.dropout_p = 0.0
+        g.zero_grad()
+        taps = {}
+        img = g(z, bbox, z_im, label, taps=taps) if size == 128 else g(z, bbox, z_im, label)
+        loss = (img * real).sum()
+        if loss_kind == "image+tap":
+            loss = loss + 0.01 * taps["res"][1].square().sum()
+        loss.backward()
+        g.arena.flush_grads()
+        torch.cuda.synchronize()
+        grads[run] = g.flat.grad.clone()
+    a, b, b2 = grads["on"], grads["off"], grads["off2"]
+    assert float(b.norm()) > 0 and bool(torch.isfinite(a).all())
+    # accumulation order only (f32 operands) -- but the order of the atomically reduced batch statistics already moves the gradient of
+    # this 25-layer train-mode network by ~1e-3 between two identical runs (batch of 3): the bar is that measured floor
+    floor = float((b2 - b).norm() / b.norm())
+    rel = float((a - b).norm() / b.norm())
+    print(f"joined vs plain {rel:.2e}, plain vs plain {floor:.2e}")
+    assert rel < max(3 * floor, 2e-4) and rel < 1e-2, (rel, floor)
+
+
 @pytest.mark.parametrize("variant", ["eager", "graph", "dual", "real_bwd_early"])
 def test_training_step_with_nan_poisoned_weight_gradient_accumulators(variant, monkeypatch):
     """The dW-bar accumulators of a pass are torch.empty: a convolution's slice is valid only because exactly one weight-gradient launch STORES

@@ -8,6 +8,6 @@ for i in 1 2; do (cd $ROOT/_ab_prev && run prev); (cd $ROOT && run new); done
 for side in prev new; do
   if [ $side = prev ]; then cd $ROOT/_ab_prev; else cd $ROOT; fi
   rm -rf /tmp/ks_$side
-  rocprofv3 --kernel-trace --stats -d /tmp/ks_$side -o ks -- python bench.py --no-cpu-baseline --no-f32-mode --no-g-forward --no-kernel-timer --steps 20 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$side -o ks -- python bench.py --no-cpu-baseline --no-f32-mode --no-g-forward --no-kernel-timer --steps 20 > /dev/null 2>&1
   echo "== $side"; python $ROOT/tools/perf/kstats.py $(find /tmp/ks_$side -name '*kernel_stats.csv' | head -1) norm_ stats | head -14
 done
