@@ -325,7 +325,8 @@ class WeightArena:
             else:
                 h.use_rows.append(LayerUse(h, **attrs))
             row[18] = 1 if h.uses > 1 else 0
-            pair_chunks = (h.co * h.ci + 255) // 256      # csrc/weights.hip: BW_PAIRS
+            bw = 2304 if taps == 1 else 256               # csrc/weights.hip: bw_chunk()
+            pair_chunks = (h.co * h.ci + bw - 1) // bw
             if h.sn:
                 for c0 in range(0, kt, 256):              # csrc/weights.hip sn_wtu_kernel: 256 columns x 4 waves x rpw rows
                     for r0 in range(0, h.co, 4 * WTU_RPW):

@@ -380,6 +380,10 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restr
 // contiguous, and the matching entries of G = dWbar ([co][tap][Ci_p] order) are contiguous in ci per tap; LDS
 // converts between the two orders so that every global access is a run. table: (layer, pairchunk)
 #define BW_PAIRS 256
+// pairs per table entry: 256 for the 3x3 layers (2304 floats of W); 1x1 / linear layers take 2304 pairs per block as well (nine per
+// thread) -- at 256 they were 1 KB blocks, as many of them as the 3x3 layers have for a fifteenth of the bytes (arena.py builds the
+// tables; tools/perf/sn_bwd_micro.py: the generator's flush 219 -> 150 us)
+__device__ __forceinline__ int bw_chunk(int taps) { return taps == 1 ? BW_PAIRS * 9 : BW_PAIRS; }
 
 // phase a: <G, W> per SN layer, one atomic per block into replica (block % 32) of ws[(r * NP + pass) * n_layers + layer].
 // NP = 2: the two passes of one optimiser step that share W (D(real) and D(fake), train_context_app_v2.py:158,167) in one
@@ -395,14 +399,30 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const long long* __restrict
     const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Ci_p = (int)LF(7);
     const int taps = KH * KH, Kp = taps * Ci_p;
-    const long long p0 = (long long)e[1] * BW_PAIRS;
-    const int np = (int)min((long long)BW_PAIRS, (long long)Co * Ci - p0);
+    const long long p0 = (long long)e[1] * bw_chunk(taps);
+    const int np = (int)min((long long)bw_chunk(taps), (long long)Co * Ci - p0);
     const float* W = params + LF(0) + p0 * taps;
-    for (int j = threadIdx.x; j < np * taps; j += 256) wl[j] = W[j];
-    __syncthreads();
     float acc[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) acc[q] = 0.f;
+    if (taps == 1) {   // W and G share the (co, ci) order up to the row pitch: nine pairs per thread, loads issued together
+        float wv[9], gv[NP][9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int j = min((int)threadIdx.x + 256 * k, np - 1);
+            const long long pr = p0 + j;
+            const int co = (int)(pr / Ci), ci = (int)(pr - (long long)co * Ci);
+            wv[k] = (int)threadIdx.x + 256 * k < np ? W[j] : 0.f;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) gv[q][k] = (q == 0 ? dwbar0 : dwbar1)[(size_t)LF(14) + (size_t)co * Kp + ci];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) acc[q] = fmaf(wv[k], gv[q][k], acc[q]);
+    } else {
+    for (int j = threadIdx.x; j < np * taps; j += 256) wl[j] = W[j];
+    __syncthreads();
     if ((int)threadIdx.x < np) {
         const long long pr = p0 + threadIdx.x;
         const int co = (int)(pr / Ci), ci = (int)(pr - (long long)co * Ci);
@@ -422,6 +442,7 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const long long* __restrict
 #pragma unroll
                 for (int q = 0; q < NP; ++q) acc[q] = fmaf(wl[threadIdx.x * taps + tap], (q == 0 ? dwbar0 : dwbar1)[goff + tap * Ci_p], acc[q]);
         }
+    }
     }
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -444,8 +465,8 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
     const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Ci_p = (int)LF(7);
     const int taps = KH * KH, Kp = taps * Ci_p;
-    const long long p0 = (long long)e[1] * BW_PAIRS;
-    const int np = (int)min((long long)BW_PAIRS, (long long)Co * Ci - p0);
+    const long long p0 = (long long)e[1] * bw_chunk(taps);
+    const int np = (int)min((long long)bw_chunk(taps), (long long)Co * Ci - p0);
     const bool sn = LF(1) >= 0;
     float inv[NP], gw[NP];
 #pragma unroll
@@ -459,6 +480,34 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
             gw[q] = d * inv[q];  // <G, Wbar>
             if (e[1] == 0 && threadIdx.x == 0) norms[4 * layer + 3] = d;
         }
+    }
+    if (taps == 1) {   // nine (co, ci) pairs per thread, no reordering: straight to the gradient buffer
+        float* dst1 = grads + LF(0) + p0;
+        float gv[NP][9], vv[NP][9], uu[NP][9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int j = min((int)threadIdx.x + 256 * k, np - 1);
+            const long long pr = p0 + j;
+            const int co = (int)(pr / Ci), ci = (int)(pr - (long long)co * Ci);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                gv[q][k] = (q == 0 ? dwbar0 : dwbar1)[(size_t)LF(14) + (size_t)co * Kp + ci];
+                vv[q][k] = sn ? (q == 0 ? uv0 : uv1)[LF(17) + ci] : 0.f;
+                uu[q][k] = sn ? (q == 0 ? uv0 : uv1)[LF(16) + co] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int j = (int)threadIdx.x + 256 * k;
+            if (j >= np) break;
+            float x = 0.f;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) x += sn ? (gv[q][k] - uu[q][k] * gw[q] * vv[q][k]) * inv[q] : gv[q][k];
+            if (LF(18)) atomicAdd(dst1 + j, x);
+            else if (overwrite) dst1[j] = x;
+            else dst1[j] += x;
+        }
+        return;
     }
     if ((int)threadIdx.x < np) {
         const long long pr = p0 + threadIdx.x;
