@@ -270,7 +270,17 @@ class WeightArena:
         def _kp(h):
             return h.kh * h.kh * h.ci_p * (3 if self.split else 1)
         dw_of = {}
+        self.bias_slots = []
         for phase in (0, 1):
+            if phase == 1:
+                # between the two: one slot of Co_p floats per convolution whose bias is shorter than its padded channel count --
+                # the weight-gradient launch sums the bias gradient over all Co_p columns there (cleared with the accumulated
+                # slices), flush_grads adds the first Co values to the bias gradient (ops.FusedConvFn.backward)
+                for h, use in rows:
+                    if use == 0 and h.kind == "conv" and h.bias is not None and h.co != h.co_p and id(h) not in member_of:
+                        h.bias_scr_off = dw_len
+                        self.bias_slots.append((dw_len, dw_len + _round_up(h.co_p, ALIGN)))
+                        dw_len += _round_up(h.co_p, ALIGN)
             for i, (h, use) in enumerate(rows):
                 if (h.kind != "conv" or id(h) in member_of) != (phase == 0):
                     continue
@@ -398,6 +408,7 @@ class WeightArena:
                     acc.append((u.dw_off, u.dw_off + _round_up(h.co_p * u.kp, ALIGN)))
         for g in self.groups.values():
             acc.append((g.dw_off, g.dw_off + _round_up(g.n_total * g.kp, ALIGN)))
+        acc += self.bias_slots
         acc.sort()
         self.acc_ranges = []
         for a, b in acc:
@@ -480,6 +491,11 @@ class WeightArena:
         from .ops import WgradSide
         WgradSide.join()   # weight-gradient launches run on side streams (ops.WgradSide)
         self.flat.flush_loose()
+        fix = [t for p in self.pending for t in p.bias_fix.values()]   # padded-channel bias gradients summed by the weight-gradient launches
+        if fix:
+            torch._foreach_add_([d for d, _ in fix], [s_ for _, s_ in fix])
+            for p in self.pending:
+                p.bias_fix = {}
         live = [p for p in self.pending if p.dwbar is not None]
         for p in live:
             p.clear_unwritten()
@@ -522,6 +538,7 @@ class PassCtx:
         buf = torch.empty(nn4 + arena.uv_len, dtype=torch.float32, device=dev)
         self.norms, self.pass_uv = buf[:4 * arena.n_layers], buf[nn4:]
         self.dwbar = None
+        self.bias_fix = {}   # slot offset -> (bias gradient view, slot[:Co]): what flush_grads adds up
 
     def __del__(self):
         try:
@@ -544,6 +561,12 @@ class PassCtx:
                     self.dwbar[lo:hi].zero_()
                 self.written = set()
         return self.dwbar
+
+    def bias_slot(self, h, bg):
+        """h's Co_p-float bias-gradient slot in the accumulator (WeightArena.bias_slots); its first Co values are added to `bg` by flush_grads."""
+        s = self.dw()[h.bias_scr_off:h.bias_scr_off + h.co_p]
+        self.bias_fix[h.bias_scr_off] = (bg, s[:h.co])   # (keyed: a second backward over the same forward adds into the same slot)
+        return s
 
     def mark_written(self, h):
         """h's dW slice has been stored by a weight-gradient launch of this pass."""

@@ -40,7 +40,10 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
     const int L = sqsums ? 2 * C : C;
     float* const sdst = ws ? ws_replica(ws, slab % L2I_WS_R, L) : sums + (size_t)group * C;
     float* const qdst = !sqsums ? nullptr : ws ? sdst + C : sqsums + (size_t)group * C;
-    for (int cbase = 0; cbase < cols4; cbase += 256) {
+    // column chunks of 256 float4 columns: blockIdx.y (the grouped projection's dY is 256 rows x 19 712 channels: with the chunks
+    // walked in a loop the whole matrix was FOUR workgroups' work, 37 us for 30 MB)
+    {
+        const int cbase = blockIdx.y * 256;
         const int ncol = min(256, cols4 - cbase);
         const int TY = 256 / ncol;
         const int tx = threadIdx.x % ncol, ty = threadIdx.x / ncol;
@@ -98,12 +101,13 @@ extern "C" int l2i_channel_stats(const float* x, long long rows, int C, long lon
                                  float* sqsums, void* raw, int dtype, float* ws, void* stream) {
     if (!x || !sums || C % 4 || rows_per_group <= 0 || rows % rows_per_group) return L2I_ERR_ARG;
     const long long G = rows / rows_per_group;
-    long long slabs = (1024 + G - 1) / G;
-    const long long max_slabs = (rows_per_group + 63) / 64;
+    const int cchunks = (C / 4 + 255) / 256;
+    long long slabs = (1024 + G * cchunks - 1) / (G * cchunks);
+    const long long max_slabs = (rows_per_group + 15) / 16;   // (two 8-row batches per wave at least)
     if (slabs > max_slabs) slabs = max_slabs;
     if (slabs < 1) slabs = 1;
     if (G != 1 || slabs <= 32) ws = nullptr;   // few workgroups per address: atomics straight into sums / sqsums
-    const dim3 grid((unsigned)(G * slabs));
+    const dim3 grid((unsigned)(G * slabs), (unsigned)cchunks);
     if (dtype == 1)
         hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, C, rows_per_group,
                            (int)slabs, sums, sqsums, (bf16_t*)raw, ws);

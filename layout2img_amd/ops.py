@@ -500,6 +500,7 @@ def _atomics_split(B, Ho, Wo, n_out, kh, k_in, op_dtype):
     return not (kh == 3 and op_dtype == torch.bfloat16 and k_in >= 64 and Wo >= 8 and STORED_SPLITS)   # (4-wide maps: the weight-stationary kernel)
 
 
+BIAS_SLOTS = __import__("os").environ.get("L2I_BIAS_SLOTS", "1") != "0"   # A/B switch: padded-channel bias gradients from the weight-gradient launch
 STORED_SPLITS = __import__("os").environ.get("L2I_CONV_PART", "1") != "0"   # (the library's switch of the same name)
 
 
@@ -656,11 +657,17 @@ class FusedConvFn(Function):
         # that received the same dY (a block's conv2 and its shortcut), else cast here -- and left on dY for the others
         dy_op = dy if ctx.op_out else _sibling(dy, "raw", opd)
         dbias = None
+        lazy_ = getattr(ctx, "lazy", None)
         if pc.need_wgrad and ctx.has_bias:
             bg = h.bias.grad
             direct = bg is not None and h.co == h.co_p and bg.is_contiguous() and bg.dtype == torch.float32
             if direct:   # the weight-gradient launch sums the bias gradient from the dY tiles it stages, straight into the
                 dbias = bg   # flat gradient buffer: no pass over dY at all when its operand copy already exists
+            elif (BIAS_SLOTS and bg is not None and getattr(h, "bias_scr_off", None) is not None and not pc.dual and dy_op is not None
+                  and bg.is_contiguous() and bg.dtype == torch.float32 and not (lazy_ is not None and lazy_["wgrad_done"])):
+                # padded channel count (the mask heads' 100 of 104, the to-RGB layer's 3 of 8): the same sum into a Co_p-wide slot
+                # of the pass's accumulator; flush_grads adds its first Co values to the bias gradient -- instead of a pass over dY
+                dbias = pc.bias_slot(h, bg)
             elif ctx.op_out:
                 d_bias = dy.float().sum(dim=(0, 1, 2))[:h.co]
             else:        # (padded channel counts: bias gradient and the dY operand cast in one pass over dY)
