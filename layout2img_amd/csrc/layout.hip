@@ -225,14 +225,15 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(AlnArgs p) {
     }
 }
 // ds = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; db[r, :D] = ds (pad columns zero); da = ds through the inverse
-// shuffle (in a's (rows, lda) layout, pad columns zero); dgamma += sum_r dy xhat, dbeta += sum_r dy (atomics, 16 rows per block)
+// shuffle (in a's (rows, lda) layout, pad columns zero); dgamma += sum_r dy xhat, dbeta += sum_r dy (atomics, 4 rows per block)
+#define ALN_BWD_RPW 1
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(AlnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[ALN_MAXE], dbt[ALN_MAXE];
 #pragma unroll
     for (int e = 0; e < ALN_MAXE; ++e) { dg[e] = 0.f; dbt[e] = 0.f; }
-    for (int q = 0; q < 4; ++q) {
-        const int r = blockIdx.x * 16 + wave * 4 + q;
+    for (int q = 0; q < ALN_BWD_RPW; ++q) {   // (one row per wave: four rows in turn were four dependent round trips, 23 us for 256 rows on 16 workgroups)
+        const int r = blockIdx.x * (4 * ALN_BWD_RPW) + wave * ALN_BWD_RPW + q;
         if (r >= p.rows) break;
         const float mean = p.mean[r], rstd = p.rstd[r];
         float xh[ALN_MAXE], g[ALN_MAXE];
@@ -299,7 +300,7 @@ extern "C" int l2i_add_layernorm_bwd(const float* a, int lda, const float* b, in
     p.a = a; p.b = b; p.gamma = gamma; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.dy = dy;
     p.da = da; p.db = db; p.dgamma = dgamma; p.dbeta = dbeta;
     p.rows = rows; p.D = D; p.lda = lda; p.ldb = ldb; p.ldy = ldy; p.perm_O = perm_O;
-    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3((rows + 4 * ALN_BWD_RPW - 1) / (4 * ALN_BWD_RPW)), dim3(256), 0, (hipStream_t)stream, p);
     return l2i_check_launch();
 }
 
@@ -449,7 +450,18 @@ __global__ __launch_bounds__(1024) void psp_stages_fwd_kernel(PspStArgs p) {
         const int b = r / ns, k = r - b * ns;
         const float* x = p.pooled + ((size_t)b * p.NB + off + k) * p.C;
         float a[PSP_FT] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < p.C; c += 4) {
+        int c = 0;
+        for (; c + 32 <= p.C; c += 32) {   // eight 16-byte loads of the row in flight (one at a time: 32 dependent round trips per row, 40 us)
+            float4 xq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xq[u] = *reinterpret_cast<const float4*>(x + c + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int ff = 0; ff < PSP_FT; ++ff)
+                    a[ff] = fmaf(xq[u].w, ws[ff][c + 4 * u + 3], fmaf(xq[u].z, ws[ff][c + 4 * u + 2], fmaf(xq[u].y, ws[ff][c + 4 * u + 1], fmaf(xq[u].x, ws[ff][c + 4 * u], a[ff]))));
+        }
+        for (; c < p.C; c += 4) {
             const float4 xv = *reinterpret_cast<const float4*>(x + c);
 #pragma unroll
             for (int ff = 0; ff < PSP_FT; ++ff)
@@ -578,11 +590,11 @@ __global__ __launch_bounds__(256) void psp_stages_bwd_mm_kernel(PspStArgs p, flo
         }
         *reinterpret_cast<float4*>(dpooled + row * p.C + c) = a;
     } else {
-        // 64 (stage, f, c) outputs per workgroup, the stage's rows split over its four waves (a serial walk over the up to
-        // 1152 rows is one dependent load round trip per row: measured 390 us) and combined in LDS
-        __shared__ float red[4][64];
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const long long o = (long long)blockIdx.x * 64 + lane;
+        // 16 (stage, f, c) outputs per workgroup, the stage's rows split over 16 slices of 16 lanes (a serial walk over the up to
+        // 1152 rows is one dependent load round trip per row: measured 390 us; four slices of a wave each: 54 us) and combined in LDS
+        __shared__ float red[16][16];
+        const int l16 = threadIdx.x & 15, slice = threadIdx.x >> 4;
+        const long long o = (long long)blockIdx.x * 16 + l16;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         const bool on = o < (long long)p.S * p.F * p.C;
         if (on) {
@@ -595,23 +607,28 @@ __global__ __launch_bounds__(256) void psp_stages_bwd_mm_kernel(PspStArgs p, flo
             const int rows = p.B * ns;
             const float* dr = p.draw + f;
             const float* pl = p.pooled + c;
-            int r = wave;
-            for (; r + 12 < rows; r += 16) {
-                const int r1 = r + 4, r2 = r + 8, r3 = r + 12;
+            int r = slice;
+            for (; r + 48 < rows; r += 64) {
+                const int r1 = r + 16, r2 = r + 32, r3 = r + 48;
                 const size_t q0 = (size_t)(r / ns) * p.NB + off + r % ns, q1 = (size_t)(r1 / ns) * p.NB + off + r1 % ns;
                 const size_t q2 = (size_t)(r2 / ns) * p.NB + off + r2 % ns, q3 = (size_t)(r3 / ns) * p.NB + off + r3 % ns;
                 const float d0 = dr[q0 * p.F], d1 = dr[q1 * p.F], d2 = dr[q2 * p.F], d3 = dr[q3 * p.F];
                 const float x0 = pl[q0 * p.C], x1 = pl[q1 * p.C], x2 = pl[q2 * p.C], x3 = pl[q3 * p.C];
                 a0 = fmaf(d0, x0, a0); a1 = fmaf(d1, x1, a1); a2 = fmaf(d2, x2, a2); a3 = fmaf(d3, x3, a3);
             }
-            for (; r < rows; r += 4) {
+            for (; r < rows; r += 16) {
                 const size_t q0 = (size_t)(r / ns) * p.NB + off + r % ns;
                 a0 = fmaf(dr[q0 * p.F], pl[q0 * p.C], a0);
             }
         }
-        red[wave][lane] = (a0 + a1) + (a2 + a3);
+        red[slice][l16] = (a0 + a1) + (a2 + a3);
         __syncthreads();
-        if (wave == 0 && on) dW[o] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (slice == 0 && on) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][l16];
+            dW[o] = t;
+        }
     }
 }
 static int psp_fill(PspStArgs& p, int B, int NB, int C, int F, int S, const int* sizes) {
@@ -654,7 +671,7 @@ extern "C" int l2i_psp_stages_bwd(const float* pooled, const float* const* W, co
     p.pooled = pooled; p.raw = const_cast<float*>(raw); p.stat = const_cast<float*>(stat);
     p.dy = dy; p.draw = draw; p.dgamma = dgamma; p.dbeta = dbeta; p.training = training;
     hipLaunchKernelGGL(psp_stages_bwd_bn_kernel, dim3((F + PSP_FT - 1) / PSP_FT, S), dim3(1024), 0, (hipStream_t)stream, p);
-    const long long n0 = ((long long)B * NB * (C / 4) + 255) / 256, n1 = ((long long)S * F * C + 63) / 64;   // workgroups of the two roles
+    const long long n0 = ((long long)B * NB * (C / 4) + 255) / 256, n1 = ((long long)S * F * C + 15) / 16;   // workgroups of the two roles
     const long long nmax = n0 > n1 ? n0 : n1;
     hipLaunchKernelGGL(psp_stages_bwd_mm_kernel, dim3((unsigned)nmax, 2), dim3(256), 0, (hipStream_t)stream, p, dpooled, dW);
     return l2i_check_launch();
