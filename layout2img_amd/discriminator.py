@@ -130,15 +130,19 @@ class ResnetDiscriminator128_app(nn.Module):
 
         feat_s = self.block_obj4(self.block_obj3(x1, pc, emit=both, join_out=jx1 if JOIN_READERS else None), pc, use=0, sole_reader=True)   # reference order :136-141
         feat_l = self.block_obj4(x2, pc, use=1, join_out=jx2 if JOIN_READERS else None)
-        obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0)  # (R,8,8,C)
+        # the ROI features are read by block_obj5 and by app_conv: the one created LATER (its backward runs first) leaves its complete
+        # gradient in jobj, block_obj5's shortcut launch adds it; ROI-align's backward is the taker of last resort (a loss over d_app alone)
+        jobj = ops.GradJoin() if (JOIN_READERS and torch.is_grad_enabled()) else None
+        obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0, join_src=jobj)  # (R,8,8,C)
 
         # appearance head (reference :148-157): Gram of the ROI features + class embedding
         if not pc.arena.split:   # both operand copies of the ROI features in ONE launch: app_conv's conv1 reads relu(obj), block_obj5 relu(obj) and obj
             ops.precast(obj, pc.arena.op_dtype)
-        a = self.app_conv(obj, pc, nimg=nimg)                             # (R, 8, 8, C) pre-ReLU
-        s2 = a.shape[3]
         # projection head (reference :160-166): l_obj(f) + sum(l_y(y) * f), f = sum_hw relu(block_obj5(obj))
-        f5 = self.block_obj5(obj, pc, nimg=nimg)
+        # (called before app_conv, reference :148-166 the other way round: the results do not depend on the order, the join above does)
+        f5 = self.block_obj5(obj, pc, nimg=nimg, join_in=jobj)
+        a = self.app_conv(obj, pc, nimg=nimg, join_out=jobj)              # (R, 8, 8, C) pre-ReLU
+        s2 = a.shape[3]
         out_app, out_obj = [], []
         for ak, fk, yk, p in zip(_rows(a, pc), _rows(f5, pc), _rows(y, pc), P):
             wa = arena_weight(self.app, p)                                # (1, 2C)

@@ -1005,8 +1005,9 @@ def split_halves(x):
 # ----------------------------------------------------------------------------- ROIAlign
 class RoiAlignFn(Function):
     @staticmethod
-    def forward(ctx, feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling):
+    def forward(ctx, feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling, join_src=None):
         _chk(feat_s, torch.float32)
+        ctx.join_src = join_src
         B, Hs, Ws, C = feat_s.shape
         Hl = Wl = 0
         if feat_l is not None:
@@ -1026,16 +1027,21 @@ class RoiAlignFn(Function):
         rois, valid = ctx.saved_tensors
         P, scale_s, scale_l, thr, sampling, shp_s, shp_l = ctx.cfg
         g = g.contiguous()
+        if ctx.join_src is not None:   # a reader of the ROI features parked its gradient for a launch that never ran (GradJoin.leftover)
+            parked = ctx.join_src.leftover()
+            if parked is not None:
+                g = g + parked
         ds = torch.zeros(shp_s, dtype=torch.float32, device=g.device)
         dl = torch.zeros(shp_l, dtype=torch.float32, device=g.device) if shp_l is not None else None
         Hl, Wl = (shp_l[1], shp_l[2]) if shp_l is not None else (0, 0)
         _lib.call("l2i_roi_align_bwd", rois.data_ptr(), _p(valid), g.data_ptr(), ds.data_ptr(), _p(dl), rois.shape[0],
                   shp_s[3], P, shp_s[1], shp_s[2], float(scale_s), Hl, Wl, float(scale_l), float(thr), sampling, _stream())
-        return ds, dl, None, None, None, None, None, None, None
+        return ds, dl, None, None, None, None, None, None, None, None
 
 
-def roi_align(feat_s, feat_l, rois, valid, P=8, scale_s=0.25, scale_l=0.125, thr=64.0, sampling=0):
-    return RoiAlignFn.apply(feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling)
+def roi_align(feat_s, feat_l, rois, valid, P=8, scale_s=0.25, scale_l=0.125, thr=64.0, sampling=0, join_src=None):
+    """join_src: the GradJoin of the result's two readers (see GradJoin: the producer is the taker of last resort)."""
+    return RoiAlignFn.apply(feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling, join_src)
 
 
 # ----------------------------------------------------------------------------- attention core

@@ -156,7 +156,7 @@ def test_weight_gradient_with_the_fused_last_arriver_reduction():
     assert p.returncode == 0, p.stdout[-3000:]
 
 
-@pytest.mark.parametrize("heads", ["obj+app", "obj", "img", "all"])
+@pytest.mark.parametrize("heads", ["obj+app", "obj", "app", "img", "all"])
 def test_two_reader_joins_never_drop_a_gradient(heads, monkeypatch):
     """The discriminator's x1 / x2 are each read by a trunk block and by an object-path block (reference
     model/rcnn_discriminator_app.py:126-141); the object path's data gradient is handed to the trunk block's shortcut launch
@@ -174,7 +174,7 @@ def test_two_reader_joins_never_drop_a_gradient(heads, monkeypatch):
         d = L.CombineDiscriminator128_app(num_classes=184).finalize(DEV, torch.float32).train()
         d.zero_grad()
         d_img, d_obj, d_app = d(real, bbox, label)
-        loss = {"obj+app": d_obj.sum() + 0.5 * d_app.sum(), "obj": d_obj.sum(), "img": d_img.sum(),
+        loss = {"obj+app": d_obj.sum() + 0.5 * d_app.sum(), "obj": d_obj.sum(), "app": d_app.sum(), "img": d_img.sum(),
                 "all": d_img.sum() + d_obj.sum() + 0.5 * d_app.sum()}[heads]
         loss.backward()
         d.arena.flush_grads()
