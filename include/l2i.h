@@ -225,7 +225,9 @@ int l2i_norm_bwd_b(const float* x, const float* dxhat, const float* sums, const 
  * model/rcnn_discriminator_app.py:98-99,131-145; rows with valid == 0 give zeros. */
 int l2i_roi_align_fwd(const float* feat_s, const float* feat_l, const float* rois, const int* valid, float* out, int R,
                       int C, int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l, float thr, int sampling,
-                      void* stream);
+                      void* out_raw_bf16, void* out_relu_bf16, void* stream);
+/* (out_raw_bf16 / out_relu_bf16, optional: bf16 copies of out and of relu(out) written by the same launch -- the operands of
+ *  the two ROI heads' first convolutions, model/rcnn_discriminator_app.py:148-166) */
 int l2i_roi_align_bwd(const float* rois, const int* valid, const float* dout, float* dfeat_s, float* dfeat_l, int R, int C,
                       int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l, float thr, int sampling,
                       void* stream);

@@ -19,6 +19,7 @@ struct RoiArgs {
     const float* rois;                         // [R][5] = batch, x1, y1, x2, y2 (image pixels)
     const int* valid;                          // [R] or null
     float* out;                                // fwd: [R][P][P][C]; bwd: incoming gradient
+    bf16_t* out_raw; bf16_t* out_relu;         // fwd, optional: bf16 operand copies of out / relu(out) (what the two ROI heads read)
     int R, C, P, Hs, Ws, Hl, Wl, sampling;
     float scale_s, scale_l, thr;
 };
@@ -32,7 +33,12 @@ __global__ __launch_bounds__(128) void roi_align_kernel(RoiArgs p) {
     const bool ok = !p.valid || p.valid[r] != 0;
     if (!ok) {
         if (!BWD)
-            for (int c4 = threadIdx.x; c4 < cols4; c4 += 128) reinterpret_cast<float4*>(o)[c4] = make_float4(0, 0, 0, 0);
+            for (int c4 = threadIdx.x; c4 < cols4; c4 += 128) {
+                reinterpret_cast<float4*>(o)[c4] = make_float4(0, 0, 0, 0);
+                const size_t oo = ((size_t)r * p.P * p.P + bin) * p.C + 4 * c4;
+                if (p.out_raw) *reinterpret_cast<uint2*>(p.out_raw + oo) = make_uint2(0u, 0u);
+                if (p.out_relu) *reinterpret_cast<uint2*>(p.out_relu + oo) = make_uint2(0u, 0u);
+            }
         return;
     }
     const float* roi = p.rois + 5 * r;
@@ -93,6 +99,10 @@ __global__ __launch_bounds__(128) void roi_align_kernel(RoiArgs p) {
         if (!BWD) {
             acc.x *= inv_count; acc.y *= inv_count; acc.z *= inv_count; acc.w *= inv_count;
             reinterpret_cast<float4*>(o)[c4] = acc;
+            const size_t oo = ((size_t)r * p.P * p.P + bin) * p.C + 4 * c4;
+            if (p.out_raw) *reinterpret_cast<uint2*>(p.out_raw + oo) = make_uint2(f2bf2(acc.x, acc.y), f2bf2(acc.z, acc.w));
+            if (p.out_relu)
+                *reinterpret_cast<uint2*>(p.out_relu + oo) = make_uint2(f2bf2(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f)), f2bf2(fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)));
         }
     }
 }
@@ -108,11 +118,11 @@ static int roi_fill(RoiArgs& a, const float* feat_s, const float* feat_l, const 
 
 extern "C" int l2i_roi_align_fwd(const float* feat_s, const float* feat_l, const float* rois, const int* valid, float* out,
                                  int R, int C, int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l,
-                                 float thr, int sampling, void* stream) {
+                                 float thr, int sampling, void* out_raw_bf16, void* out_relu_bf16, void* stream) {
     RoiArgs a = {};
     if (roi_fill(a, feat_s, feat_l, rois, valid, R, C, P, Hs, Ws, scale_s, Hl, Wl, scale_l, thr, sampling) || !out)
         return L2I_ERR_ARG;
-    a.out = out;
+    a.out = out; a.out_raw = (bf16_t*)out_raw_bf16; a.out_relu = (bf16_t*)out_relu_bf16;
     if (R == 0) return L2I_OK;
     hipLaunchKernelGGL(roi_align_kernel<false>, dim3(R * P * P), dim3(128), 0, (hipStream_t)stream, a);
     return l2i_check_launch();

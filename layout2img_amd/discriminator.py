@@ -133,7 +133,8 @@ class ResnetDiscriminator128_app(nn.Module):
         # the ROI features are read by block_obj5 and by app_conv: the one created LATER (its backward runs first) leaves its complete
         # gradient in jobj, block_obj5's shortcut launch adds it; ROI-align's backward is the taker of last resort (a loss over d_app alone)
         jobj = ops.GradJoin() if (JOIN_READERS and torch.is_grad_enabled()) else None
-        obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0, join_src=jobj)  # (R,8,8,C)
+        obj = ops.roi_align(feat_s, feat_l, rois, valid, 8, 1.0 / 4.0, 1.0 / 8.0, 64.0, 0, join_src=jobj,
+                            emit_op=pc.arena.op_dtype if not pc.arena.split else None)  # (R,8,8,C) + both operand copies
 
         # appearance head (reference :148-157): Gram of the ROI features + class embedding
         if not pc.arena.split:   # both operand copies of the ROI features in ONE launch: app_conv's conv1 reads relu(obj), block_obj5 relu(obj) and obj

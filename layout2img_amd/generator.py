@@ -197,7 +197,7 @@ class PSPModule(nn.Module):
         conv, bn = self.bottleneck
         h = fused_conv(cat, conv, pc, emit=("stats",) if self.training else ())
         spec, w, b = bn.spec(self.training, sync, conv.co_p)
-        y = ops.norm_act(h, spec, w, b)
+        y = ops.norm_act(h, spec, w, b, emit_op=pc.arena.op_dtype if (pc.arena.op_dtype == torch.bfloat16 and not pc.arena.split) else None)   # (h: read by this layer alone)
         bn.commit(conv.co_p)
         if self.training and self.dropout_p > 0:  # nn.Dropout2d: whole channels per sample (the draws are torch's: same RNG stream as before)
             y = ops.channel_dropout(y, torch.rand(B, 1, 1, y.shape[3], device=y.device).view(B, -1), self.dropout_p)

@@ -1005,7 +1005,7 @@ def split_halves(x):
 # ----------------------------------------------------------------------------- ROIAlign
 class RoiAlignFn(Function):
     @staticmethod
-    def forward(ctx, feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling, join_src=None):
+    def forward(ctx, feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling, join_src=None, emit_op=None):
         _chk(feat_s, torch.float32)
         ctx.join_src = join_src
         B, Hs, Ws, C = feat_s.shape
@@ -1016,8 +1016,13 @@ class RoiAlignFn(Function):
         rois = _chk(rois.contiguous(), torch.float32)
         R = rois.shape[0]
         out = torch.empty((R, P, P, C), dtype=torch.float32, device=feat_s.device)
+        raw = relu = None
+        if emit_op is torch.bfloat16:   # both operand copies of the ROI features from this launch (ops.precast's job otherwise)
+            raw, relu = torch.empty_like(out, dtype=emit_op), torch.empty_like(out, dtype=emit_op)
         _lib.call("l2i_roi_align_fwd", feat_s.data_ptr(), _p(feat_l), rois.data_ptr(), _p(valid), out.data_ptr(), R, C, P,
-                  Hs, Ws, float(scale_s), Hl, Wl, float(scale_l), float(thr), sampling, _stream())
+                  Hs, Ws, float(scale_s), Hl, Wl, float(scale_l), float(thr), sampling, _p(raw), _p(relu), _stream())
+        if raw is not None:
+            _attach(out, raw=raw, relu=relu)
         ctx.save_for_backward(rois, valid)
         ctx.cfg = (P, scale_s, scale_l, thr, sampling, feat_s.shape, None if feat_l is None else feat_l.shape)
         return out
@@ -1036,12 +1041,13 @@ class RoiAlignFn(Function):
         Hl, Wl = (shp_l[1], shp_l[2]) if shp_l is not None else (0, 0)
         _lib.call("l2i_roi_align_bwd", rois.data_ptr(), _p(valid), g.data_ptr(), ds.data_ptr(), _p(dl), rois.shape[0],
                   shp_s[3], P, shp_s[1], shp_s[2], float(scale_s), Hl, Wl, float(scale_l), float(thr), sampling, _stream())
-        return ds, dl, None, None, None, None, None, None, None, None
+        return ds, dl, None, None, None, None, None, None, None, None, None
 
 
-def roi_align(feat_s, feat_l, rois, valid, P=8, scale_s=0.25, scale_l=0.125, thr=64.0, sampling=0, join_src=None):
-    """join_src: the GradJoin of the result's two readers (see GradJoin: the producer is the taker of last resort)."""
-    return RoiAlignFn.apply(feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling, join_src)
+def roi_align(feat_s, feat_l, rois, valid, P=8, scale_s=0.25, scale_l=0.125, thr=64.0, sampling=0, join_src=None, emit_op=None):
+    """join_src: the GradJoin of the result's two readers (see GradJoin: the producer is the taker of last resort).
+    emit_op: torch.bfloat16 to have the launch also write the raw and ReLU'd operand copies of the result (attached to it)."""
+    return RoiAlignFn.apply(feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling, join_src, emit_op)
 
 
 # ----------------------------------------------------------------------------- attention core
