@@ -284,7 +284,8 @@ int l2i_resize_bilinear(const float* in, float* out, long long N, int h, int w, 
 int l2i_gram_head_fwd(const float* x, const float* w, float* out, float* s_keep, float* t_keep, int R, int HW, int C,
                       void* stream);
 int l2i_gram_head_bwd(const float* x, const float* w, const float* s_keep, const float* t_keep, const float* g, float* dx,
-                      float* dw, float* ws, int R, int HW, int C, void* stream);
+                      float* dw, float* ws, int R, int HW, int C, void* dx_op_bf16, void* stream);
+/* (dx_op_bf16, optional, here and in l2i_proj_head_bwd: bf16 copy of dx -- the dY operand of the convolution that produced x) */
 
 /* Class-gathered logits of the generator's mask heads (round 5): the heads end in Conv2d(100, 184, 1) and the only reader of the 184-channel
  * result is gather(m, 1, y) (reference model/resnet_generator_app_v2.py:643-651, 465-466), so only the <= 8 channels of the image's own
@@ -319,7 +320,7 @@ int l2i_proj_head_fwd(const float* x, const void* wl, const void* emb, int emb_s
                       float scale, float* out, float* feat, int R, int HW, int C, int dtype, void* stream);
 int l2i_proj_head_bwd(const float* x, const void* wl, const void* emb, int emb_stride, const long long* y, const float* g,
                       const float* feat, float scale, float* dx, float* dwl, float* demb, int demb_stride, float* dbias, int R,
-                      int HW, int C, int dtype, void* stream);
+                      int HW, int C, int dtype, void* dx_op_bf16, void* stream);
 
 /* Class-embedding term of the appearance head (model/rcnn_discriminator_app.py:154-157):
  * out[r] = sum_c emb[y[r]][c] w2[c] + bias[0]; bwd: demb[y[r]][c] += g[r] w2[c], dw2[c] += sum_r g[r] emb[y[r]][c], dbias += sum g. */

@@ -50,9 +50,9 @@ SIGNATURES = {
     "l2i_debug_occupancy": [_i, _i],
     "l2i_resize_bilinear": [_p, _p, _ll, _i, _i, _i, _i, _p],
     "l2i_gram_head_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "l2i_gram_head_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "l2i_gram_head_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
     "l2i_proj_head_fwd": [_p, _p, _p, _i, _p, _p, _f, _p, _p, _i, _i, _i, _i, _p],
-    "l2i_proj_head_bwd": [_p, _p, _p, _i, _p, _p, _p, _f, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p],
+    "l2i_proj_head_bwd": [_p, _p, _p, _i, _p, _p, _p, _f, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "l2i_emb_dot_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "l2i_emb_dot_bwd": [_p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p],
     "l2i_psp_pool_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void gram_head_fwd_kernel(const float* __restr
 //   bwd: dx[r,p,c] = [x>0] g[r]/C^2 (t[r,p] + s[r,p] w[c]);  dw[c] += sum_{r,p} g[r]/C^2 s[r,p] a[r,p,c]  (via ws replicas)
 __global__ __launch_bounds__(256) void gram_head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ s_keep, const float* __restrict__ t_keep,
-                                                            const float* __restrict__ g, float* __restrict__ dx,
+                                                            const float* __restrict__ g, float* __restrict__ dx, bf16_t* __restrict__ dx_op,
                                                             float* __restrict__ ws, int HW, int C, int parts) {
     extern __shared__ float dwl[];   // [4 waves][C]
     const int r = blockIdx.x / parts, part = blockIdx.x % parts;
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void gram_head_bwd_kernel(const float* __restr
             d.x = v.x > 0.f ? fmaf(s, ww.x, t) : 0.f; d.y = v.y > 0.f ? fmaf(s, ww.y, t) : 0.f;
             d.z = v.z > 0.f ? fmaf(s, ww.z, t) : 0.f; d.w = v.w > 0.f ? fmaf(s, ww.w, t) : 0.f;
             *reinterpret_cast<float4*>(dx + off) = d;
+            if (dx_op) *reinterpret_cast<uint2*>(dx_op + off) = make_uint2(f2bf2(d.x, d.y), f2bf2(d.z, d.w));   // (the operand copy app_conv's conv2 backward reads)
             acc.x = fmaf(s, fmaxf(v.x, 0.f), acc.x); acc.y = fmaf(s, fmaxf(v.y, 0.f), acc.y);
             acc.z = fmaf(s, fmaxf(v.z, 0.f), acc.z); acc.w = fmaf(s, fmaxf(v.w, 0.f), acc.w);
         }
@@ -303,12 +304,12 @@ extern "C" int l2i_gram_head_fwd(const float* x, const float* w, float* out, flo
 }
 
 extern "C" int l2i_gram_head_bwd(const float* x, const float* w, const float* s_keep, const float* t_keep, const float* g,
-                                 float* dx, float* dw, float* ws, int R, int HW, int C, void* stream) {
+                                 float* dx, float* dw, float* ws, int R, int HW, int C, void* dx_op_bf16, void* stream) {
     if (!x || !w || !s_keep || !t_keep || !g || !dx || !dw || !ws || C % 4 || C > 4096 || R < 0) return L2I_ERR_ARG;
     if (R == 0) return L2I_OK;
     const int parts = (HW + GH_POS - 1) / GH_POS;
     hipLaunchKernelGGL(gram_head_bwd_kernel, dim3(R * parts), dim3(256), sizeof(float) * 4 * C, (hipStream_t)stream, x, w,
-                       s_keep, t_keep, g, dx, ws, HW, C, parts);
+                       s_keep, t_keep, g, dx, (bf16_t*)dx_op_bf16, ws, HW, C, parts);
     ws_fold(ws, C, C, dw, nullptr, nullptr, nullptr, (hipStream_t)stream);
     return l2i_check_launch();
 }
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(256) void proj_head_bwd_kernel(const float* __restr
                                                             const T* __restrict__ emb, int emb_stride, const long long* __restrict__ y,
                                                             const float* __restrict__ g, const float* __restrict__ feat, float scale,
                                                             float* __restrict__ dx, float* __restrict__ dwl, float* __restrict__ demb,
-                                                            int demb_stride, float* __restrict__ dbias, int R, int HW, int C) {
+                                                            int demb_stride, float* __restrict__ dbias, int R, int HW, int C, bf16_t* __restrict__ dx_op) {
     __shared__ float red[256];
     if ((int)blockIdx.x >= R) {
         if (dwl) colsum16<float>(feat, C, nullptr, g, R, C, ((int)blockIdx.x - R) * 16, dwl, red);
@@ -746,6 +747,7 @@ __global__ __launch_bounds__(256) void proj_head_bwd_kernel(const float* __restr
             float4 d;
             d.x = v.x > 0.f ? w0 : 0.f; d.y = v.y > 0.f ? w1 : 0.f; d.z = v.z > 0.f ? w2 : 0.f; d.w = v.w > 0.f ? w3 : 0.f;
             *reinterpret_cast<float4*>(dx + base + (size_t)p * C) = d;
+            if (dx_op) *reinterpret_cast<uint2*>(dx_op + base + (size_t)p * C) = make_uint2(f2bf2(d.x, d.y), f2bf2(d.z, d.w));
         }
         if (demb && gr != 0.f) {
             const float4 f = *reinterpret_cast<const float4*>(feat + (size_t)r * C + c);
@@ -771,16 +773,16 @@ extern "C" int l2i_proj_head_fwd(const float* x, const void* wl, const void* emb
 
 extern "C" int l2i_proj_head_bwd(const float* x, const void* wl, const void* emb, int emb_stride, const long long* y,
                                  const float* g, const float* feat, float scale, float* dx, float* dwl, float* demb,
-                                 int demb_stride, float* dbias, int R, int HW, int C, int dtype, void* stream) {
+                                 int demb_stride, float* dbias, int R, int HW, int C, int dtype, void* dx_op_bf16, void* stream) {
     if (!x || !wl || !g || !feat || !dx || (emb && !y) || (demb && !emb) || C % 4 || R < 0 || HW <= 0) return L2I_ERR_ARG;
     if (R == 0) return L2I_OK;
     const int extra = (dwl || dbias) ? (C + 15) / 16 : 0;
     if (dtype == 1)
         hipLaunchKernelGGL(proj_head_bwd_kernel<bf16_t>, dim3(R + extra), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)wl,
-                           (const bf16_t*)emb, emb_stride, y, g, feat, scale, dx, dwl, demb, demb_stride, dbias, R, HW, C);
+                           (const bf16_t*)emb, emb_stride, y, g, feat, scale, dx, dwl, demb, demb_stride, dbias, R, HW, C, (bf16_t*)dx_op_bf16);
     else
         hipLaunchKernelGGL(proj_head_bwd_kernel<float>, dim3(R + extra), dim3(256), 0, (hipStream_t)stream, x, (const float*)wl,
-                           (const float*)emb, emb_stride, y, g, feat, scale, dx, dwl, demb, demb_stride, dbias, R, HW, C);
+                           (const float*)emb, emb_stride, y, g, feat, scale, dx, dwl, demb, demb_stride, dbias, R, HW, C, (bf16_t*)dx_op_bf16);
     return l2i_check_launch();
 }
 

@@ -500,6 +500,7 @@ def _atomics_split(B, Ho, Wo, n_out, kh, k_in, op_dtype):
     return not (kh == 3 and op_dtype == torch.bfloat16 and k_in >= 64 and Wo >= 8 and STORED_SPLITS)   # (4-wide maps: the weight-stationary kernel)
 
 
+HEAD_DX_OP = __import__("os").environ.get("L2I_HEAD_DX_OP", "1") != "0"   # the discriminator heads' backward writes the bf16 copy of dx (A/B switch)
 BIAS_SLOTS = __import__("os").environ.get("L2I_BIAS_SLOTS", "1") != "0"   # A/B switch: padded-channel bias gradients from the weight-gradient launch
 STORED_SPLITS = __import__("os").environ.get("L2I_CONV_PART", "1") != "0"   # (the library's switch of the same name)
 
@@ -1198,8 +1199,11 @@ class GramHeadFn(Function):
         g = g.contiguous()
         dx = torch.empty_like(x)
         dw = _zeros((C,), x.device)
+        dop = torch.empty_like(x, dtype=torch.bfloat16) if HEAD_DX_OP else None   # (x is the result of a convolution read by this head alone)
         _lib.call("l2i_gram_head_bwd", x.data_ptr(), w.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), g.data_ptr(),
-                  dx.data_ptr(), dw.data_ptr(), _ws(x.device), R, H * W, C, _stream())
+                  dx.data_ptr(), dw.data_ptr(), _ws(x.device), R, H * W, C, _p(dop), _stream())
+        if dop is not None:
+            _attach(dx, raw=dop)
         return dx, dw
 
 
@@ -1324,9 +1328,12 @@ class ProjHeadFn(Function):
         dbias = _zeros((1,), x.device) if (wg and bias is not None) else None
         dwl = pc.dw_slice(hl) if wg else None
         demb = pc.dw_slice(he) if (wg and he is not None) else None
+        dop = torch.empty_like(x, dtype=torch.bfloat16) if (HEAD_DX_OP and wl.dtype == torch.bfloat16) else None
         _lib.call("l2i_proj_head_bwd", x.data_ptr(), wl.data_ptr(), _p(emb), he.kpad if he is not None else 0, _p(y), g.data_ptr(),
                   feat.data_ptr(), scale, dx.data_ptr(), _p(dwl), _p(demb), he.kp if he is not None else 0, _p(dbias),
-                  R, H * W, C, _code(wl.dtype), _stream())
+                  R, H * W, C, _code(wl.dtype), _p(dop), _stream())
+        if dop is not None:
+            _attach(dx, raw=dop)
         return dx, dbias, None, None, None, None, None
 
 
