@@ -229,8 +229,11 @@ int l2i_roi_align_fwd(const float* feat_s, const float* feat_l, const float* roi
 /* (out_raw_bf16 / out_relu_bf16, optional: bf16 copies of out and of relu(out) written by the same launch -- the operands of
  *  the two ROI heads' first convolutions, model/rcnn_discriminator_app.py:148-166) */
 int l2i_roi_align_bwd(const float* rois, const int* valid, const float* dout, float* dfeat_s, float* dfeat_l, int R, int C,
-                      int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l, float thr, int sampling,
-                      void* stream);
+                      int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l, float thr, int sampling, int B, int fresh,
+                      void* dfeat_s_bf16, void* dfeat_l_bf16, void* stream);
+/* fresh = 0: dfeat_* += (the caller cleared them). fresh = 1 (B = images in the maps): the maps are uninitialised and receive the
+ * gradient; for map widths <= 32, P = 8, C % 32 == 0 a gather kernel then writes every pixel once (no atomics, deterministic sum,
+ * no clear) and, when given, the bf16 copies of both maps (dfeat_*_bf16, fresh only). */
 
 /* box_attention core (model/resnet_generator_app_v2.py:79-120; geo == NULL gives the VG variant,
  * model/resnet_generator_vg.py:77-122). q, k, v: rows of D floats, `ld` floats apart (D, or the width of a grouped projection

@@ -37,7 +37,7 @@ SIGNATURES = {
     "l2i_norm_mod_bwd_a": [_p, _p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _p],
     "l2i_norm_bwd_b": [_p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _f, _f, _i, _p, _p],
     "l2i_roi_align_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f, _i, _p, _p, _p],
-    "l2i_roi_align_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f, _i, _p],
+    "l2i_roi_align_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f, _i, _i, _i, _p, _p, _p],
     "l2i_box_attention_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "l2i_box_attention_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "l2i_hinge_fwd_bwd": [_p, _p, _i, _i, _f, _p, _p, _p, _p],

@@ -228,16 +228,197 @@ __global__ __launch_bounds__(256) void roi_align_bwd_sep_kernel(RoiArgs p, int c
     }
 }
 
+// Backward, gather form (round 5): one workgroup per (image, map, 8 feature rows, 32 channels) OWNS its output tile -- 8 rows x
+// <= 32 columns x 32 channels, 32 accumulators per thread -- and walks the image's ROIs on that map (<= o of them, found with a
+// ballot over the R rows: order = row order, so the sum is deterministic). Per ROI the separable products of the kernel above:
+//   G (64 bins x 32 channels) -> LDS;  T[y][pw][c] = sum_ph Wy[y][ph] G[ph][pw][c]  for the tile's rows;
+//   acc[y][x][c] += sum_pw Wx[x][pw] T[y][pw][c].
+// Every pixel of the gradient maps is written exactly once with plain stores: no atomics (20 M per pass before), no zero fill
+// of the 67 + 17 MB maps before the launch, and the bf16 operand copies the following weight / data gradient launches read
+// come out of the same stores. Needs map widths <= 32, P == 8, C % 32 == 0 (128^2 and 64^2 images); else the scatter form.
+#define RG_ROWS 8
+#define RG_C 32
+__global__ __launch_bounds__(256, 4) void roi_align_bwd_gather_kernel(RoiArgs p, bf16_t* __restrict__ dop_s, bf16_t* __restrict__ dop_l, int chunks,
+                                                                   int tiles_s, int tiles_l) {
+    __shared__ float Gs[64 * RG_C];            // [bin][c], already / count
+    __shared__ float T[RG_ROWS * 8 * RG_C];    // [y][pw][c]
+    __shared__ float Wy[RG_ROWS * 8], Wx[32 * 8];
+    __shared__ int list[256];
+    __shared__ int wcnt[4], nl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int c0 = (bid % chunks) * RG_C; bid /= chunks;
+    const int tiles = tiles_s + tiles_l;
+    const int tt = bid % tiles, b = bid / tiles;
+    const bool small = tt < tiles_s;
+    const int row0 = (small ? tt : tt - tiles_s) * RG_ROWS;
+    const int H = small ? p.Hs : p.Hl, W = small ? p.Ws : p.Wl;
+    const float scale = small ? p.scale_s : p.scale_l;
+    // ---- the ROIs of image b routed to this map, in row order
+    if (tid == 0) nl = 0;
+    __syncthreads();
+    for (int base = 0; base < p.R; base += 256) {
+        const int r = base + tid;
+        bool f = false;
+        if (r < p.R && (!p.valid || p.valid[r] != 0)) {
+            const float* roi = p.rois + 5 * r;
+            const bool sm = !p.dfeat_l || ((roi[3] - roi[1]) < p.thr && (roi[4] - roi[2]) < p.thr);
+            f = (int)roi[0] == b && sm == small;
+        }
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = nl;
+        for (int w_ = 0; w_ < wave; ++w_) off += wcnt[w_];
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        if (f && off < 256) list[off] = r;
+        __syncthreads();
+        if (tid == 0) nl = min(256, nl + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+        __syncthreads();
+    }
+    const int n_roi = nl;
+    const int c = tid & (RG_C - 1), xg = tid >> 5;   // thread: channel c, columns xg + 8 k, all 8 rows
+    float acc[RG_ROWS][4];
+#pragma unroll
+    for (int y = 0; y < RG_ROWS; ++y)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[y][k] = 0.f;
+    const int P = p.P;   // == 8
+    struct Geo { float x1, y1, bin_w, bin_h, inv_count; int gh, gw; bool hit; };
+    auto geo = [&](int r) {
+        Geo q;
+        const float* roi = p.rois + 5 * r;
+        q.x1 = roi[1] * scale; q.y1 = roi[2] * scale;
+        const float x2 = roi[3] * scale, y2 = roi[4] * scale;
+        const float roi_w = fmaxf(x2 - q.x1, 1.f), roi_h = fmaxf(y2 - q.y1, 1.f);
+        q.bin_h = roi_h / P; q.bin_w = roi_w / P;
+        q.gh = p.sampling > 0 ? p.sampling : (int)ceilf(roi_h / P);
+        q.gw = p.sampling > 0 ? p.sampling : (int)ceilf(roi_w / P);
+        q.inv_count = 1.f / fmaxf((float)(q.gh * q.gw), 1.f);
+        const int fy0 = max((int)floorf(q.y1), 0), fy1 = min((int)floorf(q.y1 + roi_h) + 1, H - 1);
+        q.hit = !(fy1 < row0 || fy0 >= row0 + RG_ROWS);   // the footprint touches this tile's rows
+        return q;
+    };
+    // the ROIs whose footprint touches the tile, one after the other; the NEXT one's 64 x 32 gradient values are requested before the
+    // current one's products are formed (the launch is four workgroups per CU deep: its latency has to hide inside the workgroup)
+    float gq[8];
+    int li = 0;
+    Geo cur = {};
+    for (; li < n_roi; ++li) {
+        cur = geo(list[li]);
+        if (cur.hit) break;
+    }
+    if (li < n_roi) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gq[j] = p.out[((size_t)list[li] * 64 + (tid >> 5) + 8 * j) * p.C + c0 + c];
+    }
+    while (li < n_roi) {
+        __syncthreads();   // the previous ROI's Gs / T / Wy / Wx are no longer read
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Gs[((tid >> 5) + 8 * j) * RG_C + c] = gq[j] * cur.inv_count;
+        int ln = li + 1;
+        Geo nxt = {};
+        for (; ln < n_roi; ++ln) {
+            nxt = geo(list[ln]);
+            if (nxt.hit) break;
+        }
+        if (ln < n_roi) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gq[j] = p.out[((size_t)list[ln] * 64 + (tid >> 5) + 8 * j) * p.C + c0 + c];
+        }
+        for (int i = tid; i < RG_ROWS * 8 + W * 8; i += 256) {
+            const bool isx = i >= RG_ROWS * 8;
+            const int j = isx ? i - RG_ROWS * 8 : i;
+            const int pix = (j >> 3) + (isx ? 0 : row0), pb = j & 7;   // absolute feature row / column
+            const int g = isx ? cur.gw : cur.gh, lim = isx ? W : H;
+            const float start = isx ? cur.x1 : cur.y1, bsz = isx ? cur.bin_w : cur.bin_h;
+            float w = 0.f;
+            for (int s_ = 0; s_ < g; ++s_) {
+                const float v = start + pb * bsz + (s_ + 0.5f) * bsz / g;
+                if (v < -1.f || v > (float)lim) continue;
+                float vv = fmaxf(v, 0.f);
+                int lo = (int)vv, hi;
+                if (lo >= lim - 1) { hi = lo = lim - 1; vv = (float)lo; } else hi = lo + 1;
+                const float l = vv - lo, h = 1.f - l;
+                if (lo == pix) w += h;
+                if (hi == pix) w += l;
+            }
+            (isx ? Wx : Wy)[j] = w;
+        }
+        __syncthreads();
+        {   // T[y = xg][pw][c]
+            float t[8];
+#pragma unroll
+            for (int pw = 0; pw < 8; ++pw) t[pw] = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < 8; ++ph) {
+                const float wy = Wy[xg * 8 + ph];
+#pragma unroll
+                for (int pw = 0; pw < 8; ++pw) t[pw] = fmaf(wy, Gs[(ph * 8 + pw) * RG_C + c], t[pw]);
+            }
+#pragma unroll
+            for (int pw = 0; pw < 8; ++pw) T[(xg * 8 + pw) * RG_C + c] = t[pw];
+        }
+        __syncthreads();
+        float wx[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int pw = 0; pw < 8; ++pw) wx[k][pw] = xg + 8 * k < W ? Wx[(xg + 8 * k) * 8 + pw] : 0.f;
+#pragma unroll
+        for (int y = 0; y < RG_ROWS; ++y) {
+            float t[8];
+#pragma unroll
+            for (int pw = 0; pw < 8; ++pw) t[pw] = T[(y * 8 + pw) * RG_C + c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int pw = 0; pw < 8; ++pw) acc[y][k] = fmaf(wx[k][pw], t[pw], acc[y][k]);
+        }
+        li = ln; cur = nxt;
+    }
+    float* dfeat = (small ? p.dfeat_s : p.dfeat_l) + (size_t)b * H * W * p.C;
+    bf16_t* dop = small ? dop_s : dop_l;
+    if (dop) dop += (size_t)b * H * W * p.C;
+#pragma unroll
+    for (int y = 0; y < RG_ROWS; ++y) {
+        if (row0 + y >= H) break;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = xg + 8 * k;
+            if (x >= W) continue;
+            const size_t o = ((size_t)(row0 + y) * W + x) * p.C + c0 + c;
+            dfeat[o] = acc[y][k];
+            if (dop) dop[o] = f2bf(acc[y][k]);
+        }
+    }
+}
+
 extern "C" int l2i_roi_align_bwd(const float* rois, const int* valid, const float* dout, float* dfeat_s, float* dfeat_l,
                                  int R, int C, int P, int Hs, int Ws, float scale_s, int Hl, int Wl, float scale_l,
-                                 float thr, int sampling, void* stream) {
+                                 float thr, int sampling, int B, int fresh, void* dfeat_s_bf16, void* dfeat_l_bf16, void* stream) {
     RoiArgs a = {};
     // the gradient maps stand in for the feature maps (only "is there a coarse map" is read from them)
     if (roi_fill(a, dfeat_s, dfeat_l, rois, valid, R, C, P, Hs, Ws, scale_s, Hl, Wl, scale_l, thr, sampling) || !dout)
         return L2I_ERR_ARG;
     a.dfeat_s = dfeat_s; a.dfeat_l = dfeat_l; a.out = const_cast<float*>(dout);
-    if (R == 0) return L2I_OK;
+    if ((dfeat_s_bf16 || dfeat_l_bf16) && !fresh) return L2I_ERR_ARG;   // (the copies are of the complete maps)
     if (P > RB_P) return L2I_ERR_ARG;
+    // fresh: the maps are uninitialised memory and receive the gradient (=, not +=). The gather form writes every pixel itself.
+    static const bool no_gather = getenv("L2I_ROI_GATHER") && atoi(getenv("L2I_ROI_GATHER")) == 0;
+    if (fresh && B <= 0) return L2I_ERR_ARG;
+    if (fresh && !no_gather && P == 8 && C % RG_C == 0 && Ws <= 32 && (!dfeat_l || Wl <= 32) && Hs > 0) {
+        const int chunks = C / RG_C;
+        const int tiles_s = (Hs + RG_ROWS - 1) / RG_ROWS, tiles_l = dfeat_l ? (Hl + RG_ROWS - 1) / RG_ROWS : 0;
+        hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3((unsigned)(B * (tiles_s + tiles_l) * chunks)), dim3(256), 0, (hipStream_t)stream, a,
+                           (bf16_t*)dfeat_s_bf16, (bf16_t*)dfeat_l_bf16, chunks, tiles_s, tiles_l);
+        return l2i_check_launch();
+    }
+    if (fresh) {
+        if (l2i_zero_async(dfeat_s, sizeof(float) * (size_t)B * Hs * Ws * C, (hipStream_t)stream) != hipSuccess) return L2I_ERR_LAUNCH;
+        if (dfeat_l && l2i_zero_async(dfeat_l, sizeof(float) * (size_t)B * Hl * Wl * C, (hipStream_t)stream) != hipSuccess) return L2I_ERR_LAUNCH;
+    }
+    if (R == 0) return L2I_OK;
     const int chunks = (C + RB_C - 1) / RB_C;
     hipLaunchKernelGGL(roi_align_bwd_sep_kernel, dim3(R * chunks), dim3(256), 0, (hipStream_t)stream, a, chunks);
     return l2i_check_launch();

@@ -500,6 +500,7 @@ def _atomics_split(B, Ho, Wo, n_out, kh, k_in, op_dtype):
     return not (kh == 3 and op_dtype == torch.bfloat16 and k_in >= 64 and Wo >= 8 and STORED_SPLITS)   # (4-wide maps: the weight-stationary kernel)
 
 
+ROI_GATHER = __import__("os").environ.get("L2I_ROI_GATHER", "1") != "0"   # (the library's switch of the same name)
 HEAD_DX_OP = __import__("os").environ.get("L2I_HEAD_DX_OP", "1") != "0"   # the discriminator heads' backward writes the bf16 copy of dx (A/B switch)
 BIAS_SLOTS = __import__("os").environ.get("L2I_BIAS_SLOTS", "1") != "0"   # A/B switch: padded-channel bias gradients from the weight-gradient launch
 STORED_SPLITS = __import__("os").environ.get("L2I_CONV_PART", "1") != "0"   # (the library's switch of the same name)
@@ -1008,7 +1009,7 @@ class RoiAlignFn(Function):
     @staticmethod
     def forward(ctx, feat_s, feat_l, rois, valid, P, scale_s, scale_l, thr, sampling, join_src=None, emit_op=None):
         _chk(feat_s, torch.float32)
-        ctx.join_src = join_src
+        ctx.join_src, ctx.emit_op = join_src, emit_op
         B, Hs, Ws, C = feat_s.shape
         Hl = Wl = 0
         if feat_l is not None:
@@ -1037,11 +1038,21 @@ class RoiAlignFn(Function):
             parked = ctx.join_src.leftover()
             if parked is not None:
                 g = g + parked
-        ds = torch.zeros(shp_s, dtype=torch.float32, device=g.device)
-        dl = torch.zeros(shp_l, dtype=torch.float32, device=g.device) if shp_l is not None else None
+        # fresh maps: the library writes every pixel (gather form) or clears them itself before scattering
+        ds = torch.empty(shp_s, dtype=torch.float32, device=g.device)
+        dl = torch.empty(shp_l, dtype=torch.float32, device=g.device) if shp_l is not None else None
         Hl, Wl = (shp_l[1], shp_l[2]) if shp_l is not None else (0, 0)
+        # the bf16 copies of both maps from the same stores (what block_obj4's conv2 backward reads), where the gather form runs
+        emit = ctx.emit_op is torch.bfloat16 and P == 8 and shp_s[3] % 32 == 0 and shp_s[2] <= 32 and Wl <= 32 and ROI_GATHER
+        ds_op = torch.empty(shp_s, dtype=torch.bfloat16, device=g.device) if emit else None
+        dl_op = torch.empty(shp_l, dtype=torch.bfloat16, device=g.device) if (emit and shp_l is not None) else None
         _lib.call("l2i_roi_align_bwd", rois.data_ptr(), _p(valid), g.data_ptr(), ds.data_ptr(), _p(dl), rois.shape[0],
-                  shp_s[3], P, shp_s[1], shp_s[2], float(scale_s), Hl, Wl, float(scale_l), float(thr), sampling, _stream())
+                  shp_s[3], P, shp_s[1], shp_s[2], float(scale_s), Hl, Wl, float(scale_l), float(thr), sampling, shp_s[0], 1,
+                  _p(ds_op), _p(dl_op), _stream())
+        if ds_op is not None:
+            _attach(ds, raw=ds_op)
+        if dl_op is not None:
+            _attach(dl, raw=dl_op)
         return ds, dl, None, None, None, None, None, None, None, None, None
 
 

@@ -66,3 +66,49 @@ def test_two_scale_routing_and_validity():
     vals = out.mean(dim=(1, 2, 3)).cpu().tolist()
     assert vals[:-1] == [1.0 if s else 2.0 for _, s in RC.ROUTING]
     assert vals[-1] == 0.0
+
+
+@pytest.mark.parametrize("size,C", [(128, 64), (64, 32), (128, 512)])
+def test_gather_backward_equals_scatter_backward(size, C):
+    """l2i_roi_align_bwd with fresh = 1 (gather form: every pixel of both gradient maps written once by the workgroup that owns it,
+    plus the bf16 copies) against fresh = 0 (the separable scatter with atomics into cleared maps) on the two-scale layout of
+    model/rcnn_discriminator_app.py:131-145: boxes that straddle the borders, one-pixel boxes, large boxes on the coarse map,
+    padding rows, an image without boxes."""
+    from layout2img_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(size + C)
+    B, o, P = 4, 6, 8
+    Hs, Hl = size // 4, size // 8
+    xy = torch.rand(B, o, 2, generator=g) * size * 0.9 - 0.05 * size
+    wh = torch.rand(B, o, 2, generator=g) * size * 0.8 + 1.0
+    wh[0, 0] = 1.0                                    # a one-pixel box
+    wh[1, 1] = torch.tensor([size * 0.95, 70.0])      # wide: coarse map
+    xy[1, 2], wh[1, 2] = torch.tensor([-9.0, -9.0]), torch.tensor([30.0, 30.0])             # straddles the top-left corner
+    xy[2, 0], wh[2, 0] = torch.tensor([size - 20.0, size - 20.0]), torch.tensor([40.0, 40.0])   # ... the bottom-right one
+    rois = torch.cat([torch.arange(B).view(B, 1, 1).expand(B, o, 1).float(), xy, xy + wh], dim=2).reshape(-1, 5)
+    valid = torch.ones(B * o, dtype=torch.int32)
+    valid[3 * o:] = 0                                 # image 3: no boxes at all
+    valid[5] = 0
+    R = B * o
+    dout = torch.randn(R, P, P, C, generator=g)
+    rois_d, valid_d, dout_d = rois.to(dev).contiguous(), valid.to(dev), dout.to(dev)
+
+    def run(fresh):
+        fill = float("nan") if fresh else 0.0
+        ds = torch.full((B, Hs, Hs, C), fill, device=dev)
+        dl = torch.full((B, Hl, Hl, C), fill, device=dev)
+        ops_s = torch.empty((B, Hs, Hs, C), dtype=torch.bfloat16, device=dev) if fresh else None
+        ops_l = torch.empty((B, Hl, Hl, C), dtype=torch.bfloat16, device=dev) if fresh else None
+        _lib.call("l2i_roi_align_bwd", rois_d.data_ptr(), valid_d.data_ptr(), dout_d.data_ptr(), ds.data_ptr(), dl.data_ptr(), R, C, P,
+                  Hs, Hs, 0.25, Hl, Hl, 0.125, 64.0, 0, B, fresh, ops_s.data_ptr() if fresh else None, ops_l.data_ptr() if fresh else None,
+                  torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return ds, dl, ops_s, ops_l
+    s0, l0, _, _ = run(0)
+    s1, l1, o_s, o_l = run(1)
+    assert bool(torch.isfinite(s1).all()) and bool(torch.isfinite(l1).all())   # every pixel written (the maps started as NaN)
+    assert float(s0.abs().max()) > 0 and float(l0.abs().max()) > 0
+    for a, b_ in ((s1, s0), (l1, l0)):
+        assert float((a - b_).abs().max()) < 2e-5 * float(b_.abs().max())
+    assert float(s1[3].abs().max()) == 0.0 and float(l1[3].abs().max()) == 0.0
+    assert torch.equal(o_s, s1.to(torch.bfloat16)) and torch.equal(o_l, l1.to(torch.bfloat16))
