@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void psp_pool_rows_kernel(const float* __restr
     const int y = blockIdx.x, b = blockIdx.y, H = gridDim.x;
     for (int i = threadIdx.x; i < NQ * W; i += 256) wl[i] = wx[i];
     __syncthreads();
+    // (round 5: the bin weights through the scalar cache instead of LDS broadcasts -- they are wave-uniform -- measured 49 -> 69 us)
     const int cl = threadIdx.x & 127, half = threadIdx.x >> 7, hw = W >> 1;
     const float* row = feats + ((size_t)(b * H + y) * W) * C;
     float* dst = T + ((size_t)(b * H + y) * NQ) * C;
@@ -150,12 +151,34 @@ __global__ __launch_bounds__(256) void psp_expand_fwd_kernel(const float* __rest
     psp_load_taps(taps, uidx, uw, (size_t)p0 * NS * 4, PSP_CH * NS * 4);
     __syncthreads();
     const int Wd = NS * F + C;
-    const int f4n = F >> 2, g_pri = NS * f4n, g_all = g_pri + (C >> 2);
+    const int f4n = F >> 2, g_pri = NS * f4n;
+    {   // the copy of feats into the last C columns: four 16-byte loads in flight per thread (one task at a time, mixed with the
+        // interpolation tasks below, left every load waiting for its own round trip: 61 us for 205 MB; round 5)
+        const int c4n = C >> 2, nt = PSP_CH * c4n;
+        for (int t0 = threadIdx.x; t0 < nt; t0 += 1024) {
+            float4 f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(t0 + 256 * u, nt - 1);
+                const int pl = t / c4n, c = 4 * (t - pl * c4n);
+                f[u] = *reinterpret_cast<const float4*>(feats + ((size_t)b * HW + p0 + pl) * C + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 256 * u;
+                if (t >= nt) break;
+                const int pl = t / c4n, c = 4 * (t - pl * c4n);
+                const float v[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
+                Op4<T>::store(cat + ((size_t)b * HW + p0 + pl) * Wd + NS * F + c, v);
+            }
+        }
+    }
+    const int g_all = g_pri;
     for (int t0 = threadIdx.x; t0 < PSP_CH * g_all; t0 += 256) {
         const int pl = t0 / g_all, gq = t0 - pl * g_all;
         T* row = cat + ((size_t)b * HW + p0 + pl) * Wd;
         float v[4];
-        if (gq < g_pri) {
+        {
             const int s = gq / f4n, j = 4 * (gq - s * f4n);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -167,11 +190,6 @@ __global__ __launch_bounds__(256) void psp_expand_fwd_kernel(const float* __rest
             }
             v[0] = acc.x; v[1] = acc.y; v[2] = acc.z; v[3] = acc.w;
             Op4<T>::store(row + s * F + j, v);
-        } else {
-            const int c = 4 * (gq - g_pri);
-            const float4 f = *reinterpret_cast<const float4*>(feats + ((size_t)b * HW + p0 + pl) * C + c);
-            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-            Op4<T>::store(row + NS * F + c, v);
         }
     }
 }

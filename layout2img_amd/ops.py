@@ -1293,9 +1293,9 @@ class ClassLogitsFn(Function):
         O, C = y.shape[1], w.shape[1]
         g = _chk(g.contiguous(), torch.float32)
         da = torch.empty_like(a)
-        dw = torch.zeros_like(w)
-        db = torch.zeros(ctx.nb, dtype=torch.float32, device=a.device) if ctx.has_bias else None
-        tmp = torch.zeros((B * O, 128), dtype=torch.float32, device=a.device)
+        dw = _zeros(tuple(w.shape), a.device)   # (slices of the step's pre-zeroed slab: consumed by the accumulations right behind this node)
+        db = _zeros((ctx.nb,), a.device) if ctx.has_bias else None
+        tmp = _zeros((B * O, 128), a.device)
         _lib.call("l2i_class_logits_bwd", a.data_ptr(), w.data_ptr(), y.data_ptr(), g.data_ptr(), da.data_ptr(), dw.data_ptr(), _p(db), tmp.data_ptr(),
                   w.shape[0], B, O, H * W, Cp, C, w.stride(0), _stream())
         da._l2i_owned = True   # (fresh, handed to exactly one consumer: NormActFn.backward may overwrite it)
