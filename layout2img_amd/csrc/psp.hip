@@ -33,46 +33,43 @@ __device__ __forceinline__ void psp_load_taps(int2* dst, const int* __restrict__
 #define PSP_MAXQ 16     // x-bins over all stages (1 + 2 + 3 + 6 = 12)
 #define PSP_MAXW 128
 
-// pooling pass 1: thread = (channel, half row); wx [NQ][W]
-__global__ __launch_bounds__(256) void psp_pool_rows_kernel(const float* __restrict__ feats, const float* __restrict__ wx,
-                                                            float* __restrict__ T, int W, int C, int NQ) {
+// pooling pass 1: thread = (4 channels, one of the workgroup's 8 image rows); wx [NQ][W]. A bin weight read from LDS serves four
+// multiply-adds (round 4's form -- one channel per thread, half a row each -- issued one LDS broadcast per multiply-add and spent
+// its 49 us there, for a 67 MB read); a thread walks its whole row, eight 16-byte loads in flight, so nothing is combined across threads.
+#define PSP_PR 2   // image rows per workgroup = one wave (8 rows in a 256-thread workgroup: 256 workgroups for the whole map, 50 us)
+__global__ __launch_bounds__(32 * PSP_PR) void psp_pool_rows_kernel(const float* __restrict__ feats, const float* __restrict__ wx,
+                                                            float* __restrict__ T, int H, int W, int C, int NQ) {
     __shared__ float wl[PSP_MAXQ * PSP_MAXW];
-    __shared__ float red[PSP_MAXQ * 128];
-    const int y = blockIdx.x, b = blockIdx.y, H = gridDim.x;
-    for (int i = threadIdx.x; i < NQ * W; i += 256) wl[i] = wx[i];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < NQ * W; i += 32 * PSP_PR) wl[i] = wx[i];
     __syncthreads();
-    // (round 5: the bin weights through the scalar cache instead of LDS broadcasts -- they are wave-uniform -- measured 49 -> 69 us)
-    const int cl = threadIdx.x & 127, half = threadIdx.x >> 7, hw = W >> 1;
+    const int cq = threadIdx.x & 31, y = blockIdx.x * PSP_PR + (threadIdx.x >> 5);
+    if (y >= H) return;
     const float* row = feats + ((size_t)(b * H + y) * W) * C;
     float* dst = T + ((size_t)(b * H + y) * NQ) * C;
-    for (int c0 = 0; c0 < C; c0 += 128) {
-        const int c = c0 + cl;
-        float acc[PSP_MAXQ];
+    for (int c = 4 * cq; c < C; c += 128) {
+        float4 acc[PSP_MAXQ];
 #pragma unroll
-        for (int q = 0; q < PSP_MAXQ; ++q) acc[q] = 0.f;
-        if (c < C) {
-            for (int x0 = half * hw; x0 < (half + 1) * hw; x0 += 16) {
-                float v[16];
+        for (int q = 0; q < PSP_MAXQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int x0 = 0; x0 < W; x0 += 8) {
+            float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = row[(size_t)min(x0 + u, W - 1) * C + c];   // (unconditional loads: all 16 in flight)
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(row + (size_t)min(x0 + u, W - 1) * C + c);   // (unconditional loads: all 8 in flight)
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const bool in = x0 + u < (half + 1) * hw;
+            for (int u = 0; u < 8; ++u) {
+                const bool in = x0 + u < W;
 #pragma unroll
-                    for (int q = 0; q < PSP_MAXQ; ++q)
-                        if (q < NQ) acc[q] = fmaf(in ? wl[q * W + min(x0 + u, W - 1)] : 0.f, v[u], acc[q]);
-                }
+                for (int q = 0; q < PSP_MAXQ; ++q)
+                    if (q < NQ) {
+                        const float w = in ? wl[q * W + min(x0 + u, W - 1)] : 0.f;
+                        acc[q].x = fmaf(w, v[u].x, acc[q].x); acc[q].y = fmaf(w, v[u].y, acc[q].y);
+                        acc[q].z = fmaf(w, v[u].z, acc[q].z); acc[q].w = fmaf(w, v[u].w, acc[q].w);
+                    }
             }
         }
-        if (half == 1)
 #pragma unroll
-            for (int q = 0; q < PSP_MAXQ; ++q) red[q * 128 + cl] = acc[q];
-        __syncthreads();
-        if (half == 0 && c < C)
-#pragma unroll
-            for (int q = 0; q < PSP_MAXQ; ++q)
-                if (q < NQ) dst[(size_t)q * C + c] = acc[q] + red[q * 128 + cl];
-        __syncthreads();
+        for (int q = 0; q < PSP_MAXQ; ++q)
+            if (q < NQ) *reinterpret_cast<float4*>(dst + (size_t)q * C + c) = acc[q];
     }
 }
 
@@ -202,37 +199,58 @@ __global__ __launch_bounds__(256) void psp_expand_fwd_kernel(const float* __rest
 template <typename T_, int WMAX>
 __global__ __launch_bounds__(256) void psp_expand_rows_kernel(const T_* __restrict__ g, const float* __restrict__ wxt,
                                                               const int* __restrict__ qoff, float* __restrict__ T,
-                                                              float* __restrict__ dfeats, int W, int C, int F, int NQ, int NS) {
+                                                              float* __restrict__ dfeats, int p_H, int W, int C, int F, int NQ, int NS) {
     __shared__ float wl[PSP_MAXQ * PSP_MAXW];
     __shared__ int qo[16];
-    const int y = blockIdx.x, b = blockIdx.y, H = gridDim.x;
+    // thread = (4 consecutive prior columns of one stage, one of the workgroup's 2 image rows): 8-byte loads, and a bin weight read
+    // from LDS serves four multiply-adds (one column per thread: one LDS read per multiply-add and 2-byte loads, 54 us; round 5)
+    const int b = blockIdx.y, H = p_H;
     for (int i = threadIdx.x; i < NQ * W; i += 256) wl[i] = wxt[i];
     if (threadIdx.x <= NS) qo[threadIdx.x] = qoff[threadIdx.x];
     __syncthreads();
     const int Wd = NS * F + C;
-    const T_* row = g + ((size_t)(b * H + y) * W) * Wd;
-    float* dst = T + ((size_t)(b * H + y) * NQ) * F;
-    for (int col = threadIdx.x; col < NS * F; col += 256) {
-        const int s = col / F, j = col - s * F;
-        float v[WMAX];
+    const int f4n = F >> 2, nquad = NS * f4n;
+    const int quad = threadIdx.x & 127, y = blockIdx.x * 2 + (threadIdx.x >> 7);
+    if (y < H && quad < nquad) {
+        const T_* row = g + ((size_t)(b * H + y) * W) * Wd;
+        float* dst = T + ((size_t)(b * H + y) * NQ) * F;
+        const int s = quad / f4n, j = 4 * (quad - s * f4n), col = s * F + j;
+        const int q0 = qo[s], nq = min(qo[s + 1] - q0, 8);
+        float4 acc[8];
 #pragma unroll
-        for (int x = 0; x < WMAX; ++x) v[x] = OpT<T_>::to(row[(size_t)min(x, W - 1) * Wd + col]);   // (unconditional: a guarded load is waited for at once; columns past W get weight 0 below)
-        const int q0 = qo[s], nq = qo[s + 1] - q0;
-        for (int q = 0; q < nq; ++q) {
-            const float* w = wl + (q0 + q) * W;
-            float acc = 0.f;
+        for (int q = 0; q < 8; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int x0 = 0; x0 < W; x0 += 16) {
+            float v[16][4];
 #pragma unroll
-            for (int x = 0; x < WMAX; ++x) acc = fmaf(x < W ? w[x] : 0.f, v[x], acc);
-            dst[(size_t)(q0 + q) * F + j] = acc;
+            for (int u = 0; u < 16; ++u) Op4<T_>::load(row + (size_t)min(x0 + u, W - 1) * Wd + col, v[u]);   // (unconditional: all 16 in flight)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool in = x0 + u < W;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < nq) {
+                        const float w = in ? wl[(q0 + q) * W + min(x0 + u, W - 1)] : 0.f;
+                        acc[q].x = fmaf(w, v[u][0], acc[q].x); acc[q].y = fmaf(w, v[u][1], acc[q].y);
+                        acc[q].z = fmaf(w, v[u][2], acc[q].z); acc[q].w = fmaf(w, v[u][3], acc[q].w);
+                    }
+            }
         }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < nq) *reinterpret_cast<float4*>(dst + (size_t)(q0 + q) * F + j) = acc[q];
     }
     const int c4n = C >> 2;
     if (dfeats)   // (null: l2i_psp_pool_bwd reads these columns of g itself)
-    for (int t = threadIdx.x; t < W * c4n; t += 256) {
-        const int x = t / c4n, c = 4 * (t - x * c4n);
-        float v[4];
-        Op4<T_>::load(row + (size_t)x * Wd + NS * F + c, v);
-        *reinterpret_cast<float4*>(dfeats + ((size_t)(b * H + y) * W + x) * C + c) = make_float4(v[0], v[1], v[2], v[3]);
+    for (int rr = 0; rr < 2; ++rr) {
+        const int yy = blockIdx.x * 2 + rr;
+        if (yy >= H) break;
+        const T_* row = g + ((size_t)(b * H + yy) * W) * Wd;
+        for (int t = threadIdx.x; t < W * c4n; t += 256) {
+            const int x = t / c4n, c = 4 * (t - x * c4n);
+            float v[4];
+            Op4<T_>::load(row + (size_t)x * Wd + NS * F + c, v);
+            *reinterpret_cast<float4*>(dfeats + ((size_t)(b * H + yy) * W + x) * C + c) = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
 }
 
@@ -246,7 +264,7 @@ extern "C" int l2i_psp_pool_fwd(const float* feats, const float* wx, const float
     if (!feats || !wx || !wy || !xq || !pooled || !rows || H <= 0 || H > PSP_MAXW || (H & 1) || NQ <= 0 || NQ > PSP_MAXQ ||
         !psp_ok(B, H * H, C, 0, NB))
         return L2I_ERR_ARG;
-    hipLaunchKernelGGL(psp_pool_rows_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, feats, wx, rows, H, C, NQ);
+    hipLaunchKernelGGL(psp_pool_rows_kernel, dim3((H + PSP_PR - 1) / PSP_PR, B), dim3(32 * PSP_PR), 0, (hipStream_t)stream, feats, wx, rows, H, H, C, NQ);
     hipLaunchKernelGGL(psp_rows_reduce_kernel, dim3((NB * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, rows, wy, xq, pooled,
                        H, NQ, C, NB);
     return l2i_check_launch();
@@ -293,9 +311,10 @@ extern "C" int l2i_psp_expand_bwd(const void* g, const float* wxt, const float* 
     if (!g || !wxt || !wy || !xq || !qoff || !dy || !rows || H <= 0 || H > PSP_MAXW || NQ <= 0 || NQ > PSP_MAXQ ||
         n_stages <= 0 || n_stages > 8 || !psp_ok(B, H * H, C, F, NB) || F == 0)
         return L2I_ERR_ARG;
-    const dim3 grid(H, B);
+    if (n_stages * (F / 4) > 128) return L2I_ERR_ARG;   // (a thread per 4 prior columns, 128 per image row)
+    const dim3 grid((H + 1) / 2, B);
     hipStream_t st = (hipStream_t)stream;
-#define PSP_ROWS(TT, WM) hipLaunchKernelGGL((psp_expand_rows_kernel<TT, WM>), grid, dim3(256), 0, st, (const TT*)g, wxt, qoff, rows, dfeats, H, C, F, NQ, n_stages)
+#define PSP_ROWS(TT, WM) hipLaunchKernelGGL((psp_expand_rows_kernel<TT, WM>), grid, dim3(256), 0, st, (const TT*)g, wxt, qoff, rows, dfeats, H, H, C, F, NQ, n_stages)
     if (dtype == 1) {
         if (H <= 32) PSP_ROWS(bf16_t, 32); else if (H <= 64) PSP_ROWS(bf16_t, 64); else PSP_ROWS(bf16_t, 128);
     } else if (dtype == 0) {

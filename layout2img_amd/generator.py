@@ -125,6 +125,7 @@ def psp_taps(H, sizes, device):
     nb = total number of bins; pwx / uwx (nq, H), pwy / uwy (nb, H), xq (nb), qoff: the separable form, see below).
     Bins are numbered stage after stage, row-major inside a stage."""
     key = (H, tuple(sizes), str(device))
+    assert max(sizes) <= 8, "csrc/psp.hip psp_expand_rows_kernel keeps at most 8 x-bins of a stage in registers"
     if key not in _PSP_TAPS:
         At = torch.cat([resample_matrix("adaptive_avg", H, s, "cpu") for s in sizes], dim=0).t().contiguous()   # (HW, NB)
         assert int((At != 0).sum(dim=1).max()) <= 12
