@@ -333,8 +333,9 @@ class GanTrainer:
             # watchdog takes the process down -- measured: 4 of 11 runs of the one-rank RCCL test. Let the lists drain first.
             import time
             time.sleep(float(os.environ.get("L2I_CAPTURE_DRAIN_S", "0.5")))
-        for net in (self.netG, self.netD):
-            net.arena.free_packs = []
+        self._graph_packs = []   # (a new capture replaces the single-iteration graph and the multi-iteration one built on it)
+        self._graph_multi = None
+        self._lend_packs()
         graph = torch.cuda.CUDAGraph()
         err = None
         try:
@@ -385,8 +386,7 @@ class GanTrainer:
         side = self._cap_stream
         side.wait_stream(cur)
         torch.cuda.synchronize()
-        for net in (self.netG, self.netD):
-            net.arena.free_packs = []
+        self._lend_packs()
         t_host = (self.g_opt.t, self.d_opt.t)
         graph = torch.cuda.CUDAGraph()
         try:
@@ -401,6 +401,18 @@ class GanTrainer:
             net.arena.free_packs = []
         self._graph_multi = graph
         return True
+
+    def _lend_packs(self):
+        """Before a capture: the pass contexts created inside it take their W / sigma pack buffers from here. A pack buffer must be
+        zero in its padding rows and K tails (the pack kernel writes only true elements): allocated INSIDE the capture, every replay
+        would clear 2 x 80 ... 130 M bf16 again (a memset node per buffer: 94 us per iteration, profiles/r05). These are cleared once,
+        here, and kept alive by the trainer for as long as the graphs exist -- a graph writes to their addresses on every replay, so
+        they must never go back to the allocator (the eager iterations' free list is emptied again right after the capture)."""
+        keep = self.__dict__.setdefault("_graph_packs", [])
+        for net, n in ((self.netG, 2), (self.netD, 3)):
+            a = net.arena
+            a.free_packs = [torch.zeros(a.packed_len, dtype=a.op_dtype, device=a.device) for _ in range(n)]
+            keep += a.free_packs
 
     def step_graphed_multi(self, batches):
         """Copies len(batches) new batches into the static inputs of the multi-iteration graph and replays it; returns the list of
