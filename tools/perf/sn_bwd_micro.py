@@ -17,7 +17,7 @@ def t(fn, n=10):
     return s.elapsed_time(e) / n * 1e3
 
 
-for name, net, npass in (("D x2", L.CombineDiscriminator128_app(num_classes=184), 2), ("G x1", L.ResnetGenerator128_context(num_classes=184), 1)):
+for name, net, npass in (("D x2", L.CombineDiscriminator128_app(num_classes=184), 2), ("D x1", L.CombineDiscriminator128_app(num_classes=184), 1), ("G x1", L.ResnetGenerator128_context(num_classes=184), 1)):
     torch.manual_seed(0)
     net.finalize(DEV, torch.bfloat16).train()
     a = net.arena
