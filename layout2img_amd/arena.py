@@ -335,7 +335,8 @@ class WeightArena:
             else:
                 h.use_rows.append(LayerUse(h, **attrs))
             row[18] = 1 if h.uses > 1 else 0
-            bw = 2304 if taps == 1 else 256               # csrc/weights.hip: bw_chunk()
+            bw_dot = 2304 if taps == 1 else 256                                           # csrc/weights.hip: bw_chunk_dot()
+            bw = 2304 if taps == 1 else (1024 if (taps == 9 and h.ci % 4 == 0) else 256)   # csrc/weights.hip: bw_chunk() (sn_apply)
             pair_chunks = (h.co * h.ci + bw - 1) // bw
             if h.sn:
                 for c0 in range(0, kt, 256):              # csrc/weights.hip sn_wtu_kernel: 256 columns x 4 waves x rpw rows
@@ -343,7 +344,7 @@ class WeightArena:
                         t_wtu[use].append((i, c0, r0, WTU_RPW))
                 for r0 in range(0, h.co, 4 * WV_R):       # sn_wv_kernel<R>: 4 R rows per block
                     t_wv[use].append((i, r0))
-                t_dot += [(i, c) for c in range(pair_chunks)]
+                t_dot += [(i, c) for c in range((h.co * h.ci + bw_dot - 1) // bw_dot)]
             tci = 256 if taps == 1 else 32
             for ct in range((h.co_p + 63) // 64):         # PK_TCO
                 for cc in range((h.ci_p + tci - 1) // tci):

@@ -383,7 +383,11 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restr
 // pairs per table entry: 256 for the 3x3 layers (2304 floats of W); 1x1 / linear layers take 2304 pairs per block as well (nine per
 // thread) -- at 256 they were 1 KB blocks, as many of them as the 3x3 layers have for a fifteenth of the bytes (arena.py builds the
 // tables; tools/perf/sn_bwd_micro.py: the generator's flush 219 -> 150 us)
-__device__ __forceinline__ int bw_chunk(int taps) { return taps == 1 ? BW_PAIRS * 9 : BW_PAIRS; }
+// 3x3 layers with Ci % 4 == 0: 1024 pairs per block, a thread owns FOUR consecutive input channels of one output channel -- its dWbar
+// loads are 16 bytes (a wave reads 1 KB runs instead of 256 B ones) and four times the bytes are in flight per thread
+#define BW_QUAD 1024
+__device__ __forceinline__ int bw_chunk(int taps, int Ci) { return taps == 1 ? BW_PAIRS * 9 : (taps == 9 && (Ci & 3) == 0) ? BW_QUAD : BW_PAIRS; }   // sn_apply
+__device__ __forceinline__ int bw_chunk_dot(int taps) { return taps == 1 ? BW_PAIRS * 9 : BW_PAIRS; }   // sn_dot: the quad form measured no faster there (143 -> 145 us)
 
 // phase a: <G, W> per SN layer, one atomic per block into replica (block % 32) of ws[(r * NP + pass) * n_layers + layer].
 // NP = 2: the two passes of one optimiser step that share W (D(real) and D(fake), train_context_app_v2.py:158,167) in one
@@ -399,8 +403,8 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const long long* __restrict
     const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Ci_p = (int)LF(7);
     const int taps = KH * KH, Kp = taps * Ci_p;
-    const long long p0 = (long long)e[1] * bw_chunk(taps);
-    const int np = (int)min((long long)bw_chunk(taps), (long long)Co * Ci - p0);
+    const long long p0 = (long long)e[1] * bw_chunk_dot(taps);
+    const int np = (int)min((long long)bw_chunk_dot(taps), (long long)Co * Ci - p0);
     const float* W = params + LF(0) + p0 * taps;
     float acc[NP];
 #pragma unroll
@@ -459,14 +463,14 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
                                                        const float* __restrict__ uv0, const float* __restrict__ uv1,
                                                        float* __restrict__ norms0, float* __restrict__ norms1,
                                                        const float* __restrict__ ws, int n_layers, float* __restrict__ grads, int overwrite) {
-    __shared__ float gl[BW_PAIRS * 9];
+    __shared__ __attribute__((aligned(16))) float gl[BW_QUAD * 9];
     const int* e = table + 2 * blockIdx.x;
     const int layer = e[0];
     const long long* L = layers + L2I_LSTRIDE * layer;
     const int Co = (int)LF(3), Ci = (int)LF(4), KH = (int)LF(5), Ci_p = (int)LF(7);
     const int taps = KH * KH, Kp = taps * Ci_p;
-    const long long p0 = (long long)e[1] * bw_chunk(taps);
-    const int np = (int)min((long long)bw_chunk(taps), (long long)Co * Ci - p0);
+    const long long p0 = (long long)e[1] * bw_chunk(taps, Ci);
+    const int np = (int)min((long long)bw_chunk(taps, Ci), (long long)Co * Ci - p0);
     const bool sn = LF(1) >= 0;
     float inv[NP], gw[NP];
 #pragma unroll
@@ -509,6 +513,41 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
         }
         return;
     }
+    if (taps == 9 && (Ci & 3) == 0) {   // four consecutive ci per thread (see bw_chunk)
+        if (4 * (int)threadIdx.x < np) {
+            const long long pq = p0 + 4 * threadIdx.x;
+            const int co = (int)(pq / Ci), ci = (int)(pq - (long long)co * Ci);
+            const size_t goff = (size_t)LF(14) + (size_t)co * Kp + ci;
+            float4 gv[NP][9], v4[NP][9];
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) gv[q][tap] = *reinterpret_cast<const float4*>((q == 0 ? dwbar0 : dwbar1) + goff + tap * Ci_p);
+            float uc[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                uc[q] = sn ? (q == 0 ? uv0 : uv1)[LF(16) + co] * gw[q] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 9; ++j)   // v[(ci + k) * 9 + tap], k < 4: 36 consecutive floats
+                    v4[q][j] = sn ? *reinterpret_cast<const float4*>((q == 0 ? uv0 : uv1) + LF(17) + (size_t)ci * 9 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float x[36];   // [k][tap] = W's order
+#pragma unroll
+            for (int m = 0; m < 36; ++m) x[m] = 0.f;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const float* vf = reinterpret_cast<const float*>(v4[q]);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float g4[4] = {gv[q][tap].x, gv[q][tap].y, gv[q][tap].z, gv[q][tap].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[k * 9 + tap] += sn ? (g4[k] - uc[q] * vf[k * 9 + tap]) * inv[q] : g4[k];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) reinterpret_cast<float4*>(gl)[9 * threadIdx.x + j] = make_float4(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
+        }
+    } else
     if ((int)threadIdx.x < np) {
         const long long pr = p0 + threadIdx.x;
         const int co = (int)(pr / Ci), ci = (int)(pr - (long long)co * Ci);
@@ -547,13 +586,18 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
     if (LF(18)) {   // rows of a multiply-applied weight update the same gradient concurrently
         for (int j = threadIdx.x; j < np * taps; j += 256) atomicAdd(dst + j, gl[j]);
     } else if (overwrite) {   // the gradient buffer is known to be zero here (first flush after zero_grad): no read
-        for (int j = threadIdx.x; j < np * taps; j += 256) dst[j] = gl[j];
-    } else if (np * taps == 9 * 256) {   // a full 3x3 block: the nine read-modify-writes of a thread in one batch
-        float dv[9];
+        if ((np * taps & 3) == 0)   // (16-byte stores: p0 * taps and the parameter offsets are multiples of 4)
+            for (int j = threadIdx.x; j < np * taps / 4; j += 256) reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(gl)[j];
+        else
+            for (int j = threadIdx.x; j < np * taps; j += 256) dst[j] = gl[j];
+    } else if ((np * taps) % (9 * 256) == 0) {   // full blocks: the read-modify-writes of a thread in batches of nine
+        for (int b0 = 0; b0 < np * taps; b0 += 9 * 256) {
+            float dv[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) dv[q] = dst[threadIdx.x + 256 * q];
+            for (int q = 0; q < 9; ++q) dv[q] = dst[b0 + threadIdx.x + 256 * q];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) dst[threadIdx.x + 256 * q] = dv[q] + gl[threadIdx.x + 256 * q];
+            for (int q = 0; q < 9; ++q) dst[b0 + threadIdx.x + 256 * q] = dv[q] + gl[b0 + threadIdx.x + 256 * q];
+        }
     } else {
         for (int j = threadIdx.x; j < np * taps; j += 256) dst[j] += gl[j];
     }
