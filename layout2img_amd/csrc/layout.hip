@@ -964,8 +964,12 @@ __global__ __launch_bounds__(256) void in_relu_up2_fwd_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < S * S; ++i) v[i] = fmaxf((v[i] - mean) * istd, 0.f);
     float* op = out + n * 4 * S * S * C + c;
+    // gridDim.z workgroups share an (object, channel chunk): each forms the statistics again (64 values from L2) and writes its share of
+    // the 2S output rows -- one workgroup per object was 256 workgroups of four waves for 117 MB of stores (37 us)
+    const int rows_per = (2 * S + (int)gridDim.z - 1) / (int)gridDim.z, oy_lo = (int)blockIdx.z * rows_per, oy_hi = min(2 * S, oy_lo + rows_per);
 #pragma unroll
     for (int oy = 0; oy < 2 * S; ++oy) {
+        if (oy < oy_lo || oy >= oy_hi) continue;
         int y0, y1; float ly;
         up2_tap(oy, S, y0, y1, ly);
         float row[S];
@@ -1051,7 +1055,7 @@ __global__ __launch_bounds__(256) void in_relu_up2_bwd_kernel(const float* __res
 }
 extern "C" int l2i_in_relu_up2_fwd(const float* x, float* out, void* out_op, int op_dtype, long long N, int S, int C, float eps, void* stream) {
     if (!x || !out || N < 1 || C < 1 || (S != 4 && S != 8) || (op_dtype != 0 && op_dtype != 1)) return L2I_ERR_ARG;
-    const dim3 grid((unsigned)N, (unsigned)((C + 255) / 256));
+    const dim3 grid((unsigned)N, (unsigned)((C + 255) / 256), S == 8 ? 4u : 2u);
     if (S == 4) hipLaunchKernelGGL(in_relu_up2_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, out, out_op, op_dtype, C, eps);
     else hipLaunchKernelGGL(in_relu_up2_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, out, out_op, op_dtype, C, eps);
     return l2i_check_launch();
