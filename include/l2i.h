@@ -233,7 +233,8 @@ int l2i_roi_align_bwd(const float* rois, const int* valid, const float* dout, fl
                       void* dfeat_s_bf16, void* dfeat_l_bf16, void* stream);
 /* fresh = 0: dfeat_* += (the caller cleared them). fresh = 1 (B = images in the maps): the maps are uninitialised and receive the
  * gradient; for map widths <= 32, P = 8, C % 32 == 0 a gather kernel then writes every pixel once (no atomics, deterministic sum,
- * no clear) and, when given, the bf16 copies of both maps (dfeat_*_bf16, fresh only). */
+ * no clear) and, when given, the bf16 copies of both maps (dfeat_*_bf16: gather form only -- R <= 1024 besides the conditions
+ * above -- an error otherwise). */
 
 /* box_attention core (model/resnet_generator_app_v2.py:79-120; geo == NULL gives the VG variant,
  * model/resnet_generator_vg.py:77-122). q, k, v: rows of D floats, `ld` floats apart (D, or the width of a grouped projection

@@ -238,12 +238,13 @@ __global__ __launch_bounds__(256) void roi_align_bwd_sep_kernel(RoiArgs p, int c
 // come out of the same stores. Needs map widths <= 32, P == 8, C % 32 == 0 (128^2 and 64^2 images); else the scatter form.
 #define RG_ROWS 8
 #define RG_C 32
+#define RG_LIST 1024   // ROIs of one image on one map a workgroup can list: the launcher takes the gather form only for R <= RG_LIST
 __global__ __launch_bounds__(256, 4) void roi_align_bwd_gather_kernel(RoiArgs p, bf16_t* __restrict__ dop_s, bf16_t* __restrict__ dop_l, int chunks,
                                                                    int tiles_s, int tiles_l) {
     __shared__ float Gs[64 * RG_C];            // [bin][c], already / count
     __shared__ float T[RG_ROWS * 8 * RG_C];    // [y][pw][c]
     __shared__ float Wy[RG_ROWS * 8], Wx[32 * 8];
-    __shared__ int list[256];
+    __shared__ int list[RG_LIST];
     __shared__ int wcnt[4], nl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -271,9 +272,9 @@ __global__ __launch_bounds__(256, 4) void roi_align_bwd_gather_kernel(RoiArgs p,
         int off = nl;
         for (int w_ = 0; w_ < wave; ++w_) off += wcnt[w_];
         off += __popcll(m & ((1ull << lane) - 1ull));
-        if (f && off < 256) list[off] = r;
+        if (f && off < RG_LIST) list[off] = r;
         __syncthreads();
-        if (tid == 0) nl = min(256, nl + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+        if (tid == 0) nl = min(RG_LIST, nl + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
         __syncthreads();
     }
     const int n_roi = nl;
@@ -407,13 +408,14 @@ extern "C" int l2i_roi_align_bwd(const float* rois, const int* valid, const floa
     // fresh: the maps are uninitialised memory and receive the gradient (=, not +=). The gather form writes every pixel itself.
     static const bool no_gather = getenv("L2I_ROI_GATHER") && atoi(getenv("L2I_ROI_GATHER")) == 0;
     if (fresh && B <= 0) return L2I_ERR_ARG;
-    if (fresh && !no_gather && P == 8 && C % RG_C == 0 && Ws <= 32 && (!dfeat_l || Wl <= 32) && Hs > 0) {
+    if (fresh && !no_gather && P == 8 && C % RG_C == 0 && Ws <= 32 && (!dfeat_l || Wl <= 32) && Hs > 0 && R <= RG_LIST) {
         const int chunks = C / RG_C;
         const int tiles_s = (Hs + RG_ROWS - 1) / RG_ROWS, tiles_l = dfeat_l ? (Hl + RG_ROWS - 1) / RG_ROWS : 0;
         hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3((unsigned)(B * (tiles_s + tiles_l) * chunks)), dim3(256), 0, (hipStream_t)stream, a,
                            (bf16_t*)dfeat_s_bf16, (bf16_t*)dfeat_l_bf16, chunks, tiles_s, tiles_l);
         return l2i_check_launch();
     }
+    if (dfeat_s_bf16 || dfeat_l_bf16) return L2I_ERR_ARG;   // (only the gather form writes the copies: refuse rather than leave them unwritten)
     if (fresh) {
         if (l2i_zero_async(dfeat_s, sizeof(float) * (size_t)B * Hs * Ws * C, (hipStream_t)stream) != hipSuccess) return L2I_ERR_LAUNCH;
         if (dfeat_l && l2i_zero_async(dfeat_l, sizeof(float) * (size_t)B * Hl * Wl * C, (hipStream_t)stream) != hipSuccess) return L2I_ERR_LAUNCH;

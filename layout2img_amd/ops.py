@@ -1043,7 +1043,8 @@ class RoiAlignFn(Function):
         dl = torch.empty(shp_l, dtype=torch.float32, device=g.device) if shp_l is not None else None
         Hl, Wl = (shp_l[1], shp_l[2]) if shp_l is not None else (0, 0)
         # the bf16 copies of both maps from the same stores (what block_obj4's conv2 backward reads), where the gather form runs
-        emit = ctx.emit_op is torch.bfloat16 and P == 8 and shp_s[3] % 32 == 0 and shp_s[2] <= 32 and Wl <= 32 and ROI_GATHER
+        emit = (ctx.emit_op is torch.bfloat16 and P == 8 and shp_s[3] % 32 == 0 and shp_s[2] <= 32 and Wl <= 32 and rois.shape[0] <= 1024
+                and ROI_GATHER)   # (the library's conditions for the gather form; it refuses the copies otherwise)
         ds_op = torch.empty(shp_s, dtype=torch.bfloat16, device=g.device) if emit else None
         dl_op = torch.empty(shp_l, dtype=torch.bfloat16, device=g.device) if (emit and shp_l is not None) else None
         _lib.call("l2i_roi_align_bwd", rois.data_ptr(), _p(valid), g.data_ptr(), ds.data_ptr(), _p(dl), rois.shape[0],

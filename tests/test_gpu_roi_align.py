@@ -112,3 +112,22 @@ def test_gather_backward_equals_scatter_backward(size, C):
         assert float((a - b_).abs().max()) < 2e-5 * float(b_.abs().max())
     assert float(s1[3].abs().max()) == 0.0 and float(l1[3].abs().max()) == 0.0
     assert torch.equal(o_s, s1.to(torch.bfloat16)) and torch.equal(o_l, l1.to(torch.bfloat16))
+
+
+def test_bf16_copies_are_refused_where_the_gather_form_cannot_run():
+    """The bf16 copies of the gradient maps come out of the gather kernel's stores only: a geometry it does not take (C % 32 != 0 here)
+    with the copies requested is an error, not a silently unwritten buffer."""
+    from layout2img_amd import _lib
+    dev = torch.device("cuda:0")
+    B, R, C, P, Hs = 1, 2, 20, 8, 16
+    rois = torch.tensor([[0, 2.0, 2.0, 30.0, 30.0], [0, 8.0, 8.0, 20.0, 20.0]], device=dev)
+    dout = torch.randn(R, P, P, C, device=dev)
+    ds = torch.empty(B, Hs, Hs, C, device=dev)
+    cp = torch.empty(B, Hs, Hs, C, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError):
+        _lib.call("l2i_roi_align_bwd", rois.data_ptr(), None, dout.data_ptr(), ds.data_ptr(), None, R, C, P, Hs, Hs, 0.25, 0, 0, 0.0, 1e30, 0,
+                  B, 1, cp.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    _lib.call("l2i_roi_align_bwd", rois.data_ptr(), None, dout.data_ptr(), ds.data_ptr(), None, R, C, P, Hs, Hs, 0.25, 0, 0, 0.0, 1e30, 0,
+              B, 1, None, None, torch.cuda.current_stream().cuda_stream)   # (without the copies: the scatter form, maps cleared by the library)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ds).all()) and float(ds.abs().max()) > 0
