@@ -169,7 +169,7 @@ def precision_mode_figures(netG, args, z, bbox, z_im, label, ms_bf16):
     """The generator forward (same weights, same inputs, eval mode) in the two modes that meet the north star's image bar
     L_inf < 1e-3 -- exact-f32 MFMA operands, and "bf16x3" (bf16 operands carried as hi + lo, three MFMA products per pair) --
     timed eagerly, with each mode's measured L_inf against the exact-f32 mode's image (which is within 9.4e-6 of the reference,
-    tests/test_gpu_models.py). Secondary figures: never `value`."""
+    tests/test_gpu_00_models.py). Secondary figures: never `value`."""
     import layout2img_amd as L
     dev = z.device
     nets = {}
@@ -194,7 +194,7 @@ def precision_mode_figures(netG, args, z, bbox, z_im, label, ms_bf16):
     netG.train(was_training)
     for name in ("bf16", "bf16x3"):
         res[name]["image_linf_vs_f32_mode"] = float((imgs[name] - imgs["f32"]).abs().max())
-    res["f32"]["image_linf_vs_reference"] = "9.4e-6 (tests/test_gpu_models.py::test_generator_coco_vs_reference[f32])"
+    res["f32"]["image_linf_vs_reference"] = "9.4e-6 (tests/test_gpu_00_models.py::test_generator_coco_vs_reference[f32])"
     res["bar"] = 1e-3
     return res
 
@@ -218,7 +218,7 @@ def f32_mode_figures(args, dev, real, label, bbox, steps=4):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return dict(images_per_sec=round(args.batch * steps / dt, 1), ms_per_step=round(1e3 * dt / steps, 2), steps=steps, launch="eager",
-                dtype="f32", image_linf_vs_reference="9.4e-6 (tests/test_gpu_models.py, bar 1e-3)")
+                dtype="f32", image_linf_vs_reference="9.4e-6 (tests/test_gpu_00_models.py, bar 1e-3)")
 
 
 def main():

@@ -584,7 +584,7 @@ class ResnetGenerator64_context(ResnetGenerator128_context):
     `res1`, blocks named res2..res5) with the app_v2 blocks: fc -> 4x4x16ch -> four up-blocks at 8/16/32/64 px, mask
     heads on the first three (PSP on the second-to-last, as :411-415 do for their last two blocks), none on the last;
     the 64x64 regressed masks and rectangle indicators are unchanged. Parity for this class is block-level (every
-    block is the 128x128 model's, checked against the reference goldens) plus an end-to-end test (tests/test_res64.py)."""
+    block is the 128x128 model's, checked against the reference goldens) plus an end-to-end test (tests/test_gpu_05_res64.py)."""
 
     def __init__(self, ch=64, z_dim=128, num_classes=10, output_dim=3):
         _GeneratorBase.__init__(self)

@@ -9,7 +9,7 @@ the oracle here, not only its batch-of-2 miniature.
 (iii) EVERY distinct conv / data-gradient / weight-gradient launch of one full-size training iteration, captured live from
       GanTrainer.step (so a new tile heuristic, fold or epilogue option is covered the moment the trainer uses it), re-issued
       through ops.conv_raw / ops.wgrad_raw on pre-rounded random operands and compared with torch's f32 convolution on the CPU:
-      accumulation order is the only difference, the bars are those of tests/test_gpu_ops.py (3e-5 / 2e-4 of the result's max).
+      accumulation order is the only difference, the bars are those of tests/test_gpu_02_ops.py (3e-5 / 2e-4 of the result's max).
       The captured signature list is written to gpurun_out/headline_launches.json.
 """
 import json

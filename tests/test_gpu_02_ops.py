@@ -2,7 +2,7 @@
 
 Operands are pre-rounded to the operand dtype before the reference is evaluated, so the bf16 cases
 compare accumulation order only and can use tight tolerances; model-level bf16 tolerances live in
-tests/test_gpu_models.py.
+tests/test_gpu_00_models.py.
 """
 import math
 

@@ -10,7 +10,7 @@ import math
 import pytest
 import torch
 
-from tests.test_gpu_ops import _pack, _ref_conv, _rt
+from tests.test_gpu_02_ops import _pack, _ref_conv, _rt
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

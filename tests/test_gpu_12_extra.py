@@ -97,8 +97,12 @@ def test_two_generator_forwards_before_one_backward():
         g.arena.flush_grads()
         torch.cuda.synchronize()
         return g.flat.grad.clone()
-    a, b = grads((z1, z2), True), grads((z1, z2), False)
-    assert float((a - b).norm() / b.norm()) < 2e-3, float((a - b).norm() / b.norm())
+    a, b, b2 = grads((z1, z2), True), grads((z1, z2), False), grads((z1, z2), False)
+    floor = float((b2 - b).norm() / b.norm())   # two identical runs: accumulation-order noise of this train-mode batch-of-2 network
+    rel = float((a - b).norm() / b.norm())
+    print(f"together vs separate {rel:.2e}, separate vs separate {floor:.2e}")
+    # a forward whose saved statistics were re-zeroed by the second forward gives an O(1) error; the bar is the measured same-run floor
+    assert rel < max(3 * floor, 3e-3), (rel, floor)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -151,7 +155,7 @@ def test_weight_gradient_with_the_fused_last_arriver_reduction():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, L2I_WGRAD_FUSE="1")
-    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_gpu_ops.py", "tests/test_gpu_dual.py", "-k",
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_gpu_02_ops.py", "tests/test_gpu_09_dual.py", "-k",
                         "conv_wgrad or dual_wgrad or device_side_image_count"], cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert p.returncode == 0, p.stdout[-3000:]
 

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import layout2img_amd as L
 from tests.golden import recipe
 from tests.helpers import load_fixture, maxdiff
-from tests import test_gpu_models as T
+from tests import test_gpu_00_models as T
 DEV = "cuda:0"
 
 

@@ -1,6 +1,6 @@
 import sys, os, torch
 sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/tests") else os.environ.get("GRAFT_REPO_ROOT", "."))
-from tests import test_gpu_models as T
+from tests import test_gpu_00_models as T
 from tests.helpers import vgg_inputs
 x0, y0 = vgg_inputs()
 taps, grads = {}, {}
