@@ -30,25 +30,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(netG, netD, size, seconds_budget=20.0):
-    """Oracle training iterations on the host CPU (all cores); returns images/sec."""
+def cpu_baseline(netG, netD, size, batch=32):
+    """The oracle's training iteration on the host CPU (all cores), the SAME workload as the GPU line: one warm-up iteration at batch 4
+    (thread pools, allocator), then ONE timed iteration at the line's own batch (batch 32 at 128x128: ~20 s on the GPU box's host).
+    Returns images/sec."""
     from oracle import model as O
     from layout2img_amd.synthetic import make_batch
-    threads = min(os.cpu_count() or 1, 32)  # more threads than this slow the small-batch oracle down
+    threads = min(os.cpu_count() or 1, 32)  # (more threads than this slow the oracle down)
     torch.set_num_threads(threads)
     sd_g = O.make_trainable({k: v.detach().float().cpu() for k, v in netG.state_dict().items()})
     sd_d = O.make_trainable({k: v.detach().float().cpu() for k, v in netD.state_dict().items()})
     tr = O.OracleTrainer(sd_g, sd_d)
-    b = 4   # (the GPU line runs batch 32: the oracle's CPU iteration is timed on a bounded sample, batch 4)
-    real, label, bbox, z, z_im = make_batch(b, size, "coco", seed=99, device="cpu")
-    tr.step(real, label, bbox, z, z_im)  # warm-up
-    t0, n = time.time(), 0
-    while n < 8 and (n == 0 or time.time() - t0 < seconds_budget):
-        tr.step(real, label, bbox, z, z_im)
-        n += 1
+    tr.step(*make_batch(4, size, "coco", seed=98, device="cpu"))  # warm-up
+    real, label, bbox, z, z_im = make_batch(batch, size, "coco", seed=99, device="cpu")
+    t0 = time.time()
+    tr.step(real, label, bbox, z, z_im)
     dt = time.time() - t0
-    return dict(value=b * n / dt, unit="images/sec", cores=threads, kind="port", batch=b,
-                sample=f"{n} training iterations at batch {b}, {size}x{size}, fp32, oracle/model.py OracleTrainer (VGG term omitted)")
+    return dict(value=batch / dt, unit="images/sec", cores=threads, kind="port", batch=batch,
+                sample=f"1 training iteration at batch {batch} (after a batch-4 warm-up), {size}x{size}, fp32, oracle/model.py OracleTrainer (VGG term omitted)")
 
 
 TRAFFIC_FILE = "r05_conv_traffic.json"   # PMC passes of this round (tools/perf/traffic2.sh); absent -> roofline.traffic is null
@@ -430,7 +429,7 @@ def main():
             f32_mode = f32_mode_figures(args, dev, real, label, bbox)
         cpu = None
         if not args.no_cpu_baseline and world == 1 and args.size == 128 and args.layout == "coco":
-            cpu = cpu_baseline(netG, netD, args.size)
+            cpu = cpu_baseline(netG, netD, args.size, args.batch)
         out = {
             "metric": f"images/sec (G+D fwd+bwd) at {args.size}x{args.size} {'COCO' if args.layout == 'coco' else 'VG'}-layout",
             "value": round(args.batch * world * args.steps / elapsed, 2),

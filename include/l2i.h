@@ -41,10 +41,13 @@ int l2i_version(void);
  * later images skip the reduction, and every row of a later image is written as zeros. This is how the ROI heads of the
  * discriminator (model/rcnn_discriminator_app.py:148-166) run over the batch's real ROIs only while the launch keeps
  * the fixed, host-sync-free shape R = b*o: ROIs are compacted to the front (reference order, :145-146, 413-417).
- * stats (optional, [2][Co] f32, ZEROED by the caller, needs `out`, Co % 4 == 0 and ws = the stream's all-zero workspace of
- * L2I_WS_FLOATS floats, see l2i_channel_stats): += per-channel sum and sum of squares of `out` over all pixels -- the
- * batch statistics of a following normalisation (model/norm_module.py:163, sync_batchnorm/batchnorm.py:77-88), gathered by
- * the epilogue instead of a separate pass over `out`. */
+ * stats (optional, [2][Co] f32, ZEROED by the caller, needs `out`, Co % 4 == 0, no `nimg`, and the caller's `scratch` of
+ * l2i_conv2d_fwd_dual -- this entry point and l2i_conv2d_fwd_sc have none and refuse `stats`): += per-channel sum and sum of
+ * squares of `out` over all pixels -- the batch statistics of a following normalisation (model/norm_module.py:163,
+ * sync_batchnorm/batchnorm.py:51-53,77-88), gathered by the epilogue instead of a separate pass over `out`. Round 6: every wave
+ * STORES one partial row in the tail of `scratch` and two small launches add the rows in a fixed order -- the statistics are
+ * bit-identical from run to run, as F.batch_norm's are on the reference's single device; `ws` is ignored (it was the
+ * replicated atomic workspace of rounds 2-5). */
 int l2i_conv2d_fwd(const void* x, const void* w, const float* bias, const float* res, const void* relu_mask,
                    float* out, void* out_op, void* out_op_raw, int dtype, int B, int Hi, int Wi, int Ci, int Ho, int Wo,
                    int Co, int KH, int up2, int pool2, int relu_op, int Kpad, float alpha, const int* nimg, float* stats,
@@ -183,12 +186,14 @@ int l2i_weights_backward2(const long long* layers, int n_layers, const int* tab_
  * Batch statistics of SynchronizedBatchNorm2d (model/sync_batchnorm/batchnorm.py:51-68), of
  * nn.InstanceNorm2d (rows_per_group = H*W) and bias gradients. raw (optional): operand-dtype copy of x written in
  * the same pass (the dY cast of a convolution's backward).
- * ws (optional, here and in l2i_norm_mod_bwd_a): all-zero f32 workspace of L2I_WS_FLOATS floats, left all-zero;
- * kernels sharing one workspace must be ordered on one stream. With it the many workgroups of a single-group
- * reduction add into 32 replicas that a small fold kernel sums, instead of serialising on one address per channel. */
+ * scratch (optional, caller-owned f32, 16-byte aligned, scratch_floats floats, contents undefined afterwards; launches sharing it must
+ * be ordered on one stream): a group's rows are split over several workgroups only when their partial rows fit there -- they are
+ * stored and summed in a fixed order (round 6: bit-identical from run to run), then added to sums / sqsums with one add per address.
+ * ws (l2i_norm_mod_bwd_a and the other entry points that take one): all-zero f32 workspace of L2I_WS_FLOATS floats, left all-zero;
+ * kernels sharing one workspace must be ordered on one stream. */
 #define L2I_WS_FLOATS (32 * 4 * 1024)
 int l2i_channel_stats(const float* x, long long rows, int C, long long rows_per_group, float* sums, float* sqsums,
-                      void* raw, int dtype, float* ws, void* stream);
+                      void* raw, int dtype, float* scratch, long long scratch_floats, void* stream);
 
 /* Normalise + modulate + ReLU in one pass. mode 0: ISLA (SpatialAdaptiveSynBatchNorm2d.forward,
  * model/norm_module.py:163-186); mode 1: per-channel affine; mode 2: none.

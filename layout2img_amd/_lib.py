@@ -32,7 +32,7 @@ SIGNATURES = {
     "l2i_weights_prepare": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p],
     "l2i_weights_backward": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "l2i_weights_backward2": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
-    "l2i_channel_stats": [_p, _ll, _i, _ll, _p, _p, _p, _i, _p, _p],
+    "l2i_channel_stats": [_p, _ll, _i, _ll, _p, _p, _p, _i, _p, _ll, _p],
     "l2i_norm_mod_fwd": [_p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _i, _p, _p, _f, _p],
     "l2i_norm_mod_bwd_a": [_p, _p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _p],
     "l2i_norm_bwd_b": [_p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _f, _f, _i, _p, _p],

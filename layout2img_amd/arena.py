@@ -469,8 +469,13 @@ class WeightArena:
             self.sn_epoch += 1   # (u / v advanced through raw pointers)
         if need_wgrad and torch.is_grad_enabled():
             self.pending.append(p)
-            if len(self.pending) > 8:  # forwards that were never followed by an optimiser step
-                self.pending.pop(0)
+            if len(self.pending) > 8:  # forwards that were never followed by an optimiser step: the oldest one WITHOUT gradients goes
+                # (a pass whose backward has run holds weight gradients in its accumulator and padded-channel bias gradients in its
+                #  bias_fix slots until flush_grads: evicting it would silently lose them -- ADVICE r05 -- so such passes stay)
+                for k, old in enumerate(self.pending[:-1]):
+                    if old.dwbar is None and not old.bias_fix:
+                        del self.pending[k]
+                        break
         return p
 
     def _pack(self, p, training):
@@ -543,7 +548,8 @@ class PassCtx:
 
     def __del__(self):
         try:
-            if len(self.arena.free_packs) < 4:
+            # (a buffer lent to a graph capture -- GanTrainer._lend_packs -- is rewritten by every replay: never back to the eager free list)
+            if len(self.arena.free_packs) < 4 and not getattr(self.packed, "_l2i_lent", False):
                 self.arena.free_packs.append(self.packed)
         except Exception:
             pass

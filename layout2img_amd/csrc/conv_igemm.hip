@@ -71,8 +71,12 @@ struct ConvArgs {
     int compact;         // conv_halo3_kernel: sub-patches are whole images, no border rows are stored
     unsigned mg_tn, mg_tc, mg_ho, mg_subh, mg_p;   // fastdiv magics of tiles_n, tiles_c, Ho, SUBH, P (igemm.h)
     float alpha;
-    float* stat_ws;      // optional: the stream's replicated workspace (common.h) -- the epilogue adds every channel's sum and sum of squares
-                         // of the f32 result there (what the batch-norm layer reading this result needs: no separate pass over it)
+    float* stat_part;    // optional: partial rows [tiles_m * stat_wm][2 Co] in the caller's scratch -- every wave of the epilogue STORES the per-channel
+                         // sum and sum of squares of its pixels of the f32 result there (what the batch-norm layer reading this result needs: no
+                         // separate pass over it), rows_fold (common.h) adds the rows in a fixed order: deterministic, no atomics (round 6)
+    int stat_wm;         // waves along M of the tile (set by the launcher)
+    long long stat_cap;  // floats available at stat_part
+    int* stat_rows_out;  // HOST side only: the launcher reports tiles_m * stat_wm here
     int roi_remap;       // tuning (L2I_ROI_REMAP=1): keep the XCD remap on launches with a live-image count (A/B)
     int no_epi;          // ablation builds only (-DL2I_ABLATIONS + L2I_CONV_NOEPI=1, results are wrong): skip the epilogue to measure what it costs
     int epi_lds;         // 1: coalesced epilogue through LDS (conv_epilogue_lds; default), 0: direct stores from the accumulator layout (L2I_EPI=0, A/B)
@@ -371,8 +375,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
     const __amdgpu_buffer_rsrc_t rs_mask = epi_rsrc(p.relu_mask, out_elems * SZT), rs_op = epi_rsrc(p.out_op, out_elems * SZT);
     const __amdgpu_buffer_rsrc_t rs_raw = epi_rsrc(p.out_op_raw, out_elems * SZT);
     const bool has_mask = p.relu_mask != nullptr, has_res = p.res != nullptr, has_out = p.out != nullptr;
-    const bool has_raw = p.out_op_raw != nullptr, has_op = p.out_op != nullptr, has_stats = p.stat_ws != nullptr;
-    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};   // per-channel statistics of this lane's pixels (stat_ws)
+    const bool has_raw = p.out_op_raw != nullptr, has_op = p.out_op != nullptr, has_stats = p.stat_part != nullptr;
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};   // per-channel statistics of this lane's pixels (stat_part)
     const int wrow_s = __builtin_amdgcn_readfirstlane(wrow);
     const unsigned tile_base = (unsigned)((tile_r * p.PH * p.Wo + tile_c * p.PW) * p.Co);
     const int nstage = p.pool2 ? NIT / 4 : NIT;   // live stages per slab
@@ -496,15 +500,17 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16_t (&
             }
         }
     }
-    if (has_stats) {   // lanes that share a channel group are L4 apart: combine them, one atomic per channel and wave into a replica
+    if (has_stats) {   // lanes that share a channel group are L4 apart: combine them (xor butterfly: a fixed order), then ONE row per wave of
+                       // the launch -- row = tile x stat_wm + the wave's position along M, columns = this wave's channels -- stored, not added
 #pragma unroll
         for (int o = L4; o < 64; o <<= 1)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { ssum[e] += __shfl_xor(ssum[e], o, 64); ssq[e] += __shfl_xor(ssq[e], o, 64); }
         if (lane < L4 && nv) {
-            float* d = ws_replica(p.stat_ws, blockIdx.x % L2I_WS_R, 2 * p.Co) + n;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { atomicAdd(d + e, ssum[e]); atomicAdd(d + p.Co + e, ssq[e]); }
+            const int row = (tile_r * p.tiles_c + tile_c) * p.stat_wm + wrow_s / (TM * 32);
+            float* d = p.stat_part + (size_t)row * (2 * p.Co) + n;
+            *reinterpret_cast<float4*>(d) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
+            *reinterpret_cast<float4*>(d + p.Co) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
         }
     }
 }
@@ -1752,6 +1758,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_split_reduce_kernel(ConvArgs
     else conv_epilogue<T, TM, TN, SC>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, 0, rows_total, rows_live);
 }
 
+// Batch statistics from the epilogue (ConvArgs::stat_part): the launcher fixes the row count of the partial matrix -- one row per wave along M
+// of every pixel tile -- and reports it to conv2d_impl, which runs rows_fold behind the launch.
+static int stat_rows(ConvArgs& a, int wm) {
+    if (!a.stat_part) return L2I_OK;
+    a.stat_wm = wm;
+    const long long rows = (long long)a.tiles_m * wm;
+    if (rows * 2 * a.Co > a.stat_cap) return L2I_ERR_ARG;
+    if (a.stat_rows_out) *a.stat_rows_out = (int)rows;
+    return L2I_OK;
+}
+
 // Split planning for the stored-partials path: a launch whose tiles fill less than 3/4 of the resident workgroup slots
 // (`per_cu` workgroups x 256 CUs) is split along K so that tiles x splits is at most ONE full round, each split keeping at least
 // two 64-channel chunks (18 K-steps); the partial tiles must fit the caller's scratch. Returns 1 when the launch stays whole.
@@ -1810,13 +1827,16 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     const int rows = a.B * a.Ho;
     a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
     a.tiles_n = (a.Co + BN - 1) / BN;
+    if (stat_rows(a, WM) != L2I_OK) return L2I_ERR_ARG;
     a.mg_tn = fastdiv_magic(a.tiles_n); a.mg_tc = fastdiv_magic(a.tiles_c); a.mg_ho = fastdiv_magic(a.Ho);
     a.mg_subh = fastdiv_magic(a.SUBH); a.mg_p = fastdiv_magic(a.P);
     const int nblk = a.tiles_m * a.tiles_n;
     const int nks = a.nks;
     // split-K for small grids with a long reduction (D block5/6, G res1/res2, ROI heads): fill the 256 CUs
     int splits = 1;
-    if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 192 && nks >= 16) {
+    // (bf16 operands only: the splits of this kernel are combined by float atomics, whose order changes from run to run -- the exact-f32
+    //  mode stays bit-reproducible, as the reference's CPU convolutions are, and pays for it on its small grids; round 6)
+    if (sizeof(T) == 2 && a.out && !a.out_op && !a.out_op_raw && !a.stat_part && nblk < 192 && nks >= 16) {
         splits = (g_split_target + nblk - 1) / nblk;
         const int min_steps = nblk < 32 ? 4 : 16;   // >= 16 K-steps per split (shorter ones are all prologue + atomic epilogue), except for the
         if (splits > nks / min_steps) splits = nks / min_steps;   // handful-of-tiles Linear layers, which otherwise run on 6 CUs
@@ -1855,7 +1875,7 @@ static int sc_unfold(ConvArgs& a, hipStream_t stream) {
     s.x = a.sc.x; s.w = a.sc.w; s.w_b = a.sc.w_b; s.bias = a.sc.bias; s.res = mf ? a.res : nullptr; s.relu_mask = nullptr;
     if (mf) { a.relu_mask = a.sc.mask_first; a.alpha = a.alpha * a.sc.pre_scale; a.sc.mask_first = nullptr; }   // (a.alpha was the tail's: s keeps it)
     s.sc.mask_first = nullptr;
-    s.out = a.sc.out; s.out_op = nullptr; s.out_op_raw = nullptr; s.stat_ws = nullptr;
+    s.out = a.sc.out; s.out_op = nullptr; s.out_op_raw = nullptr; s.stat_part = nullptr;
     s.Hi = a.sc.Hi; s.Wi = a.sc.Wi; s.Ci = a.sc.Ci; s.KH = 1; s.up2 = a.sc.up2; s.Kpad = a.sc.Kpad; s.relu_op = 0;
     s.sc.x = nullptr; s.sc.w = nullptr; s.sc.w_b = nullptr; s.sc.bias = nullptr; s.sc.out = nullptr;
     s.SUBH = 1; s.P = 1;
@@ -1897,6 +1917,7 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     const int rows = a.B * a.Ho;
     a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
     a.tiles_n = (a.Co + BN - 1) / BN;
+    if (stat_rows(a, WM) != L2I_OK) return L2I_ERR_ARG;
     a.mg_tn = fastdiv_magic(a.tiles_n); a.mg_tc = fastdiv_magic(a.tiles_c); a.mg_ho = fastdiv_magic(a.Ho);
     a.mg_subh = fastdiv_magic(a.SUBH); a.mg_p = fastdiv_magic(a.P);
     const int nblk = a.tiles_m * a.tiles_n;
@@ -1906,7 +1927,7 @@ static int launch_halo2(ConvArgs a, hipStream_t stream) {
     const int psplits = ABL ? 1 : plan_part_splits(a, nblk, nchunks, (BM == 128 && BN == 64) ? 3 : 2, (long long)BM * BN);
     if (psplits > 1) { splits = psplits; a.part = a.scratch; }
     // ... else the round-1 rule: atomics into a zeroed plain f32 result
-    else if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 192 && nchunks >= 4) {
+    else if (a.out && !a.out_op && !a.out_op_raw && !a.stat_part && nblk < 192 && nchunks >= 4) {
         splits = (g_split_target + nblk - 1) / nblk;
         if (splits > nchunks / 2) splits = nchunks / 2;   // >= 18 K-steps per split
         if (splits < 1) splits = 1;
@@ -1970,6 +1991,7 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     const int rows = a.B * a.Ho;
     a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
     a.tiles_n = (a.Co + BN - 1) / BN;
+    if (stat_rows(a, 4) != L2I_OK) return L2I_ERR_ARG;
     a.mg_tn = fastdiv_magic(a.tiles_n); a.mg_tc = fastdiv_magic(a.tiles_c); a.mg_ho = fastdiv_magic(a.Ho);
     a.mg_subh = fastdiv_magic(a.SUBH); a.mg_p = fastdiv_magic(a.P);
     const int nblk = a.tiles_m * a.tiles_n;
@@ -1977,18 +1999,18 @@ static int launch_halo3(ConvArgs a, hipStream_t stream, int force_splits = 0) {
     a.part = nullptr;
     const int psplits = ABL ? 1 : plan_part_splits(a, nblk, nchunks, BN == 64 ? 3 : 2, 256LL * BN);   // (see launch_halo2)
     if (psplits > 1) { splits = psplits; a.part = a.scratch; }
-    else if (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws && nblk < 256 && nchunks >= 4) {   // fill the 512 workgroup slots (two per CU); more than 8
+    else if (a.out && !a.out_op && !a.out_op_raw && !a.stat_part && nblk < 256 && nchunks >= 4) {   // fill the 512 workgroup slots (two per CU); more than 8
         splits = (g_split_target + nblk / 2) / nblk;                           // splits lose to their atomics (tools/perf/conv_small.py)
         if (splits > nchunks / 2) splits = nchunks / 2;   // >= 18 K-steps per split
         if (splits > 8) splits = 8;
         if (splits < 1) splits = 1;
     }
-    if (force_splits > 0 && (a.part || (a.out && !a.out_op && !a.out_op_raw && !a.stat_ws))) splits = force_splits < nchunks ? force_splits : nchunks;
+    if (force_splits > 0 && (a.part || (a.out && !a.out_op && !a.out_op_raw && !a.stat_part))) splits = force_splits < nchunks ? force_splits : nchunks;
     const int cper = (nchunks + splits - 1) / splits;
     a.ks_per = 9 * cper;
     a.splits = (nchunks + cper - 1) / cper;
     if (a.splits == 1 || (long long)nblk * a.splits * 256 * BN > a.scratch_floats) a.part = nullptr;
-    if (!a.part && a.splits > 1 && !(a.out && !a.out_op && !a.out_op_raw && !a.stat_ws)) { a.splits = 1; a.ks_per = 9 * nchunks; }
+    if (!a.part && a.splits > 1 && !(a.out && !a.out_op && !a.out_op_raw && !a.stat_part)) { a.splits = 1; a.ks_per = 9 * nchunks; }
     if (a.sc.x && (!CAN_SC || (a.splits > 1 && !a.part) || a.sc.Ci % 64 || g_no_sc_fold || a.sc.mask_first)) {   // (mask-first folds: 128-pixel tiles only)
         const int rc = sc_unfold<bf16_t>(a, stream);
         if (rc != L2I_OK) return rc;
@@ -2041,6 +2063,7 @@ static int launch_halo8(ConvArgs a, hipStream_t stream) {
     const int rows = a.B * a.Ho;
     a.tiles_m = ((rows + a.PH - 1) / a.PH) * a.tiles_c;
     a.tiles_n = (a.Co + 255) / 256;
+    if (stat_rows(a, 4) != L2I_OK) return L2I_ERR_ARG;
     a.mg_tn = fastdiv_magic(a.tiles_n); a.mg_tc = fastdiv_magic(a.tiles_c); a.mg_ho = fastdiv_magic(a.Ho);
     a.mg_subh = fastdiv_magic(a.SUBH); a.mg_p = fastdiv_magic(a.P);
     const int nblk = a.tiles_m * a.tiles_n;
@@ -2236,7 +2259,7 @@ __global__ __launch_bounds__(256) void conv_wstat_reduce_kernel(const float* __r
 static int launch_wstat(ConvArgs& a, hipStream_t stream) {
     static const int on = getenv("L2I_WSTAT") ? atoi(getenv("L2I_WSTAT")) : 1;
     if (!on || a.KH != 3 || a.Ho != 4 || a.Wo != 4 || a.up2 || a.pool2 || a.Ci % 64 || a.Ci < 256 || a.Co % 4 || a.nimg || a.half_rows || a.sc.x ||
-        !a.out || a.out_op || a.out_op_raw || a.stat_ws || !a.scratch)
+        !a.out || a.out_op || a.out_op_raw || a.stat_part || !a.scratch)
         return -100;
     WstatArgs w;
     w.x = a.x; w.w = a.w; w.part = a.scratch;
@@ -2288,7 +2311,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
         // conv_epilogue_lds addresses the result-shaped tensors through buffer descriptors with 32-bit byte offsets
         const size_t ob = (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co * 4;
         if (ob >= 0x80000000ull) {
-            if (a.stat_ws) return L2I_ERR_ARG;
+            if (a.stat_part) return L2I_ERR_ARG;
             a.epi_lds = 0;   // (64-bit addressing in the direct form)
         }
     }
@@ -2504,7 +2527,8 @@ static int conv2d_impl(const void* x, const void* w, const float* bias, const fl
         if (!sc_w || !sc_out || ((res || relu_mask) && !mask_first) || sc_Ci <= 0 || sc_Ci % 8 || sc_Kpad < sc_Ci) return L2I_ERR_ARG;
         if (sc_Hi << (sc_up2 ? 1 : 0) != Ho || sc_Wi << (sc_up2 ? 1 : 0) != Wo) return L2I_ERR_ARG;
     }
-    if (stats && (!ws || !out || Co % 4 || 2LL * Co * L2I_WS_R > L2I_WS_FLOATS)) return L2I_ERR_ARG;
+    (void)ws;   // (round 5: the statistics went through the replicated atomic workspace; round 6: stored partial rows in `scratch`, summed in a fixed order)
+    if (stats && (!scratch || !out || Co % 4 || nimg)) return L2I_ERR_ARG;
     ConvArgs a;
     a.SUBH = 1; a.P = 1;   // (halo geometry: set by the halo launchers)
 #ifdef L2I_ABLATIONS   // wrong-result switches exist only in ablation builds (L2I_EXTRA_FLAGS=-DL2I_ABLATIONS), never in the shipped library
@@ -2529,7 +2553,20 @@ static int conv2d_impl(const void* x, const void* w, const float* bias, const fl
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.relu_op = relu_op ? 1 : 0;
     a.Kpad = Kpad; a.alpha = alpha;
-    a.stat_ws = stats ? ws : nullptr;
+    a.stat_part = nullptr; a.stat_wm = 1; a.stat_cap = 0; a.stat_rows_out = nullptr;
+    int stat_nrows = 0;
+    float* stat_tmp = nullptr;
+    if (stats) {   // the tail of the scratch: [partial rows: at most one per 32 pixels + a tile row of padding][fold chunks]; split-K partial tiles keep the front
+        const long long L = 2LL * Co, rows_max = ((long long)B * Ho * Wo + 31) / 32 + 8LL * 1024;
+        const long long need = rows_max * L + (long long)L2I_FOLD_CHUNKS * L;
+        if (need > a.scratch_floats) return L2I_ERR_ARG;
+        a.scratch_floats = (a.scratch_floats - need) & ~3LL;
+        a.stat_part = scratch + a.scratch_floats;
+        a.stat_cap = rows_max * L;
+        stat_tmp = a.stat_part + a.stat_cap;
+        a.stat_rows_out = &stat_nrows;
+        if ((size_t)a.stat_part & 15) return L2I_ERR_ARG;
+    }
     static const int sc_fold_env = getenv("L2I_SC_FOLD") ? atoi(getenv("L2I_SC_FOLD")) : 1;
     g_no_sc_fold = !sc_fold_env;
     const size_t esz = dtype == 0 ? 4 : 2;
@@ -2550,7 +2587,8 @@ static int conv2d_impl(const void* x, const void* w, const float* bias, const fl
     else if (dtype == 1) rc = launch_conv<bf16_t>(a, (hipStream_t)stream);
     else return L2I_ERR_ARG;
     if (rc == L2I_OK && stats) {
-        ws_fold(ws, 2 * Co, Co, stats, stats + Co, nullptr, nullptr, (hipStream_t)stream);
+        if (stat_nrows <= 0) return L2I_ERR_ARG;   // (a kernel without the LDS epilogue took the launch: not a statistics launch)
+        rows_fold(a.stat_part, stat_nrows, 2 * Co, 1, stats, stats + Co, Co, 0, 1, stat_tmp, (hipStream_t)stream);
         rc = l2i_check_launch();
     }
     return rc;

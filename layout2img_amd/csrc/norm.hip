@@ -30,16 +30,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, long long rows, int C,
                                                             long long rows_per_group, int slabs_per_group,
                                                             float* __restrict__ sums, float* __restrict__ sqsums,
-                                                            T* __restrict__ raw, float* __restrict__ ws) {
+                                                            T* __restrict__ raw, float* __restrict__ part) {
     __shared__ float4 red[2][256];
     const int cols4 = C >> 2;
     const int group = blockIdx.x / slabs_per_group, slab = blockIdx.x % slabs_per_group;
     const long long slab_rows = (rows_per_group + slabs_per_group - 1) / slabs_per_group;
     const long long r0 = group * rows_per_group + slab * slab_rows;
     const long long r1 = min(group * rows_per_group + rows_per_group, r0 + slab_rows);
+    // slabs_per_group > 1: this workgroup's sums are ROW (group, slab) of the partial matrix part[G * slabs][L] (stored; rows_fold adds the
+    // rows in a fixed order: deterministic, round 6); one slab per group: the only contribution to its addresses, added in place
     const int L = sqsums ? 2 * C : C;
-    float* const sdst = ws ? ws_replica(ws, slab % L2I_WS_R, L) : sums + (size_t)group * C;
-    float* const qdst = !sqsums ? nullptr : ws ? sdst + C : sqsums + (size_t)group * C;
+    float* const sdst = part ? part + (size_t)blockIdx.x * L : sums + (size_t)group * C;
+    float* const qdst = !sqsums ? nullptr : part ? sdst + C : sqsums + (size_t)group * C;
     // column chunks of 256 float4 columns: blockIdx.y (the grouped projection's dY is 256 rows x 19 712 channels: with the chunks
     // walked in a loop the whole matrix was FOUR workgroups' work, 37 us for 30 MB)
     {
@@ -88,35 +90,44 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
                 q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
             }
             float* so = sdst + 4 * (cbase + tx);
-            atomicAdd(so + 0, s.x); atomicAdd(so + 1, s.y); atomicAdd(so + 2, s.z); atomicAdd(so + 3, s.w);
-            if (qdst) {
-                float* qo = qdst + 4 * (cbase + tx);
-                atomicAdd(qo + 0, q.x); atomicAdd(qo + 1, q.y); atomicAdd(qo + 2, q.z); atomicAdd(qo + 3, q.w);
+            if (part) {
+                *reinterpret_cast<float4*>(so) = s;
+                if (qdst) *reinterpret_cast<float4*>(qdst + 4 * (cbase + tx)) = q;
+            } else {   // (atomic: a bias gradient that a second stream may add to at the same time; ONE add per address from this launch)
+                atomicAdd(so + 0, s.x); atomicAdd(so + 1, s.y); atomicAdd(so + 2, s.z); atomicAdd(so + 3, s.w);
+                if (qdst) {
+                    float* qo = qdst + 4 * (cbase + tx);
+                    atomicAdd(qo + 0, q.x); atomicAdd(qo + 1, q.y); atomicAdd(qo + 2, q.z); atomicAdd(qo + 3, q.w);
+                }
             }
         }
     }
 }
 
 extern "C" int l2i_channel_stats(const float* x, long long rows, int C, long long rows_per_group, float* sums,
-                                 float* sqsums, void* raw, int dtype, float* ws, void* stream) {
+                                 float* sqsums, void* raw, int dtype, float* scratch, long long scratch_floats, void* stream) {
     if (!x || !sums || C % 4 || rows_per_group <= 0 || rows % rows_per_group) return L2I_ERR_ARG;
     const long long G = rows / rows_per_group;
     const int cchunks = (C / 4 + 255) / 256;
+    const int L = sqsums ? 2 * C : C;
     long long slabs = (1024 + G * cchunks - 1) / (G * cchunks);
     const long long max_slabs = (rows_per_group + 15) / 16;   // (two 8-row batches per wave at least)
     if (slabs > max_slabs) slabs = max_slabs;
     if (slabs < 1) slabs = 1;
-    if (G != 1 || slabs <= 32) ws = nullptr;   // few workgroups per address: atomics straight into sums / sqsums
+    // more than one slab per group: partial rows in the caller's scratch [G * slabs][L] + the fold's chunk rows behind them
+    while (slabs > 1 && (!scratch || ((size_t)scratch & 15) || G * slabs * L + rows_fold_tmp_floats((int)slabs, L, (int)G) > scratch_floats)) slabs = scratch ? slabs / 2 : 1;
+    if (G > 65535) return L2I_ERR_ARG;
+    float* part = slabs > 1 ? scratch : nullptr;
     const dim3 grid((unsigned)(G * slabs), (unsigned)cchunks);
     if (dtype == 1)
         hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, C, rows_per_group,
-                           (int)slabs, sums, sqsums, (bf16_t*)raw, ws);
+                           (int)slabs, sums, sqsums, (bf16_t*)raw, part);
     else if (dtype == 0)
         hipLaunchKernelGGL(channel_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, rows, C, rows_per_group,
-                           (int)slabs, sums, sqsums, (float*)raw, ws);
+                           (int)slabs, sums, sqsums, (float*)raw, part);
     else
         return L2I_ERR_ARG;
-    if (ws) ws_fold(ws, sqsums ? 2 * C : C, C, sums, sqsums, nullptr, nullptr, (hipStream_t)stream);
+    if (part) rows_fold(part, (int)slabs, L, (int)G, sums, sqsums, C, C, 2, part + G * slabs * L, (hipStream_t)stream);
     return l2i_check_launch();
 }
 

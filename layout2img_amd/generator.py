@@ -125,8 +125,8 @@ def psp_taps(H, sizes, device):
     nb = total number of bins; pwx / uwx (nq, H), pwy / uwy (nb, H), xq (nb), qoff: the separable form, see below).
     Bins are numbered stage after stage, row-major inside a stage."""
     key = (H, tuple(sizes), str(device))
-    assert max(sizes) <= 8, "csrc/psp.hip psp_expand_rows_kernel keeps at most 8 x-bins of a stage in registers"
     if key not in _PSP_TAPS:
+        assert max(sizes) <= 8, "csrc/psp.hip psp_expand_rows_kernel keeps at most 8 x-bins of a stage in registers"
         At = torch.cat([resample_matrix("adaptive_avg", H, s, "cpu") for s in sizes], dim=0).t().contiguous()   # (HW, NB)
         assert int((At != 0).sum(dim=1).max()) <= 12
         _, ai = torch.topk(At.abs(), 12, dim=1)
@@ -228,7 +228,9 @@ class ConvMaskHead(nn.ModuleList):
         (`seman = gather(m, 1, y)`, reference :465-466) -- the last 1x1 convolution is then evaluated for those classes alone
         (ops.class_logits) and the result is the planar (b, o, H, W) tensor of gathered logits, tagged `_l2i_planar`. None: the dense
         (b, H, W, 184) logits."""
-        gather = y is not None and CLASS_GATHER and y.shape[1] <= 8
+        # (the library's limits -- l2i_class_logits_bwd: C <= 126 input channels, padded <= 128 -- are part of the gate: a head of another hidden
+        #  width takes the dense 1x1 convolution instead of failing at backward; ADVICE r05)
+        gather = y is not None and CLASS_GATHER and y.shape[1] <= 8 and self[-1].ci <= 126 and self[-1].ci_p <= 128
         if self.psp:
             a = self[0](x, pc, sync, join_in)
             if not gather:

@@ -218,10 +218,11 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
             fl += sc["flops"]
             nbytes += (sc["x_op"].numel() + sc["wpack"].numel() * (2 if wpack_b is not None else 1)) * esz
         end = TIMER.time("conv_igemm", live * fl, live * nbytes)
-    st = _zeros((2, 1, co), dev) if (stats and out is not None and co <= 1024) else None
+    st = _zeros((2, 1, co), dev) if (stats and out is not None and co % 4 == 0) else None
     # the stream's scratch (caller-owned, shared with the weight-gradient launches of the same stream): partial tiles of the
     # 4x4 weight-stationary kernel and of every split-K launch of the halo kernels (conv_store_partial + reduce with epilogue)
-    scr, nscr = _lib.wgrad_scratch(dev) if (kh == 3 and x_op.dtype == torch.bfloat16) else (None, 0)
+    # ... and the partial rows of the epilogue's batch statistics (one per wave, summed in a fixed order: no atomics)
+    scr, nscr = _lib.wgrad_scratch(dev) if ((kh == 3 and x_op.dtype == torch.bfloat16) or st is not None) else (None, 0)
     if scr is not None and sc is None:
         _lib.call("l2i_conv2d_fwd_dual", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
                   _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
@@ -363,8 +364,9 @@ def channel_stats(x2d, rows_per_group=None, want_sq=True, cast_to=None, accumula
         buf = _zeros((2 if want_sq else 1, G, C), x2d.device)
         sums, sq = buf[0], (buf[1] if want_sq else None)
     raw = torch.empty(x2d.shape, dtype=cast_to, device=x2d.device) if cast_to is not None else None
+    scr, nscr = _lib.wgrad_scratch(x2d.device)   # partial rows of the slabs, summed in a fixed order (no atomics)
     _lib.call("l2i_channel_stats", x2d.data_ptr(), rows, C, rpg, sums.data_ptr(), _p(sq), _p(raw),
-              _code(cast_to) if cast_to is not None else _lib.F32, _ws(x2d.device) if C <= 1024 else None, _stream())
+              _code(cast_to) if cast_to is not None else _lib.F32, scr, nscr, _stream())
     if cast_to is not None:
         return sums, sq, raw
     return sums, sq
@@ -502,7 +504,11 @@ def _atomics_split(B, Ho, Wo, n_out, kh, k_in, op_dtype):
 
 ROI_GATHER = __import__("os").environ.get("L2I_ROI_GATHER", "1") != "0"   # (the library's switch of the same name)
 HEAD_DX_OP = __import__("os").environ.get("L2I_HEAD_DX_OP", "1") != "0"   # the discriminator heads' backward writes the bf16 copy of dx (A/B switch)
-BIAS_SLOTS = __import__("os").environ.get("L2I_BIAS_SLOTS", "1") != "0"   # A/B switch: padded-channel bias gradients from the weight-gradient launch
+# A/B switch: padded-channel bias gradients (mask heads 100 of 104, to-RGB 3 of 8) from the weight-gradient launch. CONTRACT: such a gradient
+# reaches `bias.grad` in WeightArena.flush_grads (before the per-group callbacks), not during backward() -- like every weight gradient of this
+# package (the spectral-norm backward runs there). Code that reads .grad straight after backward() must call net.arena.flush_grads() first; a pass
+# that holds such gradients is never evicted from arena.pending, arena.drop_pending() drops them with the pass's weight gradients.
+BIAS_SLOTS = __import__("os").environ.get("L2I_BIAS_SLOTS", "1") != "0"
 STORED_SPLITS = __import__("os").environ.get("L2I_CONV_PART", "1") != "0"   # (the library's switch of the same name)
 
 

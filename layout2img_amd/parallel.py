@@ -111,6 +111,31 @@ def grad_group():
     return _GRAD_GROUP
 
 
+_HOST_GROUP = None
+
+
+def host_group():
+    """A gloo group for HOST-side decisions every rank must take alike (GanTrainer.capture: "did every rank's capture succeed?").
+    A CPU tensor over gloo works whatever state the HIP runtime of a rank is in -- an invalidated capture leaves it in a sticky error
+    state in which a device all-reduce on the failing rank would itself fail or hang. Created collectively (every rank calls this at
+    the same point, before the capture); None at world size 1 without the forced group."""
+    global _HOST_GROUP
+    if not active():
+        return None
+    if _HOST_GROUP is None:
+        _HOST_GROUP = dist.new_group(backend="gloo")
+    return _HOST_GROUP
+
+
+def all_ranks_ok(ok, group=None):
+    """MIN over the ranks of a host-side boolean."""
+    if not active():
+        return bool(ok)
+    t = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group if group is not None else host_group())
+    return float(t) >= 1.0
+
+
 def allreduce_flat_(flat_grad, chunk_bytes=64 << 20, async_op=False, group=None):
     """SUM all-reduce of a flat buffer in large contiguous chunks (in place). Returns work handles.
     group: the process group to run on (grad_group() for gradient exchanges that should overlap other collectives)."""

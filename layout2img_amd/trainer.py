@@ -307,6 +307,7 @@ class GanTrainer:
             # graph the generator's all-reduce, its wait and its Adam step stay inside their own iteration.
             self.flush()
             self._defer_g_eager, self.defer_g = self.defer_g, False
+            host = parallel.host_group()   # (collective: created before the capture, used for the "every capture succeeded" decision)
         if ops.TIMER is not None:
             raise RuntimeError("capture with the kernel timer on")
         self._static = [None if t is None else t.detach().clone() for t in (real, label, bbox, z, z_im)]
@@ -338,6 +339,7 @@ class GanTrainer:
         self._lend_packs()
         graph = torch.cuda.CUDAGraph()
         err = None
+        t_host = (self.g_opt.t, self.d_opt.t)   # host-side step counts: a capture that fails has advanced them without running anything
         try:
             # (data parallel: RCCL's watchdog thread polls its own events while this thread captures; in the default "global"
             #  capture mode any other thread's event query invalidates the capture -- hipErrorStreamCaptureInvalidated, measured)
@@ -349,24 +351,40 @@ class GanTrainer:
             err = e
             self._graph = None
             if not self.dp:
-                torch.cuda.synchronize()
+                self._undo_failed_capture(t_host)
                 raise
         for net in (self.netG, self.netD):
             net.arena.free_packs = []   # buffers from the graph's private pool must not be handed to eager iterations
         if self.dp:
             # The decision to replay is COLLECTIVE: a rank that replays while another runs eagerly would issue its collectives
-            # in a different order and dead-lock the job. Every rank contributes "my capture succeeded"; MIN over the ranks.
-            import torch.distributed as dist
-            ok = torch.tensor([0.0 if err is not None else 1.0], device=real.device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if float(ok) < 1.0:
+            # in a different order and dead-lock the job. Every rank contributes "my capture succeeded"; MIN over the ranks -- of a
+            # HOST tensor over gloo (parallel.host_group): the failing rank's HIP runtime may be unusable.
+            if not parallel.all_ranks_ok(err is None, host):
                 self._graph = None
                 self.defer_g = self._defer_g_eager   # (back to the eager-mode overlap of the generator's all-reduce)
                 if err is not None:
                     print(f"[layout2img_amd] graph capture failed on this rank ({type(err).__name__}: {str(err)[:160]}); every rank runs eagerly", flush=True)
+                self._undo_failed_capture(t_host)
                 return False
         self._graph = graph
         return True
+
+    def _undo_failed_capture(self, t_host):
+        """Nothing of a failed (or abandoned) capture ran, but its host-side traces exist: pass contexts in arena.pending whose dW-bar
+        accumulators and packs live in the discarded graph pool and were never computed (the next eager flush_grads() would fold that
+        garbage into flat.grad), captured work handles of the optimizers' all-reduces, a "generator step pending" flag, advanced step
+        counts, and the pack buffers lent to the capture. Put the trainer back where it was before the capture."""
+        try:
+            torch.cuda.synchronize()
+        except RuntimeError:
+            pass   # (an invalidated capture can leave the runtime in a sticky error state: the caller re-launches eagerly / aborts)
+        for net in (self.netG, self.netD):
+            net.arena.drop_pending()
+            net.arena.free_packs = []
+        self._graph_packs = []
+        self.g_opt._works = self.d_opt._works = None
+        self._pending_g = False
+        self.g_opt.t, self.d_opt.t = t_host
 
     _graph = None
     _graph_multi = None
@@ -394,7 +412,8 @@ class GanTrainer:
                 self._multi_out = [self.step(*b) for b in self._static_multi]
         except Exception:
             self._graph_multi = None
-            torch.cuda.synchronize()
+            self._undo_failed_capture(t_host)
+            self._graph = None   # (the lent buffers of the single-iteration graph went with the others: capture() again before replaying)
             raise
         self.g_opt.t, self.d_opt.t = t_host   # (nothing ran: the host-side mirrors of the step counts stay where they were)
         for net in (self.netG, self.netD):
@@ -412,6 +431,8 @@ class GanTrainer:
         for net, n in ((self.netG, 2), (self.netD, 3)):
             a = net.arena
             a.free_packs = [torch.zeros(a.packed_len, dtype=a.op_dtype, device=a.device) for _ in range(n)]
+            for t in a.free_packs:
+                t._l2i_lent = True   # (PassCtx.__del__ never hands a graph-owned buffer to an eager pass)
             keep += a.free_packs
 
     def step_graphed_multi(self, batches):

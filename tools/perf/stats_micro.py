@@ -17,6 +17,6 @@ for (B, H, C) in [(32, 128, 64), (32, 64, 128), (32, 64, 64), (32, 32, 256), (32
     out = []
     for ws in (ops._ws(dev), None):
         for r in (None, raw):
-            f = lambda: _lib.call("l2i_channel_stats", x.data_ptr(), x.shape[0], C, x.shape[0], sums[0].data_ptr(), sums[1].data_ptr(), ops._p(r), 1, ws, ops._stream())
+            f = lambda: _lib.call("l2i_channel_stats", x.data_ptr(), x.shape[0], C, x.shape[0], sums[0].data_ptr(), sums[1].data_ptr(), ops._p(r), 1, *_lib.wgrad_scratch(x.device), ops._stream())
             out.append(t(f))
     print(f"H{H} C{C}", [round(v) for v in out])
