@@ -161,11 +161,16 @@ int l2i_debug_occupancy(int which, int lds_bytes);
  * layers: 20 x int64 per layer row, tables built by layout2img_amd/arena.py; one call per round (a weight the
  * reference applies twice per forward is iterated twice, second round with clear = 0).
  * packed: only elements with co < Co_p, ci < Ci_p are written -- padding rows / K tails must already be zero
- * (allocate the buffer zero-filled once; it may be reused for later passes). */
+ * (allocate the buffer zero-filled once; it may be reused for later passes).
+ * Round 6 -- no atomics: W^T u is summed per block of 64 rows into partial rows that a fold launch (tab_tfold) adds in order, and
+ * ||W v||^2 per block of 4 R rows into shares the pack / finish launches add in order, both in the caller's transient `scratch`
+ * ([npart_floats shares, at the layers' row-19 offsets | partial rows, at the tables' offsets]; launches sharing it must be
+ * ordered on one stream): u, v, sigma and every packed weight are bit-identical from run to run, as the CPU reference's are. */
 int l2i_weights_prepare(const long long* layers, int n_layers, const int* tab_wtu, int n_wtu, const int* tab_wv, int n_wv,
                         const int* tab_pack, int n_pack, const int* tab_fin, int n_fin, const float* params,
                         float* sn_state, float* pass_uv, long long uv_len, float* norms, void* packed, int dtype,
-                        int training, int clear, void* stream);
+                        int training, int clear, const int* tab_tfold, int n_tfold, float* scratch, long long scratch_floats,
+                        long long npart_floats, void* stream);
 
 /* Backward of the above: grads[w] += (G - <G,Wbar> u v^T) / sigma for every layer (G = dwbar).
  * ws: the all-zero workspace described at l2i_channel_stats (required; left all-zero). */

@@ -29,7 +29,7 @@ SIGNATURES = {
     "l2i_conv2d_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _ll, _p],
     "l2i_conv2d_wgrad_sc": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p, _p],
     "l2i_conv2d_wgrad_dual": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p],
-    "l2i_weights_prepare": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p],
+    "l2i_weights_prepare": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p, _i, _p, _ll, _ll, _p],
     "l2i_weights_backward": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "l2i_weights_backward2": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "l2i_channel_stats": [_p, _ll, _i, _ll, _p, _p, _p, _i, _p, _ll, _p],

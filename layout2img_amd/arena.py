@@ -261,6 +261,9 @@ class WeightArena:
         tab = np.zeros((L, LSTRIDE), dtype=np.int64)
         packed_len = dw_len = uv_len = 0
         t_wtu = [[] for _ in range(self.rounds)]
+        t_tfold = [[] for _ in range(self.rounds)]
+        np_len = [0] * self.rounds    # floats of sn_wv block shares per round (csrc/weights.hip: layer row 19)
+        tp_len = [0] * self.rounds    # floats of W^T u partial rows per round (behind the shares in the scratch)
         t_wv = [[] for _ in range(self.rounds)]
         t_pack = [[] for _ in range(self.rounds)]
         t_fin = [[] for _ in range(self.rounds)]
@@ -339,11 +342,18 @@ class WeightArena:
             bw = 2304 if taps == 1 else (1024 if (taps == 9 and h.ci % 4 == 0) else 256)   # csrc/weights.hip: bw_chunk() (sn_apply)
             pair_chunks = (h.co * h.ci + bw - 1) // bw
             if h.sn:
-                for c0 in range(0, kt, 256):              # csrc/weights.hip sn_wtu_kernel: 256 columns x 4 waves x rpw rows
-                    for r0 in range(0, h.co, 4 * WTU_RPW):
-                        t_wtu[use].append((i, c0, r0, WTU_RPW))
-                for r0 in range(0, h.co, 4 * WV_R):       # sn_wv_kernel<R>: 4 R rows per block
+                # csrc/weights.hip sn_wtu_kernel: 256 columns x 4 waves x rpw rows; a block STORES its column sums in row (r0 / rows per block) of the
+                # layer's partial matrix [row blocks][kt] in the scratch, sn_tfold_kernel adds the row blocks in order (no atomics: round 6)
+                nrb = (h.co + 4 * WTU_RPW - 1) // (4 * WTU_RPW)
+                for c0 in range(0, kt, 256):
+                    for rb, r0 in enumerate(range(0, h.co, 4 * WTU_RPW)):
+                        t_wtu[use].append((i, c0, r0, WTU_RPW, tp_len[use] + rb * kt))
+                    t_tfold[use].append((i, c0, tp_len[use], nrb))
+                tp_len[use] += _round_up(nrb * kt, 4)
+                row[19] = np_len[use]                     # sn_wv_kernel<R>: 4 R rows per block, one stored share of ||W v||^2 each
+                for r0 in range(0, h.co, 4 * WV_R):
                     t_wv[use].append((i, r0))
+                    np_len[use] += 1
                 t_dot += [(i, c) for c in range((h.co * h.ci + bw_dot - 1) // bw_dot)]
             tci = 256 if taps == 1 else 32
             for ct in range((h.co_p + 63) // 64):         # PK_TCO
@@ -359,7 +369,10 @@ class WeightArena:
             arr = np.array(a if a else [(0,) * width], dtype=np.int32).reshape(-1)
             return torch.from_numpy(np.ascontiguousarray(arr)).to(device), len(a)
         self.layers = torch.from_numpy(tab.reshape(-1)).to(device)
-        self.t_wtu = [dev(t, 4) for t in t_wtu]
+        self.t_wtu = [dev(t, 5) for t in t_wtu]
+        self.t_tfold = [dev(t, 4) for t in t_tfold]
+        self.np_len = [_round_up(n, 4) for n in np_len]
+        self.sn_scratch_floats = max(a + b for a, b in zip(self.np_len, tp_len)) if self.rounds else 0
         self.t_wv = [dev(t, 2) for t in t_wv]
         self.t_pack = [dev(t, 3) for t in t_pack]
         self.t_fin = [dev(t, 1) for t in t_fin]
@@ -479,14 +492,17 @@ class WeightArena:
         return p
 
     def _pack(self, p, training):
+        scr, nscr = _lib.wgrad_scratch(self.device)   # the power iteration's partial sums (stored, added in a fixed order): transient, this stream's scratch
+        assert self.sn_scratch_floats <= nscr
         for r in range(self.rounds):
             (wtu, n_wtu), (wv, n_wv), (pk, n_pk), (fin, n_fin) = self.t_wtu[r], self.t_wv[r], self.t_pack[r], self.t_fin[r]
+            tf, n_tf = self.t_tfold[r]
             if n_pk == 0:
                 continue
             _lib.call("l2i_weights_prepare", self.layers.data_ptr(), self.n_layers, wtu.data_ptr(), n_wtu, wv.data_ptr(), n_wv,
                       pk.data_ptr(), n_pk, fin.data_ptr(), n_fin, self.flat.data.data_ptr(), self.sn_flat.data.data_ptr(), p.pass_uv.data_ptr(),
                       self.uv_len, p.norms.data_ptr(), p.packed.data_ptr(), self.dtype_code, 1 if training else 0,
-                      1 if r == 0 else 0, _lib.raw_stream())
+                      1 if r == 0 else 0, tf.data_ptr(), n_tf, scr, nscr, self.np_len[r], _lib.raw_stream())
 
     def flush_grads(self, on_group=None):
         """Apply the spectral-norm backward of every pending pass into the flat gradient buffer.

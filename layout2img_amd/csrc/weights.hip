@@ -20,7 +20,7 @@
 //   0 w_off  1 u_off(-1 = no SN)  2 v_off  3 Co  4 Ci  5 KH  6 Co_p  7 Ci_p
 //   8 Kpad  9 Npad  10 fwd_off  11 Kpad_d  12 Npad_d  13 dg_off  14 dw_off  15 eps(float bits)
 //   16 pass_u_off  17 pass_v_off (offsets into the per-pass u/v snapshot)  18 multi-use (gradient needs atomics)
-//   19 reserved
+//   19 offset of the layer's sn_wv block shares in the scratch of l2i_weights_prepare (one float per block of 4 R rows)
 // norms: f32 [L][4] = {||W^T u||^2, ||W v||^2 (eval: u.Wv), sigma, <G, W>}
 #include "common.h"
 
@@ -30,23 +30,25 @@
 __device__ __forceinline__ float layer_eps(const long long* L) { return __uint_as_float((uint32_t)L[15]); }
 
 // ---------------------------------------------------------------- phase 1: t = W^T u
-// table (layer, col0, row0, rows per wave): a block covers 256 columns (one 16-byte load per lane and row) x 4 x `rows per wave`
-// rows; its four waves walk different rows of the SAME columns, their partial column sums meet in LDS and leave as one
-// atomic per column and block. (Round 2's form -- 1024 columns x 64 rows per block, four atomics per thread -- left the
+// table (layer, col0, row0, rows per wave, partial offset): a block covers 256 columns (one 16-byte load per lane and row) x 4 x `rows
+// per wave` rows; its four waves walk different rows of the SAME columns, their partial column sums meet in LDS and are STORED as the
+// block's run of 256 columns in row (row0 / rows per block) of the layer's partial matrix tpart[rows blocks][Kt] (caller's scratch);
+// sn_tfold_kernel adds the row blocks in order (round 6: t, hence sigma and every packed weight, is bit-identical from run to run --
+// rounds 1-5 left one float atomic per column and block, and the 1e-7 run-to-run noise of sigma moved bf16 roundings of the packs). (Round 2's form -- 1024 columns x 64 rows per block, four atomics per thread -- left the
 // last column chunk of most layers half empty (Kt = 9 Ci is a multiple of 256, rarely of 1024) and gave the discriminator
 // 960 blocks for 256 CUs: 2.5 TB/s.)
 __global__ __launch_bounds__(256) void sn_wtu_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                      const float* __restrict__ params, const float* __restrict__ sn_state,
-                                                     float* __restrict__ pass_uv) {
+                                                     float* __restrict__ tpart) {
     __shared__ float part[4][256];
-    const int* e = table + 4 * blockIdx.x;
+    const int* e = table + 5 * blockIdx.x;
     const long long* L = layers + L2I_LSTRIDE * e[0];
     const int Co = (int)LF(3), Kt = (int)(LF(4) * LF(5) * LF(5));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = min(Co, e[2] + wave * e[3]), r1 = min(Co, r0 + e[3]);
     const float* W = params + LF(0);
     const float* u = sn_state + LF(1);
-    float* t_out = pass_uv + LF(17);
+    float* t_out = tpart + e[4];
     if ((Kt & 3) == 0) {
         const int col = e[1] + 4 * lane;
         float4 t = make_float4(0, 0, 0, 0);
@@ -85,7 +87,27 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const long long* __restrict
     }
     __syncthreads();
     const int col = e[1] + threadIdx.x;
-    if (col < Kt) atomicAdd(t_out + col, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (col < Kt) t_out[col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// t[col] = sum over the row blocks, in order. table: (layer, col0, partial offset of the layer, row blocks)
+__global__ __launch_bounds__(256) void sn_tfold_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
+                                                       const float* __restrict__ tpart, float* __restrict__ pass_uv) {
+    const int* e = table + 4 * blockIdx.x;
+    const long long* L = layers + L2I_LSTRIDE * e[0];
+    const int Kt = (int)(LF(4) * LF(5) * LF(5));
+    const int col = e[1] + threadIdx.x;
+    if (col >= Kt) return;
+    const float* q = tpart + e[2] + col;
+    const int nrb = e[3];
+    float t = 0.f;
+    int r = 0;
+    for (; r + 4 <= nrb; r += 4) {
+        const float a = q[(size_t)r * Kt], b = q[(size_t)(r + 1) * Kt], c = q[(size_t)(r + 2) * Kt], d = q[(size_t)(r + 3) * Kt];
+        t += (a + b) + (c + d);
+    }
+    for (; r < nrb; ++r) t += q[(size_t)r * Kt];
+    pass_uv[LF(17) + col] = t;
 }
 
 // ---------------------------------------------------------------- phase 2: s = W vhat
@@ -94,7 +116,7 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const long long* __restrict
 template <int R>
 __global__ __launch_bounds__(256) void sn_wv_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                     const float* __restrict__ params, const float* __restrict__ sn_state,
-                                                    float* __restrict__ pass_uv, float* __restrict__ norms, int training) {
+                                                    float* __restrict__ pass_uv, float* __restrict__ norms, float* __restrict__ npart, int training) {
     __shared__ float red[16];
     const int* e = table + 2 * blockIdx.x;
     const int layer = e[0];
@@ -167,15 +189,22 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const long long* __restrict_
     __syncthreads();
     if (lane == 0) red[wave] = blk;
     __syncthreads();
-    if (threadIdx.x == 0) {   // one atomic per block
-        atomicAdd(norms + 4 * layer + 1, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {   // the block's share of ||W v||^2 (eval: u . W v): slot (row0 / rows per block) of the layer's run in npart (layer row 19);
+        npart[LF(19) + e[1] / (4 * R)] = (red[0] + red[1]) + (red[2] + red[3]);   // layer_sn2 adds the slots in a fixed order (no atomics: round 6)
         if (e[1] == 0) norms[4 * layer + 0] = tn2;
     }
 }
 
-__device__ __forceinline__ float layer_sigma(const long long* L, const float* norms, int layer, int training) {
-    if (LF(1) < 0) return 1.f;
-    const float sn2 = norms[4 * layer + 1];
+// ||W v||^2 (eval: u . W v) of a layer from the stored shares of its sn_wv blocks -- the whole workgroup calls this; every thread gets the
+// sum, formed in an order that depends on the layer's shape only. red: 16 floats of LDS.
+__device__ __forceinline__ float layer_sn2(const long long* L, const float* npart, int wv_rows, float* red) {
+    const int nb = ((int)LF(3) + wv_rows - 1) / wv_rows;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) a += npart[LF(19) + i];
+    return block_sum(a, red);
+}
+
+__device__ __forceinline__ float sigma_of(const long long* L, float sn2, int training) {
     return training ? sn2 / fmaxf(sqrtf(sn2), layer_eps(L)) : sn2;
 }
 
@@ -226,7 +255,7 @@ __device__ __forceinline__ void store8t(T* dst, const T (&v)[8]) {   // 8 alread
 // work: the forward-only precision mode that meets the image bar of 1e-3 at MFMA speed. The data-gradient pack is unchanged.
 template <typename T, int TAPS, bool SPLIT = false>
 __device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, const int* __restrict__ e, int layer,
-                                             const float* __restrict__ params, const float* __restrict__ norms,
+                                             const float* __restrict__ params, float sigma,
                                              T* __restrict__ packed, int training, T* tile) {
     const int Co = (int)LF(3), Ci = (int)LF(4), Co_p = (int)LF(6), Ci_p = (int)LF(7);
     constexpr int taps = TAPS;
@@ -235,7 +264,7 @@ __device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, co
     T* tile_lo = tile + PK_TCO * RUNP;   // (SPLIT: the low halves, same layout)
     const int co0 = e[1] * PK_TCO, ci0 = e[2] * TCI;
     const int nco = min(PK_TCO, Co - co0), nrun = min(TCI, Ci - ci0) * taps;   // valid rows / valid floats per row (may be <= 0)
-    const float inv = 1.f / layer_sigma(L, norms, layer, training);
+    const float inv = 1.f / sigma;
     const float* W = params + LF(0);
     // The tile is kept TAP-major in LDS ([row][tap][ci], row pitch RUNP): the forward pack's 8 consecutive input
     // channels of one tap are then one 16-byte LDS read instead of eight 2-byte gathers (the kernel was bound by its
@@ -327,15 +356,17 @@ __device__ __forceinline__ void sn_pack_body(const long long* __restrict__ L, co
 
 template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
-                                                      const float* __restrict__ params, const float* __restrict__ norms,
+                                                      const float* __restrict__ params, const float* __restrict__ npart, int wv_rows,
                                                       T* __restrict__ packed, int training) {
     extern __shared__ __attribute__((aligned(16))) char tile_raw[];
+    __shared__ float red[16];
     T* tile = reinterpret_cast<T*>(tile_raw);   // [64][RUN + 2] in the OPERAND type: 37 KB for bf16 -> four workgroups per CU in flight
     const int* e = table + 3 * blockIdx.x;
     const int layer = e[0];
     const long long* L = layers + L2I_LSTRIDE * layer;
-    if ((int)LF(5) == 3) sn_pack_body<T, 9, SPLIT>(L, e, layer, params, norms, packed, training, tile);
-    else sn_pack_body<T, 1, SPLIT>(L, e, layer, params, norms, packed, training, tile);
+    const float sigma = LF(1) < 0 ? 1.f : sigma_of(L, layer_sn2(L, npart, wv_rows, red), training);
+    if ((int)LF(5) == 3) sn_pack_body<T, 9, SPLIT>(L, e, layer, params, sigma, packed, training, tile);
+    else sn_pack_body<T, 1, SPLIT>(L, e, layer, params, sigma, packed, training, tile);
 }
 
 // ---------------------------------------------------------------- phase 3b: sigma, normalised u / v
@@ -343,7 +374,8 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const long long* __restric
 // and the persistent state; (eval) copies the stored u, v into the snapshot. table: (layer)
 __global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                         float* __restrict__ sn_state, float* __restrict__ pass_uv,
-                                                        float* __restrict__ norms, int training) {
+                                                        float* __restrict__ norms, const float* __restrict__ npart, int wv_rows, int training) {
+    __shared__ float red[16];
     const int layer = table[blockIdx.x];
     const long long* L = layers + L2I_LSTRIDE * layer;
     if (LF(1) < 0) {
@@ -352,7 +384,7 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restr
     }
     const int Co = (int)LF(3), Kt = (int)(LF(4) * LF(5) * LF(5));
     const float eps = layer_eps(L);
-    const float sn2 = norms[4 * layer + 1], tn2 = norms[4 * layer + 0];
+    const float sn2 = layer_sn2(L, npart, wv_rows, red), tn2 = norms[4 * layer + 0];
     // (gridDim.y blocks share a layer's vectors: one block per layer took 16 us for the 9216-element v of a 1024-channel 3x3 layer)
     const int i0 = blockIdx.y * 256 + threadIdx.x, istep = 256 * gridDim.y;
     if (training) {
@@ -371,8 +403,10 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restr
         for (int i = i0; i < Co; i += istep) pass_uv[LF(16) + i] = sn_state[LF(1) + i];
         for (int i = i0; i < Kt; i += istep) pass_uv[LF(17) + i] = sn_state[LF(2) + i];
     }
-    __syncthreads();   // every thread has read sn2 before sigma's slot (a different one) is written
-    if (threadIdx.x == 0 && blockIdx.y == 0) norms[4 * layer + 2] = layer_sigma(L, norms, layer, training);
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
+        norms[4 * layer + 1] = sn2;
+        norms[4 * layer + 2] = sigma_of(L, sn2, training);
+    }
 }
 
 // ---------------------------------------------------------------- backward
@@ -606,9 +640,14 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
 extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const int* tab_wtu, int n_wtu,
                                    const int* tab_wv, int n_wv, const int* tab_pack, int n_pack, const int* tab_fin,
                                    int n_fin, const float* params, float* sn_state, float* pass_uv, long long uv_len,
-                                   float* norms, void* packed, int dtype, int training, int clear, void* stream_) {
+                                   float* norms, void* packed, int dtype, int training, int clear, const int* tab_tfold, int n_tfold,
+                                   float* scratch, long long scratch_floats, long long npart_floats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!layers || !params || !packed || !norms) return L2I_ERR_ARG;
+    // scratch = [npart: one float per sn_wv block, at the layers' row-19 offsets | tpart: the W^T u partial rows, at the tables' offsets]
+    if ((n_wv > 0 || n_wtu > 0) && (!scratch || npart_floats < 0 || npart_floats > scratch_floats || (training && n_wtu > 0 && (!tab_tfold || n_tfold <= 0)))) return L2I_ERR_ARG;
+    float* npart = scratch;
+    float* tpart = scratch ? scratch + npart_floats : nullptr;
     if (dtype != 0 && dtype != 1 && dtype != 3) return L2I_ERR_ARG;   // 3: bf16 with split (hi + lo) forward packs, see sn_pack_body
     if (clear) {  // first round of a pass
         const long long gap = pass_uv - norms;   // adjacent buffers (layout2img_amd/arena.py PassCtx): one memset for both
@@ -619,14 +658,17 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
             if (uv_len > 0 && l2i_zero_async(pass_uv, sizeof(float) * uv_len, stream) != hipSuccess) return L2I_ERR_LAUNCH;
         }
     }
-    if (training && n_wtu > 0)
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3(n_wtu), dim3(256), 0, stream, layers, tab_wtu, params, sn_state, pass_uv);
+    if (training && n_wtu > 0) {
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(n_wtu), dim3(256), 0, stream, layers, tab_wtu, params, sn_state, tpart);
+        hipLaunchKernelGGL(sn_tfold_kernel, dim3(n_tfold), dim3(256), 0, stream, layers, tab_tfold, tpart, pass_uv);
+    }
+    static const int wv_r = getenv("L2I_SN_WV_R") ? atoi(getenv("L2I_SN_WV_R")) : 4;   // must match layout2img_amd/arena.py (rows per block = 4 R)
+    const int wv_rows = 4 * (wv_r == 2 ? 2 : 4);
     if (n_wv > 0) {
-        static const int wv_r = getenv("L2I_SN_WV_R") ? atoi(getenv("L2I_SN_WV_R")) : 4;   // must match layout2img_amd/arena.py (rows per block = 4 R)
         if (wv_r == 2)
-            hipLaunchKernelGGL(sn_wv_kernel<2>, dim3(n_wv), dim3(256), 0, stream, layers, tab_wv, params, sn_state, pass_uv, norms, training);
+            hipLaunchKernelGGL(sn_wv_kernel<2>, dim3(n_wv), dim3(256), 0, stream, layers, tab_wv, params, sn_state, pass_uv, norms, npart, training);
         else
-            hipLaunchKernelGGL(sn_wv_kernel<4>, dim3(n_wv), dim3(256), 0, stream, layers, tab_wv, params, sn_state, pass_uv, norms, training);
+            hipLaunchKernelGGL(sn_wv_kernel<4>, dim3(n_wv), dim3(256), 0, stream, layers, tab_wv, params, sn_state, pass_uv, norms, npart, training);
     }
     if (n_pack > 0) {
         const size_t lds = (dtype == 0 ? sizeof(float) : sizeof(bf16_t)) * PK_TCO * (32 * 9 + 2);   // >= 64 * (256 + 2) elements
@@ -637,7 +679,7 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
             ready = true;
         }
         if (dtype == 0)
-            hipLaunchKernelGGL(sn_pack_kernel<float>, dim3(n_pack), dim3(256), lds, stream, layers, tab_pack, params, norms,
+            hipLaunchKernelGGL(sn_pack_kernel<float>, dim3(n_pack), dim3(256), lds, stream, layers, tab_pack, params, npart, wv_rows,
                                (float*)packed, training);
         else if (dtype == 3) {
             static bool ready3 = false;
@@ -645,14 +687,14 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
                 (void)hipFuncSetAttribute((const void*)sn_pack_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
                 ready3 = true;
             }
-            hipLaunchKernelGGL((sn_pack_kernel<bf16_t, true>), dim3(n_pack), dim3(256), 2 * lds, stream, layers, tab_pack, params, norms,
+            hipLaunchKernelGGL((sn_pack_kernel<bf16_t, true>), dim3(n_pack), dim3(256), 2 * lds, stream, layers, tab_pack, params, npart, wv_rows,
                                (bf16_t*)packed, training);
         } else
-            hipLaunchKernelGGL(sn_pack_kernel<bf16_t>, dim3(n_pack), dim3(256), lds, stream, layers, tab_pack, params, norms,
+            hipLaunchKernelGGL(sn_pack_kernel<bf16_t>, dim3(n_pack), dim3(256), lds, stream, layers, tab_pack, params, npart, wv_rows,
                                (bf16_t*)packed, training);
     }
     if (n_fin > 0)
-        hipLaunchKernelGGL(sn_finish_kernel, dim3(n_fin, 8), dim3(256), 0, stream, layers, tab_fin, sn_state, pass_uv, norms,
+        hipLaunchKernelGGL(sn_finish_kernel, dim3(n_fin, 8), dim3(256), 0, stream, layers, tab_fin, sn_state, pass_uv, norms, npart, wv_rows,
                            training);
     return l2i_check_launch();
 }

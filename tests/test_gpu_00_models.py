@@ -465,9 +465,21 @@ def test_vgg_loss_bf16_operands_tap_by_tap():
     assert cos > 0.91 and rel < 0.52, (cos, rel, errs)
 
 
+_EAGER_GRADS = {}
+
+
 def _grads_after_one_iteration(dt, mode, b=32, seed=5):
     """Flat gradients of both networks after ONE training iteration from a fixed state, run eagerly or as the replayed HIP
     graph (GanTrainer.capture: its warm-up iterations are undone by restoring the state before the replay)."""
+    if mode == "eager" and (dt, b, seed) in _EAGER_GRADS:   # (the eager iteration is the reference of two tests: run once)
+        return _EAGER_GRADS[(dt, b, seed)]
+    out = _grads_after_one_iteration_uncached(dt, mode, b, seed)
+    if mode == "eager":
+        _EAGER_GRADS[(dt, b, seed)] = out
+    return out
+
+
+def _grads_after_one_iteration_uncached(dt, mode, b, seed):
     import layout2img_amd as L
     from layout2img_amd.synthetic import make_batch
     from layout2img_amd.trainer import restore_state, snapshot_state
@@ -518,7 +530,7 @@ def test_graph_replay_gradients_match_eager_at_full_size(dt):
     assert med < (9e-4 if f32 else 1.7e-2), med
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.bfloat16])   # (the off-by-default one-batch form at the headline dtype; its f32 arithmetic is test_gpu_09_dual.py's)
 def test_dual_discriminator_step_gradients_match_two_passes_at_full_size(dt):
     """128x128, b = 32: the discriminator step as ONE batch of 64 images (every D-step conv / data-gradient / weight-gradient
     launch dual: two packs, two accumulators, the ROI heads' live-row count per half) gives the two-pass iteration's gradients

@@ -17,18 +17,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bf16_training_tracks_f32_training_over_the_first_20_iterations():
+def test_bf16_training_tracks_f32_training_over_the_first_10_iterations():
     sys.path.insert(0, os.path.join(ROOT, "tools", "parity"))
     import bf16_vs_f32_training as T
-    rows = {r["it"]: r for r in T.compare(iters=20, batch=32, size=128, n_f32=2, n_bf16=1)}
+    rows = {r["it"]: r for r in T.compare(iters=10, batch=32, size=128, n_f32=2, n_bf16=1)}
     rel = lambda a, b: abs(a - b) / max(1.0, abs(b))
     for t, (d_bar, g_bar) in {1: (1e-3, 1e-3), 2: (1.5e-3, 1.5e-3), 5: (3e-3, 5e-2)}.items():
         a, c = rows[t]["runs"]["f32 A"]["at"], rows[t]["runs"]["bf16 A"]["at"]
         assert rel(c[0], a[0]) < d_bar and rel(c[1], a[1]) < g_bar and rel(c[2], a[2]) < 3e-3, (t, a, c)
     # parameter distance to f32 A in units of the distance f32 A has moved: (G bar, D bar) for bf16; the floor (f32 B) must sit well below
-    # (iterations 10 and 20 sit in the chaotic transition -- 0.17 ... 0.48 (G) and 0.26 ... 0.55 (D) were seen at t = 10 for the SAME code on
-    #  different runs -- so their bars only say "not yet further than decorrelated"; the early rows are stable to three digits)
-    for t, (g_bar, d_bar) in {1: (0.40, 0.17), 2: (0.34, 0.13), 5: (0.24, 0.18), 10: (0.95, 1.0), 20: (1.1, 1.1)}.items():
+    # (iteration 10 sits in the chaotic transition -- 0.17 ... 0.48 (G) and 0.26 ... 0.55 (D) were seen at t = 10 for the SAME code on
+    #  different runs -- so its bar only says "not yet further than decorrelated"; the early rows are stable to three digits)
+    for t, (g_bar, d_bar) in {1: (0.40, 0.17), 2: (0.34, 0.13), 5: (0.24, 0.18), 10: (0.95, 1.0)}.items():
         b, c = rows[t]["runs"]["f32 B"], rows[t]["runs"]["bf16 A"]
         assert c["G"] < g_bar and c["D"] < d_bar, (t, c["G"], c["D"])
         if t <= 5:

@@ -72,10 +72,21 @@ def _run(rank, world, port, out):
         torch.distributed.destroy_process_group()
 
 
+_SINGLE = {}
+
+
+def _single_process_reference():
+    """Two iterations of the plain single-process trainer on the 4-image batch (one child process, shared by the tests of this file)."""
+    if not _SINGLE:
+        out = mp.Manager().dict()
+        mp.spawn(_run, args=(1, _free_port(), out), nprocs=1, join=True)
+        _SINGLE.update(out)
+    return _SINGLE
+
+
 def test_two_ranks_equal_single_process():
     mgr = mp.Manager()
-    single, multi = mgr.dict(), mgr.dict()
-    mp.spawn(_run, args=(1, _free_port(), single), nprocs=1, join=True)
+    single, multi = _single_process_reference(), mgr.dict()
     mp.spawn(_run, args=(2, _free_port(), multi), nprocs=2, join=True)
     # global-count losses: rank 0 holds its share of the global mean; the sum over ranks is the global loss, so
     # compare parameters (which see the all-reduced gradients) and synchronised BN statistics instead.
@@ -124,7 +135,7 @@ def _run_grads(rank, world, port, out, dt_name):
         torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("dt_name", ["bfloat16", "float32"])
+@pytest.mark.parametrize("dt_name", ["bfloat16"])   # (config 4's operand dtype; the exact-f32 exchange is the 64x64 test above. r05 ran both: 112 s)
 def test_two_rank_gradients_equal_single_process_at_128(dt_name):
     """BASELINE config 4's arithmetic at its resolution and operand dtype: two data-parallel ranks (8 images each) produce the
     single-process gradient of the 16-image batch -- SyncBN statistics in both directions, global-count losses, SUM
@@ -204,10 +215,9 @@ def test_forced_one_rank_collectives_over_rccl(graph):
     on RCCL communicator streams. A SUM over one rank is the identity: losses, parameters and synchronised statistics must
     equal the short-circuited single-process run (same bar as the two-rank test above)."""
     mgr = mp.Manager()
-    plain, forced = mgr.dict(), mgr.dict()
-    mp.spawn(_run_forced, args=(_free_port(), plain, False, False), nprocs=1, join=True)
+    plain, forced = _single_process_reference(), mgr.dict()   # (the same two plain iterations the two-rank test compares with)
     mp.spawn(_run_forced, args=(_free_port(), forced, True, graph), nprocs=1, join=True)
-    assert plain["collectives"] == 0 and forced["collectives"] >= 20, forced["collectives"]   # (per eager iteration: ~30 SyncBN pairs + count + gradients)
+    assert forced["collectives"] >= 20, forced["collectives"]   # (per eager iteration: ~30 SyncBN pairs + count + gradients)
     assert abs(forced["d_loss"] - plain["d_loss"]) < 2e-4 * abs(plain["d_loss"]) + 1e-5
     assert abs(forced["g_loss"] - plain["g_loss"]) < 2e-4 * abs(plain["g_loss"]) + 1e-5
     assert torch.allclose(forced["bn_mean"], plain["bn_mean"], atol=2e-3)

@@ -155,9 +155,10 @@ def test_weight_gradient_with_the_fused_last_arriver_reduction():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, L2I_WGRAD_FUSE="1")
-    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_gpu_02_ops.py", "tests/test_gpu_09_dual.py", "-k",
-                        "conv_wgrad or dual_wgrad or device_side_image_count"], cwd=root, env=env, capture_output=True, text=True, timeout=1200)
-    assert p.returncode == 0, p.stdout[-3000:]
+    # (an off-by-default experiment: the plain weight-gradient cases only -- a dozen shapes, both dtypes -- not the whole file as in round 5: 28 s)
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "tests/test_gpu_02_ops.py", "-k",
+                        "test_conv_wgrad and scratch and (case0 or case1 or case5 or case13 or case21)"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]
 
 
 @pytest.mark.parametrize("heads", ["obj+app", "obj", "app", "img", "all"])
@@ -205,13 +206,18 @@ def test_generator_block_results_join_their_two_gradients(size, loss_kind, monke
     from layout2img_amd.synthetic import make_batch
     real, label, bbox, z, z_im = make_batch(3, size, "coco", seed=5, device=torch.device(DEV))
     grads = {}
+    torch.manual_seed(0)
+    g = (L.ResnetGenerator128_context if size == 128 else L.ResnetGenerator64_context)(num_classes=184).finalize(DEV, torch.float32).train()
+    for m in g.modules():
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = 0.0
+    state = {k: v.clone() for k, v in g.state_dict().items()}   # (one network, put back to the same state for each of the three runs)
+    sn = g.arena.sn_flat.data.clone()
     for run, join in (("on", True), ("off", False), ("off2", False)):
         monkeypatch.setattr(G, "JOIN_HEADS", join)
-        torch.manual_seed(0)
-        g = (L.ResnetGenerator128_context if size == 128 else L.ResnetGenerator64_context)(num_classes=184).finalize(DEV, torch.float32).train()
-        for m in g.modules():
-            if hasattr(m, "dropout_p"):
-                m.dropout_p = 0.0
+        g.load_state_dict(state)
+        g.arena.sn_flat.data.copy_(sn)
+        g.arena.drop_pending()
         g.zero_grad()
         taps = {}
         img = g(z, bbox, z_im, label, taps=taps) if size == 128 else g(z, bbox, z_im, label)
