@@ -230,16 +230,17 @@ extern "C" int l2i_relu_bwd(const float* g, const float* mask, const float* add,
 // a = relu(x). One pass over x forward (keeping s[r,p], t[r,p]), one pass backward (dx, dw1).
 //   x [R][HW][C] f32 (pre-ReLU), w [C];  fwd: out[r] += gram_term (out pre-zeroed), s,t [R][HW]
 #define GH_POS 16   // positions per block (4 per wave)
-__global__ __launch_bounds__(256) void gram_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            float* __restrict__ out, float* __restrict__ s_keep,
-                                                            float* __restrict__ t_keep, int HW, int C, int parts) {
+// One workgroup of 16 waves per ROI (a wave per position, four positions each at HW = 64): the ROI's term is the sum of its positions in a
+// fixed order and has ONE writer (rounds 1-5: four 4-wave workgroups per ROI and a float atomic each -- the appearance logit moved in its
+// last bit from run to run). Same number of waves in flight as before.
+__global__ __launch_bounds__(1024) void gram_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ out, float* __restrict__ s_keep,
+                                                             float* __restrict__ t_keep, int HW, int C) {
     __shared__ float red[16];
-    const int r = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int r = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float blk = 0.f;
-    for (int pi = wave; pi < GH_POS; pi += 4) {
-        const int pos = part * GH_POS + pi;
-        if (pos >= HW) break;
+    for (int pos = wave; pos < HW; pos += 16) {
         const float* row = x + ((size_t)r * HW + pos) * C;
         float s = 0.f, t = 0.f;
         for (int c = 4 * lane; c < C; c += 256) {
@@ -254,10 +255,14 @@ __global__ __launch_bounds__(256) void gram_head_fwd_kernel(const float* __restr
         if (lane == 0) { s_keep[(size_t)r * HW + pos] = s; t_keep[(size_t)r * HW + pos] = t; }
         blk += s * t;
     }
-    __syncthreads();
     if (lane == 0) red[wave] = blk;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out + r, (red[0] + red[1] + red[2] + red[3]) / ((float)C * (float)C));
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += red[i];
+        out[r] += a / ((float)C * (float)C);
+    }
 }
 
 //   bwd: dx[r,p,c] = [x>0] g[r]/C^2 (t[r,p] + s[r,p] w[c]);  dw[c] += sum_{r,p} g[r]/C^2 s[r,p] a[r,p,c]  (via ws replicas)
@@ -297,9 +302,7 @@ extern "C" int l2i_gram_head_fwd(const float* x, const float* w, float* out, flo
                                  int C, void* stream) {
     if (!x || !w || !out || !s_keep || !t_keep || C % 4 || R < 0) return L2I_ERR_ARG;
     if (R == 0) return L2I_OK;
-    const int parts = (HW + GH_POS - 1) / GH_POS;
-    hipLaunchKernelGGL(gram_head_fwd_kernel, dim3(R * parts), dim3(256), 0, (hipStream_t)stream, x, w, out, s_keep, t_keep, HW,
-                       C, parts);
+    hipLaunchKernelGGL(gram_head_fwd_kernel, dim3(R), dim3(1024), 0, (hipStream_t)stream, x, w, out, s_keep, t_keep, HW, C);
     return l2i_check_launch();
 }
 
