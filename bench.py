@@ -337,11 +337,20 @@ def main():
     t0 = time.perf_counter()
     run_steps(args.steps)
     trainer.flush()   # (data parallel: the last iteration's deferred generator all-reduce + Adam belong to the timed region)
+    torch.cuda.synchronize()
+    local = time.perf_counter() - t0   # this rank's own K steps, before the closing barrier: a straggler shows up in the spread below
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    rank_ms = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lo = torch.tensor([local], device=dev, dtype=torch.float64)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        rank_ms = {"min": round(1e3 * float(lo) / args.steps, 3), "max": round(1e3 * float(hi) / args.steps, 3),
+                   "note": "per-rank ms per step up to the rank's own device synchronisation, before the closing barrier"}
     elapsed = float(t)
     if not args.no_kernel_timer:
         # roofline leg: ONE eager iteration on one stream with HIP events on every conv / weight-gradient dispatch, right behind
@@ -447,7 +456,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": ("HIP graph replay of the whole iteration incl. the draw of z (every timed step)" if graphed else "eager"),
                        "iterations_per_replay": n_multi},
-            "roofline": roof, "env": l2i_env(), "comm": comm,
+            "roofline": roof, "env": l2i_env(), "comm": comm, "rank_ms_per_step": rank_ms,
             "cpu_baseline": cpu, "g_forward": g_fwd, "eager": eager, "f32_mode": f32_mode,
             "g_forward_images_per_sec": None if g_fwd is None else g_fwd["images_per_sec"],
         }

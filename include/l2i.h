@@ -459,6 +459,12 @@ int l2i_in_relu_up2_fwd(const float* x, float* out, void* out_op, int op_dtype, 
 int l2i_in_relu_up2_bwd(const float* x, const float* g, float* dx, void* dx_op, int op_dtype, long long N, int S, int C, float eps,
                         void* stream);
 
+/* Plain bilinear x2 (align_corners = False) of NHWC maps x [N][S][S][C] f32 -> out [N][2S][2S][C] f32 (+ out_op, the operand-dtype copy the
+ * next convolution reads): F.interpolate(x, size, mode="bilinear") between the convolutions of the VG generator's MaskRegressNet
+ * (model/mask_regression.py:20-33,42-58). bwd: the adjoint, dx [N][S][S][C] (written; every value has one writer) + its operand copy. C % 4 == 0. */
+int l2i_up2_nhwc_fwd(const float* x, float* out, void* out_op, int op_dtype, long long N, int S, int C, void* stream);
+int l2i_up2_nhwc_bwd(const float* g, float* dx, void* dx_op, int op_dtype, long long N, int S, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

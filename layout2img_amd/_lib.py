@@ -23,6 +23,8 @@ SIGNATURES = {
     "l2i_conv2d_dgrad_sc": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _ll, _p],
     "l2i_in_relu_up2_fwd": [_p, _p, _p, _i, _ll, _i, _i, _f, _p],
     "l2i_in_relu_up2_bwd": [_p, _p, _p, _p, _i, _ll, _i, _i, _f, _p],
+    "l2i_up2_nhwc_fwd": [_p, _p, _p, _i, _ll, _i, _i, _p],
+    "l2i_up2_nhwc_bwd": [_p, _p, _p, _i, _ll, _i, _i, _p],
     "l2i_set_conv_config": [_i],
     "l2i_timing": [_i],
     "l2i_timing_read": [_i, _p, _p],

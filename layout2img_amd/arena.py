@@ -513,10 +513,14 @@ class WeightArena:
         from .ops import WgradSide
         WgradSide.join()   # weight-gradient launches run on side streams (ops.WgradSide)
         self.flat.flush_loose()
-        fix = [t for p in self.pending for t in p.bias_fix.values()]   # padded-channel bias gradients summed by the weight-gradient launches
-        if fix:
-            torch._foreach_add_([d for d, _ in fix], [s_ for _, s_ in fix])
-            for p in self.pending:
+        # padded-channel bias gradients summed by the weight-gradient launches: one multi-tensor add PER PASS. (Round 5 issued one add over all
+        # pending passes: two passes of one network name the SAME bias gradient twice, and a multi-tensor kernel that reads and writes one
+        # destination from two list entries at once keeps only one of the two addends -- or both, from run to run: final.2.bias differed by 6 %
+        # between identical runs of "two forwards, then backward", which is what made tests/test_gpu_12_extra.py flicker at 2.1e-3 in round 5.)
+        for p in self.pending:
+            if p.bias_fix:
+                fix = list(p.bias_fix.values())
+                torch._foreach_add_([d for d, _ in fix], [s_ for _, s_ in fix])
                 p.bias_fix = {}
         live = [p for p in self.pending if p.dwbar is not None]
         for p in live:

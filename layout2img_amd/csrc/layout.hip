@@ -1053,6 +1053,79 @@ __global__ __launch_bounds__(256) void in_relu_up2_bwd_kernel(const float* __res
         }
     }
 }
+// Plain bilinear x2 (align_corners = False) of NHWC maps x [N][S][S][C] -> [N][2S][2S][C] + the operand copy the next convolution reads:
+// F.interpolate(x, size, mode="bilinear") between the convolutions of the VG generator's MaskRegressNet (reference model/mask_regression.py:
+// 20-33,42-58), whose normalisation is a BatchNorm (ops.norm_act) rather than the InstanceNorm the kernel above folds in. It ran as a
+// batched torch.matmul with the dense resampling matrix (rocBLAS) through round 5. One thread = four channels of one output pixel.
+// Backward (the adjoint): an input pixel gathers from the <= 4 x 4 output pixels whose taps can name it -- every dx value has one writer.
+__global__ __launch_bounds__(256) void up2_nhwc_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, void* out_op, int op_dtype,
+                                                          long long total4, int S, int C4) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int c4 = (int)(idx % C4);
+    long long r = idx / C4;
+    const int ox = (int)(r % (2 * S)); r /= 2 * S;
+    const int oy = (int)(r % (2 * S));
+    const long long n = r / (2 * S);
+    int y0, y1, x0, x1; float ly, lx;
+    up2_tap(oy, S, y0, y1, ly);
+    up2_tap(ox, S, x0, x1, lx);
+    const float4* xp = reinterpret_cast<const float4*>(x) + n * S * S * C4 + c4;
+    const float4 a = xp[(long long)(y0 * S + x0) * C4], b = xp[(long long)(y0 * S + x1) * C4];
+    const float4 c = xp[(long long)(y1 * S + x0) * C4], d = xp[(long long)(y1 * S + x1) * C4];
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    const float v[4] = {w00 * a.x + w01 * b.x + w10 * c.x + w11 * d.x, w00 * a.y + w01 * b.y + w10 * c.y + w11 * d.y,
+                        w00 * a.z + w01 * b.z + w10 * c.z + w11 * d.z, w00 * a.w + w01 * b.w + w10 * c.w + w11 * d.w};
+    reinterpret_cast<float4*>(out)[idx] = make_float4(v[0], v[1], v[2], v[3]);
+    if (out_op) {
+        if (op_dtype == 1) Op4<bf16_t>::store(reinterpret_cast<bf16_t*>(out_op) + 4 * idx, v);
+        else Op4<float>::store(reinterpret_cast<float*>(out_op) + 4 * idx, v);
+    }
+}
+__global__ __launch_bounds__(256) void up2_nhwc_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, void* dx_op, int op_dtype,
+                                                          long long total4, int S, int C4) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int c4 = (int)(idx % C4);
+    long long r = idx / C4;
+    const int ix = (int)(r % S); r /= S;
+    const int iy = (int)(r % S);
+    const long long n = r / S;
+    const float4* gp = reinterpret_cast<const float4*>(g) + n * 4 * S * S * C4 + c4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int oy = max(0, 2 * iy - 1); oy <= min(2 * S - 1, 2 * iy + 2); ++oy) {
+        int y0, y1; float ly;
+        up2_tap(oy, S, y0, y1, ly);
+        const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = max(0, 2 * ix - 1); ox <= min(2 * S - 1, 2 * ix + 2); ++ox) {
+            int x0, x1; float lx;
+            up2_tap(ox, S, x0, x1, lx);
+            const float w = wy * ((x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f));
+            if (w == 0.f) continue;
+            const float4 v = gp[(long long)(oy * 2 * S + ox) * C4];
+            acc[0] = fmaf(w, v.x, acc[0]); acc[1] = fmaf(w, v.y, acc[1]); acc[2] = fmaf(w, v.z, acc[2]); acc[3] = fmaf(w, v.w, acc[3]);
+        }
+    }
+    reinterpret_cast<float4*>(dx)[idx] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (dx_op) {
+        if (op_dtype == 1) Op4<bf16_t>::store(reinterpret_cast<bf16_t*>(dx_op) + 4 * idx, acc);
+        else Op4<float>::store(reinterpret_cast<float*>(dx_op) + 4 * idx, acc);
+    }
+}
+extern "C" int l2i_up2_nhwc_fwd(const float* x, float* out, void* out_op, int op_dtype, long long N, int S, int C, void* stream) {
+    if (!x || !out || N < 1 || S < 1 || C < 4 || C % 4 || (op_dtype != 0 && op_dtype != 1)) return L2I_ERR_ARG;
+    const long long total4 = N * 4 * S * S * (C / 4);
+    hipLaunchKernelGGL(up2_nhwc_fwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, out_op, op_dtype, total4, S, C / 4);
+    return l2i_check_launch();
+}
+extern "C" int l2i_up2_nhwc_bwd(const float* g, float* dx, void* dx_op, int op_dtype, long long N, int S, int C, void* stream) {
+    if (!g || !dx || N < 1 || S < 1 || C < 4 || C % 4 || (op_dtype != 0 && op_dtype != 1)) return L2I_ERR_ARG;
+    const long long total4 = N * S * S * (C / 4);
+    hipLaunchKernelGGL(up2_nhwc_bwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, dx, dx_op, op_dtype, total4, S, C / 4);
+    return l2i_check_launch();
+}
+
 extern "C" int l2i_in_relu_up2_fwd(const float* x, float* out, void* out_op, int op_dtype, long long N, int S, int C, float eps, void* stream) {
     if (!x || !out || N < 1 || C < 1 || (S != 4 && S != 8) || (op_dtype != 0 && op_dtype != 1)) return L2I_ERR_ARG;
     const dim3 grid((unsigned)N, (unsigned)((C + 255) / 256), S == 8 ? 4u : 2u);

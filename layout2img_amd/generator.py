@@ -366,7 +366,7 @@ class MaskRegressNetv2(nn.Module):
             a = ops.norm_act(h, spec, wa, ba)
             if not self.instance:
                 blk_prev[1].commit()
-            a = torch.matmul(resample_matrix("bilinear", size // 2, size, a.device), a.view(N, -1, self.ch)).view(N, size, size, self.ch)
+            a = ops.up2_nhwc(a.view(N, size // 2, size // 2, self.ch), pc.arena.op_dtype)   # bilinear x2 + the operand copy: one launch (csrc/layout.hip)
             h = fused_conv(a, blk[0], pc)
         spec, wa, ba = self._spec(self.conv3, sync)
         m = fused_conv(h, self.conv3[3], pc, prologue=spec, wproj=wa, bproj=ba, dx_raw=True)   # (N, 16, 16, 8): channel 0 = the logits

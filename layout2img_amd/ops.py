@@ -1825,6 +1825,38 @@ def in_relu_up2(x, eps, op_dtype):
     return InReluUp2Fn.apply(x, eps, op_dtype)
 
 
+class Up2NhwcFn(Function):
+    """Bilinear x2 (align_corners=False) of NHWC maps (N, S, S, C) f32 -> (N, 2S, 2S, C) + the operand copy the next convolution reads:
+    F.interpolate between the convolutions of the VG generator's MaskRegressNet (reference model/mask_regression.py:20-33,42-58).
+    One launch each way (csrc/layout.hip) -- a batched torch.matmul with the dense resampling matrix (rocBLAS) through round 5."""
+
+    @staticmethod
+    def forward(ctx, x, op_dtype):
+        x = _chk(x.contiguous(), torch.float32)
+        N, S, S2, C = x.shape
+        assert S == S2 and C % 4 == 0
+        out = torch.empty((N, 2 * S, 2 * S, C), dtype=torch.float32, device=x.device)
+        op = torch.empty((N, 2 * S, 2 * S, C), dtype=op_dtype, device=x.device)
+        _lib.call("l2i_up2_nhwc_fwd", x.data_ptr(), out.data_ptr(), op.data_ptr(), _code(op_dtype), N, S, C, _stream())
+        _attach(out, raw=op)
+        ctx.meta = (N, S, C, op_dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, S, C, op_dtype = ctx.meta
+        g = _chk(g.contiguous(), torch.float32)
+        dx = torch.empty((N, S, S, C), dtype=torch.float32, device=g.device)
+        dx_op = torch.empty((N, S, S, C), dtype=op_dtype, device=g.device)
+        _lib.call("l2i_up2_nhwc_bwd", g.data_ptr(), dx.data_ptr(), dx_op.data_ptr(), _code(op_dtype), N, S, C, _stream())
+        _attach(dx, raw=dx_op)
+        return dx, None
+
+
+def up2_nhwc(x, op_dtype):
+    return Up2NhwcFn.apply(x, op_dtype)
+
+
 class PspStagesFn(Function):
     """The four pyramid stages of the PSP head between the pooling and the expansion kernels (reference
     model/resnet_generator_app_v2.py:741-746: Conv2d(C, F, 1, bias=False) -> BatchNorm2d -> ReLU on the s x s pooled maps):

@@ -3,7 +3,7 @@ the oracle here, not only its batch-of-2 miniature.
 
 (i)   generator forward, batch 32, recipe weights: exact-f32 operands and the split "bf16x3" mode against
       oracle.generator_forward on the CPU at the north star's bar (image L_inf < 1e-3, pre-tanh tap 1e-3 relative); the
-      bf16-operand throughput mode at its own stated bar (L_inf 1.2e-1, rms 1.5e-2).
+      bf16-operand throughput mode at its own stated bar (L_inf 8.5e-2, rms 7.6e-3: 1.25 x the now run-to-run identical measured values).
 (ii)  discriminator forward on the same batch (the 157-of-256 live ROI layout of synthetic.make_batch) against
       oracle.discriminator_forward, rows in the reference's output order.
 (iii) EVERY distinct conv / data-gradient / weight-gradient launch of one full-size training iteration, captured live from
@@ -79,10 +79,10 @@ def test_generator_forward_full_size_vs_oracle(mode, oracle_g):
     print(f"full-size G forward [{mode}]: image L_inf {e_img:.2e} (rms {rms:.2e}), pre-tanh rel {e_pre:.2e}")
     assert tuple(img.shape) == (BATCH, 3, 128, 128) and bool(torch.isfinite(img).all())
     if mode == "bf16":   # the throughput mode's own bar (2^-9 per operand pair, a random walk over ~25 layers).
-        # L_inf is the maximum over 1.5 M pixels of that walk and moves with the order of the atomically reduced batch statistics:
-        # 6.2e-2 ... 6.4e-2 on most runs, one run of the round-5 suite above 8e-2 -- so the L_inf ceiling is 1.2e-1 and the stable
-        # statistic, the rms error, carries the tight bar
-        assert e_img < 1.2e-1 and e_pre < 5e-2 and rms < 1.5e-2, (e_img, e_pre, rms)
+        # Rounds 1-5: the maximum over 1.5 M pixels moved from run to run (6.2e-2 ... > 8e-2) with the order of the atomic batch statistics and
+        # power-iteration sums, and the ceiling had to be 1.2e-1. Round 6: the forward is bit-identical from run to run (tests/test_gpu_06b_
+        # determinism.py); measured on an MI355X: L_inf 6.59e-2, rms 6.07e-3, pre-tanh 1.70e-2 -- bars 1.25x that.
+        assert e_img < 8.5e-2 and e_pre < 2.2e-2 and rms < 7.6e-3, (e_img, e_pre, rms)
     else:                # the north star's bar
         assert e_img < 1e-3 and e_pre < 1e-3, (e_img, e_pre)
 
@@ -383,7 +383,7 @@ def test_vg_models_full_size_vs_oracle(mode, oracle_vg):
         img = g(z, bbox, z_im, label)
     e_img = maxdiff(img, ref_img)
     print(f"full-size VG G forward [{mode}]: image L_inf {e_img:.2e}")
-    assert e_img < (1e-1 if mode == "bf16" else 1e-3), e_img
+    assert e_img < (9e-2 if mode == "bf16" else 1e-3), e_img   # (bf16: 7.17e-2 measured, identical from run to run since round 6)
     del g
     d = L.CombineDiscriminator128_app(num_classes=179)
     d.load_state_dict(fixture_state(load_fixture("d_vg.npz"), 54))

@@ -258,3 +258,25 @@ def test_in_relu_up2_matches_the_torch_chain(S, C, N, dt):
     op = ops._sibling(out, "raw", dt)
     assert op is not None and float((op.float().cpu() - ref.detach()).abs().max()) < (2e-5 if dt == torch.float32 else 2e-2)
     assert float((xd.grad.cpu() - xr.grad).abs().max()) < 2e-4 * max(1.0, float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,S,C", [(62, 4, 128), (62, 8, 128), (3, 8, 64), (2, 16, 8)])
+def test_up2_nhwc_matches_interpolate(N, S, C, dt):
+    """ops.up2_nhwc == F.interpolate(scale 2, bilinear, align_corners=False) on NHWC maps, forward and backward (the VG generator's
+    MaskRegressNet, reference model/mask_regression.py:20-33,42-58), with the operand copies of the result and of dx."""
+    import torch.nn.functional as F
+    from layout2img_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + S)
+    x = torch.randn(N, S, S, C, generator=g)
+    gy = torch.randn(N, 2 * S, 2 * S, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr.permute(0, 3, 1, 2), size=(2 * S, 2 * S), mode="bilinear").permute(0, 2, 3, 1)
+    ref.backward(gy)
+    xd = x.to("cuda:0").requires_grad_(True)
+    out = ops.up2_nhwc(xd, dt)
+    out.backward(gy.to("cuda:0"))
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 1e-5
+    assert float((xd.grad.cpu() - xr.grad).abs().max()) < 1e-5
+    op = ops._sibling(out, "raw", dt)
+    assert op is not None and op.dtype == dt and float((op.float().cpu() - ref.detach()).abs().max()) < (1e-5 if dt == torch.float32 else 4e-2)

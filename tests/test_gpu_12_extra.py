@@ -101,8 +101,11 @@ def test_two_generator_forwards_before_one_backward():
     floor = float((b2 - b).norm() / b.norm())   # two identical runs: accumulation-order noise of this train-mode batch-of-2 network
     rel = float((a - b).norm() / b.norm())
     print(f"together vs separate {rel:.2e}, separate vs separate {floor:.2e}")
-    # a forward whose saved statistics were re-zeroed by the second forward gives an O(1) error; the bar is the measured same-run floor
-    assert rel < max(3 * floor, 3e-3), (rel, floor)
+    # A forward whose saved statistics were re-zeroed by the second forward gives an O(1) error. Round 5's bar was a fixed 2e-3 and the test
+    # flickered at 2.1e-3: not summation noise but a RACE -- flush_grads added the two passes' padded-channel bias gradients (final.2.bias) with
+    # one multi-tensor add that named the same destination twice and kept one addend or both from run to run (fixed in arena.flush_grads). With
+    # that gone and the forward bit-identical the two orders differ by the backward's remaining float atomics only: 6e-7 measured.
+    assert floor < 2e-5 and rel < max(20 * floor, 1e-4), (rel, floor)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -230,12 +233,13 @@ def test_generator_block_results_join_their_two_gradients(size, loss_kind, monke
         grads[run] = g.flat.grad.clone()
     a, b, b2 = grads["on"], grads["off"], grads["off2"]
     assert float(b.norm()) > 0 and bool(torch.isfinite(a).all())
-    # accumulation order only (f32 operands) -- but the order of the atomically reduced batch statistics already moves the gradient of
-    # this 25-layer train-mode network by ~1e-3 between two identical runs (batch of 3): the bar is that measured floor
+    # accumulation order only (f32 operands). Rounds 1-5: the atomically reduced batch statistics moved the gradient of this 25-layer train-mode
+    # network by ~1e-3 between two identical runs; round 6: the forward is bit-identical, two runs differ by the backward's float atomics
+    # (1.2e-6 ... 1.9e-6 measured), and a gradient term dropped at the 1e-3 level is now caught
     floor = float((b2 - b).norm() / b.norm())
     rel = float((a - b).norm() / b.norm())
     print(f"joined vs plain {rel:.2e}, plain vs plain {floor:.2e}")
-    assert rel < max(3 * floor, 3e-3), (rel, floor)   # (the floor itself moves 3e-4 ... 1.2e-3 from run to run; a dropped gradient is an O(0.1) error)
+    assert floor < 2e-5 and rel < max(20 * floor, 1e-4), (rel, floor)
 
 
 @pytest.mark.parametrize("variant", ["eager", "graph", "dual", "real_bwd_early"])

@@ -27,6 +27,8 @@ def test_bench_two_ranks_through_the_self_spawn_path():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 16 * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]
     assert d["env"]["L2I_DIST_BACKEND"] == "gloo"          # tuning / test switches are part of the line
+    r = d["rank_ms_per_step"]                              # per-rank spread (a straggler among the ranks shows up here)
+    assert 0 < r["min"] <= r["max"] <= d["ms_per_step"] * 1.001
 
 
 def test_bench_refuses_wrong_result_switches():

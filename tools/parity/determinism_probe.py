@@ -66,10 +66,22 @@ def main():
         torch.cuda.synchronize()
         return [t.detach().clone() for t in o], d.flat.grad.clone(), d.arena.sn_flat.data.clone()
 
-    for name, f in (("G", g_pass), ("D", d_pass)):
+    for name, f, net in (("G", g_pass, g), ("D", d_pass, d)):
         (o1, g1, s1), (o2, g2, s2) = f(), f()
         print(f"{name} {a.dtype} b={a.batch}: forward max|diff| per output/tap {[float((x - y).abs().max()) for x, y in zip(o1, o2)]}")
         print(f"{name}   power-iteration state rel {rel(s1, s2):.3e}   flat gradient rel {rel(g1, g2):.3e}")
+        # per parameter: which gradients differ between the two runs (views of the flat gradient buffer, in registration order)
+        base = net.flat.grad.data_ptr()
+        rows = []
+        for n, p_ in net.named_parameters():
+            off = (p_.grad.data_ptr() - base) // 4
+            x, y = g1[off:off + p_.numel()], g2[off:off + p_.numel()]
+            rows.append((rel(x, y) if float(y.norm()) > 0 else float((x - y).abs().max()), n, tuple(p_.shape)))
+        same = sum(1 for r in rows if r[0] == 0.0)
+        print(f"{name}   {same} of {len(rows)} parameter gradients bit-identical; the others:")
+        for r in rows:
+            if r[0] != 0.0:
+                print(f"        {r[0]:.2e}  {r[1]}  {r[2]}")
 
     def train(n):
         reset()
