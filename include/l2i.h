@@ -173,10 +173,13 @@ int l2i_weights_prepare(const long long* layers, int n_layers, const int* tab_wt
                         long long npart_floats, void* stream);
 
 /* Backward of the above: grads[w] += (G - <G,Wbar> u v^T) / sigma for every layer (G = dwbar).
- * ws: the all-zero workspace described at l2i_channel_stats (required; left all-zero). */
+ * ws: the all-zero workspace described at l2i_channel_stats (required; left all-zero; n_dot * passes + passes * n_layers floats of it are used).
+ * dot_range: (first entry of the FULL dot table, number of entries) per layer row, int32 [n_layers][2]; dot_base: the index in the full table of
+ * tab_dot[0] (a launch may cover a sub-range of whole layers: arena.grad_groups). Round 6: every sn_dot block stores its share of <G, W> and
+ * a fold launch adds a layer's shares in order -- no float atomics, the correction term is bit-identical from run to run. */
 int l2i_weights_backward(const long long* layers, int n_layers, const int* tab_dot, int n_dot, const int* tab_apply,
                          int n_apply, const float* params, const float* dwbar, const float* pass_uv, float* norms,
-                         float* grads, float* ws, void* stream);
+                         float* grads, float* ws, const int* dot_range, int dot_base, void* stream);
 /* The same for TWO passes that share the weights and are flushed together (the discriminator's real and fake forward of one
  * optimiser step, train_context_app_v2.py:158,167): grads += corr0(dwbar0) + corr1(dwbar1) with each pass's own u, v,
  * sigma -- W is read once, the gradient buffer is read and written once. dwbar1 == NULL: one pass (= l2i_weights_backward).
@@ -185,7 +188,7 @@ int l2i_weights_backward(const long long* layers, int n_layers, const int* tab_d
 int l2i_weights_backward2(const long long* layers, int n_layers, const int* tab_dot, int n_dot, const int* tab_apply,
                           int n_apply, const float* params, const float* dwbar0, const float* pass_uv0, float* norms0,
                           const float* dwbar1, const float* pass_uv1, float* norms1, float* grads, float* ws, int overwrite,
-                          void* stream);
+                          const int* dot_range, int dot_base, void* stream);
 
 /* Per-channel sum / sum of squares over rows of x [rows][C] (grouped): sums/sqsums [G][C] +=.
  * Batch statistics of SynchronizedBatchNorm2d (model/sync_batchnorm/batchnorm.py:51-68), of
@@ -294,11 +297,13 @@ int l2i_resize_bilinear(const float* in, float* out, long long N, int h, int w, 
 /* Appearance head of the discriminator without the (R, C, C) Gram matrices
  * (model/rcnn_discriminator_app.py:148-157; see csrc/misc.hip): x [R][HW][C] pre-ReLU features, w [C] the first half
  * of the head's Linear(2C -> 1) weight. fwd: out[r] += (1/C^2) sum_p (sum_c a)(sum_c a w), a = relu(x); keeps the two
- * per-position sums s, t [R][HW]. bwd: dx [R][HW][C] (written), dw [C] += ; ws as at l2i_channel_stats (required). */
+ * per-position sums s, t [R][HW]. bwd: dx [R][HW][C] (written), dw [C] += ; scratch (required, 16-byte aligned, caller-owned, contents undefined
+ * afterwards, >= R * ceil(HW / 16) * C floats + the fold's chunk rows): every workgroup stores its share of dw as a row there and a fold launch
+ * adds the rows in order (round 6: no float atomics; the forward has one writer per ROI). */
 int l2i_gram_head_fwd(const float* x, const float* w, float* out, float* s_keep, float* t_keep, int R, int HW, int C,
                       void* stream);
 int l2i_gram_head_bwd(const float* x, const float* w, const float* s_keep, const float* t_keep, const float* g, float* dx,
-                      float* dw, float* ws, int R, int HW, int C, void* dx_op_bf16, void* stream);
+                      float* dw, float* scratch, long long scratch_floats, int R, int HW, int C, void* dx_op_bf16, void* stream);
 /* (dx_op_bf16, optional, here and in l2i_proj_head_bwd: bf16 copy of dx -- the dY operand of the convolution that produced x) */
 
 /* Class-gathered logits of the generator's mask heads (round 5): the heads end in Conv2d(100, 184, 1) and the only reader of the 184-channel

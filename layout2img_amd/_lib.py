@@ -32,8 +32,8 @@ SIGNATURES = {
     "l2i_conv2d_wgrad_sc": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p, _p],
     "l2i_conv2d_wgrad_dual": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p],
     "l2i_weights_prepare": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _p, _i, _p, _ll, _ll, _p],
-    "l2i_weights_backward": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p],
-    "l2i_weights_backward2": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "l2i_weights_backward": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    "l2i_weights_backward2": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p],
     "l2i_channel_stats": [_p, _ll, _i, _ll, _p, _p, _p, _i, _p, _ll, _p],
     "l2i_norm_mod_fwd": [_p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _i, _p, _p, _f, _p],
     "l2i_norm_mod_bwd_a": [_p, _p, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _p, _p, _ll, _ll, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _p],
@@ -52,7 +52,7 @@ SIGNATURES = {
     "l2i_debug_occupancy": [_i, _i],
     "l2i_resize_bilinear": [_p, _p, _ll, _i, _i, _i, _i, _p],
     "l2i_gram_head_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "l2i_gram_head_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
+    "l2i_gram_head_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _i, _p, _p],
     "l2i_proj_head_fwd": [_p, _p, _p, _i, _p, _p, _f, _p, _p, _i, _i, _i, _i, _p],
     "l2i_proj_head_bwd": [_p, _p, _p, _i, _p, _p, _p, _f, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _p],
     "l2i_emb_dot_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],

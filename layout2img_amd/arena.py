@@ -404,6 +404,13 @@ class WeightArena:
             return b
         self.grad_groups = dict(n=ng, dot=_bounds(t_dot), apply=_bounds(t_apply), lo=starts, hi=starts[1:] + [flat.numel])
         self.grad_groups["lo"][0] = 0
+        # (first dot-table entry, number of entries) per layer row: sn_dotfold_kernel adds a layer's stored shares of <G, W> in that order
+        rng = np.zeros((L, 2), dtype=np.int32)
+        for k, (li, _) in enumerate(t_dot):
+            if rng[li, 1] == 0:
+                rng[li, 0] = k
+            rng[li, 1] += 1
+        self.t_dot_range = torch.from_numpy(rng.reshape(-1).copy()).to(device)
         self.t_dot, self.n_dot = dev(t_dot, 2)
         self.t_apply, self.n_apply = dev(t_apply, 2)
         self.pending = []
@@ -537,7 +544,7 @@ class WeightArena:
                               self.t_apply.data_ptr() + 8 * a0, a1 - a0, self.flat.data.data_ptr(), p.dwbar.data_ptr(),
                               p.pass_uv.data_ptr(), p.norms.data_ptr(), q.dwbar.data_ptr() if q else None,
                               q.pass_uv.data_ptr() if q else None, q.norms.data_ptr() if q else None, self.flat.grad.data_ptr(),
-                              _lib.workspace(self.device), 1 if (fresh and i == 0) else 0, _lib.raw_stream())
+                              _lib.workspace(self.device), 1 if (fresh and i == 0) else 0, self.t_dot_range.data_ptr(), d0, _lib.raw_stream())
             if on_group is not None:
                 on_group(lo, hi)
         if live:

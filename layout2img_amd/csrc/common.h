@@ -131,22 +131,22 @@ static inline void ws_fold(float* ws, int L, int C, float* d0, float* d1, float*
 // order: dst[z * zs + i] (+)= sum_r part[z][r][i]. One small launch up to 1024 rows, two above (row chunks -> tmp[z][chunk][L], chunks -> dst). Plain stores also run at several times the rate of float atomics on this chip (DESIGN A.3 4.1b).
 // The pairwise order inside a thread, across the row lanes of a workgroup and across the chunks is fixed by (R, L) alone.
 #define L2I_FOLD_CHUNKS 64
-static __global__ __launch_bounds__(256) void rows_fold1_kernel(const float* __restrict__ part, int R, int L, int rc, float* __restrict__ tmp) {
+static __global__ __launch_bounds__(256) void rows_fold1_kernel(const float* __restrict__ part, int R, int L, int rc, float* __restrict__ tmp, int ld) {
     __shared__ float4 red[256];
     const int L4 = L >> 2, cbase = blockIdx.x * 64, ncol = min(64, L4 - cbase), TY = 256 / ncol;
     const int tx = threadIdx.x % ncol, ty = threadIdx.x / ncol;
     const int r0 = blockIdx.y * rc, r1 = min(R, r0 + rc);
-    const float* src = part + (size_t)blockIdx.z * R * L + 4 * (cbase + tx);
+    const float* src = part + (size_t)blockIdx.z * R * ld + 4 * (cbase + tx);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ty < TY) {
         int r = r0 + ty;
         for (; r + 3 * TY < r1; r += 4 * TY) {
-            const float4 a = *reinterpret_cast<const float4*>(src + (size_t)r * L), b = *reinterpret_cast<const float4*>(src + (size_t)(r + TY) * L);
-            const float4 c = *reinterpret_cast<const float4*>(src + (size_t)(r + 2 * TY) * L), d = *reinterpret_cast<const float4*>(src + (size_t)(r + 3 * TY) * L);
+            const float4 a = *reinterpret_cast<const float4*>(src + (size_t)r * ld), b = *reinterpret_cast<const float4*>(src + (size_t)(r + TY) * ld);
+            const float4 c = *reinterpret_cast<const float4*>(src + (size_t)(r + 2 * TY) * ld), d = *reinterpret_cast<const float4*>(src + (size_t)(r + 3 * TY) * ld);
             s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y); s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
         }
         for (; r < r1; r += TY) {
-            const float4 a = *reinterpret_cast<const float4*>(src + (size_t)r * L);
+            const float4 a = *reinterpret_cast<const float4*>(src + (size_t)r * ld);
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
         }
     }
@@ -163,21 +163,21 @@ static __global__ __launch_bounds__(256) void rows_fold1_kernel(const float* __r
 // lane order. Up to L2I_FOLD_DIRECT rows in this one launch.
 #define L2I_FOLD_DIRECT 1024
 static __global__ __launch_bounds__(256) void rows_fold2_kernel(const float* __restrict__ src, int R, int L, float* __restrict__ dst0, float* __restrict__ dst1, int C0,
-                                                                long long zs, int mode) {
+                                                                long long zs, int mode, float* __restrict__ dup, int ld) {
     __shared__ float4 red[256];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int c4 = blockIdx.x * 16 + tx;   // float4 column
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (4 * c4 < L) {
-        const float* q = src + (size_t)blockIdx.z * R * L + 4 * c4;
+        const float* q = src + (size_t)blockIdx.z * R * ld + 4 * c4;
         int r = ty;
         for (; r + 48 < R; r += 64) {
-            const float4 a = *reinterpret_cast<const float4*>(q + (size_t)r * L), b = *reinterpret_cast<const float4*>(q + (size_t)(r + 16) * L);
-            const float4 c = *reinterpret_cast<const float4*>(q + (size_t)(r + 32) * L), d = *reinterpret_cast<const float4*>(q + (size_t)(r + 48) * L);
+            const float4 a = *reinterpret_cast<const float4*>(q + (size_t)r * ld), b = *reinterpret_cast<const float4*>(q + (size_t)(r + 16) * ld);
+            const float4 c = *reinterpret_cast<const float4*>(q + (size_t)(r + 32) * ld), d = *reinterpret_cast<const float4*>(q + (size_t)(r + 48) * ld);
             s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y); s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
         }
         for (; r < R; r += 16) {
-            const float4 a = *reinterpret_cast<const float4*>(q + (size_t)r * L);
+            const float4 a = *reinterpret_cast<const float4*>(q + (size_t)r * ld);
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
         }
     }
@@ -190,22 +190,29 @@ static __global__ __launch_bounds__(256) void rows_fold2_kernel(const float* __r
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int i = 4 * c4 + e;
+            if (i >= C0 && !dst1) continue;   // (padding columns of the partial rows: no destination)
             float* d = (i < C0 ? dst0 + i : dst1 + (i - C0)) + (size_t)blockIdx.z * zs;
             if (mode == 2) atomicAdd(d, v[e]);
             else *d = mode ? *d + v[e] : v[e];
+            if (dup && i < C0) {   // a second destination of the same sums (a block's conv2 and shortcut share dY: one bias gradient, two biases)
+                if (mode == 2) atomicAdd(dup + i, v[e]);
+                else dup[i] = mode ? dup[i] + v[e] : v[e];
+            }
         }
     }
 }
 // floats of tmp a fold of (R rows, L columns, Z groups) needs
 static inline long long rows_fold_tmp_floats(int R, int L, int Z) { return R <= L2I_FOLD_DIRECT ? 0 : (long long)Z * L2I_FOLD_CHUNKS * L; }
 // columns [0, C0) go to dst0[z * zs + i], columns [C0, L) to dst1[z * zs + i - C0]; L % 4 == 0, part 16-byte aligned
-static inline void rows_fold(const float* part, int R, int L, int Z, float* dst0, float* dst1, int C0, long long zs, int mode, float* tmp, hipStream_t stream) {
+static inline void rows_fold(const float* part, int R, int L, int Z, float* dst0, float* dst1, int C0, long long zs, int mode, float* tmp, hipStream_t stream,
+                             float* dup = nullptr, int ld = 0) {   // ld: floats between two rows of `part` (0: L); a group's rows are R * ld apart
+    if (ld <= 0) ld = L;
     if (R > L2I_FOLD_DIRECT) {
         const int rc = (R + L2I_FOLD_CHUNKS - 1) / L2I_FOLD_CHUNKS, nch = (R + rc - 1) / rc;
-        hipLaunchKernelGGL(rows_fold1_kernel, dim3((L / 4 + 63) / 64, nch, Z), dim3(256), 0, stream, part, R, L, rc, tmp);
-        part = tmp; R = nch;
+        hipLaunchKernelGGL(rows_fold1_kernel, dim3((L / 4 + 63) / 64, nch, Z), dim3(256), 0, stream, part, R, L, rc, tmp, ld);
+        part = tmp; R = nch; ld = L;
     }
-    hipLaunchKernelGGL(rows_fold2_kernel, dim3((L / 4 + 15) / 16, 1, Z), dim3(256), 0, stream, part, R, L, dst0, dst1, C0, zs, mode);
+    hipLaunchKernelGGL(rows_fold2_kernel, dim3((L / 4 + 15) / 16, 1, Z), dim3(256), 0, stream, part, R, L, dst0, dst1, C0, zs, mode, dup, ld);
 }
 
 // ---------------------------------------------------------------- clearing a buffer from inside the library

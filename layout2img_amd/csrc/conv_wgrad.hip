@@ -59,6 +59,10 @@ struct WgradArgs {
     int nw2_layout;   // (the register-order decode of the partial tiles: as wgrad_reduce_kernel's nw2)
     int zero_targets; // overwrite + a reduce that combines split GROUPS with atomics: the main kernel (which writes only partial tiles to
                       // scratch) clears the dW slices on its way in, so the reduce kernel behind it adds into zeros -- no memset launches
+    // Round 6, no float atomics when the caller's scratch has room:
+    float* bpart;     // bias-gradient shares: row (split x nb_bias + tile_k) of [splits * nb_bias][bpart_ld], alpha applied, STORED by the workgroups
+    int bpart_ld;     // that sum the bias (tiles_co * BMO columns); rows_fold adds the rows in order behind the launch. null: one atomic per channel
+    float* part_rm;   // generic kernel (f32 operands, odd shapes): partial tiles stored ROW-major [tile][split][BMO][128], summed by wgrad_reduce_rm_kernel
 };
 
 // grid-wide clear of one dW slice (n floats) by the threads of the weight-gradient kernel
@@ -257,10 +261,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     if (p.dbias && tile_k == 0 && tid < 2 * BMO) {
         bsum += __shfl_xor(bsum, 1, 64);
         const int co = co0 + (tid >> 1);
-        if (!(tid & 1) && co < p.Co && bsum != 0.f) atomicAdd(p.dbias + co, p.alpha * bsum);
+        if (!(tid & 1)) {
+            if (p.bpart) p.bpart[(size_t)split * p.bpart_ld + co] = p.alpha * bsum;   // (every split's row is written, zeros included)
+            else if (co < p.Co && bsum != 0.f) atomicAdd(p.dbias + co, p.alpha * bsum);
+        }
     }
 
     const int c = lane & 31, h = lane >> 5;
+    if (p.part_rm) {   // the split's partial tile, row-major and unscaled (wgrad_reduce_rm_kernel adds the splits in order)
+        float* t = p.part_rm + ((size_t)(tile_co * p.tiles_k + tile_k) * p.splits + split) * (size_t)(BMO * 128);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    t[(size_t)(wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 128 + wcol + j * 32 + c] = acc[i][j][e];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -276,6 +294,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
                 else atomicAdd(dwp + (size_t)row * p.ldw + col, p.alpha * acc[i][j][e]);
             }
         }
+}
+
+// dw[row][col] (+)= alpha * sum over the splits of the generic kernel's row-major partial tiles (WgradArgs::part_rm), in order.
+// One thread = four consecutive columns of one row of one tile; gridDim.z = 2: dual launch (second half of the splits -> dw_b).
+__global__ __launch_bounds__(256) void wgrad_reduce_rm_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dw_b, int BMO,
+                                                              int tiles_k, int ntiles, int splits, int Co, int K, int ldw, float alpha, int overwrite) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int per_tile = BMO * 32;
+    const int tile = (int)(gid / per_tile), f = (int)(gid - (long long)tile * per_tile);
+    if (tile >= ntiles) return;
+    const int tile_k = tile % tiles_k, tile_co = tile / tiles_k;
+    const int row = tile_co * BMO + (f >> 5), col = tile_k * 128 + 4 * (f & 31);
+    if (row >= Co || col >= K) return;
+    const int hs = splits / (int)gridDim.z, s_off = (int)blockIdx.z * hs;
+    if (blockIdx.z) dw = dw_b;
+    const float4* src = reinterpret_cast<const float4*>(part + ((size_t)tile * splits) * (size_t)(BMO * 128)) + f;
+    const size_t tsz4 = (size_t)BMO * 32;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = s_off;
+    for (; s + 4 <= s_off + hs; s += 4) {
+        const float4 v0 = src[(size_t)s * tsz4], v1 = src[(size_t)(s + 1) * tsz4], v2 = src[(size_t)(s + 2) * tsz4], v3 = src[(size_t)(s + 3) * tsz4];
+        a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+        a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < s_off + hs; ++s) {
+        const float4 v0 = src[(size_t)s * tsz4];
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    }
+    float* d = dw + (size_t)row * ldw + col;
+    const float v[4] = {alpha * a.x, alpha * a.y, alpha * a.z, alpha * a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (col + e < K) d[e] = overwrite ? v[e] : d[e] + v[e];
 }
 
 // ---------------------------------------------------------------- bf16 fast path: LDS-DMA + transposing LDS reads
@@ -615,7 +666,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
             float v = 0.f;
 #pragma unroll
             for (int w_ = 0; w_ < NW; ++w_) v += red[w_ * BMO + tid];
-            if (co0 + tid < p.Co && v != 0.f) {
+            if (p.bpart) {   // this workgroup's share (its steps of this split): one row of the partial matrix, zeros included
+                p.bpart[(size_t)(split * nb_bias + tile_k) * p.bpart_ld + co0 + tid] = p.alpha * v;
+            } else if (co0 + tid < p.Co && v != 0.f) {
                 if (p.dbias) atomicAdd(p.dbias + co0 + tid, p.alpha * v);
                 if (p.dbias2) atomicAdd(p.dbias2 + co0 + tid, p.alpha * v);
             }
@@ -761,7 +814,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int BMO, int tiles_k,
                                                            int ntiles, int splits, int Co, int K, int ldw, float alpha, int nw2, int sper,
                                                            int tiles_k_main, float* __restrict__ dw2, int K2, int ldw2,
-                                                           float* __restrict__ dw_b, float* __restrict__ dw2_b, int overwrite) {
+                                                           float* __restrict__ dw_b, float* __restrict__ dw2_b, int overwrite, float4* __restrict__ part_out) {
     // blockIdx.y = group of `sper` consecutive splits: layers with few tiles and many splits (the 64-channel layers at
     // 128 x 128: 5 tiles x 153 splits) otherwise run on 40 workgroups, each thread walking 153 partial tiles one dependent
     // load after the other (18 us of a 69-us weight gradient). Groups combine with f32 atomics (gridDim.y > 1 only).
@@ -797,6 +850,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (; s < s_end; ++s) {
         const float4 v0 = src[(size_t)s * tsz4];
         a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    }
+    if (part_out) {   // first stage of a two-stage reduction (split groups): the group's sum, unscaled, in the partial tiles' own layout
+        part_out[((size_t)tile * (gridDim.y * gridDim.z) + blockIdx.z * gridDim.y + blockIdx.y) * tsz4 + f] = a;   // [tile][pass][group]: the second
+        return;                                                                                                     // stage reads it as `splits` = groups
     }
     if (col >= K) return;
     float* d = dw + (size_t)row0 * ldw + col;   // (a half-wave writes 32 consecutive columns of one row per statement)
@@ -975,7 +1032,30 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             a.fuse_cnt = cnt_base + cnt_next;
             cnt_next += need;
         }
-        a.zero_targets = (a.overwrite && a.part && !a.fuse_cnt && sg > 1) ? 1 : 0;   // (the reduce's split groups add with atomics)
+        // Round 6: the split groups of the reduce kernel combine through a SECOND region of stored tiles ([tile][pass][group], the main kernel's
+        // layout) and a second reduce launch over the groups, and the bias-gradient shares are stored rows that rows_fold adds in order -- both
+        // where the caller's scratch has room behind the partial tiles; otherwise the atomics of rounds 2-5.
+        const int nz_ = dual ? 2 : 1;
+        long long used = a.part ? (long long)nblk * BMO * 128 : 0;
+        float* part2 = nullptr;
+        if (a.part && sg > 1 && !a.fuse_cnt) {
+            const long long need2 = (long long)tiles * sg * nz_ * BMO * 128;
+            if (used + need2 <= scratch_floats) { part2 = scratch + used; used += need2; }
+        }
+        a.bpart = nullptr; a.bpart_ld = 0; a.part_rm = nullptr;
+        const int nb_bias = a.tiles_k_main >= 4 ? 4 : (a.tiles_k_main >= 2 ? 2 : 1);   // (as in conv_wgrad_dma_kernel)
+        const int bias_rows = a.splits * nb_bias, bias_ld = a.tiles_co * BMO;
+        if ((a.dbias || a.dbias2) && scratch) {
+            const long long needb = (long long)bias_rows * bias_ld + rows_fold_tmp_floats(bias_rows, bias_ld, 1);
+            if (used + needb <= scratch_floats) { a.bpart = scratch + used; a.bpart_ld = bias_ld; used += needb; }
+        }
+        a.zero_targets = (a.overwrite && a.part && !a.fuse_cnt && sg > 1 && !part2) ? 1 : 0;   // (split groups that still add with atomics)
+        auto fold_bias = [&]() {
+            if (!a.bpart) return;
+            float* d0 = a.dbias ? a.dbias : a.dbias2;
+            rows_fold(a.bpart, bias_rows, bias_ld, 1, d0, nullptr, a.Co, 0, 2, a.bpart + (size_t)bias_rows * bias_ld, stream,
+                      (a.dbias && a.dbias2) ? a.dbias2 : nullptr);
+        };
         int lgW = 0, lgH = 0;
         while ((1 << lgW) < a.Wo) ++lgW;
         while ((1 << lgH) < a.Ho) ++lgH;
@@ -1014,24 +1094,51 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             else if (mode == 2) L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 2>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
             else L2I_LAUNCH(1, (conv_wgrad_dma_kernel<128, 0>), dim3(nblk), dim3(256), lds2, stream, a, lgW, lgH);
         }
-        if (a.part && a.fuse_cnt) return l2i_check_launch();   // (the last arrivers reduced the splits)
+        if (a.part && a.fuse_cnt) { fold_bias(); return l2i_check_launch(); }   // (the last arrivers reduced the splits)
         if (a.part) {
             const long long nthr = (long long)tiles * BMO * 32;
             const unsigned nbx = (unsigned)((nthr + 255) / 256);
+            const int nw2l = (int)(nw2 && !nw8 && BMO == 128);
             // split groups: enough workgroups to fill the chip (>= ~512), at least 8 splits per group
             // (sg split groups of sper splits each: computed above)
-            L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg, dual ? 2u : 1u), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
-                       a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, (int)(nw2 && !nw8 && BMO == 128), sper,
-                       a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite);
+            if (part2) {   // two stages, no atomics: groups -> part2, then the groups of a tile in order -> dw
+                L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg, (unsigned)nz_), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
+                           a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, nw2l, sper,
+                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, reinterpret_cast<float4*>(part2));
+                L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, 1u, (unsigned)nz_), dim3(256), 0, stream, (const float*)part2, a.dw, BMO,
+                           a.tiles_k, tiles, sg * nz_, a.Co, a.K, a.ldw, a.alpha, nw2l, sg,
+                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, (float4*)nullptr);
+            } else {
+                L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg, (unsigned)nz_), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
+                           a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, nw2l, sper,
+                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, (float4*)nullptr);
+            }
         }
+        fold_bias();
         return l2i_check_launch();
     }
-    if (a.splits > 1 && clear_targets() != L2I_OK) return L2I_ERR_LAUNCH;
+    // generic kernel (f32 operands, maps that are not powers of two): the splits' tiles row-major in the scratch + an ordered reduce when they fit
+    a.bpart = nullptr; a.bpart_ld = 0; a.part_rm = nullptr;
+    long long used = 0;
+    const int nz_ = dual ? 2 : 1;
+    if (scratch && (a.splits > 1 || dual) && (long long)nblk * BMO * 128 <= scratch_floats) { a.part_rm = scratch; used = (long long)nblk * BMO * 128; }
+    const int bias_ld = a.tiles_co * BMO;
+    if (a.dbias && scratch) {
+        const long long needb = (long long)a.splits * bias_ld + rows_fold_tmp_floats(a.splits, bias_ld, 1);
+        if (used + needb <= scratch_floats) { a.bpart = scratch + used; a.bpart_ld = bias_ld; }
+    }
+    if (!a.part_rm && a.splits > 1 && clear_targets() != L2I_OK) return L2I_ERR_LAUNCH;
     const size_t lds = (size_t)(BMO + 128) * IG_ROWB;
     if (BMO == 64)
         L2I_LAUNCH(1, (conv_wgrad_kernel<T, 64>), dim3(nblk), dim3(256), lds, stream, a);
     else
         L2I_LAUNCH(1, (conv_wgrad_kernel<T, 128>), dim3(nblk), dim3(256), lds, stream, a);
+    if (a.part_rm) {
+        const unsigned nbx = (unsigned)(((long long)tiles * BMO * 32 + 255) / 256);
+        L2I_LAUNCH(1, wgrad_reduce_rm_kernel, dim3(nbx, 1u, (unsigned)nz_), dim3(256), 0, stream, (const float*)a.part_rm, a.dw, a.dw_b, BMO, a.tiles_k, tiles,
+                   a.splits, a.Co, a.K, a.ldw, a.alpha, a.overwrite);
+    }
+    if (a.bpart) rows_fold(a.bpart, a.splits, bias_ld, 1, a.dbias, nullptr, a.Co, 0, 2, a.bpart + (size_t)a.splits * bias_ld, stream);
     return l2i_check_launch();
 }
 

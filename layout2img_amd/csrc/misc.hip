@@ -294,8 +294,10 @@ __global__ __launch_bounds__(256) void gram_head_bwd_kernel(const float* __restr
         *reinterpret_cast<float4*>(dwl + wave * C + c) = acc;
     }
     __syncthreads();
-    float* rep = ws_replica(ws, blockIdx.x % L2I_WS_R, C);
-    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(rep + c, dwl[c] + dwl[C + c] + dwl[2 * C + c] + dwl[3 * C + c]);
+    // this workgroup's row of the partial matrix [R * parts][C] (stored; rows_fold adds the rows in order behind the launch: round 6 -- rounds 2-5
+    // added into 32 replicas of the workspace with float atomics, and the head's weight gradient moved in its last bits from run to run)
+    float* row = ws + (size_t)blockIdx.x * C;
+    for (int c = threadIdx.x; c < C; c += 256) row[c] = (dwl[c] + dwl[C + c]) + (dwl[2 * C + c] + dwl[3 * C + c]);
 }
 
 extern "C" int l2i_gram_head_fwd(const float* x, const float* w, float* out, float* s_keep, float* t_keep, int R, int HW,
@@ -307,13 +309,15 @@ extern "C" int l2i_gram_head_fwd(const float* x, const float* w, float* out, flo
 }
 
 extern "C" int l2i_gram_head_bwd(const float* x, const float* w, const float* s_keep, const float* t_keep, const float* g,
-                                 float* dx, float* dw, float* ws, int R, int HW, int C, void* dx_op_bf16, void* stream) {
-    if (!x || !w || !s_keep || !t_keep || !g || !dx || !dw || !ws || C % 4 || C > 4096 || R < 0) return L2I_ERR_ARG;
+                                 float* dx, float* dw, float* scratch, long long scratch_floats, int R, int HW, int C, void* dx_op_bf16, void* stream) {
+    if (!x || !w || !s_keep || !t_keep || !g || !dx || !dw || !scratch || ((size_t)scratch & 15) || C % 4 || C > 4096 || R < 0) return L2I_ERR_ARG;
     if (R == 0) return L2I_OK;
     const int parts = (HW + GH_POS - 1) / GH_POS;
+    const long long rows = (long long)R * parts;
+    if (rows * C + rows_fold_tmp_floats((int)rows, C, 1) > scratch_floats) return L2I_ERR_ARG;
     hipLaunchKernelGGL(gram_head_bwd_kernel, dim3(R * parts), dim3(256), sizeof(float) * 4 * C, (hipStream_t)stream, x, w,
-                       s_keep, t_keep, g, dx, (bf16_t*)dx_op_bf16, ws, HW, C, parts);
-    ws_fold(ws, C, C, dw, nullptr, nullptr, nullptr, (hipStream_t)stream);
+                       s_keep, t_keep, g, dx, (bf16_t*)dx_op_bf16, scratch, HW, C, parts);
+    rows_fold(scratch, (int)rows, C, 1, dw, nullptr, C, 0, 2, scratch + rows * C, (hipStream_t)stream);
     return l2i_check_launch();
 }
 

@@ -152,6 +152,10 @@ struct NormArgs {
     int B, HW, C, O, mode, relu, stat_stride;
     float count, eps;
     int dmask_store;       // bwd, <= 8 objects, C within one channel chunk: dmask = (plain stores) instead of += (atomics)
+    // round 6, no float atomics when the caller lends scratch (l2i_norm_mod_bwd_a):
+    float* spart;          // bwd: per-channel totals (s1, s2; affine mode also dW, dB) of a workgroup = row (image x segment) of [B * nseg][nval * C],
+                           // channel chunks side by side, STORED; rows_fold adds the rows in order behind the launch. null: atomics / the workspace
+    float* dmpart;         // bwd, several channel chunks: dmask contribution of chunk tc = row tc of [tiles_c][B * O * HW], STORED; rows_fold adds the chunks
 };
 
 __device__ __forceinline__ float4 f4mad(float a, float4 b, float4 c) {
@@ -561,7 +565,9 @@ __global__ __launch_bounds__(256) void norm_bwd_a_kernel(NormArgs p, int nseg, i
                 if (px >= px_end) continue;
                 float t0 = 0.f;
                 for (int oo = 0; oo < O; ++oo) t0 = fmaf(mn[oo * NB_PX + pl], partl[oo * NB_PX + pl], t0);
-                atomicAdd(p.dmask + ((size_t)b * O + o) * p.HW + px, (partl[i] - t0) * sinv[pl]);
+                const float v = (partl[i] - t0) * sinv[pl];
+                if (p.dmpart) p.dmpart[((size_t)tc * p.B * O + (size_t)b * O + o) * p.HW + px] = v;   // this chunk's row: rows_fold adds the chunks
+                else atomicAdd(p.dmask + ((size_t)b * O + o) * p.HW + px, v);
             }
         }
     }
@@ -598,6 +604,10 @@ __global__ __launch_bounds__(256) void norm_bwd_a_kernel(NormArgs p, int nseg, i
             a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
         const int cch = c0 + 4 * lc;
+        if (p.spart) {   // this workgroup's row of the partial matrix (one writer per value)
+            *reinterpret_cast<float4*>(p.spart + (size_t)(blockIdx.x / tiles_c) * (nval * p.C) + k * p.C + cch) = a;
+            continue;
+        }
         float* dst;
         if (p.ws) {
             dst = ws_replica(p.ws, (blockIdx.x / tiles_c) % L2I_WS_R, nval * p.C) + k * p.C + cch;
@@ -769,7 +779,8 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_a8_kernel(NormArgs p, int nse
                                  mb.z * partl[6 * NB_PX + pl] + mb.w * partl[7 * NB_PX + pl];
                 float* dm = p.dmask + ((size_t)b * O + o) * p.HW + px;
                 const float v = (partl[i] - t0) * sinv[pl];
-                if (p.dmask_store) *dm = v;   // one channel chunk: this thread is the only writer (4 M atomics of the 128^2 layer = 10 us)
+                if (p.dmpart) p.dmpart[((size_t)tc * p.B * O + (size_t)b * O + o) * p.HW + px] = v;   // this chunk's row: rows_fold adds the chunks
+                else if (p.dmask_store) *dm = v;   // one channel chunk: this thread is the only writer (4 M atomics of the 128^2 layer = 10 us)
                 else atomicAdd(dm, v);
             }
         }
@@ -843,6 +854,10 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_a8_kernel(NormArgs p, int nse
             a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
         const int cch = c0 + 4 * lc;
+        if (p.spart) {   // this workgroup's row of the partial matrix (one writer per value)
+            *reinterpret_cast<float4*>(p.spart + (size_t)(blockIdx.x / tiles_c) * (2 * p.C) + k * p.C + cch) = a;
+            continue;
+        }
         float* dst;
         if (p.ws) dst = ws_replica(p.ws, (blockIdx.x / tiles_c) % L2I_WS_R, 2 * p.C) + k * p.C + cch;
         else dst = (k == 0 ? p.s1 : p.s2) + (size_t)b * p.stat_stride + cch;
@@ -1066,7 +1081,7 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
     if (nseg < 1) nseg = 1;
     const int seg_pixels = ((subtiles + nseg - 1) / nseg) * NB_PX;
     nseg = (HW + seg_pixels - 1) / seg_pixels;
-    a.ws = (stat_stride == 0 && B * nseg > 32) ? ws : nullptr;   // batch statistics shared by many workgroups
+    a.ws = (stat_stride == 0 && B * nseg > 32) ? ws : nullptr;   // batch statistics shared by many workgroups (unless their rows are stored: a.spart below)
     // <= 8 objects: dW / dB through per-workgroup partial rows (16 x 64 or 16 x 128 floats each) when the caller lends scratch
     const bool vec_ok = mode == 0 && dwproj && dbproj && ((uintptr_t)dwproj % 16 == 0) && ((uintptr_t)dbproj % 16 == 0) && pstride_b % 4 == 0 && pstride_o % 4 == 0;
     int fin_ns = 0, fin_tc = 0, fin_cv = 0;
@@ -1085,10 +1100,43 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
     }
     static const bool no_a8 = getenv("L2I_NORM_A8") && atoi(getenv("L2I_NORM_A8")) == 0;   // tuning: the LDS version for every layer
     const bool a8 = mode == 0 && O <= 8 && !no_a8;
-    if (dmask && dmask_fresh) {   // the caller's dmask is uninitialised: overwrite it where one workgroup owns a pixel, else clear it first
+    // Round 6: the per-channel totals and the channel chunks' dmask contributions as STORED rows in the tail of the caller's scratch, added in a
+    // fixed order by rows_fold behind the launch (the gradient of every layer below a normalisation was moving in its last bits from run to run
+    // with the order of these float atomics). Geometry of the kernel that will run:
+    const int nval = mode == 1 ? 4 : 2;
+    int k_ns = nseg, k_tc = tiles_c;
+    if (a8 && C <= 64) {
+        k_tc = (C + 63) / 64;
+        int ns = wg_target / (B * k_tc);
+        if (ns > subtiles) ns = subtiles;
+        if (ns < 1) ns = 1;
+        const int sp = ((subtiles + ns - 1) / ns) * NB_PX;
+        k_ns = (HW + sp - 1) / sp;
+    }
+    const long long n_dm = (long long)B * O * HW;
+    long long tail = part_floats;   // floats of `part` still free (the dW / dB partial rows of the <= 8-object kernel keep the front)
+    float* stat_tmp = nullptr; float* dm_tmp = nullptr;
+    const int stat_rows = stat_stride == 0 ? B * k_ns : k_ns, stat_z = stat_stride == 0 ? 1 : B;
+    if (part && !((uintptr_t)part & 15) && C % 4 == 0) {
+        const long long need = (long long)B * k_ns * nval * C + rows_fold_tmp_floats(stat_rows, nval * C, stat_z);
+        const long long front = a8 ? (long long)B * k_tc * k_ns * 16 * (C <= 64 ? 64 : 128) : 0;
+        if (front + need <= tail) {
+            tail = (tail - need) & ~3LL;
+            a.spart = part + tail;
+            stat_tmp = a.spart + (long long)B * k_ns * nval * C;
+        }
+        if (dmask && k_tc > 1 && n_dm % 4 == 0) {
+            const long long needm = (long long)k_tc * n_dm;
+            if (front + needm <= tail) { tail = (tail - needm) & ~3LL; a.dmpart = part + tail; }
+        }
+        part_floats = tail;   // (what `lend` below may still hand to the dW / dB rows)
+    }
+    (void)dm_tmp;
+    if (dmask && dmask_fresh && !a.dmpart) {   // the caller's dmask is uninitialised: overwrite it where one workgroup owns a pixel, else clear it first
         if (a8 && C <= NM_CC) a.dmask_store = 1;
         else if (l2i_zero_async(dmask, sizeof(float) * (size_t)B * O * HW, (hipStream_t)stream) != hipSuccess) return L2I_ERR_LAUNCH;
     }
+    if (a.spart) a.ws = nullptr;
     if (a8) {   // COCO layouts: the register-resident version
         const size_t lds8 = sizeof(float) * (8 * NB_PX + NB_PX + 8 * NB_PX) + 32 * 1024 + 16;
         if (C <= 64) {
@@ -1098,7 +1146,7 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
             if (ns < 1) ns = 1;
             const int sp = ((subtiles + ns - 1) / ns) * NB_PX;
             ns = (HW + sp - 1) / sp;
-            a.ws = (stat_stride == 0 && B * ns > 32) ? ws : nullptr;
+            a.ws = (stat_stride == 0 && B * ns > 32 && !a.spart) ? ws : nullptr;
             lend(ns, t64, 64);
             hipLaunchKernelGGL(norm_bwd_a8_kernel<16>, dim3(B * ns * t64), dim3(256), lds8, (hipStream_t)stream, a, ns, sp);
         } else {
@@ -1116,6 +1164,12 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
         hipLaunchKernelGGL(norm_a8_finish_kernel, dim3(nfold + nfin), dim3(256), 0, (hipStream_t)stream, f, nfold, (const float4*)part, dwproj,
                            dbproj, B, fin_tc, fin_ns, fin_cv, C, O, pstride_b, pstride_o);
     } else if (a.ws) ws_fold(a.ws, (mode == 1 ? 4 : 2) * C, C, s1, s2, dwproj, dbproj, (hipStream_t)stream);
+    if (a.spart) {   // s1 / s2 += the workgroups' rows, in order (batch statistics: all rows; per-image statistics: an image's segments)
+        rows_fold(a.spart, stat_rows, 2 * C, stat_z, s1, s2, C, stat_stride, 1, stat_tmp, (hipStream_t)stream, nullptr, nval * C);
+        if (mode == 1)   // the affine layer's dW / dB: columns [2C, 4C) of the same rows, over ALL images
+            rows_fold(a.spart + 2 * C, B * k_ns, 2 * C, 1, dwproj, dbproj, C, 0, 2, stat_tmp, (hipStream_t)stream, nullptr, nval * C);
+    }
+    if (a.dmpart) rows_fold(a.dmpart, k_tc, (int)n_dm, 1, dmask, nullptr, (int)n_dm, 0, dmask_fresh ? 0 : 1, nullptr, (hipStream_t)stream);
     return l2i_check_launch();
 }
 

@@ -423,7 +423,9 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restr
 __device__ __forceinline__ int bw_chunk(int taps, int Ci) { return taps == 1 ? BW_PAIRS * 9 : (taps == 9 && (Ci & 3) == 0) ? BW_QUAD : BW_PAIRS; }   // sn_apply
 __device__ __forceinline__ int bw_chunk_dot(int taps) { return taps == 1 ? BW_PAIRS * 9 : BW_PAIRS; }   // sn_dot: the quad form measured no faster there (143 -> 145 us)
 
-// phase a: <G, W> per SN layer, one atomic per block into replica (block % 32) of ws[(r * NP + pass) * n_layers + layer].
+// phase a: <G, W> per SN layer: every block STORES its share at ws[block * NP + pass] and sn_dotfold_kernel adds a layer's shares in order into
+// ws[n_dot * NP + pass * n_layers + layer] (round 6; rounds 1-5: one float atomic per block into 32 replicas, and the correction term
+// <G, Wbar> u v^T of every spectrally normalised weight moved in its last bits from run to run).
 // NP = 2: the two passes of one optimiser step that share W (D(real) and D(fake), train_context_app_v2.py:158,167) in one
 // launch -- W is read once, each pass's G once.
 template <int NP>
@@ -485,8 +487,26 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const long long* __restrict
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const float t = block_sum(acc[q], red);
-        if (threadIdx.x == 0) atomicAdd(ws + ((size_t)(blockIdx.x % L2I_WS_R) * NP + q) * n_layers + layer, t);
-        __syncthreads();   // `red` is reused by the next pass's sum
+        if (threadIdx.x == 0) ws[(size_t)blockIdx.x * NP + q] = t;
+        (void)layer; (void)n_layers;
+    }
+}
+
+// one block per layer row: dsum[pass * n_layers + layer] = the sum of the layer's sn_dot shares, in a fixed order.
+// range: (first dot-table entry, number of entries) per layer row, absolute; dot_base: the first entry of THIS launch's sub-table.
+template <int NP>
+__global__ __launch_bounds__(256) void sn_dotfold_kernel(const int* __restrict__ range, int dot_base, int n_dot, const float* __restrict__ part,
+                                                         float* __restrict__ dsum, int n_layers) {
+    __shared__ float red[16];
+    const int layer = blockIdx.x;
+    const int start = range[2 * layer] - dot_base, cnt = range[2 * layer + 1];
+    if (cnt <= 0 || start < 0 || start >= n_dot) return;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        float a = 0.f;
+        for (int i = threadIdx.x; i < cnt; i += 256) a += part[(size_t)(start + i) * NP + q];
+        const float t = block_sum(a, red);
+        if (threadIdx.x == 0) dsum[(size_t)q * n_layers + layer] = t;
     }
 }
 
@@ -513,8 +533,7 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const long long* __restri
         inv[q] = 1.f / norms[4 * layer + 2];
         gw[q] = 0.f;
         if (sn) {
-            float d = 0.f;
-            for (int r = 0; r < L2I_WS_R; ++r) d += ws[((size_t)r * NP + q) * n_layers + layer];
+            const float d = ws[(size_t)q * n_layers + layer];   // (sn_dotfold_kernel's sum of the layer's shares)
             gw[q] = d * inv[q];  // <G, Wbar>
             if (e[1] == 0 && threadIdx.x == 0) norms[4 * layer + 3] = d;
         }
@@ -702,31 +721,39 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
 extern "C" int l2i_weights_backward2(const long long* layers, int n_layers, const int* tab_dot, int n_dot,
                                      const int* tab_apply, int n_apply, const float* params, const float* dwbar0,
                                      const float* pass_uv0, float* norms0, const float* dwbar1, const float* pass_uv1,
-                                     float* norms1, float* grads, float* ws, int overwrite, void* stream_) {
+                                     float* norms1, float* grads, float* ws, int overwrite, const int* dot_range, int dot_base, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!layers || !params || !dwbar0 || !norms0 || !grads || !ws) return L2I_ERR_ARG;
+    if (!layers || !params || !dwbar0 || !norms0 || !grads || !ws || (n_dot > 0 && !dot_range)) return L2I_ERR_ARG;
     const int np = dwbar1 ? 2 : 1;
     if (np == 2 && (!pass_uv1 || !norms1)) return L2I_ERR_ARG;
-    if ((long long)n_layers * L2I_WS_R * np > 32 * 4 * 1024) return L2I_ERR_ARG;   // L2I_WS_FLOATS
+    // ws = [n_dot x np shares of <G, W> | np x n_layers sums], cleared again behind the launches (the workspace is all-zero between calls)
+    const size_t used = (size_t)n_dot * np + (size_t)np * n_layers;
+    if (used > 32 * 4 * 1024) return L2I_ERR_ARG;   // L2I_WS_FLOATS
+    float* dsum = ws + (size_t)n_dot * np;
     if (n_dot > 0) {
-        if (np == 2) hipLaunchKernelGGL(sn_dot_kernel<2>, dim3(n_dot), dim3(256), 0, stream, layers, tab_dot, params, dwbar0, dwbar1, ws, n_layers);
-        else hipLaunchKernelGGL(sn_dot_kernel<1>, dim3(n_dot), dim3(256), 0, stream, layers, tab_dot, params, dwbar0, dwbar0, ws, n_layers);
+        if (np == 2) {
+            hipLaunchKernelGGL(sn_dot_kernel<2>, dim3(n_dot), dim3(256), 0, stream, layers, tab_dot, params, dwbar0, dwbar1, ws, n_layers);
+            hipLaunchKernelGGL(sn_dotfold_kernel<2>, dim3(n_layers), dim3(256), 0, stream, dot_range, dot_base, n_dot, ws, dsum, n_layers);
+        } else {
+            hipLaunchKernelGGL(sn_dot_kernel<1>, dim3(n_dot), dim3(256), 0, stream, layers, tab_dot, params, dwbar0, dwbar0, ws, n_layers);
+            hipLaunchKernelGGL(sn_dotfold_kernel<1>, dim3(n_layers), dim3(256), 0, stream, dot_range, dot_base, n_dot, ws, dsum, n_layers);
+        }
     }
     if (n_apply > 0) {
         if (np == 2)
             hipLaunchKernelGGL(sn_apply_kernel<2>, dim3(n_apply), dim3(256), 0, stream, layers, tab_apply, dwbar0, dwbar1, pass_uv0, pass_uv1,
-                               norms0, norms1, ws, n_layers, grads, overwrite);
+                               norms0, norms1, dsum, n_layers, grads, overwrite);
         else
             hipLaunchKernelGGL(sn_apply_kernel<1>, dim3(n_apply), dim3(256), 0, stream, layers, tab_apply, dwbar0, dwbar0, pass_uv0, pass_uv0,
-                               norms0, norms0, ws, n_layers, grads, overwrite);
+                               norms0, norms0, dsum, n_layers, grads, overwrite);
     }
-    if (n_dot > 0 && l2i_zero_async(ws, sizeof(float) * L2I_WS_R * np * n_layers, stream) != hipSuccess) return L2I_ERR_LAUNCH;
+    if (n_dot > 0 && l2i_zero_async(ws, sizeof(float) * ((used + 3) & ~(size_t)3), stream) != hipSuccess) return L2I_ERR_LAUNCH;
     return l2i_check_launch();
 }
 
 extern "C" int l2i_weights_backward(const long long* layers, int n_layers, const int* tab_dot, int n_dot,
                                     const int* tab_apply, int n_apply, const float* params, const float* dwbar,
-                                    const float* pass_uv, float* norms, float* grads, float* ws, void* stream_) {
+                                    const float* pass_uv, float* norms, float* grads, float* ws, const int* dot_range, int dot_base, void* stream_) {
     return l2i_weights_backward2(layers, n_layers, tab_dot, n_dot, tab_apply, n_apply, params, dwbar, pass_uv, norms, nullptr, nullptr,
-                                 nullptr, grads, ws, 0, stream_);
+                                 nullptr, grads, ws, 0, dot_range, dot_base, stream_);
 }

@@ -471,7 +471,9 @@ def norm_bwd_raw(x, dy, sums, sq, count, stat_stride, spec, mask, wproj, bproj, 
     elif spec.mode == 1:
         dw, db = _zeros(wproj.shape, dev), _zeros(bproj.shape, dev)
     keep = None
-    part, npart = _lib.wgrad_scratch(dev) if (spec.mode == 0 and O <= 8) else (None, 0)   # partial dW / dB rows (no atomics)
+    # the stream's scratch: partial dW / dB rows of the <= 8-object kernel, the workgroups' rows of the per-channel totals and the channel
+    # chunks' dmask rows -- stored, then added in a fixed order (no float atomics: round 6)
+    part, npart = _lib.wgrad_scratch(dev)
     _lib.call("l2i_norm_mod_bwd_a", x.data_ptr(), dy.data_ptr(), B, H * W, C, sums.data_ptr(), sq.data_ptr(), float(count),
               float(spec.eps), stat_stride, _p(mask), O, _p(wproj), _p(bproj), psb, pso, spec.mode, int(spec.relu),
               dy.data_ptr(), s1.data_ptr(), s2.data_ptr(), _p(dw), _p(db), _p(dm), _p(keep),
@@ -1219,7 +1221,7 @@ class GramHeadFn(Function):
         dw = _zeros((C,), x.device)
         dop = torch.empty_like(x, dtype=torch.bfloat16) if HEAD_DX_OP else None   # (x is the result of a convolution read by this head alone)
         _lib.call("l2i_gram_head_bwd", x.data_ptr(), w.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), g.data_ptr(),
-                  dx.data_ptr(), dw.data_ptr(), _ws(x.device), R, H * W, C, _p(dop), _stream())
+                  dx.data_ptr(), dw.data_ptr(), *_lib.wgrad_scratch(x.device), R, H * W, C, _p(dop), _stream())
         if dop is not None:
             _attach(dx, raw=dop)
         return dx, dw

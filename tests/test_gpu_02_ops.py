@@ -501,7 +501,7 @@ def test_spectral_norm_backward_two_passes_in_one_launch():
         for pc in pcs:
             _lib.call("l2i_weights_backward", arena.layers.data_ptr(), arena.n_layers, arena.t_dot.data_ptr(), arena.n_dot,
                       arena.t_apply.data_ptr(), arena.n_apply, flat.data.data_ptr(), pc.dwbar.data_ptr(), pc.pass_uv.data_ptr(),
-                      pc.norms.data_ptr(), flat.grad.data_ptr(), _lib.workspace(arena.device), _lib.raw_stream())
+                      pc.norms.data_ptr(), flat.grad.data_ptr(), _lib.workspace(arena.device), arena.t_dot_range.data_ptr(), 0, _lib.raw_stream())
         torch.cuda.synchronize()
         assert float(fused.abs().max()) > 0
         assert float((fused - flat.grad).abs().max()) < 1e-5 * float(flat.grad.abs().max())
