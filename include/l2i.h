@@ -310,25 +310,27 @@ int l2i_gram_head_bwd(const float* x, const float* w, const float* s_keep, const
  * result is gather(m, 1, y) (reference model/resnet_generator_app_v2.py:643-651, 465-466), so only the <= 8 channels of the image's own
  * object classes are computed:  lg[b,o,p] = bias[y[b,o]] + sum_c a[b,p,c] w[y[b,o]][c]  (a [B][HH][Cp] f32 NHWC, w [classes][ldw] f32, y [B][O]
  * int64, lg planar [B][O][HH] f32; O <= 8, C <= 128, Cp >= C a multiple of 4). Backward: da[b,p,c] = sum_o gl[b,o,p] w[y_o][c] (every element of
- * da written, pad channels zero); dw[y_o][c] += sum_p gl a; dbias[y_o] += sum_p gl: first per (image, object) into tmp ([B * O][128] f32, ZEROED by the
- * caller; the padding class 0 is carried by most images, so direct atomics on dw[0][:] serialise), then one workgroup per class (`classes` rows of dw) adds
- * its slots' rows into dw / dbias without atomics. C <= 126.
+ * da written, pad channels zero); dw[y_o][c] += sum_p gl a; dbias[y_o] += sum_p gl: first per (pixel part, image, object) STORED into tmp
+ * ([l2i_class_logits_bwd_parts(HH) * B * O][128] f32, contents undefined before and after; the padding class 0 is carried by most images, so direct
+ * atomics on dw[0][:] would serialise), then one workgroup per class (`classes` rows of dw) adds its slots' rows into dw / dbias in a fixed order --
+ * no atomics anywhere (round 6). C <= 126.
  * l2i_stage_mask_fwd / _bwd take such planar logits with Cp = 0 (their gradient is then `gl`, dlogits may be null). */
 int l2i_class_logits_fwd(const float* a, const float* w, const float* bias, const long long* y, float* lg, int B, int O, int HH, int Cp, int C,
                          int ldw, void* stream);
 int l2i_class_logits_bwd(const float* a, const float* w, const long long* y, const float* gl, float* da, float* dw, float* dbias, float* tmp,
                          int classes, int B, int O, int HH, int Cp, int C, int ldw, void* stream);
+int l2i_class_logits_bwd_parts(int HH);   /* pixel parts per image of the launch above (rows of `tmp` per (image, object) slot) */
 
 /* Stage-mask blend of the generator (model/resnet_generator_app_v2.py:465-470): per object
  *   out = bilinear(bmask, H) * (1 - a) + sigmoid(logits[..., y]) * nearest(boxm, H) * a,  a = sigmoid(alpha[y]).
  * logits [B][H][H][Cp] f32 NHWC (Cp % 4 == 0); bmask, boxm [B][O][S][S] planar f32 with S = f*H, f = 1 or even;
  * y [B][O] int64 class ids < Cp; alpha [Cp]; out [B][O][H][H]; keep [2][B][O][H][H] (sigmoid and resized bmask, for bwd).
- * bwd: g [B][O][H][H] -> dlogits [B][H][H][Cp] and dbmask [B][O][S][S] (both fully written), dalpha [Cp] += ;
- * gl [B][O][H][H] is scratch. */
+ * bwd: g [B][O][H][H] -> dlogits [B][H][H][Cp] and dbmask [B][O][S][S] (both fully written), dalpha [n_alpha] += (the slots' shares go to
+ * `share` [B * O], scratch, and one thread per class adds its slots' shares in slot order: no atomics, round 6); gl [B][O][H][H] is scratch. */
 int l2i_stage_mask_fwd(const float* logits, const float* bmask, const float* boxm, const float* alpha, const long long* y,
                        float* out, float* keep, int B, int O, int H, int Cp, int S, void* stream);
 int l2i_stage_mask_bwd(const float* g, const float* keep, const float* boxm, const float* alpha, const long long* y, float* gl,
-                       float* dlogits, float* dbmask, float* dalpha, int B, int O, int H, int Cp, int S, void* stream);
+                       float* dlogits, float* dbmask, float* dalpha, int B, int O, int H, int Cp, int S, float* share, int n_alpha, void* stream);
 
 /* Projection heads of the discriminator (model/rcnn_discriminator_app.py:127-129 image head, :160-166 object head):
  *   f[r,c] = scale * sum_p relu(x[r,p,c]);  out[r] = sum_c f[r,c] (wl[c] + emb[y[r]][c]) + bias[0]
@@ -404,7 +406,7 @@ int l2i_add_layernorm_fwd(const float* a, int lda, const float* b, int ldb, cons
                           void* stream);
 int l2i_add_layernorm_bwd(const float* a, int lda, const float* b, int ldb, const float* gamma, const float* mean, const float* rstd,
                           const float* dy, int ldy, float* da, float* db, float* dgamma, float* dbeta, int rows, int D, int perm_O,
-                          void* stream);
+                          float* scratch, long long scratch_floats, void* stream);   /* scratch (optional): the workgroups' dgamma / dbeta rows, added in order */
 
 /* out[r] = [z[r] (Z) | emb[y[r]] (E) | zeros to ld] (model/resnet_generator_app_v2.py:437-441), keyvalid[r] = y[r] != 0
  * (optional). bwd: demb[y[r]] += g[r, Z:Z+E]. */

@@ -63,15 +63,16 @@ SIGNATURES = {
     "l2i_psp_expand_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "l2i_class_logits_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "l2i_class_logits_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "l2i_class_logits_bwd_parts": [_i],
     "l2i_stage_mask_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "l2i_stage_mask_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "l2i_stage_mask_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p],
     "l2i_relu_bwd": [_p, _p, _p, _p, _ll, _p],
     "l2i_box_geometry_fwd": [_p, _p, _p, _p, _p, _i, _i, _p],
     "l2i_box_geometry_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
     "l2i_layout_masks_fwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "l2i_layout_masks_bwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "l2i_add_layernorm_fwd": [_p, _i, _p, _i, _p, _p, _f, _p, _i, _p, _i, _p, _p, _i, _i, _i, _p],
-    "l2i_add_layernorm_bwd": [_p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    "l2i_add_layernorm_bwd": [_p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _ll, _p],
     "l2i_latent_fwd": [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p],
     "l2i_latent_bwd": [_p, _p, _p, _i, _i, _i, _i, _p],
     "l2i_fc_to_nhwc": [_p, _p, _p, _i, _ll, _i, _i, _i, _p],

@@ -709,7 +709,8 @@ __global__ __launch_bounds__(WM* WN * 64, ((160 * 1024) / (NS * (BM + BN) * (HK 
     }
 
     L2I_TR(2);
-    if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
+    if (p.splits > 1 && p.part) conv_store_partial<TM, TN>(p, acc, bid, split, WM * WN, wave, lane);   // (round 6: stored partial tiles + conv_split_reduce_kernel, as the halo kernels)
+    else if (p.splits > 1) conv_epilogue_splitk<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, split, rows_live, smem);
     else if (p.epi_lds) conv_epilogue_lds<T, TM, TN>(p, acc, wrow, wcol, lane, wave, tile_r, tile_c, n0, rows_total, rows_live, smem);
     else conv_epilogue<T, TM, TN>(p, acc, wrow, wcol, lane, tile_r, tile_c, n0, split, rows_total, rows_live);
     L2I_TR(3);
@@ -1844,7 +1845,13 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     }
     a.ks_per = (nks + splits - 1) / splits;
     a.splits = (nks + a.ks_per - 1) / a.ks_per;
-    if (a.splits > 1) {
+    a.part = nullptr;
+    // Round 6: the splits of this kernel too are STORED partial tiles summed (in order, with the whole epilogue) by conv_split_reduce_kernel when
+    // the caller's scratch has room -- the tile configurations a split launch can take (128 x 128 and 128 x 64, four waves) have their reduce
+    // kernels from the halo path. Without scratch: float atomics into the cleared result, as before.
+    constexpr bool can_part = sizeof(T) == 2 && WM == 2 && WN == 2 && BM == 128 && (BN == 128 || BN == 64) && !HK;
+    if (a.splits > 1 && can_part && a.scratch && (long long)nblk * a.splits * BM * BN <= a.scratch_floats && !a.nimg && !a.half_rows) a.part = a.scratch;
+    if (a.splits > 1 && !a.part) {
         const size_t bytes = sizeof(float) * (size_t)a.B * (a.Ho >> a.pool2) * (a.Wo >> a.pool2) * a.Co;
         if (l2i_zero_async(a.out, bytes, stream) != hipSuccess) return L2I_ERR_LAUNCH;
     }
@@ -1857,6 +1864,9 @@ static int launch_cfg(ConvArgs a, hipStream_t stream) {
     }
     (void)BK;
     L2I_LAUNCH(0, (conv_igemm_kernel<T, BM, BN, WM, WN, NS, HK>), dim3(nblk * a.splits), dim3(WM * WN * 64), lds, stream, a);
+    if constexpr (can_part) {
+        if (a.part) return launch_split_reduce<BM, BN, WM, WN, false>(a, nblk, epi, stream);
+    }
     return l2i_check_launch();
 }
 

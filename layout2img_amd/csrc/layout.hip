@@ -128,27 +128,50 @@ __global__ __launch_bounds__(256) void layout_masks_fwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void layout_masks_bwd_kernel(const float* __restrict__ m, int m_stride, const float* __restrict__ bbox,
                                                                const float* __restrict__ lin, const float* __restrict__ g,
                                                                float* __restrict__ dm, int d_stride, int M, int H) {
-    __shared__ float acc[LM_MAXM * LM_MAXM];
+    // The adjoint of the bilinear sampling is SEPARABLE: pixel (y, x) feeds cells (y_n | y_s, x_w | x_e) with weights wy * wx. Round 6: a
+    // gather in two fixed-order passes -- T[y][cx] = sum_x wx(x, cx) g[y][x], acc[cy][cx] = sum_y wy(y, cy) T[y][cx] -- every value has one
+    // writer (rounds 2-5 scattered four LDS float atomics per pixel, whose order over the four waves changed the sums' last bits from run to run).
+    extern __shared__ float lm_smem[];
+    float* acc = lm_smem;                 // [M][M]
+    float* T = acc + M * M;               // [H][M]
+    float* wl = T + H * M;                // [2 axes][H]: weight of the low cell (x_w / y_n), 0 when it is outside
+    float* wh = wl + 2 * H;               // [2 axes][H]: weight of the high cell
+    int* cl = reinterpret_cast<int*>(wh + 2 * H);   // [2 axes][H]: index of the low cell (may be -1)
     const int n = blockIdx.x;
-    for (int i = threadIdx.x; i < M * M; i += 256) acc[i] = 0.f;
-    __syncthreads();
     const float x0 = bbox[n * 4], y0 = bbox[n * 4 + 1], ww = bbox[n * 4 + 2], hh = bbox[n * 4 + 3];
-    for (int p = threadIdx.x; p < H * H; p += 256) {
-        const int y = p / H, x = p - y * H;
-        const float X = (lin[x] - x0) / ww, Y = (lin[y] - y0) / hh;
-        const float gx = X * 2.f - 1.f, gy = Y * 2.f - 1.f;
-        const float ix = ((gx + 1.f) * M - 1.f) / 2.f, iy = ((gy + 1.f) * M - 1.f) / 2.f;
-        const float fx = floorf(ix), fy = floorf(iy);
-        const int x_w = (int)fx, y_n = (int)fy, x_e = x_w + 1, y_s = y_n + 1;
-        const float nw = ((fx + 1.f) - ix) * ((fy + 1.f) - iy), ne = (ix - fx) * ((fy + 1.f) - iy);
-        const float sw = ((fx + 1.f) - ix) * (iy - fy), se = (ix - fx) * (iy - fy);
-        const bool vx_w = ix == ix && fx >= 0.f && fx <= (float)(M - 1), vx_e = ix == ix && fx >= -1.f && fx <= (float)(M - 2);
-        const bool vy_n = iy == iy && fy >= 0.f && fy <= (float)(M - 1), vy_s = iy == iy && fy >= -1.f && fy <= (float)(M - 2);
-        const float gv = g[(size_t)n * H * H + p];
-        if (vx_w && vy_n) atomicAdd(&acc[y_n * M + x_w], gv * nw);
-        if (vx_e && vy_n) atomicAdd(&acc[y_n * M + x_e], gv * ne);
-        if (vx_w && vy_s) atomicAdd(&acc[y_s * M + x_w], gv * sw);
-        if (vx_e && vy_s) atomicAdd(&acc[y_s * M + x_e], gv * se);
+    for (int i = threadIdx.x; i < 2 * H; i += 256) {
+        const int ax = i / H, q = i - ax * H;   // axis 0: x, 1: y
+        const float U = (lin[q] - (ax ? y0 : x0)) / (ax ? hh : ww);
+        const float gq = U * 2.f - 1.f;
+        const float iq = ((gq + 1.f) * M - 1.f) / 2.f;
+        const float fq = floorf(iq);
+        const bool v_lo = iq == iq && fq >= 0.f && fq <= (float)(M - 1), v_hi = iq == iq && fq >= -1.f && fq <= (float)(M - 2);
+        wl[i] = v_lo ? (fq + 1.f) - iq : 0.f;
+        wh[i] = v_hi ? iq - fq : 0.f;
+        cl[i] = (v_lo || v_hi) ? (int)fq : -4;
+    }
+    __syncthreads();
+    const float* gp = g + (size_t)n * H * H;
+    for (int i = threadIdx.x; i < H * M; i += 256) {
+        const int y = i / M, cx = i - y * M;
+        float t = 0.f;
+        for (int x = 0; x < H; ++x) {
+            const int c = cl[x];
+            const float w = (c == cx ? wl[x] : 0.f) + (c + 1 == cx ? wh[x] : 0.f);
+            if (w != 0.f) t = fmaf(w, gp[y * H + x], t);
+        }
+        T[i] = t;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < M * M; i += 256) {
+        const int cy = i / M, cx = i - cy * M;
+        float a = 0.f;
+        for (int y = 0; y < H; ++y) {
+            const int c = cl[H + y];
+            const float w = (c == cy ? wl[H + y] : 0.f) + (c + 1 == cy ? wh[H + y] : 0.f);
+            if (w != 0.f) a = fmaf(w, T[y * M + cx], a);
+        }
+        acc[i] = a;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < M * M; i += 256) {
@@ -168,7 +191,9 @@ extern "C" int l2i_layout_masks_fwd(const float* m, int m_stride, const float* b
 extern "C" int l2i_layout_masks_bwd(const float* m, int m_stride, const float* bbox, const float* lin, const float* g, float* dm,
                                     int d_stride, int N, int M, int H, void* stream) {
     if (!m || !bbox || !lin || !g || !dm || N < 1 || M < 1 || M > LM_MAXM || H < 1 || m_stride < 1 || d_stride < 1) return L2I_ERR_ARG;
-    hipLaunchKernelGGL(layout_masks_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, m, m_stride, bbox, lin, g, dm, d_stride, M, H);
+    const size_t lds = sizeof(float) * ((size_t)M * M + (size_t)H * M + 6 * (size_t)H);
+    if (lds > 64 * 1024) return L2I_ERR_ARG;
+    hipLaunchKernelGGL(layout_masks_bwd_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, m, m_stride, bbox, lin, g, dm, d_stride, M, H);
     return l2i_check_launch();
 }
 
@@ -183,6 +208,7 @@ struct AlnArgs {
     const float* dy; float* da; float* db; float* dgamma; float* dbeta;
     int rows, D, lda, ldb, ldy, perm_O, op_dtype;
     float eps;
+    float* gpart; int Dp;   // bwd: per-workgroup rows of dgamma / dbeta in the caller's scratch (null: one float atomic per channel and workgroup)
 };
 __device__ __forceinline__ float aln_a(const AlnArgs& p, int r, int c) {
     if (p.perm_O <= 0) return p.a[(size_t)r * p.lda + c];
@@ -274,6 +300,14 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(AlnArgs p) {
 #pragma unroll
     for (int e = 0; e < ALN_MAXE; ++e) { red[0][wave][lane + 64 * e] = dg[e]; red[1][wave][lane + 64 * e] = dbt[e]; }
     __syncthreads();
+    if (p.gpart) {   // this workgroup's row [dgamma (Dp) | dbeta (Dp)] of the partial matrix: stored, added in order by rows_fold (round 6)
+        float* row = p.gpart + (size_t)blockIdx.x * 2 * p.Dp;
+        for (int c = threadIdx.x; c < p.Dp; c += 256) {
+            row[c] = c < p.D ? (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]) : 0.f;
+            row[p.Dp + c] = c < p.D ? (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]) : 0.f;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < p.D; c += 256) {
         atomicAdd(p.dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
         atomicAdd(p.dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
@@ -293,14 +327,22 @@ extern "C" int l2i_add_layernorm_fwd(const float* a, int lda, const float* b, in
 }
 extern "C" int l2i_add_layernorm_bwd(const float* a, int lda, const float* b, int ldb, const float* gamma, const float* mean,
                                      const float* rstd, const float* dy, int ldy, float* da, float* db, float* dgamma, float* dbeta,
-                                     int rows, int D, int perm_O, void* stream) {
+                                     int rows, int D, int perm_O, float* scratch, long long scratch_floats, void* stream) {
     if (!a || !b || !gamma || !mean || !rstd || !dy || !dgamma || !dbeta || rows < 1 || D < 1 || D > 64 * ALN_MAXE || ldb > 64 * ALN_MAXE)
         return L2I_ERR_ARG;
     AlnArgs p = {};
     p.a = a; p.b = b; p.gamma = gamma; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.dy = dy;
     p.da = da; p.db = db; p.dgamma = dgamma; p.dbeta = dbeta;
     p.rows = rows; p.D = D; p.lda = lda; p.ldb = ldb; p.ldy = ldy; p.perm_O = perm_O;
-    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3((rows + 4 * ALN_BWD_RPW - 1) / (4 * ALN_BWD_RPW)), dim3(256), 0, (hipStream_t)stream, p);
+    const int nblk = (rows + 4 * ALN_BWD_RPW - 1) / (4 * ALN_BWD_RPW);
+    p.Dp = (D + 3) & ~3;
+    p.gpart = (scratch && !((size_t)scratch & 15) && (long long)nblk * 2 * p.Dp + rows_fold_tmp_floats(nblk, 2 * p.Dp, 1) <= scratch_floats) ? scratch : nullptr;
+    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.gpart) {   // columns [0, D) -> dgamma, [Dp, Dp + D) -> dbeta: two folds over the same rows (row stride 2 Dp)
+        float* tmp = p.gpart + (size_t)nblk * 2 * p.Dp;
+        rows_fold(p.gpart, nblk, p.Dp, 1, dgamma, nullptr, D, 0, 1, tmp, (hipStream_t)stream, nullptr, 2 * p.Dp);
+        rows_fold(p.gpart + p.Dp, nblk, p.Dp, 1, dbeta, nullptr, D, 0, 1, tmp, (hipStream_t)stream, nullptr, 2 * p.Dp);
+    }
     return l2i_check_launch();
 }
 
@@ -322,10 +364,19 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
 }
 __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ g, const long long* __restrict__ y,
                                                          float* __restrict__ demb, int rows, int Z, int E, int ld) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)rows * E) return;
-    const int r = (int)(idx / E), c = (int)(idx - (long long)r * E);
-    atomicAdd(demb + (size_t)y[r] * E + c, g[(size_t)r * ld + Z + c]);
+    // dE[class] += the embedding part of the gradient rows that carry the class: the workgroup of the FIRST such row adds them all in row order
+    // and is the only writer of dE[class] (round 6; one float atomic per row and column before: the order changed from run to run)
+    const int r = blockIdx.x;
+    const long long cls = y[r];
+    int hit = 0;
+    for (int rr = threadIdx.x; rr < r; rr += 256) hit |= (y[rr] == cls);
+    if (__syncthreads_or(hit)) return;
+    for (int c = threadIdx.x; c < E; c += 256) {
+        float s = 0.f;
+        for (int rr = r; rr < rows; ++rr)
+            if (y[rr] == cls) s += g[(size_t)rr * ld + Z + c];
+        demb[(size_t)cls * E + c] += s;
+    }
 }
 extern "C" int l2i_latent_fwd(const float* z, const float* emb, const long long* y, float* out, void* out_op, int op_dtype, int* keyvalid,
                               int rows, int Z, int E, int ld, void* stream) {
@@ -337,8 +388,7 @@ extern "C" int l2i_latent_fwd(const float* z, const float* emb, const long long*
 }
 extern "C" int l2i_latent_bwd(const float* g, const long long* y, float* demb, int rows, int Z, int E, int ld, void* stream) {
     if (!g || !y || !demb || rows < 1) return L2I_ERR_ARG;
-    const long long n = (long long)rows * E;
-    hipLaunchKernelGGL(latent_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, y, demb, rows, Z, E, ld);
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, g, y, demb, rows, Z, E, ld);
     return l2i_check_launch();
 }
 

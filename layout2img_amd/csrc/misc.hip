@@ -429,7 +429,17 @@ __global__ __launch_bounds__(256) void stage_mask_bwd_planar_kernel(const float*
         db[q] = v;
     }
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(dalpha + cls, acc * a * (1.f - a));
+    if (threadIdx.x == 0) dalpha[bo] = acc * a * (1.f - a);   // (dalpha: here the per-slot shares [B * O]; stage_mask_dalpha_kernel adds a class's slots in order)
+}
+
+// dalpha[class] += the shares of the slots that carry the class, in slot order: one thread per class (round 6; one float atomic per slot before).
+__global__ __launch_bounds__(256) void stage_mask_dalpha_kernel(const float* __restrict__ share, const long long* __restrict__ y, float* __restrict__ dalpha, int BO, int n) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int r = 0; r < BO; ++r)
+        if ((int)y[r] == c) s += share[r];
+    if (s != 0.f) dalpha[c] += s;
 }
 
 // backward, logits: dlogits[b,p,c] = sum_o [y[b,o] == c] gl[b,o,p] -- every element written (no zero fill + scatter_add).
@@ -469,11 +479,12 @@ extern "C" int l2i_stage_mask_fwd(const float* logits, const float* bmask, const
 
 extern "C" int l2i_stage_mask_bwd(const float* g, const float* keep, const float* boxm, const float* alpha, const long long* y,
                                   float* gl, float* dlogits, float* dbmask, float* dalpha, int B, int O, int H, int Cp, int S,
-                                  void* stream) {
-    if (!g || !keep || !boxm || !alpha || !y || !gl || (!dlogits && Cp) || !dbmask || !dalpha || !stage_mask_geom_ok(B, O, H, Cp, S))
+                                  float* share, int n_alpha, void* stream) {
+    if (!g || !keep || !boxm || !alpha || !y || !gl || (!dlogits && Cp) || !dbmask || !dalpha || !share || n_alpha <= 0 || !stage_mask_geom_ok(B, O, H, Cp, S))
         return L2I_ERR_ARG;
     hipLaunchKernelGGL(stage_mask_bwd_planar_kernel, dim3(B * O), dim3(256), 0, (hipStream_t)stream, g, keep, boxm, alpha, y, gl,
-                       dbmask, dalpha, O, H, S);
+                       dbmask, share, O, H, S);
+    hipLaunchKernelGGL(stage_mask_dalpha_kernel, dim3((n_alpha + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)share, y, dalpha, B * O, n_alpha);
     if (Cp == 0) return l2i_check_launch();   // planar logits: gl IS their gradient (no dense [B][H][H][Cp] tensor exists)
     const long long total4 = (long long)B * H * H * (Cp / 4);
     long long nblk = (total4 + 255) / 256;
@@ -594,13 +605,15 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
         }
         __syncthreads();
     }
-    // per-(image, object) rows of `tmp` ([B * O][128], zeroed by the caller): at most `parts` workgroups add into one address. Adding into
-    // dw[class] directly put every image's padding slots (class 0) on the same 100 addresses: ~3000 same-address atomics = 90 us.
+    // this workgroup's rows of `tmp` ([parts][B * O][128]): STORED (round 6; rounds 4-5 added the `parts` workgroups of an image into one row with
+    // float atomics). The finish kernel adds the parts and the slots of a class in a fixed order. (Adding into dw[class] directly would put every
+    // image's padding slots (class 0) on the same 100 addresses: ~3000 same-address atomics = 90 us.)
+    float* mine = dw + ((size_t)blockIdx.y * gridDim.x * O + (size_t)b * O) * 128;
     for (int i = threadIdx.x; i < CL_O * 128; i += 256) {
         const int o = i >> 7, ch = i & 127;
-        if (o < O && ch < C) atomicAdd(dw + ((size_t)b * O + o) * 128 + ch, red[o][ch]);
+        if (o < O && ch < 127) mine[(size_t)o * 128 + ch] = ch < C ? red[o][ch] : 0.f;
     }
-    if (dbias) {   // (uniform; column 127 of the row) bias gradient: wave-level sums of the staging threads' partials, one atomic per object
+    {   // column 127 of the row: the bias gradient (zero when there is no bias) -- wave-level sums of the staging threads' partials
         __syncthreads();
 #pragma unroll
         for (int o = 0; o < CL_O; ++o) {
@@ -611,14 +624,14 @@ __global__ __launch_bounds__(256) void class_logits_bwd_kernel(const float* __re
         }
         __syncthreads();
         if (threadIdx.x < CL_O && (int)threadIdx.x < O)
-            atomicAdd(dw + ((size_t)b * O + threadIdx.x) * 128 + 127, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+            mine[(size_t)threadIdx.x * 128 + 127] = dbias ? (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]) : 0.f;
     }
 }
 
 // second kernel: one workgroup per CLASS gathers the rows of the (image, object) slots that carry it -- no atomics, fixed summation order.
 // 128 channels x 8 slot phases: the padding class is carried by ~100 slots, and a single thread walking them is 100 dependent loads (36 us measured).
 __global__ __launch_bounds__(1024) void class_logits_bwd_finish_kernel(const float* __restrict__ tmp, const long long* __restrict__ y, float* __restrict__ dw,
-                                                                       float* __restrict__ dbias, int BO, int C, int ldw) {
+                                                                       float* __restrict__ dbias, int BO, int C, int ldw, int parts) {
     __shared__ int ys[1024];
     __shared__ float part[8][128];
     const int k = blockIdx.x, c = threadIdx.x & 127, ph = threadIdx.x >> 7;
@@ -629,7 +642,8 @@ __global__ __launch_bounds__(1024) void class_logits_bwd_finish_kernel(const flo
         if ((int)threadIdx.x < n) ys[threadIdx.x] = (int)y[r0 + threadIdx.x];
         __syncthreads();
         for (int r = ph; r < n; r += 8)
-            if (ys[r] == k) v += tmp[(size_t)(r0 + r) * 128 + c];
+            if (ys[r] == k)
+                for (int pt = 0; pt < parts; ++pt) v += tmp[((size_t)pt * BO + r0 + r) * 128 + c];
     }
     part[ph][c] = v;
     __syncthreads();
@@ -649,8 +663,9 @@ extern "C" int l2i_class_logits_fwd(const float* a, const float* w, const float*
     return l2i_check_launch();
 }
 
-// dw [classes][ldw] and dbias [classes] are ADDED to (one workgroup per class, no atomics: deterministic). tmp: [B * O][128] f32 scratch, ZEROED by
-// the caller: the per-(image, object) rows the first kernel accumulates (column 127: the bias gradient).
+// dw [classes][ldw] and dbias [classes] are ADDED to (one workgroup per class, no atomics: deterministic). tmp: f32 scratch of
+// l2i_class_logits_bwd_parts(HH) * B * O * 128 floats (contents undefined before and after): the per-(pixel part, image, object) rows the first kernel
+// stores (column 127: the bias gradient).
 extern "C" int l2i_class_logits_bwd(const float* a, const float* w, const long long* y, const float* gl, float* da, float* dw, float* dbias,
                                     float* tmp, int classes, int B, int O, int HH, int Cp, int C, int ldw, void* stream) {
     if (!a || !w || !y || !gl || !da || !dw || !tmp || classes <= 0 || B <= 0 || O <= 0 || O > CL_O || HH <= 0 || C <= 0 || C > 126 || Cp < C || Cp > 128 ||
@@ -658,10 +673,11 @@ extern "C" int l2i_class_logits_bwd(const float* a, const float* w, const long l
         return L2I_ERR_ARG;
     const int per = HH >= 2048 ? 128 : 256;   // pixels per workgroup (more, shorter workgroups on the large maps: the loop is latency-bound)
     const int parts = (HH + per - 1) / per;
-    hipLaunchKernelGGL(class_logits_bwd_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, a, w, y, gl, da, tmp, tmp, O, HH, Cp, C, ldw, per);
-    hipLaunchKernelGGL(class_logits_bwd_finish_kernel, dim3(classes), dim3(1024), 0, (hipStream_t)stream, (const float*)tmp, y, dw, dbias, B * O, C, ldw);
+    hipLaunchKernelGGL(class_logits_bwd_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, a, w, y, gl, da, tmp, dbias ? tmp : nullptr, O, HH, Cp, C, ldw, per);
+    hipLaunchKernelGGL(class_logits_bwd_finish_kernel, dim3(classes), dim3(1024), 0, (hipStream_t)stream, (const float*)tmp, y, dw, dbias, B * O, C, ldw, parts);
     return l2i_check_launch();
 }
+extern "C" int l2i_class_logits_bwd_parts(int HH) { return (HH + (HH >= 2048 ? 128 : 256) - 1) / (HH >= 2048 ? 128 : 256); }
 
 // ---------------------------------------------------------------- projection heads of the discriminator
 // reference model/rcnn_discriminator_app.py:127-129 (image head) and :160-166 (object head):
@@ -756,10 +772,23 @@ __global__ __launch_bounds__(256) void proj_head_bwd_kernel(const float* __restr
             *reinterpret_cast<float4*>(dx + base + (size_t)p * C) = d;
             if (dx_op) *reinterpret_cast<uint2*>(dx_op + base + (size_t)p * C) = make_uint2(f2bf2(d.x, d.y), f2bf2(d.z, d.w));
         }
-        if (demb && gr != 0.f) {
-            const float4 f = *reinterpret_cast<const float4*>(feat + (size_t)r * C + c);
+    }
+    if (demb) {
+        // dE[class] += sum over the rows that carry the class of g[r] f[r]: the FIRST such row's workgroup adds them all, in row order, and is the
+        // only writer of dE[class] in this launch (round 6; rounds 2-5: one float atomic per row and channel, whose order changed from run to run)
+        int hit = 0;
+        for (int rr = threadIdx.x; rr < r; rr += 256) hit |= (y[rr] == cls);
+        if (__syncthreads_or(hit)) return;
+        for (int c = 4 * threadIdx.x; c < C; c += 1024) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int rr = r; rr < R; ++rr) {
+                const float g2 = g[rr];
+                if (y[rr] != cls || g2 == 0.f) continue;
+                const float4 f = *reinterpret_cast<const float4*>(feat + (size_t)rr * C + c);
+                a.x = fmaf(g2, f.x, a.x); a.y = fmaf(g2, f.y, a.y); a.z = fmaf(g2, f.z, a.z); a.w = fmaf(g2, f.w, a.w);
+            }
             float* d = demb + (size_t)cls * demb_stride + c;
-            atomicAdd(d, gr * f.x); atomicAdd(d + 1, gr * f.y); atomicAdd(d + 2, gr * f.z); atomicAdd(d + 3, gr * f.w);
+            d[0] += a.x; d[1] += a.y; d[2] += a.z; d[3] += a.w;
         }
     }
 }
@@ -816,12 +845,18 @@ __global__ __launch_bounds__(256) void emb_dot_bwd_kernel(const T* __restrict__ 
                                                           float* __restrict__ demb, int demb_stride, float* __restrict__ dw2,
                                                           float* __restrict__ dbias, int R, int C) {
     __shared__ float red[256];
-    if ((int)blockIdx.x < R) {
-        const int r = blockIdx.x;
-        const float gr = g[r];
-        if (gr == 0.f) return;
-        float* d = demb + (size_t)y[r] * demb_stride;
-        for (int c = threadIdx.x; c < C; c += 256) atomicAdd(d + c, gr * OpT<T>::to(w2[c]));
+    if ((int)blockIdx.x < R) {   // dE[class][c] += (sum of g over the class's rows) w2[c]: the first row of a class adds for all of them, in row order
+        const int r = blockIdx.x;   // -- one writer per class row, no float atomics (round 6)
+        const long long cls = y[r];
+        int hit = 0;
+        for (int rr = threadIdx.x; rr < r; rr += 256) hit |= (y[rr] == cls);
+        if (__syncthreads_or(hit)) return;
+        float s = 0.f;
+        for (int rr = r; rr < R; ++rr)
+            if (y[rr] == cls) s += g[rr];
+        if (s == 0.f) return;
+        float* d = demb + (size_t)cls * demb_stride;
+        for (int c = threadIdx.x; c < C; c += 256) d[c] += s * OpT<T>::to(w2[c]);
         return;
     }
     colsum16<T>(emb, emb_stride, y, g, R, C, ((int)blockIdx.x - R) * 16, dw2, red);

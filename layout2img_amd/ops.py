@@ -222,7 +222,7 @@ def conv_raw(x_op, wpack, kpad, co, kh, *, bias=None, res=None, relu_mask=None, 
     # the stream's scratch (caller-owned, shared with the weight-gradient launches of the same stream): partial tiles of the
     # 4x4 weight-stationary kernel and of every split-K launch of the halo kernels (conv_store_partial + reduce with epilogue)
     # ... and the partial rows of the epilogue's batch statistics (one per wave, summed in a fixed order: no atomics)
-    scr, nscr = _lib.wgrad_scratch(dev) if ((kh == 3 and x_op.dtype == torch.bfloat16) or st is not None) else (None, 0)
+    scr, nscr = _lib.wgrad_scratch(dev) if (x_op.dtype == torch.bfloat16 or st is not None) else (None, 0)
     if scr is not None and sc is None:
         _lib.call("l2i_conv2d_fwd_dual", x_op.data_ptr(), wpack.data_ptr(), _p(bias), _p(res), _p(relu_mask), _p(out), _p(out_op),
                   _p(out_raw), _code(x_op.dtype), B, Hi, Wi, Ci, Ho, Wo, co, kh, int(up2), int(pool2), int(relu_op), kpad,
@@ -1268,8 +1268,9 @@ class StageMaskFn(Function):
         dlogits = torch.empty((B, H, H, Cp), dtype=torch.float32, device=dev) if Cp else None
         dbmask = torch.empty((B, o, S, S), dtype=torch.float32, device=dev)
         dalpha = _zeros(tuple(alpha.shape), dev)
+        share = torch.empty((B * o,), dtype=torch.float32, device=dev)   # the slots' shares of dalpha, added per class in slot order (no atomics)
         _lib.call("l2i_stage_mask_bwd", g.data_ptr(), keep.data_ptr(), boxm.data_ptr(), alpha.data_ptr(), y.data_ptr(),
-                  gl.data_ptr(), _p(dlogits), dbmask.data_ptr(), dalpha.data_ptr(), B, o, H, Cp, S, _stream())
+                  gl.data_ptr(), _p(dlogits), dbmask.data_ptr(), dalpha.data_ptr(), B, o, H, Cp, S, share.data_ptr(), alpha.numel(), _stream())
         return (dlogits if Cp else gl), dbmask, None, dalpha, None, None
 
 
@@ -1304,7 +1305,8 @@ class ClassLogitsFn(Function):
         da = torch.empty_like(a)
         dw = _zeros(tuple(w.shape), a.device)   # (slices of the step's pre-zeroed slab: consumed by the accumulations right behind this node)
         db = _zeros((ctx.nb,), a.device) if ctx.has_bias else None
-        tmp = _zeros((B * O, 128), a.device)
+        parts = -(-(H * W) // (128 if H * W >= 2048 else 256))   # (l2i_class_logits_bwd_parts: pixel parts of an image, one stored row each)
+        tmp = torch.empty((parts * B * O, 128), dtype=torch.float32, device=a.device)
         _lib.call("l2i_class_logits_bwd", a.data_ptr(), w.data_ptr(), y.data_ptr(), g.data_ptr(), da.data_ptr(), dw.data_ptr(), _p(db), tmp.data_ptr(),
                   w.shape[0], B, O, H * W, Cp, C, w.stride(0), _stream())
         da._l2i_owned = True   # (fresh, handed to exactly one consumer: NormActFn.backward may overwrite it)
@@ -1678,7 +1680,7 @@ class AddLayerNormFn(Function):
         db = torch.empty(b_shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         dgb = _zeros((2, D), dev)
         _lib.call("l2i_add_layernorm_bwd", a.data_ptr(), lda, b.data_ptr(), ldb, gamma.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
-                  g.data_ptr(), ldy, _p(da), _p(db), dgb[0].data_ptr(), dgb[1].data_ptr(), rows, D, perm_O, _stream())
+                  g.data_ptr(), ldy, _p(da), _p(db), dgb[0].data_ptr(), dgb[1].data_ptr(), rows, D, perm_O, *_lib.wgrad_scratch(dev), _stream())
         return da, db, dgb[0], dgb[1], None, None, None, None, None
 
 
