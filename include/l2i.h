@@ -311,7 +311,7 @@ int l2i_gram_head_bwd(const float* x, const float* w, const float* s_keep, const
  * object classes are computed:  lg[b,o,p] = bias[y[b,o]] + sum_c a[b,p,c] w[y[b,o]][c]  (a [B][HH][Cp] f32 NHWC, w [classes][ldw] f32, y [B][O]
  * int64, lg planar [B][O][HH] f32; O <= 8, C <= 128, Cp >= C a multiple of 4). Backward: da[b,p,c] = sum_o gl[b,o,p] w[y_o][c] (every element of
  * da written, pad channels zero); dw[y_o][c] += sum_p gl a; dbias[y_o] += sum_p gl: first per (pixel part, image, object) STORED into tmp
- * ([l2i_class_logits_bwd_parts(HH) * B * O][128] f32, contents undefined before and after; the padding class 0 is carried by most images, so direct
+ * ([(l2i_class_logits_bwd_parts(HH) + 1) * B * O][128] f32, contents undefined before and after; the padding class 0 is carried by most images, so direct
  * atomics on dw[0][:] would serialise), then one workgroup per class (`classes` rows of dw) adds its slots' rows into dw / dbias in a fixed order --
  * no atomics anywhere (round 6). C <= 126.
  * l2i_stage_mask_fwd / _bwd take such planar logits with Cp = 0 (their gradient is then `gl`, dlogits may be null). */

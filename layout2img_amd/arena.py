@@ -348,7 +348,9 @@ class WeightArena:
                 for c0 in range(0, kt, 256):
                     for rb, r0 in enumerate(range(0, h.co, 4 * WTU_RPW)):
                         t_wtu[use].append((i, c0, r0, WTU_RPW, tp_len[use] + rb * kt))
-                    t_tfold[use].append((i, c0, tp_len[use], nrb))
+                cw = 256 if nrb <= 8 else (64 if nrb <= 32 else 16)   # columns per fold workgroup: 256 / cw row lanes walk the row blocks
+                for c0 in range(0, kt, cw):
+                    t_tfold[use].append((i, c0, tp_len[use], nrb, cw))
                 tp_len[use] += _round_up(nrb * kt, 4)
                 row[19] = np_len[use]                     # sn_wv_kernel<R>: 4 R rows per block, one stored share of ||W v||^2 each
                 for r0 in range(0, h.co, 4 * WV_R):
@@ -370,7 +372,7 @@ class WeightArena:
             return torch.from_numpy(np.ascontiguousarray(arr)).to(device), len(a)
         self.layers = torch.from_numpy(tab.reshape(-1)).to(device)
         self.t_wtu = [dev(t, 5) for t in t_wtu]
-        self.t_tfold = [dev(t, 4) for t in t_tfold]
+        self.t_tfold = [dev(t, 5) for t in t_tfold]
         self.np_len = [_round_up(n, 4) for n in np_len]
         self.sn_scratch_floats = max(a + b for a, b in zip(self.np_len, tp_len)) if self.rounds else 0
         self.t_wv = [dev(t, 2) for t in t_wv]

@@ -123,6 +123,36 @@ static inline void ws_fold(float* ws, int L, int C, float* d0, float* d1, float*
     hipLaunchKernelGGL(ws_fold_kernel, dim3((L + 255) / 256), dim3(256), 0, stream, a);
 }
 
+// ---------------------------------------------------------------- one writer per class row (round 6)
+// Gradients of embedding-like tables (dE[y[r]] += g[r] f[r]) were scattered with one float atomic per row and column: rows of the same
+// class met in an order that changed from run to run. Now the workgroup of the FIRST row that carries a class adds all of the class's
+// rows itself, in ascending row order, and is the only writer of dE[class] in the launch. Helpers for 256-thread workgroups:
+// class_first(): true when no row in front of r carries r's class; class_rows(): the rows >= r with the class, ascending, in LDS.
+#define L2I_CLASS_LIST 2048
+__device__ __forceinline__ bool class_first(const long long* __restrict__ y, int r, long long cls) {
+    int hit = 0;
+    for (int rr = threadIdx.x; rr < r; rr += 256) hit |= (y[rr] == cls);
+    return !__syncthreads_or(hit);
+}
+__device__ __forceinline__ int class_rows(const long long* __restrict__ y, int r0, int R, long long cls, int* list /* [L2I_CLASS_LIST] */, int* wsum /* [4] */) {
+    int n = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = r0; base < R; base += 256) {
+        const int rr = base + (int)threadIdx.x;
+        const bool m = rr < R && y[rr] == cls;
+        const unsigned long long b = __ballot(m);
+        if (lane == 0) wsum[wave] = __popcll(b);
+        __syncthreads();
+        int off = n;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        const int pos = off + __popcll(b & ((1ull << lane) - 1ull));
+        if (m && pos < L2I_CLASS_LIST) list[pos] = rr;
+        n += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    return n < L2I_CLASS_LIST ? n : L2I_CLASS_LIST;   // (callers refuse R > L2I_CLASS_LIST on the host)
+}
+
 // ---------------------------------------------------------------- deterministic column sums of stored partial rows (round 6)
 // The replicated workspace above still ends in float atomics: which workgroup's partial lands first in a replica changes from run to
 // run, so a per-channel total -- a batch statistic -- moves in its last bits, a ReLU gate further on flips, and two runs of the same f32
@@ -159,60 +189,86 @@ static __global__ __launch_bounds__(256) void rows_fold1_kernel(const float* __r
 }
 // mode 0: dst = total; 1: dst += total (plain: the caller owns dst on this stream); 2: atomicAdd (a gradient that two passes of one
 // network, on two streams, may fold into at the same time: one add per address and launch).
-// 16 float4 columns x 16 row lanes per workgroup: a thread adds every 16th row (four loads in flight), the row lanes are added in LDS in
-// lane order. Up to L2I_FOLD_DIRECT rows in this one launch.
+// A workgroup = cl float4 columns x (256 / cl) row lanes (cl a power of two <= 16, chosen by the host so that narrow matrices still make
+// many workgroups and tall ones many row lanes): a thread adds every (256 / cl)-th row, four loads in flight, the row lanes meet in a
+// fixed-order tree in LDS. Up to L2I_FOLD_DIRECT rows in this one launch. The body is a device function so that a kernel which runs behind
+// the producer anyway (wgrad_reduce_kernel, norm_a8_finish_kernel) can carry a fold in extra workgroups instead of one more launch.
 #define L2I_FOLD_DIRECT 1024
-static __global__ __launch_bounds__(256) void rows_fold2_kernel(const float* __restrict__ src, int R, int L, float* __restrict__ dst0, float* __restrict__ dst1, int C0,
-                                                                long long zs, int mode, float* __restrict__ dup, int ld) {
-    __shared__ float4 red[256];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int c4 = blockIdx.x * 16 + tx;   // float4 column
+struct RowsFoldArgs {
+    const float* src; int R, L; float* dst0; float* dst1; int C0; long long zs; int mode; float* dup; int ld; int cl; int nbx;   // nbx: workgroups along x
+};
+__device__ __forceinline__ void rows_fold2_body(const RowsFoldArgs& p, int bx, int bz, float4* red) {
+    const int cl = p.cl, rl = 256 / cl;
+    const int tx = threadIdx.x & (cl - 1), ty = threadIdx.x / cl;
+    const int c4 = bx * cl + tx;   // float4 column
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (4 * c4 < L) {
-        const float* q = src + (size_t)blockIdx.z * R * ld + 4 * c4;
+    const bool on = 4 * c4 < p.L;
+    if (on) {
+        const float* q = p.src + (size_t)bz * p.R * p.ld + 4 * c4;
         int r = ty;
-        for (; r + 48 < R; r += 64) {
-            const float4 a = *reinterpret_cast<const float4*>(q + (size_t)r * ld), b = *reinterpret_cast<const float4*>(q + (size_t)(r + 16) * ld);
-            const float4 c = *reinterpret_cast<const float4*>(q + (size_t)(r + 32) * ld), d = *reinterpret_cast<const float4*>(q + (size_t)(r + 48) * ld);
+        for (; r + 3 * rl < p.R; r += 4 * rl) {
+            const float4 a = *reinterpret_cast<const float4*>(q + (size_t)r * p.ld), b = *reinterpret_cast<const float4*>(q + (size_t)(r + rl) * p.ld);
+            const float4 c = *reinterpret_cast<const float4*>(q + (size_t)(r + 2 * rl) * p.ld), d = *reinterpret_cast<const float4*>(q + (size_t)(r + 3 * rl) * p.ld);
             s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y); s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
         }
-        for (; r < R; r += 16) {
-            const float4 a = *reinterpret_cast<const float4*>(q + (size_t)r * ld);
+        for (; r < p.R; r += rl) {
+            const float4 a = *reinterpret_cast<const float4*>(q + (size_t)r * p.ld);
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
         }
     }
     red[threadIdx.x] = s;
     __syncthreads();
-    if (ty == 0 && 4 * c4 < L) {
-#pragma unroll
-        for (int j = 1; j < 16; ++j) { const float4 a = red[j * 16 + tx]; s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
-        const float v[4] = {s.x, s.y, s.z, s.w};
+    for (int st = rl >> 1; st >= 1; st >>= 1) {   // row lane ty += row lane ty + st: the same tree whatever the timing
+        if (ty < st) {
+            const float4 a = red[threadIdx.x], b = red[threadIdx.x + st * cl];
+            red[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        }
+        __syncthreads();
+    }
+    if (ty == 0 && on) {
+        const float4 t = red[threadIdx.x];
+        const float v[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int i = 4 * c4 + e;
-            if (i >= C0 && !dst1) continue;   // (padding columns of the partial rows: no destination)
-            float* d = (i < C0 ? dst0 + i : dst1 + (i - C0)) + (size_t)blockIdx.z * zs;
-            if (mode == 2) atomicAdd(d, v[e]);
-            else *d = mode ? *d + v[e] : v[e];
-            if (dup && i < C0) {   // a second destination of the same sums (a block's conv2 and shortcut share dY: one bias gradient, two biases)
-                if (mode == 2) atomicAdd(dup + i, v[e]);
-                else dup[i] = mode ? dup[i] + v[e] : v[e];
+            if (i >= p.C0 && !p.dst1) continue;   // (padding columns of the partial rows: no destination)
+            float* d = (i < p.C0 ? p.dst0 + i : p.dst1 + (i - p.C0)) + (size_t)bz * p.zs;
+            if (p.mode == 2) atomicAdd(d, v[e]);
+            else *d = p.mode ? *d + v[e] : v[e];
+            if (p.dup && i < p.C0) {   // a second destination of the same sums (a block's conv2 and shortcut share dY: one bias gradient, two biases)
+                if (p.mode == 2) atomicAdd(p.dup + i, v[e]);
+                else p.dup[i] = p.mode ? p.dup[i] + v[e] : v[e];
             }
         }
     }
 }
+static __global__ __launch_bounds__(256) void rows_fold2_kernel(RowsFoldArgs p) {
+    __shared__ float4 red[256];
+    rows_fold2_body(p, blockIdx.x, blockIdx.z, red);
+}
 // floats of tmp a fold of (R rows, L columns, Z groups) needs
 static inline long long rows_fold_tmp_floats(int R, int L, int Z) { return R <= L2I_FOLD_DIRECT ? 0 : (long long)Z * L2I_FOLD_CHUNKS * L; }
-// columns [0, C0) go to dst0[z * zs + i], columns [C0, L) to dst1[z * zs + i - C0]; L % 4 == 0, part 16-byte aligned
+// The direct fold's arguments (R <= L2I_FOLD_DIRECT): columns [0, C0) go to dst0[z * zs + i], columns [C0, L) to dst1[z * zs + i - C0]
+// (dst1 null: nowhere); L % 4 == 0, part 16-byte aligned; ld: floats between two rows (0: L), a group's rows are R * ld apart.
+static inline RowsFoldArgs rows_fold_args(const float* part, int R, int L, int Z, float* dst0, float* dst1, int C0, long long zs, int mode, float* dup, int ld) {
+    RowsFoldArgs a;
+    a.src = part; a.R = R; a.L = L; a.dst0 = dst0; a.dst1 = dst1; a.C0 = C0; a.zs = zs; a.mode = mode; a.dup = dup; a.ld = ld > 0 ? ld : L;
+    int cl = 16;
+    const int L4 = L / 4;
+    while (cl > 1 && (long long)((L4 + cl - 1) / cl) * Z < 128 && 256 / cl < R) cl >>= 1;
+    a.cl = cl; a.nbx = (L4 + cl - 1) / cl;
+    return a;
+}
 static inline void rows_fold(const float* part, int R, int L, int Z, float* dst0, float* dst1, int C0, long long zs, int mode, float* tmp, hipStream_t stream,
-                             float* dup = nullptr, int ld = 0) {   // ld: floats between two rows of `part` (0: L); a group's rows are R * ld apart
+                             float* dup = nullptr, int ld = 0) {
     if (ld <= 0) ld = L;
     if (R > L2I_FOLD_DIRECT) {
         const int rc = (R + L2I_FOLD_CHUNKS - 1) / L2I_FOLD_CHUNKS, nch = (R + rc - 1) / rc;
         hipLaunchKernelGGL(rows_fold1_kernel, dim3((L / 4 + 63) / 64, nch, Z), dim3(256), 0, stream, part, R, L, rc, tmp, ld);
         part = tmp; R = nch; ld = L;
     }
-    hipLaunchKernelGGL(rows_fold2_kernel, dim3((L / 4 + 15) / 16, 1, Z), dim3(256), 0, stream, part, R, L, dst0, dst1, C0, zs, mode, dup, ld);
+    const RowsFoldArgs a = rows_fold_args(part, R, L, Z, dst0, dst1, C0, zs, mode, dup, ld);
+    hipLaunchKernelGGL(rows_fold2_kernel, dim3(a.nbx, 1, Z), dim3(256), 0, stream, a);
 }
 
 // ---------------------------------------------------------------- clearing a buffer from inside the library

@@ -814,7 +814,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int BMO, int tiles_k,
                                                            int ntiles, int splits, int Co, int K, int ldw, float alpha, int nw2, int sper,
                                                            int tiles_k_main, float* __restrict__ dw2, int K2, int ldw2,
-                                                           float* __restrict__ dw_b, float* __restrict__ dw2_b, int overwrite, float4* __restrict__ part_out) {
+                                                           float* __restrict__ dw_b, float* __restrict__ dw2_b, int overwrite, float4* __restrict__ part_out,
+                                                           RowsFoldArgs bias_fold, int nbx_main) {
+    // workgroups [nbx_main, gridDim.x) of the first (group, pass) plane: the ordered sum of the launch's bias-gradient rows (rows_fold2_body) --
+    // carried here instead of one more launch behind every weight-gradient launch (round 6)
+    if ((int)blockIdx.x >= nbx_main) {
+        __shared__ float4 fold_red[256];
+        if (blockIdx.y == 0 && blockIdx.z == 0 && bias_fold.src) rows_fold2_body(bias_fold, (int)blockIdx.x - nbx_main, 0, fold_red);
+        return;
+    }
     // blockIdx.y = group of `sper` consecutive splits: layers with few tiles and many splits (the 64-channel layers at
     // 128 x 128: 5 tiles x 153 splits) otherwise run on 40 workgroups, each thread walking 153 partial tiles one dependent
     // load after the other (18 us of a 69-us weight gradient). Groups combine with f32 atomics (gridDim.y > 1 only).
@@ -1050,8 +1058,15 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             if (used + needb <= scratch_floats) { a.bpart = scratch + used; a.bpart_ld = bias_ld; used += needb; }
         }
         a.zero_targets = (a.overwrite && a.part && !a.fuse_cnt && sg > 1 && !part2) ? 1 : 0;   // (split groups that still add with atomics)
+        RowsFoldArgs bf = {};   // the bias fold: rides on the reduce launch when there is one (<= L2I_FOLD_DIRECT rows), else its own launch
+        bool bias_ride = false;
+        if (a.bpart) {
+            float* d0 = a.dbias ? a.dbias : a.dbias2;
+            bf = rows_fold_args(a.bpart, bias_rows, bias_ld, 1, d0, nullptr, a.Co, 0, 2, (a.dbias && a.dbias2) ? a.dbias2 : nullptr, bias_ld);
+            bias_ride = bias_rows <= L2I_FOLD_DIRECT && a.part && !a.fuse_cnt;
+        }
         auto fold_bias = [&]() {
-            if (!a.bpart) return;
+            if (!a.bpart || bias_ride) return;
             float* d0 = a.dbias ? a.dbias : a.dbias2;
             rows_fold(a.bpart, bias_rows, bias_ld, 1, d0, nullptr, a.Co, 0, 2, a.bpart + (size_t)bias_rows * bias_ld, stream,
                       (a.dbias && a.dbias2) ? a.dbias2 : nullptr);
@@ -1101,17 +1116,19 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             const int nw2l = (int)(nw2 && !nw8 && BMO == 128);
             // split groups: enough workgroups to fill the chip (>= ~512), at least 8 splits per group
             // (sg split groups of sper splits each: computed above)
+            RowsFoldArgs nobf = {};
+            const unsigned nbx_b = nbx + (bias_ride ? (unsigned)bf.nbx : 0u);
             if (part2) {   // two stages, no atomics: groups -> part2, then the groups of a tile in order -> dw
                 L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg, (unsigned)nz_), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
                            a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, nw2l, sper,
-                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, reinterpret_cast<float4*>(part2));
-                L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, 1u, (unsigned)nz_), dim3(256), 0, stream, (const float*)part2, a.dw, BMO,
+                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, reinterpret_cast<float4*>(part2), nobf, (int)nbx);
+                L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx_b, 1u, (unsigned)nz_), dim3(256), 0, stream, (const float*)part2, a.dw, BMO,
                            a.tiles_k, tiles, sg * nz_, a.Co, a.K, a.ldw, a.alpha, nw2l, sg,
-                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, (float4*)nullptr);
+                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, (float4*)nullptr, bias_ride ? bf : nobf, (int)nbx);
             } else {
-                L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg, (unsigned)nz_), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
+                L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx_b, (unsigned)sg, (unsigned)nz_), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
                            a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, nw2l, sper,
-                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, (float4*)nullptr);
+                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, (float4*)nullptr, bias_ride ? bf : nobf, (int)nbx);
             }
         }
         fold_bias();

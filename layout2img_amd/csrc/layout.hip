@@ -151,14 +151,27 @@ __global__ __launch_bounds__(256) void layout_masks_bwd_kernel(const float* __re
         cl[i] = (v_lo || v_hi) ? (int)fq : -4;
     }
     __syncthreads();
+    // pixel range [lo, hi) per axis and cell: the low-cell index is monotone along an axis, so the pixels that reach cell c are contiguous
+    int* lo = cl + 2 * H;   // [2 axes][M]
+    int* hi = lo + 2 * M;
+    for (int i = threadIdx.x; i < 2 * M; i += 256) {
+        const int ax = i / M, c = i - ax * M;
+        int l = H, h = 0;
+        for (int q = 0; q < H; ++q) {
+            const int k = cl[ax * H + q];
+            if (k == c || k + 1 == c) { l = min(l, q); h = max(h, q + 1); }
+        }
+        lo[i] = l; hi[i] = h;
+    }
+    __syncthreads();
     const float* gp = g + (size_t)n * H * H;
     for (int i = threadIdx.x; i < H * M; i += 256) {
         const int y = i / M, cx = i - y * M;
         float t = 0.f;
-        for (int x = 0; x < H; ++x) {
+        for (int x = lo[cx]; x < hi[cx]; ++x) {
             const int c = cl[x];
             const float w = (c == cx ? wl[x] : 0.f) + (c + 1 == cx ? wh[x] : 0.f);
-            if (w != 0.f) t = fmaf(w, gp[y * H + x], t);
+            t = fmaf(w, gp[y * H + x], t);
         }
         T[i] = t;
     }
@@ -166,10 +179,10 @@ __global__ __launch_bounds__(256) void layout_masks_bwd_kernel(const float* __re
     for (int i = threadIdx.x; i < M * M; i += 256) {
         const int cy = i / M, cx = i - cy * M;
         float a = 0.f;
-        for (int y = 0; y < H; ++y) {
+        for (int y = lo[M + cy]; y < hi[M + cy]; ++y) {
             const int c = cl[H + y];
             const float w = (c == cy ? wl[H + y] : 0.f) + (c + 1 == cy ? wh[H + y] : 0.f);
-            if (w != 0.f) a = fmaf(w, T[y * M + cx], a);
+            a = fmaf(w, T[y * M + cx], a);
         }
         acc[i] = a;
     }
@@ -191,7 +204,7 @@ extern "C" int l2i_layout_masks_fwd(const float* m, int m_stride, const float* b
 extern "C" int l2i_layout_masks_bwd(const float* m, int m_stride, const float* bbox, const float* lin, const float* g, float* dm,
                                     int d_stride, int N, int M, int H, void* stream) {
     if (!m || !bbox || !lin || !g || !dm || N < 1 || M < 1 || M > LM_MAXM || H < 1 || m_stride < 1 || d_stride < 1) return L2I_ERR_ARG;
-    const size_t lds = sizeof(float) * ((size_t)M * M + (size_t)H * M + 6 * (size_t)H);
+    const size_t lds = sizeof(float) * ((size_t)M * M + (size_t)H * M + 6 * (size_t)H + 4 * (size_t)M);
     if (lds > 64 * 1024) return L2I_ERR_ARG;
     hipLaunchKernelGGL(layout_masks_bwd_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, m, m_stride, bbox, lin, g, dm, d_stride, M, H);
     return l2i_check_launch();
@@ -366,15 +379,15 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
                                                          float* __restrict__ demb, int rows, int Z, int E, int ld) {
     // dE[class] += the embedding part of the gradient rows that carry the class: the workgroup of the FIRST such row adds them all in row order
     // and is the only writer of dE[class] (round 6; one float atomic per row and column before: the order changed from run to run)
+    __shared__ int rlist[L2I_CLASS_LIST];
+    __shared__ int wsum[4];
     const int r = blockIdx.x;
     const long long cls = y[r];
-    int hit = 0;
-    for (int rr = threadIdx.x; rr < r; rr += 256) hit |= (y[rr] == cls);
-    if (__syncthreads_or(hit)) return;
+    if (!class_first(y, r, cls)) return;
+    const int nl = class_rows(y, r, rows, cls, rlist, wsum);
     for (int c = threadIdx.x; c < E; c += 256) {
         float s = 0.f;
-        for (int rr = r; rr < rows; ++rr)
-            if (y[rr] == cls) s += g[(size_t)rr * ld + Z + c];
+        for (int i = 0; i < nl; ++i) s += g[(size_t)rlist[i] * ld + Z + c];
         demb[(size_t)cls * E + c] += s;
     }
 }
@@ -387,7 +400,7 @@ extern "C" int l2i_latent_fwd(const float* z, const float* emb, const long long*
     return l2i_check_launch();
 }
 extern "C" int l2i_latent_bwd(const float* g, const long long* y, float* demb, int rows, int Z, int E, int ld, void* stream) {
-    if (!g || !y || !demb || rows < 1) return L2I_ERR_ARG;
+    if (!g || !y || !demb || rows < 1 || rows > L2I_CLASS_LIST) return L2I_ERR_ARG;
     hipLaunchKernelGGL(latent_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, g, y, demb, rows, Z, E, ld);
     return l2i_check_launch();
 }

@@ -434,12 +434,18 @@ __global__ __launch_bounds__(256) void stage_mask_bwd_planar_kernel(const float*
 
 // dalpha[class] += the shares of the slots that carry the class, in slot order: one thread per class (round 6; one float atomic per slot before).
 __global__ __launch_bounds__(256) void stage_mask_dalpha_kernel(const float* __restrict__ share, const long long* __restrict__ y, float* __restrict__ dalpha, int BO, int n) {
+    __shared__ int ys[1024];
+    __shared__ float sh[1024];
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
     float s = 0.f;
-    for (int r = 0; r < BO; ++r)
-        if ((int)y[r] == c) s += share[r];
-    if (s != 0.f) dalpha[c] += s;
+    for (int r0 = 0; r0 < BO; r0 += 1024) {   // (slots staged in LDS: the scan is 256 LDS reads per thread, not 256 dependent global loads)
+        const int nr = min(1024, BO - r0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr; i += 256) { ys[i] = (int)y[r0 + i]; sh[i] = share[r0 + i]; }
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) s += ys[r] == c ? sh[r] : 0.f;
+    }
+    if (c < n && s != 0.f) dalpha[c] += s;
 }
 
 // backward, logits: dlogits[b,p,c] = sum_o [y[b,o] == c] gl[b,o,p] -- every element written (no zero fill + scatter_add).
@@ -664,7 +670,7 @@ extern "C" int l2i_class_logits_fwd(const float* a, const float* w, const float*
 }
 
 // dw [classes][ldw] and dbias [classes] are ADDED to (one workgroup per class, no atomics: deterministic). tmp: f32 scratch of
-// l2i_class_logits_bwd_parts(HH) * B * O * 128 floats (contents undefined before and after): the per-(pixel part, image, object) rows the first kernel
+// (l2i_class_logits_bwd_parts(HH) + 1) * B * O * 128 floats (contents undefined before and after): the per-(pixel part, image, object) rows the first kernel
 // stores (column 127: the bias gradient).
 extern "C" int l2i_class_logits_bwd(const float* a, const float* w, const long long* y, const float* gl, float* da, float* dw, float* dbias,
                                     float* tmp, int classes, int B, int O, int HH, int Cp, int C, int ldw, void* stream) {
@@ -674,7 +680,13 @@ extern "C" int l2i_class_logits_bwd(const float* a, const float* w, const long l
     const int per = HH >= 2048 ? 128 : 256;   // pixels per workgroup (more, shorter workgroups on the large maps: the loop is latency-bound)
     const int parts = (HH + per - 1) / per;
     hipLaunchKernelGGL(class_logits_bwd_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, a, w, y, gl, da, tmp, dbias ? tmp : nullptr, O, HH, Cp, C, ldw, per);
-    hipLaunchKernelGGL(class_logits_bwd_finish_kernel, dim3(classes), dim3(1024), 0, (hipStream_t)stream, (const float*)tmp, y, dw, dbias, B * O, C, ldw, parts);
+    const float* rows = tmp;
+    if (parts > 1) {   // the pixel parts of every (image, object) slot first, in order (slab `parts` of tmp), then the slots of a class
+        float* sum = tmp + (size_t)parts * B * O * 128;
+        rows_fold(tmp, parts, B * O * 128, 1, sum, nullptr, B * O * 128, 0, 0, nullptr, (hipStream_t)stream);
+        rows = sum;
+    }
+    hipLaunchKernelGGL(class_logits_bwd_finish_kernel, dim3(classes), dim3(1024), 0, (hipStream_t)stream, rows, y, dw, dbias, B * O, C, ldw, 1);
     return l2i_check_launch();
 }
 extern "C" int l2i_class_logits_bwd_parts(int HH) { return (HH + (HH >= 2048 ? 128 : 256) - 1) / (HH >= 2048 ? 128 : 256); }
@@ -776,14 +788,15 @@ __global__ __launch_bounds__(256) void proj_head_bwd_kernel(const float* __restr
     if (demb) {
         // dE[class] += sum over the rows that carry the class of g[r] f[r]: the FIRST such row's workgroup adds them all, in row order, and is the
         // only writer of dE[class] in this launch (round 6; rounds 2-5: one float atomic per row and channel, whose order changed from run to run)
-        int hit = 0;
-        for (int rr = threadIdx.x; rr < r; rr += 256) hit |= (y[rr] == cls);
-        if (__syncthreads_or(hit)) return;
+        __shared__ int rlist[L2I_CLASS_LIST];
+        __shared__ int wsum[4];
+        if (!class_first(y, r, cls)) return;
+        const int nl = class_rows(y, r, R, cls, rlist, wsum);
         for (int c = 4 * threadIdx.x; c < C; c += 1024) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int rr = r; rr < R; ++rr) {
+            for (int i = 0; i < nl; ++i) {
+                const int rr = rlist[i];
                 const float g2 = g[rr];
-                if (y[rr] != cls || g2 == 0.f) continue;
                 const float4 f = *reinterpret_cast<const float4*>(feat + (size_t)rr * C + c);
                 a.x = fmaf(g2, f.x, a.x); a.y = fmaf(g2, f.y, a.y); a.z = fmaf(g2, f.z, a.z); a.w = fmaf(g2, f.w, a.w);
             }
@@ -810,7 +823,7 @@ extern "C" int l2i_proj_head_fwd(const float* x, const void* wl, const void* emb
 extern "C" int l2i_proj_head_bwd(const float* x, const void* wl, const void* emb, int emb_stride, const long long* y,
                                  const float* g, const float* feat, float scale, float* dx, float* dwl, float* demb,
                                  int demb_stride, float* dbias, int R, int HW, int C, int dtype, void* dx_op_bf16, void* stream) {
-    if (!x || !wl || !g || !feat || !dx || (emb && !y) || (demb && !emb) || C % 4 || R < 0 || HW <= 0) return L2I_ERR_ARG;
+    if (!x || !wl || !g || !feat || !dx || (emb && !y) || (demb && !emb) || C % 4 || R < 0 || HW <= 0 || (demb && R > L2I_CLASS_LIST)) return L2I_ERR_ARG;
     if (R == 0) return L2I_OK;
     const int extra = (dwl || dbias) ? (C + 15) / 16 : 0;
     if (dtype == 1)
@@ -848,12 +861,12 @@ __global__ __launch_bounds__(256) void emb_dot_bwd_kernel(const T* __restrict__ 
     if ((int)blockIdx.x < R) {   // dE[class][c] += (sum of g over the class's rows) w2[c]: the first row of a class adds for all of them, in row order
         const int r = blockIdx.x;   // -- one writer per class row, no float atomics (round 6)
         const long long cls = y[r];
-        int hit = 0;
-        for (int rr = threadIdx.x; rr < r; rr += 256) hit |= (y[rr] == cls);
-        if (__syncthreads_or(hit)) return;
+        __shared__ int rlist[L2I_CLASS_LIST];
+        __shared__ int wsum[4];
+        if (!class_first(y, r, cls)) return;
+        const int nl = class_rows(y, r, R, cls, rlist, wsum);
         float s = 0.f;
-        for (int rr = r; rr < R; ++rr)
-            if (y[rr] == cls) s += g[rr];
+        for (int i = 0; i < nl; ++i) s += g[rlist[i]];
         if (s == 0.f) return;
         float* d = demb + (size_t)cls * demb_stride;
         for (int c = threadIdx.x; c < C; c += 256) d[c] += s * OpT<T>::to(w2[c]);
@@ -884,7 +897,7 @@ extern "C" int l2i_emb_dot_fwd(const void* emb, int emb_stride, const long long*
 
 extern "C" int l2i_emb_dot_bwd(const void* emb, int emb_stride, const long long* y, const void* w2, const float* g, float* demb,
                                int demb_stride, float* dw2, float* dbias, int R, int C, int dtype, void* stream) {
-    if (!emb || !y || !w2 || !g || !demb || !dw2 || R < 0 || C <= 0) return L2I_ERR_ARG;
+    if (!emb || !y || !w2 || !g || !demb || !dw2 || R < 0 || C <= 0 || R > L2I_CLASS_LIST) return L2I_ERR_ARG;
     if (R == 0) return L2I_OK;
     if (dtype == 1)
         hipLaunchKernelGGL(emb_dot_bwd_kernel<bf16_t>, dim3(R + (C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)emb,

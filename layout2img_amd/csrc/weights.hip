@@ -90,24 +90,39 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const long long* __restrict
     if (col < Kt) t_out[col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-// t[col] = sum over the row blocks, in order. table: (layer, col0, partial offset of the layer, row blocks)
+// t[col] = sum over the row blocks, in a fixed order. table: (layer, col0, partial offset of the layer, row blocks, columns per workgroup cw):
+// a workgroup = cw columns x (256 / cw) row lanes (cw = 256 for layers with few row blocks, 16 for the 16384-row fc layer: 256 blocks), the lanes
+// meet in a fixed-order tree in LDS.
 __global__ __launch_bounds__(256) void sn_tfold_kernel(const long long* __restrict__ layers, const int* __restrict__ table,
                                                        const float* __restrict__ tpart, float* __restrict__ pass_uv) {
-    const int* e = table + 4 * blockIdx.x;
+    __shared__ float red[256];
+    const int* e = table + 5 * blockIdx.x;
     const long long* L = layers + L2I_LSTRIDE * e[0];
     const int Kt = (int)(LF(4) * LF(5) * LF(5));
-    const int col = e[1] + threadIdx.x;
-    if (col >= Kt) return;
-    const float* q = tpart + e[2] + col;
+    const int cw = e[4], rl = 256 / cw;
+    const int tx = threadIdx.x & (cw - 1), ty = threadIdx.x / cw;
+    const int col = e[1] + tx;
     const int nrb = e[3];
     float t = 0.f;
-    int r = 0;
-    for (; r + 4 <= nrb; r += 4) {
-        const float a = q[(size_t)r * Kt], b = q[(size_t)(r + 1) * Kt], c = q[(size_t)(r + 2) * Kt], d = q[(size_t)(r + 3) * Kt];
-        t += (a + b) + (c + d);
+    if (col < Kt) {
+        const float* q = tpart + e[2] + col;
+        int r = ty;
+        for (; r + 3 * rl < nrb; r += 4 * rl) {
+            const float a = q[(size_t)r * Kt], b = q[(size_t)(r + rl) * Kt], c = q[(size_t)(r + 2 * rl) * Kt], d = q[(size_t)(r + 3 * rl) * Kt];
+            t += (a + b) + (c + d);
+        }
+        for (; r < nrb; r += rl) t += q[(size_t)r * Kt];
     }
-    for (; r < nrb; ++r) t += q[(size_t)r * Kt];
-    pass_uv[LF(17) + col] = t;
+    if (rl > 1) {
+        red[threadIdx.x] = t;
+        __syncthreads();
+        for (int st = rl >> 1; st >= 1; st >>= 1) {
+            if (ty < st) red[threadIdx.x] += red[threadIdx.x + st * cw];
+            __syncthreads();
+        }
+        t = red[threadIdx.x];
+    }
+    if (ty == 0 && col < Kt) pass_uv[LF(17) + col] = t;
 }
 
 // ---------------------------------------------------------------- phase 2: s = W vhat

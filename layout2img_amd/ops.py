@@ -1306,7 +1306,7 @@ class ClassLogitsFn(Function):
         dw = _zeros(tuple(w.shape), a.device)   # (slices of the step's pre-zeroed slab: consumed by the accumulations right behind this node)
         db = _zeros((ctx.nb,), a.device) if ctx.has_bias else None
         parts = -(-(H * W) // (128 if H * W >= 2048 else 256))   # (l2i_class_logits_bwd_parts: pixel parts of an image, one stored row each)
-        tmp = torch.empty((parts * B * O, 128), dtype=torch.float32, device=a.device)
+        tmp = torch.empty(((parts + 1) * B * O, 128), dtype=torch.float32, device=a.device)   # (+ one slab: the parts' sums)
         _lib.call("l2i_class_logits_bwd", a.data_ptr(), w.data_ptr(), y.data_ptr(), g.data_ptr(), da.data_ptr(), dw.data_ptr(), _p(db), tmp.data_ptr(),
                   w.shape[0], B, O, H * W, Cp, C, w.stride(0), _stream())
         da._l2i_owned = True   # (fresh, handed to exactly one consumer: NormActFn.backward may overwrite it)
