@@ -195,7 +195,9 @@ static __global__ __launch_bounds__(256) void rows_fold1_kernel(const float* __r
 // the producer anyway (wgrad_reduce_kernel, norm_a8_finish_kernel) can carry a fold in extra workgroups instead of one more launch.
 #define L2I_FOLD_DIRECT 1024
 struct RowsFoldArgs {
-    const float* src; int R, L; float* dst0; float* dst1; int C0; long long zs; int mode; float* dup; int ld; int cl; int nbx;   // nbx: workgroups along x
+    const float* src; int R, L;
+    float* dst[4]; int seg, segv;   // column i = segment k (= i / seg) x position j: added to dst[k][j] when j < segv and dst[k] is not null
+    long long zs; int mode; float* dup; int ld; int cl; int nbx;   // dup: a second destination of segment 0; nbx: workgroups along x
 };
 __device__ __forceinline__ void rows_fold2_body(const RowsFoldArgs& p, int bx, int bz, float4* red) {
     const int cl = p.cl, rl = 256 / cl;
@@ -231,13 +233,14 @@ __device__ __forceinline__ void rows_fold2_body(const RowsFoldArgs& p, int bx, i
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int i = 4 * c4 + e;
-            if (i >= p.C0 && !p.dst1) continue;   // (padding columns of the partial rows: no destination)
-            float* d = (i < p.C0 ? p.dst0 + i : p.dst1 + (i - p.C0)) + (size_t)bz * p.zs;
+            const int k = i / p.seg, jcol = i - k * p.seg;
+            if (k > 3 || !p.dst[k] || jcol >= p.segv) continue;   // (padding columns of the partial rows: no destination)
+            float* d = p.dst[k] + jcol + (size_t)bz * p.zs;
             if (p.mode == 2) atomicAdd(d, v[e]);
             else *d = p.mode ? *d + v[e] : v[e];
-            if (p.dup && i < p.C0) {   // a second destination of the same sums (a block's conv2 and shortcut share dY: one bias gradient, two biases)
-                if (p.mode == 2) atomicAdd(p.dup + i, v[e]);
-                else p.dup[i] = p.mode ? p.dup[i] + v[e] : v[e];
+            if (p.dup && k == 0) {   // a second destination of the same sums (a block's conv2 and shortcut share dY: one bias gradient, two biases)
+                if (p.mode == 2) atomicAdd(p.dup + jcol, v[e]);
+                else p.dup[jcol] = p.mode ? p.dup[jcol] + v[e] : v[e];
             }
         }
     }
@@ -246,18 +249,38 @@ static __global__ __launch_bounds__(256) void rows_fold2_kernel(RowsFoldArgs p) 
     __shared__ float4 red[256];
     rows_fold2_body(p, blockIdx.x, blockIdx.z, red);
 }
+// up to three independent folds (one group each) in one launch: blockIdx.y picks the job
+static __global__ __launch_bounds__(256) void rows_fold_multi_kernel(RowsFoldArgs a, RowsFoldArgs b, RowsFoldArgs c) {
+    __shared__ float4 red[256];
+    const RowsFoldArgs& p = blockIdx.y == 0 ? a : (blockIdx.y == 1 ? b : c);
+    if (!p.src || (int)blockIdx.x >= p.nbx) return;
+    rows_fold2_body(p, blockIdx.x, 0, red);
+}
 // floats of tmp a fold of (R rows, L columns, Z groups) needs
 static inline long long rows_fold_tmp_floats(int R, int L, int Z) { return R <= L2I_FOLD_DIRECT ? 0 : (long long)Z * L2I_FOLD_CHUNKS * L; }
 // The direct fold's arguments (R <= L2I_FOLD_DIRECT): columns [0, C0) go to dst0[z * zs + i], columns [C0, L) to dst1[z * zs + i - C0]
 // (dst1 null: nowhere); L % 4 == 0, part 16-byte aligned; ld: floats between two rows (0: L), a group's rows are R * ld apart.
-static inline RowsFoldArgs rows_fold_args(const float* part, int R, int L, int Z, float* dst0, float* dst1, int C0, long long zs, int mode, float* dup, int ld) {
+static inline RowsFoldArgs rows_fold_args4(const float* part, int R, int L, int Z, float* d0, float* d1, float* d2, float* d3, int seg, int segv, long long zs,
+                                           int mode, float* dup, int ld) {
     RowsFoldArgs a;
-    a.src = part; a.R = R; a.L = L; a.dst0 = dst0; a.dst1 = dst1; a.C0 = C0; a.zs = zs; a.mode = mode; a.dup = dup; a.ld = ld > 0 ? ld : L;
+    a.src = part; a.R = R; a.L = L; a.dst[0] = d0; a.dst[1] = d1; a.dst[2] = d2; a.dst[3] = d3; a.seg = seg > 0 ? seg : L; a.segv = segv;
+    a.zs = zs; a.mode = mode; a.dup = dup; a.ld = ld > 0 ? ld : L;
     int cl = 16;
     const int L4 = L / 4;
     while (cl > 1 && (long long)((L4 + cl - 1) / cl) * Z < 128 && 256 / cl < R) cl >>= 1;
     a.cl = cl; a.nbx = (L4 + cl - 1) / cl;
     return a;
+}
+static inline RowsFoldArgs rows_fold_args(const float* part, int R, int L, int Z, float* dst0, float* dst1, int C0, long long zs, int mode, float* dup, int ld) {
+    return rows_fold_args4(part, R, L, Z, dst0, dst1, nullptr, nullptr, dst1 ? C0 : L, C0, zs, mode, dup, ld);
+}
+// several direct folds (R <= L2I_FOLD_DIRECT, one group each) as ONE launch; jobs with src == null are skipped
+static inline void rows_fold_multi(const RowsFoldArgs& a, const RowsFoldArgs& b, const RowsFoldArgs& c, hipStream_t stream) {
+    int nbx = 0, ny = 0;
+    const RowsFoldArgs* js[3] = {&a, &b, &c};
+    for (int k = 0; k < 3; ++k)
+        if (js[k]->src) { ny = k + 1; if (js[k]->nbx > nbx) nbx = js[k]->nbx; }
+    if (ny) hipLaunchKernelGGL(rows_fold_multi_kernel, dim3(nbx, ny, 1), dim3(256), 0, stream, a, b, c);
 }
 static inline void rows_fold(const float* part, int R, int L, int Z, float* dst0, float* dst1, int C0, long long zs, int mode, float* tmp, hipStream_t stream,
                              float* dup = nullptr, int ld = 0) {

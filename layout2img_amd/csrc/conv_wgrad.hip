@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int ntiles, int splits, int Co, int K, int ldw, float alpha, int nw2, int sper,
                                                            int tiles_k_main, float* __restrict__ dw2, int K2, int ldw2,
                                                            float* __restrict__ dw_b, float* __restrict__ dw2_b, int overwrite, float4* __restrict__ part_out,
-                                                           RowsFoldArgs bias_fold, int nbx_main) {
+                                                           RowsFoldArgs bias_fold, int nbx_main, int sl) {
     // workgroups [nbx_main, gridDim.x) of the first (group, pass) plane: the ordered sum of the launch's bias-gradient rows (rows_fold2_body) --
     // carried here instead of one more launch behind every weight-gradient launch (round 6)
     if ((int)blockIdx.x >= nbx_main) {
@@ -823,13 +823,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         if (blockIdx.y == 0 && blockIdx.z == 0 && bias_fold.src) rows_fold2_body(bias_fold, (int)blockIdx.x - nbx_main, 0, fold_red);
         return;
     }
-    // blockIdx.y = group of `sper` consecutive splits: layers with few tiles and many splits (the 64-channel layers at
-    // 128 x 128: 5 tiles x 153 splits) otherwise run on 40 workgroups, each thread walking 153 partial tiles one dependent
-    // load after the other (18 us of a 69-us weight gradient). Groups combine with f32 atomics (gridDim.y > 1 only).
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    // Layers with few tiles and many splits (the 64-channel layers at 128 x 128: 5 tiles x 153 splits) would run on 40 workgroups, each thread
+    // walking 153 partial tiles one dependent load after the other (18 us of a 69-us weight gradient). Round 6: `sl` SPLIT LANES per float4 slot
+    // (a power of two <= 16): a workgroup owns 256 / sl slots, lane q of a slot adds splits q, q + sl, ... and the lanes meet in a fixed-order
+    // tree in LDS -- one launch, one writer per value, no atomics (rounds 2-5: split GROUPS on blockIdx.y combined by float atomics).
+    __shared__ float4 lane_red[256];
+    const int nslots = 256 / sl, slot = threadIdx.x % nslots, q = threadIdx.x / nslots;
+    const long long gid = (long long)blockIdx.x * nslots + slot;
     const int per_tile = BMO * 32;                      // float4 per tile
     const int tile = (int)(gid / per_tile), f = (int)(gid - (long long)tile * per_tile);
-    if (tile >= ntiles) return;
+    const bool live = tile < ntiles;
     int tile_k = tile % tiles_k;
     const int tile_co = tile / tiles_k;
     // dual launch (gridDim.z == 2): the second half of the splits belongs to the second pass's accumulators
@@ -845,20 +848,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int wrow = nw2 ? 0 : (wq >> 1) * (BMO / 2), wcol = (nw2 ? wq : (wq & 1)) * 64;
     const int row0 = tile_co * BMO + wrow + i * 32 + 8 * g + 4 * (lane >> 5), col = tile_k * 128 + wcol + j * 32 + (lane & 31);
     const size_t tsz4 = (size_t)BMO * 32;
-    const float4* src = reinterpret_cast<const float4*>(part) + (size_t)tile * splits * tsz4 + f;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = s_off + blockIdx.y * sper;
-    const int s_end = min(s_off + hs, s + sper);
-    for (; s + 4 <= s_end; s += 4) {
-        const float4 v0 = src[(size_t)s * tsz4], v1 = src[(size_t)(s + 1) * tsz4];
-        const float4 v2 = src[(size_t)(s + 2) * tsz4], v3 = src[(size_t)(s + 3) * tsz4];
-        a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
-        a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    if (live) {
+        const float4* src = reinterpret_cast<const float4*>(part) + (size_t)tile * splits * tsz4 + f;
+        int s = s_off + blockIdx.y * sper + q;
+        const int s_end = min(s_off + hs, s_off + (int)blockIdx.y * sper + sper);
+        for (; s + 3 * sl < s_end; s += 4 * sl) {
+            const float4 v0 = src[(size_t)s * tsz4], v1 = src[(size_t)(s + sl) * tsz4];
+            const float4 v2 = src[(size_t)(s + 2 * sl) * tsz4], v3 = src[(size_t)(s + 3 * sl) * tsz4];
+            a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+            a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; s < s_end; s += sl) {
+            const float4 v0 = src[(size_t)s * tsz4];
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+        }
     }
-    for (; s < s_end; ++s) {
-        const float4 v0 = src[(size_t)s * tsz4];
-        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    if (sl > 1) {
+        lane_red[threadIdx.x] = a;
+        __syncthreads();
+        for (int st = sl >> 1; st >= 1; st >>= 1) {
+            if (q < st) {
+                const float4 u = lane_red[threadIdx.x], v = lane_red[threadIdx.x + st * nslots];
+                lane_red[threadIdx.x] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+            }
+            __syncthreads();
+        }
+        a = lane_red[threadIdx.x];
     }
+    if (!live || q != 0) return;
     if (part_out) {   // first stage of a two-stage reduction (split groups): the group's sum, unscaled, in the partial tiles' own layout
         part_out[((size_t)tile * (gridDim.y * gridDim.z) + blockIdx.z * gridDim.y + blockIdx.y) * tsz4 + f] = a;   // [tile][pass][group]: the second
         return;                                                                                                     // stage reads it as `splits` = groups
@@ -1010,16 +1028,16 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
         static const int use_part = getenv("L2I_WGRAD_PART") ? atoi(getenv("L2I_WGRAD_PART")) : 1;   // (0: atomics, A/B)
         if (use_part && scratch && (a.splits > 1 || dual) && (long long)nblk * BMO * 128 <= scratch_floats) a.part = scratch;
         // split groups of the reduce kernel (computed here: the groups combine with atomics, which needs cleared slices under `overwrite`)
-        int sg = 1, sper = a.splits;
+        int sg = 1, sper = a.splits, sl = 1;   // (sg / sper: the split GROUPS of rounds 2-5, kept in the kernel, no longer planned: sl split lanes instead)
         if (a.part) {
             const unsigned nbx_ = (unsigned)(((long long)tiles * BMO * 32 + 255) / 256);
             const int hsp_ = dual ? a.splits / 2 : a.splits;
+            sper = hsp_;
             if (nbx_ * (dual ? 2u : 1u) < 512 && hsp_ > 8) {
-                sg = (int)((512 + nbx_ - 1) / nbx_);
-                if (sg > (hsp_ + 7) / 8) sg = (hsp_ + 7) / 8;
+                int want = (int)((512 + nbx_ - 1) / nbx_);
+                if (want > (hsp_ + 7) / 8) want = (hsp_ + 7) / 8;
+                while (sl < want && sl < 16) sl <<= 1;
             }
-            sper = (hsp_ + sg - 1) / sg;
-            sg = (hsp_ + sper - 1) / sper;
         }
         if (!a.part && a.splits > 1 && clear_targets() != L2I_OK) return L2I_ERR_LAUNCH;   // (atomics straight from the main kernel)
         // fused reduction (last arriver per tile): the plain four-wave kernel with <= 16 splits per accumulator; its counters are a
@@ -1112,7 +1130,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
         if (a.part && a.fuse_cnt) { fold_bias(); return l2i_check_launch(); }   // (the last arrivers reduced the splits)
         if (a.part) {
             const long long nthr = (long long)tiles * BMO * 32;
-            const unsigned nbx = (unsigned)((nthr + 255) / 256);
+            const unsigned nbx = (unsigned)((nthr + 256 / sl - 1) / (256 / sl));
             const int nw2l = (int)(nw2 && !nw8 && BMO == 128);
             // split groups: enough workgroups to fill the chip (>= ~512), at least 8 splits per group
             // (sg split groups of sper splits each: computed above)
@@ -1121,14 +1139,14 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             if (part2) {   // two stages, no atomics: groups -> part2, then the groups of a tile in order -> dw
                 L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx, (unsigned)sg, (unsigned)nz_), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
                            a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, nw2l, sper,
-                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, reinterpret_cast<float4*>(part2), nobf, (int)nbx);
+                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, reinterpret_cast<float4*>(part2), nobf, (int)nbx, sl);
                 L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx_b, 1u, (unsigned)nz_), dim3(256), 0, stream, (const float*)part2, a.dw, BMO,
                            a.tiles_k, tiles, sg * nz_, a.Co, a.K, a.ldw, a.alpha, nw2l, sg,
-                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, (float4*)nullptr, bias_ride ? bf : nobf, (int)nbx);
+                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, (float4*)nullptr, bias_ride ? bf : nobf, (int)nbx, sl);
             } else {
                 L2I_LAUNCH(1, wgrad_reduce_kernel, dim3(nbx_b, (unsigned)sg, (unsigned)nz_), dim3(256), 0, stream, (const float*)a.part, a.dw, BMO,
                            a.tiles_k, tiles, a.splits, a.Co, a.K, a.ldw, a.alpha, nw2l, sper,
-                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, (float4*)nullptr, bias_ride ? bf : nobf, (int)nbx);
+                           a.tiles_k_main, a.sc_dw, a.sc_Ci, a.sc_ldw, a.dw_b, a.sc_dw_b, a.overwrite, (float4*)nullptr, bias_ride ? bf : nobf, (int)nbx, sl);
             }
         }
         fold_bias();

@@ -351,10 +351,15 @@ extern "C" int l2i_add_layernorm_bwd(const float* a, int lda, const float* b, in
     p.Dp = (D + 3) & ~3;
     p.gpart = (scratch && !((size_t)scratch & 15) && (long long)nblk * 2 * p.Dp + rows_fold_tmp_floats(nblk, 2 * p.Dp, 1) <= scratch_floats) ? scratch : nullptr;
     hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
-    if (p.gpart) {   // columns [0, D) -> dgamma, [Dp, Dp + D) -> dbeta: two folds over the same rows (row stride 2 Dp)
-        float* tmp = p.gpart + (size_t)nblk * 2 * p.Dp;
-        rows_fold(p.gpart, nblk, p.Dp, 1, dgamma, nullptr, D, 0, 1, tmp, (hipStream_t)stream, nullptr, 2 * p.Dp);
-        rows_fold(p.gpart + p.Dp, nblk, p.Dp, 1, dbeta, nullptr, D, 0, 1, tmp, (hipStream_t)stream, nullptr, 2 * p.Dp);
+    if (p.gpart) {   // columns [0, D) -> dgamma, [Dp, Dp + D) -> dbeta: two segments of one fold
+        if (nblk <= L2I_FOLD_DIRECT) {
+            const RowsFoldArgs f = rows_fold_args4(p.gpart, nblk, 2 * p.Dp, 1, dgamma, dbeta, nullptr, nullptr, p.Dp, D, 0, 1, nullptr, 2 * p.Dp);
+            hipLaunchKernelGGL(rows_fold2_kernel, dim3(f.nbx, 1, 1), dim3(256), 0, (hipStream_t)stream, f);
+        } else {
+            float* tmp = p.gpart + (size_t)nblk * 2 * p.Dp;
+            rows_fold(p.gpart, nblk, p.Dp, 1, dgamma, nullptr, D, 0, 1, tmp, (hipStream_t)stream, nullptr, 2 * p.Dp);
+            rows_fold(p.gpart + p.Dp, nblk, p.Dp, 1, dbeta, nullptr, D, 0, 1, tmp, (hipStream_t)stream, nullptr, 2 * p.Dp);
+        }
     }
     return l2i_check_launch();
 }

@@ -869,14 +869,16 @@ __global__ __launch_bounds__(256, 2) void norm_bwd_a8_kernel(NormArgs p, int nse
 // the others add the nseg partial dW / dB rows of every (image, channel chunk) into dwproj / dbproj (float4 per thread).
 __global__ __launch_bounds__(256) void norm_a8_finish_kernel(WsFoldArgs f, int nfold, const float4* __restrict__ part, float* dw, float* db,
                                                              int B, int tiles_c, int nseg, int CV, int C, int O, long long psb, long long pso,
-                                                             RowsFoldArgs sf, int n_sf) {
-    if ((int)blockIdx.x < n_sf) {   // the ordered sum of the workgroups' s1 / s2 rows (round 6) rides on this launch
+                                                             RowsFoldArgs sf, RowsFoldArgs df) {
+    const int n_sf = sf.src ? sf.nbx : 0, n_df = df.src ? df.nbx : 0;
+    if ((int)blockIdx.x < n_sf + n_df) {   // the ordered sums of the workgroups' s1 / s2 rows and of the channel chunks' dmask rows (round 6) ride on this launch
         __shared__ float4 fold_red[256];
-        rows_fold2_body(sf, blockIdx.x, 0, fold_red);
+        if ((int)blockIdx.x < n_sf) rows_fold2_body(sf, blockIdx.x, 0, fold_red);
+        else rows_fold2_body(df, blockIdx.x - n_sf, 0, fold_red);
         return;
     }
-    if ((int)blockIdx.x < n_sf + nfold) { ws_fold_body(f, blockIdx.x - n_sf); return; }
-    const int idx = (blockIdx.x - n_sf - nfold) * 256 + threadIdx.x;
+    if ((int)blockIdx.x < n_sf + n_df + nfold) { ws_fold_body(f, blockIdx.x - n_sf - n_df); return; }
+    const int idx = (blockIdx.x - n_sf - n_df - nfold) * 256 + threadIdx.x;
     const int row = 16 * CV;   // float4 values per partial row: [2 passes][8 objects][CV]
     const int r = idx % row, bt = idx / row;
     if (bt >= B * tiles_c) return;
@@ -1162,28 +1164,29 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
     } else
     hipLaunchKernelGGL(norm_bwd_a_kernel, dim3(B * nseg * tiles_c), dim3(256), norm_bwd_lds(a), (hipStream_t)stream, a, nseg,
                        seg_pixels);
-    bool stats_folded = false;
-    if (fin_ns) {   // one launch: the workspace fold (if any) and the sum of the partial rows
+    // The ordered folds behind the launch: s1 / s2 (+ the affine layer's dW / dB: four destinations of one job) and the channel chunks' dmask rows.
+    // Direct jobs over one group ride on the finish launch when there is one, else they are ONE multi-job launch; others get their own launches.
+    RowsFoldArgs sf = {}, df = {};
+    const bool stats_direct = a.spart && stat_z == 1 && stat_rows <= L2I_FOLD_DIRECT;
+    if (stats_direct) sf = rows_fold_args4(a.spart, stat_rows, nval * C, 1, s1, s2, mode == 1 ? dwproj : nullptr, mode == 1 ? dbproj : nullptr, C, C, 0, 2, nullptr, nval * C);
+    if (a.dmpart) df = rows_fold_args4(a.dmpart, k_tc, (int)n_dm, 1, dmask, nullptr, nullptr, nullptr, (int)n_dm, (int)n_dm, 0, dmask_fresh ? 0 : 1, nullptr, (int)n_dm);
+    if (fin_ns) {   // one launch: the workspace fold (if any), the sum of the partial dW / dB rows, and the folds above
         WsFoldArgs f = {};
         f.ws = a.ws; f.dst[0] = s1; f.dst[1] = s2; f.L = 2 * C; f.C = C;
         const int nfold = a.ws ? (2 * C + 255) / 256 : 0;
         const int nfin = (int)(((long long)B * fin_tc * 16 * fin_cv + 255) / 256);
-        RowsFoldArgs sf = {};
-        int n_sf = 0;
-        if (a.spart && stat_z == 1 && stat_rows <= L2I_FOLD_DIRECT && mode != 1) {   // the s1 / s2 fold rides on this launch
-            sf = rows_fold_args(a.spart, stat_rows, 2 * C, 1, s1, s2, C, 0, 1, nullptr, nval * C);
-            n_sf = sf.nbx;
-            stats_folded = true;
-        }
-        hipLaunchKernelGGL(norm_a8_finish_kernel, dim3(n_sf + nfold + nfin), dim3(256), 0, (hipStream_t)stream, f, nfold, (const float4*)part, dwproj,
-                           dbproj, B, fin_tc, fin_ns, fin_cv, C, O, pstride_b, pstride_o, sf, n_sf);
-    } else if (a.ws) ws_fold(a.ws, (mode == 1 ? 4 : 2) * C, C, s1, s2, dwproj, dbproj, (hipStream_t)stream);
-    if (a.spart && !stats_folded) {   // s1 / s2 += the workgroups' rows, in order (batch statistics: all rows; per-image statistics: an image's segments)
+        hipLaunchKernelGGL(norm_a8_finish_kernel, dim3(sf.nbx + df.nbx + nfold + nfin), dim3(256), 0, (hipStream_t)stream, f, nfold, (const float4*)part, dwproj,
+                           dbproj, B, fin_tc, fin_ns, fin_cv, C, O, pstride_b, pstride_o, sf, df);
+    } else {
+        if (a.ws) ws_fold(a.ws, (mode == 1 ? 4 : 2) * C, C, s1, s2, dwproj, dbproj, (hipStream_t)stream);
+        RowsFoldArgs none = {};
+        rows_fold_multi(sf, df, none, (hipStream_t)stream);
+    }
+    if (a.spart && !stats_direct) {   // (per-image statistics, or more rows than one direct fold takes)
         rows_fold(a.spart, stat_rows, 2 * C, stat_z, s1, s2, C, stat_stride, 1, stat_tmp, (hipStream_t)stream, nullptr, nval * C);
         if (mode == 1)   // the affine layer's dW / dB: columns [2C, 4C) of the same rows, over ALL images
             rows_fold(a.spart + 2 * C, B * k_ns, 2 * C, 1, dwproj, dbproj, C, 0, 2, stat_tmp, (hipStream_t)stream, nullptr, nval * C);
     }
-    if (a.dmpart) rows_fold(a.dmpart, k_tc, (int)n_dm, 1, dmask, nullptr, (int)n_dm, 0, dmask_fresh ? 0 : 1, nullptr, (hipStream_t)stream);
     return l2i_check_launch();
 }
 
