@@ -158,7 +158,7 @@ __device__ __forceinline__ int class_rows(const long long* __restrict__ y, int r
 // run, so a per-channel total -- a batch statistic -- moves in its last bits, a ReLU gate further on flips, and two runs of the same f32
 // training step differ by ~1e-3 of the gradient. Where the partial sums of a launch have a natural owner (a wave of a convolution tile,
 // a slab of a statistics pass) they are STORED as rows part[z][r][0..L) in the stream's scratch instead and summed here in a fixed
-// order: dst[z * zs + i] (+)= sum_r part[z][r][i]. One small launch up to 1024 rows, two above (row chunks -> tmp[z][chunk][L], chunks -> dst). Plain stores also run at several times the rate of float atomics on this chip (DESIGN A.3 4.1b).
+// order: dst[z * zs + i] (+)= sum_r part[z][r][i]. One small launch up to 16384 rows, two above (row chunks -> tmp[z][chunk][L], chunks -> dst). Plain stores also run at several times the rate of float atomics on this chip (DESIGN A.3 4.1b).
 // The pairwise order inside a thread, across the row lanes of a workgroup and across the chunks is fixed by (R, L) alone.
 #define L2I_FOLD_CHUNKS 64
 static __global__ __launch_bounds__(256) void rows_fold1_kernel(const float* __restrict__ part, int R, int L, int rc, float* __restrict__ tmp, int ld) {
@@ -193,7 +193,7 @@ static __global__ __launch_bounds__(256) void rows_fold1_kernel(const float* __r
 // many workgroups and tall ones many row lanes): a thread adds every (256 / cl)-th row, four loads in flight, the row lanes meet in a
 // fixed-order tree in LDS. Up to L2I_FOLD_DIRECT rows in this one launch. The body is a device function so that a kernel which runs behind
 // the producer anyway (wgrad_reduce_kernel, norm_a8_finish_kernel) can carry a fold in extra workgroups instead of one more launch.
-#define L2I_FOLD_DIRECT 1024
+#define L2I_FOLD_DIRECT 16384
 struct RowsFoldArgs {
     const float* src; int R, L;
     float* dst[4]; int seg, segv;   // column i = segment k (= i / seg) x position j: added to dst[k][j] when j < segv and dst[k] is not null

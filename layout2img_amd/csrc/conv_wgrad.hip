@@ -63,6 +63,7 @@ struct WgradArgs {
     float* bpart;     // bias-gradient shares: row (split x nb_bias + tile_k) of [splits * nb_bias][bpart_ld], alpha applied, STORED by the workgroups
     int bpart_ld;     // that sum the bias (tiles_co * BMO columns); rows_fold adds the rows in order behind the launch. null: one atomic per channel
     float* part_rm;   // generic kernel (f32 operands, odd shapes): partial tiles stored ROW-major [tile][split][BMO][128], summed by wgrad_reduce_rm_kernel
+    int nb_bias;      // LDS-DMA kernel: column tiles that share a (channel tile, split)'s bias sum (1, 2 or 4: set by the launcher)
 };
 
 // grid-wide clear of one dW slice (n floats) by the threads of the weight-gradient kernel
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_wgrad_dma_kerne
     // 256 / A_CH partial sums per channel are combined at the end.
     // (Shared by only min(tiles_k, 4) of them, and combined across the four waves in LDS: every atomic on a bias
     // address costs ~0.09 us of serialised tail, and 500+ workgroups adding to the same 128 addresses tripled the launch.)
-    const int nb_bias = p.tiles_k_main >= 4 ? 4 : (p.tiles_k_main >= 2 ? 2 : 1);   // (a power of two)
+    const int nb_bias = p.nb_bias;   // (a power of two: 4 / 2 / 1 by the number of column tiles; 1 on unsplit launches, see launch_wgrad)
     const bool do_bias = (p.dbias != nullptr || p.dbias2 != nullptr) && tile_k < nb_bias;
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr int BS_PG = NT / A_CH, BS_PP = BK / BS_PG;   // pixel groups, pixels per thread per step
@@ -1069,9 +1070,14 @@ static int launch_wgrad(WgradArgs& a, hipStream_t stream, float* scratch, long l
             if (used + need2 <= scratch_floats) { part2 = scratch + used; used += need2; }
         }
         a.bpart = nullptr; a.bpart_ld = 0; a.part_rm = nullptr;
-        const int nb_bias = a.tiles_k_main >= 4 ? 4 : (a.tiles_k_main >= 2 ? 2 : 1);   // (as in conv_wgrad_dma_kernel)
+        // an unsplit single-pass launch (the 1024-channel layers on 4- / 8-pixel maps: more tiles than workgroup slots, few pixels): ONE column
+        // tile sums a channel tile's bias and adds it with one atomic per channel -- a single contribution per address and launch is already
+        // order-independent, and there is no reduce launch for a fold to ride on
+        const bool lone = a.splits == 1 && !dual;
+        const int nb_bias = lone ? 1 : (a.tiles_k_main >= 4 ? 4 : (a.tiles_k_main >= 2 ? 2 : 1));
+        a.nb_bias = nb_bias;
         const int bias_rows = a.splits * nb_bias, bias_ld = a.tiles_co * BMO;
-        if ((a.dbias || a.dbias2) && scratch) {
+        if ((a.dbias || a.dbias2) && scratch && !lone) {
             const long long needb = (long long)bias_rows * bias_ld + rows_fold_tmp_floats(bias_rows, bias_ld, 1);
             if (used + needb <= scratch_floats) { a.bpart = scratch + used; a.bpart_ld = bias_ld; used += needb; }
         }
@@ -1223,7 +1229,7 @@ extern "C" int l2i_conv2d_wgrad_dual(const void* x, const void* dy, float* dw, i
     a.sc_x = sc_x; a.sc_dw = sc_x ? sc_dw : nullptr; a.dbias2 = sc_x ? sc_dbias : nullptr; a.sc_Ci = sc_Ci; a.sc_ldw = sc_ldw; a.sc_up2 = sc_up2 ? 1 : 0;
     a.sc_x_bytes = 0; a.tiles_k_main = 0;
     a.dw_b = dw_b; a.sc_dw_b = (sc_x && dw_b) ? sc_dw_b : nullptr;
-    a.fuse_cnt = nullptr; a.nw2_layout = 0; a.overwrite = overwrite ? 1 : 0; a.zero_targets = 0;
+    a.fuse_cnt = nullptr; a.nw2_layout = 0; a.overwrite = overwrite ? 1 : 0; a.zero_targets = 0; a.nb_bias = 1; a.bpart = nullptr; a.bpart_ld = 0; a.part_rm = nullptr;
     a.x = x; a.dy = dy; a.dw = dw;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.KH = KH;
     a.up2 = up2 ? 1 : 0; a.pool2 = pool2 ? 1 : 0; a.ldw = ldw; a.alpha = alpha;
