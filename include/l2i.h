@@ -265,7 +265,8 @@ int l2i_hinge_fwd_bwd(const float* x, const int* valid, int n, int mode, float w
                       float* loss_out, float* grad, void* stream);
 
 /* L1 pixel loss with fused backward (train_context_app_v2.py:143,184). */
-int l2i_l1_fwd_bwd(const float* a, const float* b, long long n, float weight, float* loss_out, float* grad, void* stream);
+int l2i_l1_fwd_bwd(const float* a, const float* b, long long n, float weight, float* loss_out, float* grad, float* part, void* stream);
+/* (part: optional scratch of >= 4096 floats, 16-byte aligned: the workgroups' shares of the loss, added in order behind the launch -- no float atomics) */
 
 /* torch.optim.Adam step over one flat buffer (train_context_app_v2.py:121,127,174,189). step_ptr (optional): device
  * int holding the step count t >= 1, read by the kernel instead of `step` -- lets a captured HIP graph of the whole

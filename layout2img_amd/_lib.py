@@ -43,7 +43,7 @@ SIGNATURES = {
     "l2i_box_attention_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "l2i_box_attention_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "l2i_hinge_fwd_bwd": [_p, _p, _i, _i, _f, _p, _p, _p, _p],
-    "l2i_l1_fwd_bwd": [_p, _p, _ll, _f, _p, _p, _p],
+    "l2i_l1_fwd_bwd": [_p, _p, _ll, _f, _p, _p, _p, _p],
     "l2i_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p, _p],
     "l2i_cast_op": [_p, _p, _p, _ll, _i, _p],
     "l2i_split_cast": [_p, _p, _ll, _i, _i, _p],

@@ -280,7 +280,11 @@ class WeightArena:
                 # the weight-gradient launch sums the bias gradient over all Co_p columns there (cleared with the accumulated
                 # slices), flush_grads adds the first Co values to the bias gradient (ops.FusedConvFn.backward)
                 for h, use in rows:
-                    if use == 0 and h.kind == "conv" and h.bias is not None and h.co != h.co_p and id(h) not in member_of:
+                    # (also: a convolution applied several times per forward -- block_obj4. Its bias gradient has 2 uses x 2 passes = 4 contributions;
+                    #  added straight into the shared gradient from two streams they would meet in an order that changes with the interleaving of
+                    #  the streams -- eager and replayed iterations differed in their last bits. Per pass the uses add in stream order into the slot,
+                    #  flush_grads adds the passes' slots in a fixed order: round 6)
+                    if use == 0 and h.kind == "conv" and h.bias is not None and (h.co != h.co_p or h.uses > 1) and id(h) not in member_of:
                         h.bias_scr_off = dw_len
                         self.bias_slots.append((dw_len, dw_len + _round_up(h.co_p, ALIGN)))
                         dw_len += _round_up(h.co_p, ALIGN)

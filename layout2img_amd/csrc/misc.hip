@@ -45,7 +45,7 @@ extern "C" int l2i_hinge_fwd_bwd(const float* x, const int* valid, int n, int mo
 }
 
 __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
-                                                 float weight, float* __restrict__ loss_out, float* __restrict__ grad) {
+                                                 float weight, float* __restrict__ loss_out, float* __restrict__ grad, float* __restrict__ part) {
     __shared__ float red[16];
     float acc = 0.f;
     const float gs = weight / (float)n;
@@ -55,15 +55,24 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, co
         grad[i] = d > 0.f ? gs : d < 0.f ? -gs : 0.f;
     }
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(loss_out, acc * gs);
+    if (threadIdx.x == 0) {
+        if (part) *reinterpret_cast<float4*>(part + 4 * blockIdx.x) = make_float4(acc * gs, 0.f, 0.f, 0.f);   // this workgroup's share: a 4-float row
+        else atomicAdd(loss_out, acc * gs);
+    }
 }
 
-extern "C" int l2i_l1_fwd_bwd(const float* a, const float* b, long long n, float weight, float* loss_out, float* grad,
+// part (optional, 16-byte aligned, >= 4096 floats, contents undefined afterwards): the workgroups' shares of the loss are stored there and added in
+// order by a fold launch -- the loss VALUE is then bit-identical from run to run like its gradient (round 6); null: one float atomic per workgroup.
+extern "C" int l2i_l1_fwd_bwd(const float* a, const float* b, long long n, float weight, float* loss_out, float* grad, float* part,
                               void* stream) {
-    if (!a || !b || !loss_out || !grad || n <= 0) return L2I_ERR_ARG;
+    if (!a || !b || !loss_out || !grad || n <= 0 || ((size_t)part & 15)) return L2I_ERR_ARG;
     long long nblk = (n + 255) / 256;
     if (nblk > 1024) nblk = 1024;
-    hipLaunchKernelGGL(l1_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a, b, n, weight, loss_out, grad);
+    hipLaunchKernelGGL(l1_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a, b, n, weight, loss_out, grad, part);
+    if (part) {
+        const RowsFoldArgs f = rows_fold_args4(part, (int)nblk, 4, 1, loss_out, nullptr, nullptr, nullptr, 4, 1, 0, 1, nullptr, 4);
+        hipLaunchKernelGGL(rows_fold2_kernel, dim3(f.nbx, 1, 1), dim3(256), 0, (hipStream_t)stream, f);
+    }
     return l2i_check_launch();
 }
 

@@ -670,7 +670,7 @@ class FusedConvFn(Function):
         lazy_ = getattr(ctx, "lazy", None)
         if pc.need_wgrad and ctx.has_bias:
             bg = h.bias.grad
-            direct = bg is not None and h.co == h.co_p and bg.is_contiguous() and bg.dtype == torch.float32
+            direct = bg is not None and h.co == h.co_p and bg.is_contiguous() and bg.dtype == torch.float32 and getattr(h, "uses", 1) == 1
             if direct:   # the weight-gradient launch sums the bias gradient from the dY tiles it stages, straight into the
                 dbias = bg   # flat gradient buffer: no pass over dY at all when its operand copy already exists
             elif (BIAS_SLOTS and bg is not None and getattr(h, "bias_scr_off", None) is not None and not pc.dual and dy_op is not None
@@ -701,6 +701,9 @@ class FusedConvFn(Function):
                 hs = sl["holder"]
                 bgs = hs.bias.grad if hs.bias is not None else None
                 direct_s = hs.bias is None or (bgs is not None and hs.co == hs.co_p and bgs.is_contiguous() and bgs.dtype == torch.float32)
+                if direct_s and hs.bias is not None and getattr(hs, "uses", 1) > 1:   # a weight applied several times per forward: through the pass's slot
+                    bgs = pc.bias_slot(hs, bgs) if (BIAS_SLOTS and getattr(hs, "bias_scr_off", None) is not None and not pc.dual) else None
+                    direct_s = bgs is not None
                 if direct_s and hs.co_p == h.co_p:
                     scw = dict(x_op=sl["x_op"], dw=pc.dw_slice(hs), dw_b=pc.dw_slice_b(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"], up2=sl["up2"])
                     sl["wgrad_done"] = True
@@ -1531,7 +1534,7 @@ class L1Fn(Function):
         loss = torch.zeros((), dtype=torch.float32, device=a.device)
         grad = torch.empty_like(ac)
         _lib.call("l2i_l1_fwd_bwd", ac.data_ptr(), bc.data_ptr(), ac.numel(), float(weight), loss.data_ptr(), grad.data_ptr(),
-                  _stream())
+                  _lib.wgrad_scratch(a.device)[0], _stream())   # (the workgroups' shares of the loss: stored in the scratch, added in order)
         ctx.save_for_backward(grad)
         return loss
 
