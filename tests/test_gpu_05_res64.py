@@ -163,9 +163,9 @@ def test_graph_replay_matches_eager():
         ob = tb.step_graphed(real, label, bbox, z, z_im)
     torch.cuda.synchronize()
     assert int(tb.d_opt.t_dev) == 5 and int(tb.g_opt.t_dev) == 5
+    # round 6: five eager iterations == two eager warm-ups + three replays, bit for bit (no float atomics on the path; rounds 2-5: 93 % of the
+    # parameters within 1e-4)
     for k in ("d_loss", "g_loss"):
-        assert abs(float(oa[k]) - float(ob[k])) <= 5e-2 * max(1.0, abs(float(oa[k]))), (k, float(oa[k]), float(ob[k]))
+        assert float(oa[k]) == float(ob[k]), (k, float(oa[k]), float(ob[k]))
     for a, b in ((ga.flat.data, gb.flat.data), (da.flat.data, db.flat.data)):
-        diff = (a - b).abs()
-        assert float((diff < 1e-4).float().mean()) > 0.93   # (two eager runs agree to 0.995-0.998 by this measure)
-        assert float(diff.max()) <= 3e-3
+        assert torch.equal(a, b), float((a - b).abs().max())
