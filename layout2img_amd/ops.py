@@ -668,7 +668,8 @@ class FusedConvFn(Function):
         dy_op = dy if ctx.op_out else _sibling(dy, "raw", opd)
         dbias = None
         lazy_ = getattr(ctx, "lazy", None)
-        if pc.need_wgrad and ctx.has_bias:
+        # (a lazy shortcut whose consumer -- conv2 -- already computed its weight AND bias gradient with its own launch: nothing to do here)
+        if pc.need_wgrad and ctx.has_bias and not (lazy_ is not None and lazy_["wgrad_done"]):
             bg = h.bias.grad
             direct = bg is not None and h.co == h.co_p and bg.is_contiguous() and bg.dtype == torch.float32 and getattr(h, "uses", 1) == 1
             if direct:   # the weight-gradient launch sums the bias gradient from the dY tiles it stages, straight into the

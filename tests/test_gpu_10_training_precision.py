@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bf16_training_tracks_f32_training_over_the_first_10_iterations():
     sys.path.insert(0, os.path.join(ROOT, "tools", "parity"))
     import bf16_vs_f32_training as T
-    rows = {r["it"]: r for r in T.compare(iters=10, batch=32, size=128, n_f32=2, n_bf16=1)}
+    rows = {r["it"]: r for r in T.compare(iters=10, batch=32, size=128, n_f32=1, n_bf16=1)}
     rel = lambda a, b: abs(a - b) / max(1.0, abs(b))
     # (round 6: the bf16 run is reproducible -- forward bit-identical from run to run -- so one run is THE value, not a draw: measured on an MI355X at
     #  t = 2: d_loss 5.3e-4, g_loss 2.24e-3 of max(1, |f32|); the round-5 bars (1.5 x the largest of three noisy runs, 1.5e-3) sat below it)
@@ -31,9 +31,7 @@ def test_bf16_training_tracks_f32_training_over_the_first_10_iterations():
     # (iteration 10 sits in the chaotic transition -- 0.17 ... 0.48 (G) and 0.26 ... 0.55 (D) were seen at t = 10 for the SAME code on
     #  different runs -- so its bar only says "not yet further than decorrelated"; the early rows are stable to three digits)
     for t, (g_bar, d_bar) in {1: (0.40, 0.17), 2: (0.34, 0.13), 5: (0.24, 0.18), 10: (0.95, 1.0)}.items():
-        b, c = rows[t]["runs"]["f32 B"], rows[t]["runs"]["bf16 A"]
+        c = rows[t]["runs"]["bf16 A"]
         assert c["G"] < g_bar and c["D"] < d_bar, (t, c["G"], c["D"])
-        if t <= 5:
-            assert b["G"] < 0.6 * g_bar and b["D"] < 0.6 * d_bar, (t, b["G"], b["D"])
-    print({t: (round(r["runs"]["f32 B"]["G"], 4), round(r["runs"]["bf16 A"]["G"], 4), round(r["runs"]["f32 B"]["D"], 4), round(r["runs"]["bf16 A"]["D"], 4))
-           for t, r in rows.items()})
+    # (round 6: a second f32 run is the first one bit for bit -- tests/test_gpu_06b_determinism.py -- so the "f32 B" floor run of round 5 is gone)
+    print({t: (round(r["runs"]["bf16 A"]["G"], 4), round(r["runs"]["bf16 A"]["D"], 4)) for t, r in rows.items()})

@@ -148,16 +148,19 @@ def test_two_rank_gradients_equal_single_process_at_128(dt_name):
     typical value. A broken exchange -- unsynchronised batch statistics, local loss counts, a missing all-reduce -- moves
     the gradient by O(0.1 - 1)."""
     mgr = mp.Manager()
-    single, again, multi = mgr.dict(), mgr.dict(), mgr.dict()
+    single, multi = mgr.dict(), mgr.dict()
     mp.spawn(_run_grads, args=(1, _free_port(), single, dt_name), nprocs=1, join=True)
-    mp.spawn(_run_grads, args=(1, _free_port(), again, dt_name), nprocs=1, join=True)
     mp.spawn(_run_grads, args=(2, _free_port(), multi, dt_name), nprocs=2, join=True)
     for k in ("g", "d"):
         b = single[k]
-        floor = max(float((again[k] - b).norm() / b.norm()), 2e-4 if dt_name == "float32" else 7e-3)
+        # Round 6: a single-process run is bit-reproducible (tests/test_gpu_06b_determinism.py), so the second single-process run that used to
+        # measure the run-to-run floor is gone. Two ranks still sum in another partition (per-rank statistics and gradients, then the all-reduce):
+        # rounding differs, in bf16 a value on a rounding boundary goes the other way. The bar is the one of rounds 3-5: 2.5 x the typical
+        # distance of two bf16 runs then (7e-3), far below what a broken exchange gives (O(0.1 - 1)).
+        floor = 2e-4 if dt_name == "float32" else 7e-3
         err = float((multi[k] - b).norm() / b.norm())
+        print(f"two ranks vs one process [{dt_name}] {k}: {err:.2e}")
         assert err < 2.5 * floor + 1e-5, (k, err, floor)
-        assert err < (5e-3 if dt_name == "float32" else 8e-2), (k, err)   # (and an absolute ceiling, far below a broken exchange)
 
 
 def _run_forced(rank, port, out, force, graph):
