@@ -538,7 +538,8 @@ def test_dual_discriminator_step_gradients_match_two_passes_at_full_size(dt):
     dual = _grads_after_one_iteration(dt, "dual")
     whole, med = _grad_errors(dual, eager)
     print(f"dual vs two-pass at b = 32 [{dt}]: whole-gradient relative L2 {whole:.2e}, median per parameter {med:.2e}")
-    # (another launch structure -- one batch of 64 images, other tiles and splits -- so other summation orders: not bit-identical. The
-    #  bars are those of rounds 4-5, 1.5 x the then eager-vs-eager floor of the bf16 mode)
-    assert whole < 8.7e-3, whole
-    assert med < 1.7e-2, med
+    # (another launch structure -- one batch of 64 images, other tiles and splits -- so other summation orders: not bit-identical, and in bf16 a
+    #  value on a rounding boundary goes the other way. Round 6, both sides reproducible: 6.6e-4 / 2.1e-3 measured; bars 3 x that. Rounds 4-5:
+    #  8.7e-3 / 1.7e-2, 1.5 x the then run-to-run floor.)
+    assert whole < 2e-3, whole
+    assert med < 6.5e-3, med

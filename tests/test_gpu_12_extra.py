@@ -104,8 +104,9 @@ def test_two_generator_forwards_before_one_backward():
     # A forward whose saved statistics were re-zeroed by the second forward gives an O(1) error. Round 5's bar was a fixed 2e-3 and the test
     # flickered at 2.1e-3: not summation noise but a RACE -- flush_grads added the two passes' padded-channel bias gradients (final.2.bias) with
     # one multi-tensor add that named the same destination twice and kept one addend or both from run to run (fixed in arena.flush_grads). With
-    # that gone and the forward bit-identical the two orders differ by the backward's remaining float atomics only: 6e-7 measured.
-    assert floor < 2e-5 and rel < max(20 * floor, 1e-4), (rel, floor)
+    # that gone and no float atomics left on the path, two identical runs are the same bits (floor 0) and the two orders agree to the last
+    # bit as well (0.0 measured; 1e-5 leaves room for a + b against b + a in the flat gradient).
+    assert floor == 0.0 and rel < 1e-5, (rel, floor)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -234,12 +235,11 @@ def test_generator_block_results_join_their_two_gradients(size, loss_kind, monke
     a, b, b2 = grads["on"], grads["off"], grads["off2"]
     assert float(b.norm()) > 0 and bool(torch.isfinite(a).all())
     # accumulation order only (f32 operands). Rounds 1-5: the atomically reduced batch statistics moved the gradient of this 25-layer train-mode
-    # network by ~1e-3 between two identical runs; round 6: the forward is bit-identical, two runs differ by the backward's float atomics
-    # (1.2e-6 ... 1.9e-6 measured), and a gradient term dropped at the 1e-3 level is now caught
+    # network by ~1e-3 between two identical runs; round 6: two runs are bit-identical, and a gradient term dropped at the 1e-4 level is caught
     floor = float((b2 - b).norm() / b.norm())
     rel = float((a - b).norm() / b.norm())
     print(f"joined vs plain {rel:.2e}, plain vs plain {floor:.2e}")
-    assert floor < 2e-5 and rel < max(20 * floor, 1e-4), (rel, floor)
+    assert floor == 0.0 and rel < 2e-5, (rel, floor)   # (round 6: two plain runs are bit-identical; joined vs plain 1.2e-6 ... 1.8e-6: another order of two additions)
 
 
 @pytest.mark.parametrize("variant", ["eager", "graph", "dual", "real_bwd_early"])
