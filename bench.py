@@ -50,7 +50,7 @@ def cpu_baseline(netG, netD, size, batch=32):
                 sample=f"1 training iteration at batch {batch} (after a batch-4 warm-up), {size}x{size}, fp32, oracle/model.py OracleTrainer (VGG term omitted)")
 
 
-TRAFFIC_FILE = "r05_conv_traffic.json"   # PMC passes of this round (tools/perf/traffic2.sh); absent -> roofline.traffic is null
+TRAFFIC_FILE = "r06_conv_traffic.json"   # PMC passes of this round (tools/perf/traffic2.sh); absent -> roofline.traffic is null
 
 
 RESULT_CHANGING_ENV = ("L2I_CONV_NOEPI", "L2I_WGRAD_NOEPI")   # ablation switches (results are wrong; -DL2I_ABLATIONS builds only)
