@@ -572,8 +572,19 @@ __global__ __launch_bounds__(256) void norm_bwd_a_kernel(NormArgs p, int nseg, i
         }
     }
 
-    // ---- per-object gradients: each thread owns (object, 4 channels) -- one atomic per value per block
-    if (p.mode == 0 && con) {
+    // ---- per-object gradients: each thread owns (object, 4 channels). With p.part (the launcher lends scratch: round 6) the workgroup's values go
+    // to ITS row (image, segment) of [B * nseg][2][O][C] with plain stores and norm_a_finish_kernel adds an image's segments in order; else one
+    // atomic per value per block
+    if (p.mode == 0 && con && p.part) {
+        float* mine = p.part + (size_t)(b * nseg + seg) * (2 * (size_t)O * p.C);
+#pragma unroll
+        for (int k = 0; k < NB_MAXCH; ++k) {
+            const int o = k * NB_OC + o2;
+            if (o >= O) continue;
+            *reinterpret_cast<float4*>(mine + (size_t)o * p.C + c) = adw[k];
+            *reinterpret_cast<float4*>(mine + ((size_t)O + o) * p.C + c) = adb[k];
+        }
+    } else if (p.mode == 0 && con) {
 #pragma unroll
         for (int k = 0; k < NB_MAXCH; ++k) {
             const int o = k * NB_OC + o2;
@@ -901,6 +912,24 @@ __global__ __launch_bounds__(256) void norm_a8_finish_kernel(WsFoldArgs f, int n
     *dst = d;
 }
 
+// Behind norm_bwd_a_kernel (more than 8 objects: VG layouts): dW / dB [b][o][c] += the sum of the image's nseg stored rows, in order.
+__global__ __launch_bounds__(256) void norm_a_finish_kernel(const float* __restrict__ part, float* dw, float* db, int B, int nseg, int O, int C,
+                                                            long long psb, long long pso) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = C >> 2;
+    if (idx >= (long long)B * 2 * O * c4n) return;
+    const int c4 = (int)(idx % c4n), o = (int)((idx / c4n) % O), pass = (int)((idx / ((long long)c4n * O)) % 2), b = (int)(idx / ((long long)c4n * O * 2));
+    const size_t row = 2 * (size_t)O * C;
+    const float* src = part + (size_t)b * nseg * row + ((size_t)pass * O + o) * C + 4 * c4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < nseg; ++s0) {
+        const float4 t = *reinterpret_cast<const float4*>(src + (size_t)s0 * row);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    float* d = (pass == 0 ? dw : db) + (size_t)b * psb + (size_t)o * pso + 4 * c4;
+    d[0] += a.x; d[1] += a.y; d[2] += a.z; d[3] += a.w;
+}
+
 static size_t norm_bwd_lds(const NormArgs& a) {
     const int O = a.mode == 0 ? a.O : 0;
     const size_t tile = a.mode == 0 ? (size_t)2 * NB_PX * NM_CC : (size_t)4 * 4 * 8 * 32;   // g, gx | reduction buffer (float4 x 4 x 8 x 32)
@@ -1127,7 +1156,7 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
     const int stat_rows = stat_stride == 0 ? B * k_ns : k_ns, stat_z = stat_stride == 0 ? 1 : B;
     if (part && !((uintptr_t)part & 15) && C % 4 == 0) {
         const long long need = (long long)B * k_ns * nval * C + rows_fold_tmp_floats(stat_rows, nval * C, stat_z);
-        const long long front = a8 ? (long long)B * k_tc * k_ns * 16 * (C <= 64 ? 64 : 128) : 0;
+        const long long front = a8 ? (long long)B * k_tc * k_ns * 16 * (C <= 64 ? 64 : 128) : (mode == 0 ? (long long)B * k_ns * 2 * O * C : 0);
         if (front + need <= tail) {
             tail = (tail - need) & ~3LL;
             a.spart = part + tail;
@@ -1161,9 +1190,20 @@ extern "C" int l2i_norm_mod_bwd_a(const float* x, const float* dy, int B, int HW
             lend(nseg, tiles_c, 128);
             hipLaunchKernelGGL(norm_bwd_a8_kernel<32>, dim3(B * nseg * tiles_c), dim3(256), lds8, (hipStream_t)stream, a, nseg, seg_pixels);
         }
-    } else
-    hipLaunchKernelGGL(norm_bwd_a_kernel, dim3(B * nseg * tiles_c), dim3(256), norm_bwd_lds(a), (hipStream_t)stream, a, nseg,
-                       seg_pixels);
+    } else {
+        // more than 8 objects (VG layouts): the projections' dW / dB as stored rows per (image, segment) + an ordered finish launch (round 6)
+        a.part = nullptr;
+        const bool rows_ok = mode == 0 && part && !((uintptr_t)part & 15) && C % 4 == 0 && dwproj && dbproj && pstride_b % 4 == 0 && pstride_o % 4 == 0 &&
+                             ((uintptr_t)dwproj % 16 == 0) && ((uintptr_t)dbproj % 16 == 0) && (long long)B * nseg * 2 * O * C <= part_floats;
+        if (rows_ok) a.part = part;
+        hipLaunchKernelGGL(norm_bwd_a_kernel, dim3(B * nseg * tiles_c), dim3(256), norm_bwd_lds(a), (hipStream_t)stream, a, nseg,
+                           seg_pixels);
+        if (rows_ok) {
+            const long long n = (long long)B * 2 * O * (C / 4);
+            hipLaunchKernelGGL(norm_a_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)part, dwproj, dbproj,
+                               B, nseg, O, C, pstride_b, pstride_o);
+        }
+    }
     // The ordered folds behind the launch: s1 / s2 (+ the affine layer's dW / dB: four destinations of one job) and the channel chunks' dmask rows.
     // Direct jobs over one group ride on the finish launch when there is one, else they are ONE multi-job launch; others get their own launches.
     RowsFoldArgs sf = {}, df = {};

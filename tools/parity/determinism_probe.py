@@ -24,17 +24,21 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--layout", default="coco")   # vg: context_aware_generator, 31 object slots (BASELINE config 5)
     a = ap.parse_args()
     dt = torch.float32 if a.dtype == "f32" else torch.bfloat16
     torch.manual_seed(0)
     G = L.ResnetGenerator128_context if a.size == 128 else L.ResnetGenerator64_context
     D = L.CombineDiscriminator128_app if a.size == 128 else L.CombineDiscriminator64
-    g = G(num_classes=184).finalize(DEV, dt).train()
-    d = D(num_classes=184).finalize(DEV, dt).train()
+    ncls = 184
+    if a.layout == "vg":
+        G, ncls = L.context_aware_generator, 179
+    g = G(num_classes=ncls).finalize(DEV, dt).train()
+    d = D(num_classes=ncls).finalize(DEV, dt).train()
     for m in g.modules():
         if hasattr(m, "dropout_p"):
             m.dropout_p = 0.0
-    real, label, bbox, z, z_im = make_batch(a.batch, a.size, "coco", seed=3, device=DEV)
+    real, label, bbox, z, z_im = make_batch(a.batch, a.size, a.layout, seed=3, device=DEV)
     gs = {k: v.clone() for k, v in g.state_dict().items()}
     gsn = g.arena.sn_flat.data.clone()
     ds = {k: v.clone() for k, v in d.state_dict().items()}
@@ -47,7 +51,7 @@ def main():
     def g_pass():
         reset()
         taps = {}
-        img = g(z, bbox, z_im, label, taps=taps) if a.size == 128 else g(z, bbox, z_im, label)
+        img = g(z, bbox, z_im, label, taps=taps) if (a.size == 128 and a.layout == "coco") else g(z, bbox, z_im, label)
         (img * real).sum().backward()
         g.arena.flush_grads()
         torch.cuda.synchronize()
