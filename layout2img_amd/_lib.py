@@ -150,12 +150,17 @@ _WGS = {}
 
 
 def wgrad_scratch(device):
-    """(pointer, floats) of the (device, current stream)'s scratch for the partial tiles of split weight-gradient
-    launches (l2i_conv2d_wgrad). Created on first use; GanTrainer.capture creates the ones of its streams before capturing."""
+    """(pointer, floats) of the (device, current stream)'s scratch: partial tiles of split weight-gradient / convolution launches and,
+    since round 6, every launch's stored partial rows (batch statistics, power iteration, bias gradients, channel totals ...), which an
+    ordered fold adds up behind the launch. Created on first use; GanTrainer.capture creates the ones of its streams before capturing.
+    (Called ~400 times per iteration: the fast path is two C calls and a dict lookup.)"""
     import torch
-    idx = torch.device(device).index
-    key = (current_device() if idx is None else idx, raw_stream())
+    idx = device.index if type(device) is torch.device else torch.device(device).index
+    if idx is None:
+        idx = torch._C._cuda_getDevice()
+    key = (idx, torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
     w = _WGS.get(key)
     if w is None:
-        w = _WGS[key] = torch.empty(WGRAD_SCRATCH_FLOATS, dtype=torch.float32, device=device)
-    return w.data_ptr(), WGRAD_SCRATCH_FLOATS
+        t = torch.empty(WGRAD_SCRATCH_FLOATS, dtype=torch.float32, device=device)
+        w = _WGS[key] = (t, t.data_ptr())
+    return w[1], WGRAD_SCRATCH_FLOATS
