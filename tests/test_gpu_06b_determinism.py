@@ -184,3 +184,25 @@ def test_graph_replays_are_bit_identical_to_eager_iterations(dt):
     a, b = _trainer_run(dt, "graph"), _trainer_run_cached(dt, "eager")
     for k, (x, y) in enumerate(zip(a, b)):
         assert torch.equal(x, y), (k, float((x - y).abs().max()), float((x - y).norm() / y.norm().clamp_min(1e-30)))
+
+
+def test_vg_training_iteration_is_bit_identical_from_run_to_run():
+    """BASELINE config 5's models (context_aware_generator, 31 object slots: the > 8-object ISLA backward, whose projection gradients are stored
+    rows + an ordered finish launch since round 6): two iterations twice from the same state leave the same bits."""
+    import layout2img_amd as L
+    from layout2img_amd.synthetic import make_batch
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        g = L.context_aware_generator(num_classes=179).finalize(DEV, torch.bfloat16).train()
+        d = L.CombineDiscriminator128_app(num_classes=179).finalize(DEV, torch.bfloat16).train()
+        tr = L.GanTrainer(g, d)
+        real, label, bbox, z, z_im = make_batch(2, 128, "vg", seed=3, device=torch.device(DEV))
+        for _ in range(2):
+            r = tr.step(real, label, bbox, z, z_im)
+        tr.flush()
+        torch.cuda.synchronize()
+        outs.append([g.flat.data.clone(), d.flat.data.clone(), g.flat.grad.clone(), d.flat.grad.clone(), r["g_loss"].detach().clone().view(1)])
+    for k, (x, y) in enumerate(zip(*outs)):
+        assert torch.equal(x, y), (k, float((x - y).abs().max()))
+    assert float((outs[0][2] != 0).float().mean()) > 0.5
