@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restr
     const int layer = table[blockIdx.x];
     const long long* L = layers + L2I_LSTRIDE * layer;
     if (LF(1) < 0) {
-        if (threadIdx.x == 0 && blockIdx.y == 0) norms[4 * layer + 2] = 1.f;
+        if (threadIdx.x == 0 && blockIdx.y == 0) { norms[4 * layer + 0] = 0.f; norms[4 * layer + 1] = 0.f; norms[4 * layer + 2] = 1.f; norms[4 * layer + 3] = 0.f; }
         return;
     }
     const int Co = (int)LF(3), Kt = (int)(LF(4) * LF(5) * LF(5));
@@ -421,6 +421,7 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const long long* __restr
     if (threadIdx.x == 0 && blockIdx.y == 0) {
         norms[4 * layer + 1] = sn2;
         norms[4 * layer + 2] = sigma_of(L, sn2, training);
+        norms[4 * layer + 3] = 0.f;   // (<G, W>: written by the backward; defined from here on -- the buffer is no longer cleared per pass)
     }
 }
 
@@ -683,7 +684,10 @@ extern "C" int l2i_weights_prepare(const long long* layers, int n_layers, const 
     float* npart = scratch;
     float* tpart = scratch ? scratch + npart_floats : nullptr;
     if (dtype != 0 && dtype != 1 && dtype != 3) return L2I_ERR_ARG;   // 3: bf16 with split (hi + lo) forward packs, see sn_pack_body
-    if (clear) {  // first round of a pass
+    // Round 6: nothing of norms / pass_uv is ACCUMULATED into any more (t = W^T u is written by sn_tfold_kernel, u and ||t||^2 by sn_wv_kernel,
+    // ||W v||^2 / sigma by sn_finish_kernel, <G, W> by the backward) -- every value a later kernel reads has been stored first, so the clear that
+    // rounds 1-5 needed in front of the atomics is skipped in train and eval mode alike (7 launches per iteration); `clear == 2` still forces it.
+    if (clear == 2) {  // (a caller that wants defined padding)
         const long long gap = pass_uv - norms;   // adjacent buffers (layout2img_amd/arena.py PassCtx): one memset for both
         if (uv_len > 0 && gap >= 4LL * n_layers && gap <= 4LL * n_layers + 64) {
             if (l2i_zero_async(norms, sizeof(float) * (size_t)(gap + uv_len), stream) != hipSuccess) return L2I_ERR_LAUNCH;
