@@ -57,8 +57,14 @@ def _worker(rank, world, port, ret):
     torch.distributed.all_reduce(lt)
     p = torch.full((7,), float(rank))
     parallel.broadcast_flat_(p, src=0)
+    # the host-side "did every rank succeed" decision of GanTrainer.capture (round 6: over a gloo group of its own, on CPU tensors --
+    # a rank whose HIP runtime is unusable after an invalidated capture can still take part): MIN over the ranks
+    host = parallel.host_group()
+    votes = (parallel.all_ranks_ok(True, host), parallel.all_ranks_ok(rank == 0, host), parallel.all_ranks_ok(rank == 1, host))
     if rank == 0:
-        ret.update(grad=flat[:-3].view_as(grad), mean=mean, var=var, loss=lt, n_roi=float(n_roi), bc=p)
+        ret.update(grad=flat[:-3].view_as(grad), mean=mean, var=var, loss=lt, n_roi=float(n_roi), bc=p, votes=votes)
+    else:
+        ret.update(votes1=votes)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -80,3 +86,4 @@ def test_two_rank_gloo_equals_single_process():
     assert torch.allclose(ret["loss"], loss.view(1), atol=1e-6)
     assert torch.allclose(ret["grad"], grad, atol=1e-6)
     assert torch.equal(ret["bc"], torch.zeros(7))
+    assert tuple(ret["votes"]) == tuple(ret["votes1"]) == (True, False, False)   # every rank reaches the same decision

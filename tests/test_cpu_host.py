@@ -185,3 +185,136 @@ def test_reference_checkpoint_loading_strips_the_dataparallel_prefix():
     sd, ss = dst.state_dict(), src.state_dict()
     for k in loaded:
         assert torch.equal(sd[k], ss[k] + 1.0), k
+
+
+def test_power_iteration_partial_row_tables_on_cpu():
+    """Round 6: the power iteration sums W^T u per block of 64 rows into stored partial rows that `sn_tfold_kernel` adds in order, and ||W v||^2 per
+    block of 4 R rows into shares (csrc/weights.hip). The tables that place those rows in the caller's scratch are host logic (arena.py): here
+    the kernels' address arithmetic is replayed in numpy from the tables alone -- every partial row is written exactly once, nothing overlaps, the
+    fold of the rows is W^T u, the shares are disjoint -- and the <G, W> ranges of the backward name exactly a layer's dot-table entries."""
+    import numpy as np
+    from layout2img_amd import arena as A
+    from layout2img_amd.arena import FlatParams, GemmWeight, WeightArena
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = GemmWeight("conv", 200, 24, 3, sn=True, eps=1e-4)        # 4 row blocks of 64, Kt = 216
+            self.b = GemmWeight("linear", 1100, 128, sn=True)                # 18 row blocks: the narrow fold workgroups (cw = 64)
+            self.c = GemmWeight("conv", 100, 16, 1, sn=False, bias=False)    # no spectral norm: no entries
+            self.d = GemmWeight("conv", 72, 40, 3, sn=True, uses=2)          # applied twice: a second round with its own rows
+            self.e = GemmWeight("linear", 4500, 16, sn=True)                 # 71 row blocks: cw = 16
+    net = Net()
+    flat = FlatParams(net, "cpu")
+    ar = WeightArena(net, flat, "cpu", torch.bfloat16)
+    tab = ar.layers.view(-1, 20).numpy()
+    rows_per_block, wv_rows = 4 * A.WTU_RPW, 4 * A.WV_R
+    for r in range(ar.rounds):
+        wtu = ar.t_wtu[r][0].view(-1, 5).numpy()[:ar.t_wtu[r][1]]
+        tf = ar.t_tfold[r][0].view(-1, 5).numpy()[:ar.t_tfold[r][1]]
+        wv = ar.t_wv[r][0].view(-1, 2).numpy()[:ar.t_wv[r][1]]
+        scratch = np.full(ar.sn_scratch_floats, np.nan)
+        tpart = scratch[ar.np_len[r]:]
+        layers = sorted(set(int(e[0]) for e in wtu))
+        assert layers == sorted(set(int(e[0]) for e in tf)) == sorted(set(int(e[0]) for e in wv))
+        W, U = {}, {}
+        for li in layers:
+            co, kt = int(tab[li, 3]), int(tab[li, 4] * tab[li, 5] * tab[li, 5])
+            W[li], U[li] = np.random.RandomState(li).randn(co, kt), np.random.RandomState(100 + li).randn(co)
+        for li, c0, r0, rpw, off in wtu:      # sn_wtu_kernel: 256 columns x (4 x rpw) rows -> columns [c0, c0 + 256) of one partial row
+            co, kt = W[li].shape
+            cols = slice(c0, min(c0 + 256, kt))
+            assert np.all(np.isnan(tpart[off + cols.start:off + cols.stop])), "a partial row written twice"
+            tpart[off + cols.start:off + cols.stop] = (U[li][r0:r0 + 4 * rpw, None] * W[li][r0:r0 + 4 * rpw, cols]).sum(0)
+        seen = {li: np.zeros(W[li].shape[1], dtype=int) for li in layers}
+        for li, c0, off, nrb, cw in tf:       # sn_tfold_kernel: cw columns, all row blocks, in order
+            co, kt = W[li].shape
+            assert nrb == -(-co // rows_per_block) and cw == (256 if nrb <= 8 else 64 if nrb <= 32 else 16) and 256 % cw == 0
+            cols = slice(c0, min(c0 + cw, kt))
+            t = sum(tpart[off + rb * kt + cols.start:off + rb * kt + cols.stop] for rb in range(nrb))
+            assert np.allclose(t, (U[li][:, None] * W[li][:, cols]).sum(0)), (li, c0)
+            seen[li][cols] += 1
+        assert all(np.all(v == 1) for v in seen.values())          # every column of t folded exactly once
+        share = scratch[:ar.np_len[r]]
+        for li, r0 in wv:                      # sn_wv_kernel: one share per block of 4 R rows at the layer's row-19 offset
+            idx = int(tab[li, 19]) + r0 // wv_rows
+            assert np.isnan(share[idx]), "two sn_wv blocks share a slot"
+            share[idx] = 1.0
+        for li in layers:
+            nb = -(-int(tab[li, 3]) // wv_rows)
+            assert np.all(share[int(tab[li, 19]):int(tab[li, 19]) + nb] == 1.0)
+    # the backward's <G, W>: (first entry, count) per layer row names exactly that row's dot-table entries
+    dot = ar.t_dot.view(-1, 2).numpy()[:ar.n_dot]
+    rng = ar.t_dot_range.view(-1, 2).numpy()
+    for li in range(ar.n_layers):
+        mine = np.nonzero(dot[:, 0] == li)[0]
+        assert rng[li, 1] == len(mine) and (len(mine) == 0 or (rng[li, 0] == mine[0] and np.all(np.diff(mine) == 1)))
+    assert rng[[i for i in range(ar.n_layers) if tab[i, 1] < 0], 1].sum() == 0      # layers without spectral norm: no entries
+
+
+def test_bias_slots_and_pass_bookkeeping_on_cpu(monkeypatch):
+    """Round 6 / ADVICE r05: (i) a convolution applied several times per forward gets a per-pass bias-gradient slot like the padded ones (its 2 uses x
+    2 passes otherwise meet in stream order in the shared gradient); (ii) flush_grads adds the slots of EACH pass with its own multi-tensor add --
+    one add over all passes names a destination twice, and the GPU kernel then keeps one addend or both (the 2.1e-3 flicker of round 5);
+    (iii) a pass that holds gradients is never evicted from the pending list."""
+    from layout2img_amd import arena as A
+    from layout2img_amd.arena import FlatParams, GemmWeight, PassCtx, WeightArena
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pad = GemmWeight("conv", 100, 16, 3, sn=False)            # 100 of 104 channels
+            self.twice = GemmWeight("conv", 64, 16, 3, sn=True, uses=2)    # applied twice per forward
+            self.plain = GemmWeight("conv", 64, 16, 3, sn=True)
+    net = Net()
+    flat = FlatParams(net, "cpu")
+    ar = WeightArena(net, flat, "cpu", torch.bfloat16)
+    assert getattr(net.pad, "bias_scr_off", None) is not None and getattr(net.twice, "bias_scr_off", None) is not None
+    assert getattr(net.plain, "bias_scr_off", None) is None
+    (lo, hi), = ar.acc_ranges
+    for h in (net.pad, net.twice):
+        assert lo <= h.bias_scr_off and h.bias_scr_off + h.co_p <= hi      # cleared with the accumulated-into slices of every pass
+    flat.zero_grad()
+
+    def fake_pass(value):
+        p = PassCtx.__new__(PassCtx)
+        p.arena, p.training, p.need_wgrad, p.written = ar, True, True, None
+        p.dwbar = torch.zeros(ar.dw_len)
+        p.norms, p.pass_uv = torch.zeros(4 * ar.n_layers), torch.zeros(ar.uv_len)
+        p.bias_fix = {}
+        for h in (net.pad, net.twice):
+            p.bias_slot(h, h.bias.grad).fill_(value)
+        return p
+    ar.pending = [fake_pass(1.0), fake_pass(2.0)]
+    calls = []
+    real_add = torch._foreach_add_
+
+    def recording(dsts, srcs):
+        calls.append([d.data_ptr() for d in dsts])
+        return real_add(dsts, srcs)
+    monkeypatch.setattr(torch, "_foreach_add_", recording)
+    monkeypatch.setattr(A._lib, "call", lambda *a, **k: None)              # (the spectral-norm backward launches: not on the CPU)
+    monkeypatch.setattr(A._lib, "workspace", lambda dev: 0)
+    monkeypatch.setattr(A._lib, "raw_stream", lambda: 0)
+    from layout2img_amd import ops
+    monkeypatch.setattr(ops.WgradSide, "join", classmethod(lambda cls: None))   # (side-stream bookkeeping: queries the current CUDA stream)
+    ar.flush_grads()
+    assert len(calls) == 2 and all(len(set(c)) == len(c) for c in calls)   # one add per pass, no destination twice in a call
+    assert torch.all(net.pad.bias.grad == 3.0) and net.pad.bias.grad.numel() == 100 and torch.all(net.twice.bias.grad == 3.0)
+    assert ar.pending == []
+    # eviction: nine forwards without an optimiser step -- only passes WITHOUT gradients leave the list
+    keep = fake_pass(5.0)
+    ar.pending = [keep] + [PassCtx.__new__(PassCtx) for _ in range(8)]
+    for q in ar.pending[1:]:
+        q.dwbar, q.bias_fix = None, {}
+    newest = PassCtx.__new__(PassCtx)
+    newest.dwbar, newest.bias_fix = None, {}
+    ar.pending.append(newest)
+    if len(ar.pending) > 8:   # (WeightArena.prepare's rule)
+        for k, old in enumerate(ar.pending[:-1]):
+            if old.dwbar is None and not old.bias_fix:
+                del ar.pending[k]
+                break
+    assert keep in ar.pending and newest in ar.pending and len(ar.pending) == 9
