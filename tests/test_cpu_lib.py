@@ -36,3 +36,46 @@ def test_product_path_never_imports_the_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert "oracle" not in src.replace("no oracle", ""), f
+
+
+def _params(arglist):
+    """parameter declarations of a C parameter list: (kind, ...) with kind in p (pointer), i (int), l (long long), f (float)"""
+    out = []
+    for a in [x.strip() for x in arglist.replace("\n", " ").split(",") if x.strip() and x.strip() != "void"]:
+        if "*" in a:
+            out.append("p")
+        elif re.search(r"\blong long\b", a):
+            out.append("l")
+        elif re.search(r"\bfloat\b", a):
+            out.append("f")
+        elif re.search(r"\b(int|unsigned)\b", a):
+            out.append("i")
+        else:
+            raise AssertionError(a)
+    return out
+
+
+def test_header_definitions_and_ctypes_table_agree_argument_by_argument():
+    """Three places state every entry point's signature: include/l2i.h (what a maintainer binds), the `extern "C"` definitions in csrc/*.hip (what
+    is exported) and layout2img_amd/_lib.py::SIGNATURES (what the package calls through ctypes). A drifted prototype is a silent stack-garbage bug
+    -- and round 6 changed a dozen argument lists: compare the three, type class by type class (pointer / int / long long / float)."""
+    import ctypes
+    from layout2img_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "l2i.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = {m.group(1): _params(m.group(2)) for m in re.finditer(r"^int\s+(l2i_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.M | re.S)}
+    defs = {}
+    csrc = os.path.join(ROOT, "layout2img_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip"):
+            src = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read())
+            for m in re.finditer(r'extern\s+"C"\s+int\s+(l2i_\w+)\s*\(([^{;]*?)\)\s*\{', src, flags=re.S):
+                defs[m.group(1)] = _params(m.group(2))
+    kind = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_longlong: "l", ctypes.c_float: "f"}
+    assert sorted(protos) == sorted(_lib.SIGNATURES)
+    for name, sig in _lib.SIGNATURES.items():
+        table = [kind[t] for t in sig]
+        assert protos[name] == table, (name, "header", protos[name], "ctypes", table)
+        if name in defs:   # (debug / trace readers are defined through macros)
+            assert defs[name] == table, (name, "definition", defs[name], "ctypes", table)
+    assert len([n for n in _lib.SIGNATURES if n in defs]) >= 60
