@@ -88,6 +88,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_FN = {}     # name -> bound foreign function; filled by load() so call() is one dict lookup per launch
 
 
 def load():
@@ -104,12 +105,17 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _i
+        _FN[name] = fn
     _lib = lib
     return lib
 
 
 def call(name, *args):
-    rc = getattr(load(), name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        load()
+        fn = _FN[name]   # KeyError: a name that include/l2i.h does not declare
+    rc = fn(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed with code {rc} ({'bad argument' if rc == -1 else 'HIP launch error'})")
 
