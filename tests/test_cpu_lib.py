@@ -79,3 +79,17 @@ def test_header_definitions_and_ctypes_table_agree_argument_by_argument():
         if name in defs:   # (debug / trace readers are defined through macros)
             assert defs[name] == table, (name, "definition", defs[name], "ctypes", table)
     assert len([n for n in _lib.SIGNATURES if n in defs]) >= 60
+
+
+def test_integration_document_stubs_bind_the_current_signatures():
+    """INTEGRATION.md shows the reference-side ctypes stubs a maintainer would add; their `argtypes` lists are evaluated here and compared with
+    the package's own table, so the document cannot drift behind a changed prototype."""
+    import ctypes
+    from layout2img_amd import _lib
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stubs = re.findall(r"^_l2i\.(l2i_\w+)\.argtypes\s*=\s*(.+?)(?=^\S)", txt, flags=re.M | re.S)
+    assert len(stubs) >= 2
+    for name, expr in stubs:
+        assert eval(expr, {"ctypes": ctypes}) == _lib.SIGNATURES[name], name
+    for name in set(re.findall(r"\bl2i_\w+", txt)):   # every entry point the document names exists
+        assert name in _lib.SIGNATURES or (name.endswith("_") and any(k.startswith(name) for k in _lib.SIGNATURES)), name   # (`l2i_psp_pool_*`)
