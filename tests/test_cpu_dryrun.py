@@ -161,3 +161,61 @@ def test_two_rank_iteration_communication_schedule():
     assert conv == 186
     # Adam runs chunk by chunk behind the chunks of the exchange: every parameter stepped exactly once
     assert sum(a[4] for n, a in per_it[1][1] if n == "l2i_adam_step") == n_params and census["l2i_adam_step"] > 2
+
+
+def test_roofline_numerators_of_the_committed_bench_line_reproduce_without_a_gpu():
+    """bench.py's `roofline.achieved` = accounted algorithmic FLOPs / HIP-event time. The numerator is host arithmetic (ops.KernelTimer: every
+    conv / weight-gradient launch adds its 2 M N K and its operand / result bytes, ROI launches scaled by the live-ROI fraction): the dry run
+    repeats bench.py's instrumented iteration at the headline batch (same seed, same batch, one stream) and must arrive at the launches,
+    GFLOP per launch and algorithmic bytes per launch that the committed line of the round carries."""
+    import json
+    import os
+    from layout2img_amd import ops
+    from layout2img_amd.synthetic import make_batch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.load(open(os.path.join(root, "profiles", "r06_bench_final_b.json")))
+    roof = line["roofline"]
+    assert line["config"]["global_batch"] == 32 and line["n_gpus"] == 1
+    real, label, bbox, z, z_im = make_batch(32, 128, "coco", seed=1234, device="cpu")
+    live = float((label != 0).sum()) / label.numel()
+    assert round(live, 4) == roof["live_roi_fraction"]
+    saved = ops.LIVE_IMAGE_FRACTION, ops.TIMER
+    try:
+        with dryrun.dry_run() as trace:
+            tr, _ = dryrun.build("coco", torch.bfloat16)
+            real, label, bbox = (t.to("meta") for t in (real, label, bbox))
+            ops.LIVE_IMAGE_FRACTION = live
+            tr.overlap = False
+            tr.step(real, label, bbox, None, None)
+            tr.flush()
+            del trace[:]
+            ops.TIMER = ops.KernelTimer()
+            tr.step(real, label, bbox, None, None)
+            tr.flush()
+            acc = {k: list(v) for k, v in ops.TIMER.acc.items()}
+    finally:
+        ops.LIVE_IMAGE_FRACTION, ops.TIMER = saved
+    n, work, nbytes = acc["conv_igemm"]
+    assert n == roof["launches_per_step"] == 186
+    assert round(work / n / 1e9, 3) == roof["gflop_per_launch"]
+    assert round(nbytes / n) == roof["algorithmic_bytes_per_launch"]
+    assert acc["conv_wgrad"][0] == roof["wgrad_launches_per_step"] == 70
+    # and the line is consistent with itself: achieved = GFLOP per launch / average launch time; frac = achieved / peak
+    assert abs(roof["gflop_per_launch"] / roof["avg_launch_us"] * 1e3 - roof["achieved"]) < 1e-3 * roof["achieved"]   # (GFLOP / us = 1000 TFLOP/s)
+    assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-3
+    # SURVEY section 8(d): 26.35 GFLOP per generated image, forward
+    assert line["g_forward"]["gflop_per_image"] == 26.35
+    # the accounting never credits more than the launches are dimensioned for: 2 B Ho Wo Co KH^2 Ci (+ the folded 1x1 shortcut) of every
+    # launch's ARGUMENTS (channel counts padded to the kernels' multiples there) bounds the accounted work from above, closely
+    names = dryrun.header_parameters()
+    dim = {"conv": 0.0, "wgrad": 0.0}
+    for name, args in trace:
+        a = dict(zip(names[name], args))
+        if name in ("l2i_conv2d_fwd_dual", "l2i_conv2d_wgrad_dual"):
+            f = 2.0 * a["B"] * a["Ho"] * a["Wo"] * a["Co"] * (a["KH"] ** 2 * a["Ci"] + (a["sc_Ci"] if a["sc_x"] is not None else 0))
+        elif name == "l2i_conv2d_dgrad_sc":
+            f = 2.0 * a["B"] * a["H"] * a["W"] * a["Co"] * (9 * a["Ci"] + a["sc_Ci"])
+        else:
+            continue
+        dim["wgrad" if "wgrad" in name else "conv"] += f * (live if a["nimg"] is not None else 1.0)
+    assert 0.99 * dim["conv"] < work <= dim["conv"] and 0.99 * dim["wgrad"] < acc["conv_wgrad"][1] <= dim["wgrad"], (dim, acc)
