@@ -1,0 +1,11 @@
+#!/bin/bash
+# One gpurun call at the round's HEAD: the driver's test command (full log kept), the parity file's measured errors, one default bench line.
+# usage: gpurun --timeout 1800 -- 'bash tools/perf/r06_final.sh'
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q --durations=25 -p no:cacheprovider > gpurun_out/r06_suite_head.txt 2>&1
+echo "suite rc $?" | tee -a gpurun_out/r06_suite_head.txt
+tail -1 gpurun_out/r06_suite_head.txt
+python -m pytest tests/test_gpu_00_models.py -q -m gpu -rP -p no:cacheprovider 2>&1 | grep -E "^(loop|gradient norms|G coco|grad_|VGG|[0-9]+ passed)" > gpurun_out/r06_models_measured.txt
+python bench.py > gpurun_out/r06_bench_head.json 2> gpurun_out/r06_bench_head.err
+python tools/perf/cpu_time.py > gpurun_out/r06_host_time_head.txt 2>&1
+tail -c 600 gpurun_out/r06_bench_head.json
