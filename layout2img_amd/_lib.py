@@ -106,6 +106,14 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _i
         _FN[name] = fn
+    if os.environ.get("L2I_FASTCALL", "0") == "1":
+        # the generated CPython binding instead of ctypes' per-argument conversion (fastcall.py: same symbols, same values; opt-in until it
+        # has run on a GPU box). Calls whose arguments it does not take (ctypes.byref objects: l2i_timing_read) stay on ctypes.
+        from . import fastcall
+        mod = fastcall.load(lib=lib)
+        for name in SIGNATURES:
+            if name != "l2i_timing_read":
+                _FN[name] = getattr(mod, name)
     _lib = lib
     return lib
 

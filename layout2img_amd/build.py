@@ -22,6 +22,8 @@ def _stale():
 
 
 def build(force=False, verbose=True):
+    from . import fastcall
+    fastcall.build(force=force)   # the generated CPython binding of the C ABI (gcc, a second or two; no device code)
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
