@@ -9,3 +9,7 @@ python -m pytest tests/test_gpu_00_models.py -q -m gpu -rP -p no:cacheprovider 2
 python bench.py > gpurun_out/r06_bench_head.json 2> gpurun_out/r06_bench_head.err
 python tools/perf/cpu_time.py > gpurun_out/r06_host_time_head.txt 2>&1
 tail -c 600 gpurun_out/r06_bench_head.json
+# the generated binding on the GPU: the parity + determinism files through it, and the eager host time with / without it
+L2I_FASTCALL=1 python -m pytest tests/test_gpu_00_models.py tests/test_gpu_06b_determinism.py tests/test_gpu_03_layout.py -q -m gpu -x -p no:cacheprovider 2>&1 | tail -2 > gpurun_out/r06_fastcall_tests.txt
+L2I_FASTCALL=1 python tools/perf/cpu_time.py >> gpurun_out/r06_fastcall_tests.txt 2>&1
+cat gpurun_out/r06_host_time_head.txt gpurun_out/r06_fastcall_tests.txt
