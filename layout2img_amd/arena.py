@@ -561,6 +561,25 @@ class WeightArena:
         self.pending = []
 
 
+class Span:
+    """(address, element count) of a slice of one of a pass's long-lived buffers (weight packs, dWbar accumulator): all a launch needs of
+    it. The eager iteration names ~375 such slices; as tensor views each costs a trip through torch's dispatcher (~1.5 us) for the sake
+    of one `data_ptr()`. Quacks like the view where ops.conv_raw / wgrad_raw look at it: data_ptr(), numel(), record_stream()."""
+    __slots__ = ("ptr", "n", "base")
+
+    def __init__(self, base, ptr, n):
+        self.base, self.ptr, self.n = base, ptr, n
+
+    def data_ptr(self):
+        return self.ptr
+
+    def numel(self):
+        return self.n
+
+    def record_stream(self, stream):
+        self.base.record_stream(stream)
+
+
 class PassCtx:
     """Packed weights, u/v snapshots, sigma and the dWbar accumulator of ONE forward pass."""
 
@@ -572,6 +591,7 @@ class PassCtx:
         # The pack kernel writes only the true (co < Co_p, ci < Ci_p) elements; padding rows and K tails must be
         # zero, so buffers are zero-filled once and recycled through the arena when their pass dies.
         self.packed = arena.free_packs.pop() if arena.free_packs else torch.zeros(arena.packed_len, dtype=arena.op_dtype, device=dev)
+        self._packed_ptr, self._esz = self.packed.data_ptr(), self.packed.element_size()   # (for the spans below: the buffer is this pass's for life)
         # (one allocation: the library clears norms and pass_uv with a single memset when they are adjacent)
         nn4 = _round_up(4 * arena.n_layers, ALIGN)
         buf = torch.empty(nn4 + arena.uv_len, dtype=torch.float32, device=dev)
@@ -647,6 +667,26 @@ class PassCtx:
     def dw_slice(self, h):
         return self.dw()[h.dw_off:h.dw_off + h.co_p * h.kp]
 
+    # the same three as `Span`s, for callers that only launch on them (ops.FusedConvFn)
+    def fwd_span(self, h):
+        return Span(self.packed, self._packed_ptr + self._esz * h.fwd_off, h.npad * h.kpad)
+
+    def dgrad_span(self, h):
+        return Span(self.packed, self._packed_ptr + self._esz * h.dg_off, h.npad_d * h.kpad_d)
+
+    def dw_span(self, h):
+        d = self.dw()
+        return Span(d, d.data_ptr() + 4 * h.dw_off, h.co_p * h.kp)
+
+    def fwd_span_b(self, h):
+        return None
+
+    def dgrad_span_b(self, h):
+        return None
+
+    def dw_span_b(self, h):
+        return None
+
     def sigma(self, h):
         return self.norms[4 * h.layer_id + 2]
 
@@ -703,6 +743,24 @@ class DualPass:
 
     def dw_slice_b(self, h):
         return self.b.dw_slice(h)
+
+    def fwd_span(self, h):
+        return self.a.fwd_span(h)
+
+    def dgrad_span(self, h):
+        return self.a.dgrad_span(h)
+
+    def dw_span(self, h):
+        return self.a.dw_span(h)
+
+    def fwd_span_b(self, h):
+        return self.b.fwd_span(h)
+
+    def dgrad_span_b(self, h):
+        return self.b.dgrad_span(h)
+
+    def dw_span_b(self, h):
+        return self.b.dw_span(h)
 
     def mark_written(self, h):
         self.a.mark_written(h)

@@ -623,14 +623,14 @@ class FusedConvFn(Function):
             assert holder.kh == 1 and res is None and not emit and not op_out and pro.kind not in ("norm",)
             Hq, Wq = (Ho // 2, Wo // 2) if pool2 else (Ho, Wo)
             out = torch.empty((B, Hq, Wq, holder.co_p), dtype=torch.float32, device=x.device)
-            out._l2i_lazy_sc = dict(x_op=x_op, wpack=pc.fwd_pack(holder), wpack_b=pc.fwd_pack_b(holder), kpad=holder.kpad, bias=bias_p, up2=bool(up2),
+            out._l2i_lazy_sc = dict(x_op=x_op, wpack=pc.fwd_span(holder), wpack_b=pc.fwd_span_b(holder), kpad=holder.kpad, bias=bias_p, up2=bool(up2),
                                     pool2=bool(pool2), nimg=nimg, flops=flops, ver=out._version, holder=holder, wgrad_done=False)
             ctx.lazy = out._l2i_lazy_sc   # (shared with the consumer: its backward may compute this node's weight gradient, see below)
         else:
         # `op_out`: the ONLY reader of the result is a pre-activation conv -- the epilogue writes relu(result) in the operand
         # dtype and nothing else; that tensor is the autograd edge (its gradient arrives, and is used, in the operand dtype)
-            out, o_relu, o_raw = conv_raw(x_op, pc.fwd_pack(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p,
-                                          res=None if sc is not None else res, sc=sc, wpack_b=pc.fwd_pack_b(holder),
+            out, o_relu, o_raw = conv_raw(x_op, pc.fwd_span(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p,
+                                          res=None if sc is not None else res, sc=sc, wpack_b=pc.fwd_span_b(holder),
                                           up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops, nimg=nimg,
                                           want_f32=not op_out, want_op=op_out or "relu" in emit, relu_op=True,
                                           want_raw="raw" in emit, stats="stats" in emit and not op_out)
@@ -706,7 +706,7 @@ class FusedConvFn(Function):
                     bgs = pc.bias_slot(hs, bgs) if (BIAS_SLOTS and getattr(hs, "bias_scr_off", None) is not None and not pc.dual) else None
                     direct_s = bgs is not None
                 if direct_s and hs.co_p == h.co_p:
-                    scw = dict(x_op=sl["x_op"], dw=pc.dw_slice(hs), dw_b=pc.dw_slice_b(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"], up2=sl["up2"])
+                    scw = dict(x_op=sl["x_op"], dw=pc.dw_span(hs), dw_b=pc.dw_span_b(hs), ldw=hs.kp, dbias=bgs, flops=sl["flops"], up2=sl["up2"])
                     sl["wgrad_done"] = True
             # stored, not accumulated, when this is the slice's first launch of the pass (a second backward over the same forward adds)
             ow = WGRAD_OVERWRITE and h.kind == "conv" and not pc.was_written(h) and (scw is None or not pc.was_written(sl["holder"]))
@@ -714,8 +714,8 @@ class FusedConvFn(Function):
                 pc.dw_acc(h)
                 if scw is not None:
                     pc.dw_acc(sl["holder"])
-            wgrad_side(x_op, dy_op, pc.dw_slice(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
-                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw, dw_b=pc.dw_slice_b(h), overwrite=ow)
+            wgrad_side(x_op, dy_op, pc.dw_span(h), h.kp, h.co_p, h.kh, up2=ctx.up2, pool2=ctx.pool2, alpha=alpha,
+                       flops=ctx.flops, nimg=ctx.nimg, dbias=dbias, sc=scw, dw_b=pc.dw_span_b(h), overwrite=ow)
             pc.mark_written(h)
             if scw is not None:
                 pc.mark_written(sl["holder"])
@@ -733,9 +733,9 @@ class FusedConvFn(Function):
             # (a) this is a block's 1x1 shortcut and the block's conv1 can fold its data gradient (GradJoin.fold_ok): hand over the
             #     OPERANDS instead of launching -- conv1's launch computes mask(alpha1 W1^T dh) + alpha W_sc^T dy (+ this node's residual)
             if (DGRAD_FOLD and ctx.join is not None and ctx.join[1] == "give" and ctx.join[0].fold_ok and ctx.join[0].state == "open" and need_x
-                    and h.kh == 1 and pro.kind == "cast" and opd == torch.bfloat16 and not pc.arena.split and pc.dgrad_pack_b(h) is None
+                    and h.kh == 1 and pro.kind == "cast" and opd == torch.bfloat16 and not pc.arena.split and pc.dgrad_span_b(h) is None
                     and not ctx.up2 and h.co_p % 64 == 0 and not op_in and ctx.join_out is None):
-                ctx.join[0].give(dict(x_op=dy_op, wpack=pc.dgrad_pack(h), kpad=h.kpad_d, up2=bool(ctx.pool2), alpha=alpha, flops=ctx.flops,
+                ctx.join[0].give(dict(x_op=dy_op, wpack=pc.dgrad_span(h), kpad=h.kpad_d, up2=bool(ctx.pool2), alpha=alpha, flops=ctx.flops,
                                       res=joined, mask_first=True, nimg=ctx.nimg))
                 d_res = dy if ctx.has_res else None
                 return None, d_res, d_bias, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
@@ -746,9 +746,9 @@ class FusedConvFn(Function):
                 if relu_mask is None or h.kh != 3 or ctx.up2 or ctx.pool2 or op_in or sc_fold["nimg"] is not ctx.nimg or pro.kind == "norm":
                     raise RuntimeError("GradJoin.fold_ok was set on a join whose taker cannot fold the shortcut's data gradient")
                 sc_fold = dict(sc_fold, bias=None, out=torch.empty((Bq, Hq, Wq, h.ci_p), dtype=torch.float32, device=dy.device))
-            dxo, _, dx_op = conv_raw(dy_op, pc.dgrad_pack(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
+            dxo, _, dx_op = conv_raw(dy_op, pc.dgrad_span(h), h.kpad_d, h.ci_p, h.kh, relu_mask=relu_mask, up2=ctx.pool2,
                                      pool2=ctx.up2, alpha=alpha, flops=ctx.flops, nimg=ctx.nimg, want_raw=emit_raw,
-                                     want_f32=not op_in, res=joined if pro.kind != "norm" else None, wpack_b=pc.dgrad_pack_b(h), sc=sc_fold)
+                                     want_f32=not op_in, res=joined if pro.kind != "norm" else None, wpack_b=pc.dgrad_span_b(h), sc=sc_fold)
             if op_in:
                 dxo = dx_op
             elif emit_raw:

@@ -43,12 +43,68 @@ class _FakeStreamCtx:
         return False
 
 
+SCRATCH_PTR, WORKSPACE_PTR = 0x7000 << 40, 0x7001 << 40
+
+
+class _Aten(torch.utils._python_dispatch.TorchDispatchMode):
+    """Records every stock torch operator the iteration issues between the C-ABI calls: ("aten::...", operands) with each tensor operand as
+    (pointer, shape, strides, dtype) -- on the GPU these are launches (or views) too, so a refactoring that is to leave the GPU's work
+    unchanged must leave them unchanged as well."""
+
+    def __init__(self, trace):
+        super().__init__()
+        self.trace = trace
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+
+        def d(x):
+            if isinstance(x, torch.Tensor):
+                return ("T", x.data_ptr(), tuple(x.shape), tuple(x.stride()), str(x.dtype))
+            if isinstance(x, (list, tuple)):
+                return tuple(d(y) for y in x)
+            if isinstance(x, (int, float, bool, str, type(None))):
+                return x
+            return str(x)
+        self.trace.append((str(func), (d(args), d(tuple(sorted((kwargs or {}).items()))), d(out))))
+        return out
+
+
+def canonical(trace):
+    """The trace with every fake address replaced by (index of its buffer in order of first appearance, byte offset): two runs that hand
+    the GPU the same work in the same buffers-by-role compare equal whatever the allocator did."""
+    ids = {}
+
+    def c(x):
+        if isinstance(x, tuple):
+            if len(x) == 5 and x[0] == "T":
+                return ("T", c(x[1])) + x[2:]
+            return tuple(c(y) for y in x)
+        if type(x) is int and x >= (1 << 40):
+            base = x >> 40
+            return ("buf", ids.setdefault(base, len(ids)), x & ((1 << 40) - 1))
+        return x
+    return [(name, c(args)) for name, args in trace]
+
+
 @contextlib.contextmanager
-def dry_run():
+def dry_run(pointers=False, aten=False):
     """Inside the block: tensors report `is_cuda`, streams / events are inert, every C-ABI call is appended to the yielded list as
-    (name, args) after being checked against the ctypes table the way ctypes itself would convert it."""
+    (name, args) after being checked against the ctypes table the way ctypes itself would convert it.
+    pointers: `Tensor.data_ptr()` returns a fake address, (storage number << 40) + byte offset, so that the trace shows which calls share
+    which buffers (compare with `canonical`); every storage seen stays alive until the block ends, so no address is ever reused.
+    aten: stock torch operators are recorded as well (`_Aten`)."""
     from layout2img_amd import _lib, ops
     trace = []
+    bases, keep = {}, []
+
+    def data_ptr(self):
+        st = self.untyped_storage()
+        base = bases.get(st._cdata)
+        if base is None:
+            base = bases[st._cdata] = (len(bases) + 1) << 40
+            keep.append(st)
+        return base + self.storage_offset() * self.element_size()
     kinds = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_longlong: "l", ctypes.c_float: "f"}
 
     def record(name, *args):
@@ -82,8 +138,8 @@ def dry_run():
     _lib.call = record
     _lib.raw_stream = lambda: 0
     _lib.current_device = lambda: None          # == torch.device("meta").index
-    _lib.workspace = lambda device: 0
-    _lib.wgrad_scratch = lambda device: (0, _lib.WGRAD_SCRATCH_FLOATS)
+    _lib.workspace = lambda device: WORKSPACE_PTR if pointers else 0
+    _lib.wgrad_scratch = lambda device: (SCRATCH_PTR if pointers else 0, _lib.WGRAD_SCRATCH_FLOATS)
     ops._ws = _lib.workspace
     torch.cuda.current_stream = lambda *a: _FakeStream()
     torch.cuda.Stream = _FakeStream
@@ -92,11 +148,17 @@ def dry_run():
     torch.cuda.synchronize = lambda *a: None
     torch.cuda.is_current_stream_capturing = lambda: False
     torch.Tensor.is_cuda = property(lambda self: True)   # (shadows TensorBase's descriptor; deleted again below)
+    if pointers:
+        torch.Tensor.data_ptr = data_ptr
     pool = (ops.POOL.__dict__.pop("slabs", None), ops.POOL.buf)
+    mode = _Aten(trace) if aten else contextlib.nullcontext()
     try:
-        yield trace
+        with mode:
+            yield trace
     finally:
         del torch.Tensor.is_cuda
+        if pointers:
+            del torch.Tensor.data_ptr
         for obj, name, val in saved:
             setattr(obj, name, val)
         ops.POOL.__dict__.pop("slabs", None)
