@@ -219,3 +219,31 @@ def test_roofline_numerators_of_the_committed_bench_line_reproduce_without_a_gpu
             continue
         dim["wgrad" if "wgrad" in name else "conv"] += f * (live if a["nimg"] is not None else 1.0)
     assert 0.99 * dim["conv"] < work <= dim["conv"] and 0.99 * dim["wgrad"] < acc["conv_wgrad"][1] <= dim["wgrad"], (dim, acc)
+
+
+def test_steady_state_holds_buffer_by_buffer_and_for_the_stock_operators():
+    """The stronger form of the steady-state check: with fake addresses (dry_run(pointers=True): storage number << 40 + byte offset) and the
+    stock torch operators recorded between the C-ABI calls, iterations 2 and 3 hand the GPU the same work on the same buffers-by-role --
+    every launch reads and writes the same slices of the same arena buffers, every temporary is created and consumed at the same place.
+    And within one iteration no call is handed the null address where the header expects a tensor it was given."""
+    with dryrun.dry_run(pointers=True, aten=True) as trace:
+        tr, (real, label, bbox, z, z_im) = dryrun.build("coco", torch.bfloat16)
+        its = []
+        for _ in range(3):
+            del trace[:]
+            tr.step(real, label, bbox, z, None)
+            its.append(list(trace))
+    a, b = (dryrun.canonical(_static(t)) for t in its[1:])
+    assert a == b and len(a) > 1500
+    calls = [(n, args) for n, args in its[2] if n.startswith("l2i_")]
+    assert len(calls) == 433
+    # every conv launch's weight pack lies inside ONE buffer per pass (the pass's pack arena) and inside its bounds
+    names = dryrun.header_parameters()
+    packs = {}
+    for n, args in calls:
+        if n == "l2i_conv2d_fwd_dual":
+            w = dict(zip(names[n], args))["w"]
+            packs.setdefault(w >> 40, []).append(w & ((1 << 40) - 1))
+    assert 3 <= len(packs) <= 8          # D(real), D(fake), D(G-step), G (+ the eval-mode VGG has none here)
+    for offs in packs.values():
+        assert max(offs) < 2 * max(tr.netD.arena.packed_len, tr.netG.arena.packed_len)
