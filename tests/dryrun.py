@@ -234,3 +234,70 @@ def dry_ddp(world=2):
         for obj, name, val in saved:
             setattr(obj, name, val)
         parallel._GRAD_GROUP, parallel._HOST_GROUP = groups
+
+
+def header_pointer_kinds():
+    """{entry point: [None (not a pointer) | "in" (const T*) | "out" (T*), ...]} from include/l2i.h."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "l2i.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", " ", hdr)
+    out = {}
+    for m in re.finditer(r"^int\s+(l2i_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.M | re.S):
+        ps = [x.strip() for x in m.group(2).replace("\n", " ").split(",") if x.strip() and x.strip() != "void"]
+        out[m.group(1)] = [None if "*" not in a else ("in" if a.startswith("const") else "out") for a in ps]
+    return out
+
+
+_ALLOC = ("aten.empty.memory_format", "aten.empty_like.default", "aten.new_empty.default", "aten.empty_strided.default", "aten.new_empty_strided.default")
+_VIEWS = ("aten.slice.Tensor", "aten.view.default", "aten.select.int", "aten.detach.default", "aten.as_strided.default", "aten.alias.default",
+          "aten.expand.default", "aten.permute.default", "aten.transpose.int", "aten.t.default", "aten.unsqueeze.default", "aten._unsafe_view.default",
+          "aten.squeeze.dim", "aten.narrow.default")
+
+
+def uninitialised_reads(previous, trace, kinds=None):
+    """Launches of `trace` (dry_run(pointers=True, aten=True)) that read a buffer nothing has written: a buffer that did not exist in the
+    `previous` iteration's trace is a temporary; one made by torch.empty(_like) holds garbage until a C-ABI call names it through a
+    non-const parameter or a stock operator produces / updates it; naming it through a `const` parameter (or as a stock operator's input)
+    before that is a read of uninitialised memory. Whole buffers, not byte ranges: a partly written buffer counts as written.
+    Returns [(position, entry point | operator, parameter, buffer number)]."""
+    kinds = header_pointer_kinds() if kinds is None else kinds
+    names = header_parameters()
+
+    def buffers(x, out):
+        if isinstance(x, tuple):
+            if len(x) == 5 and x[0] == "T":
+                out.append(x[1] >> 40)
+            else:
+                for y in x:
+                    buffers(y, out)
+        return out
+
+    persistent = {SCRATCH_PTR >> 40, WORKSPACE_PTR >> 40}
+    for name, args in previous:
+        if name.startswith("l2i_"):
+            persistent.update(a >> 40 for a in args if type(a) is int and a >= (1 << 40))
+        else:
+            persistent.update(buffers(args, []))
+    written, found = set(), []
+    for pos, (name, args) in enumerate(trace):
+        if name.startswith("l2i_"):
+            for kind, pname, a in zip(kinds[name], names[name], args):
+                if kind is None or type(a) is not int or a < (1 << 40) or (a >> 40) in persistent:
+                    continue
+                if kind == "out":
+                    written.add(a >> 40)
+                elif (a >> 40) not in written:
+                    found.append((pos, name, pname, a >> 40))
+        elif name in _VIEWS:
+            continue
+        else:
+            ins, outs = buffers(args[0], []), buffers(args[2], [])
+            if name not in _ALLOC:
+                found.extend((pos, name, "operand", b) for b in ins if b not in persistent and b not in written and b not in outs)
+                written.update(outs)
+                if name.split(".")[1].endswith("_"):
+                    written.update(ins[:1])
+    return found

@@ -247,3 +247,26 @@ def test_steady_state_holds_buffer_by_buffer_and_for_the_stock_operators():
     assert 3 <= len(packs) <= 8          # D(real), D(fake), D(G-step), G (+ the eval-mode VGG has none here)
     for offs in packs.values():
         assert max(offs) < 2 * max(tr.netD.arena.packed_len, tr.netG.arena.packed_len)
+
+
+@pytest.mark.parametrize("cfg", [dict(kind="coco", dtype=torch.bfloat16), dict(kind="coco", dtype=torch.float32), dict(kind="vg", dtype=torch.bfloat16, vgg=True),
+                                 dict(kind="coco", dtype=torch.float32, size=64)], ids=["coco-bf16", "coco-f32", "vg-vgg", "res64"])
+def test_no_launch_reads_a_temporary_that_nothing_has_written(cfg):
+    """include/l2i.h says which pointer parameters are inputs (`const T*`); the traced iteration says which buffers are fresh `torch.empty`
+    temporaries. No call of the iteration may name such a buffer as an input before some call has produced it (the weight-gradient
+    accumulators and the lazily folded shortcut's placeholder are made by torch.empty on purpose: their first user must be their writer).
+    The detector is shown to see: declaring the convolution's `out` an input makes every consumer chain light up."""
+    with dryrun.dry_run(pointers=True, aten=True) as trace:
+        tr, (real, label, bbox, z, z_im) = dryrun.build(**cfg)
+        its = []
+        for _ in range(3):
+            del trace[:]
+            tr.step(real, label, bbox, z, z_im if cfg["kind"] == "vg" else None)
+            its.append(list(trace))
+    assert dryrun.uninitialised_reads(its[1], its[2]) == []
+    kinds = dryrun.header_pointer_kinds()
+    entry = "l2i_conv2d_fwd_dual"
+    k = dryrun.header_parameters()[entry].index("out")
+    assert kinds[entry][k] == "out"
+    kinds[entry] = kinds[entry][:k] + ["in"] + kinds[entry][k + 1:]
+    assert len(dryrun.uninitialised_reads(its[1], its[2], kinds)) > 50
