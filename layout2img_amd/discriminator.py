@@ -43,7 +43,7 @@ class OptimizedBlock(nn.Module):
         self.conv1, self.conv2, self.c_sc = _conv(in_ch, out_ch, 3), _conv(out_ch, out_ch, 3), _conv(in_ch, out_ch, 1)
         self.downsample = downsample
 
-    def forward(self, x, pc, emit=()):
+    def forward(self, x, pc, emit=(), f32_dead=False):
         h = fused_conv(x, self.conv1, pc, relu_op_out=True)   # conv2's ReLU'd operand comes out of conv1's epilogue
         xs = x
         if self.downsample:
@@ -51,7 +51,7 @@ class OptimizedBlock(nn.Module):
             if xs is None:
                 xs = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
         sc = fused_conv(xs, self.c_sc, pc)
-        return fused_conv(h, self.conv2, pc, prologue=RELU, res=sc, pool2=self.downsample, emit=emit, dx_raw=True)
+        return fused_conv(h, self.conv2, pc, prologue=RELU, res=sc, pool2=self.downsample, emit=emit, dx_raw=True, f32_dead=f32_dead)
 
 
 class ResBlock(nn.Module):
@@ -65,8 +65,9 @@ class ResBlock(nn.Module):
         if self.learnable_sc:
             self.c_sc = _conv(in_ch, out_ch, 1, uses)
 
-    def forward(self, x, pc, use=0, nimg=None, emit=(), sole_reader=False, join_in=None, join_out=None, join_src=None):
-        """`sole_reader`: x is the result of another block's conv2 and this block is its ONLY reader -- the data-gradient launch
+    def forward(self, x, pc, use=0, nimg=None, emit=(), sole_reader=False, join_in=None, join_out=None, join_src=None, f32_dead=False):
+        """`f32_dead`: every reader of this block's result is a block with a learnable shortcut (reads the emitted copies only): ops.fused_conv.
+        `sole_reader`: x is the result of another block's conv2 and this block is its ONLY reader -- the data-gradient launch
         of conv1 (which also takes the shortcut branch's gradient as its residual: the complete dx) then writes the operand
         copy of dx that the producing conv2's backward needs, instead of a separate cast pass over the f32 gradient.
         `join_in` / `join_out` (ops.fused_conv): x is read by TWO blocks -- the one created later (its backward runs first) leaves
@@ -91,7 +92,7 @@ class ResBlock(nn.Module):
         sc = (fused_conv(x, self.c_sc.use(use), pc, pool2=self.downsample, nimg=nimg, join=(j, "give"), lazy_sc=True, join_in=join_in)
               if self.learnable_sc else x)
         return fused_conv(h, self.conv2.use(use), pc, prologue=RELU, res=sc, pool2=self.downsample, nimg=nimg, emit=emit,
-                          dx_raw=True, join=None if self.learnable_sc else (j, "give_res"), join_src=join_src)
+                          dx_raw=True, join=None if self.learnable_sc else (j, "give_res"), join_src=join_src, f32_dead=f32_dead)
 
 
 class ResnetDiscriminator128_app(nn.Module):
@@ -118,17 +119,18 @@ class ResnetDiscriminator128_app(nn.Module):
         """x (b,H,W,8) f32 NHWC (3 real channels); y (R,) labels; rois (R,5); valid (R,) int32; nimg: device int32 =
         number of valid rows when they are compacted to the front (the ROI heads then skip the rest)."""
         both = ("relu", "raw")   # what a following block with a learnable shortcut reads
-        x = self.block1(x, pc, emit=both)
+        # (f32_dead: each of these results is read by blocks with a learnable shortcut only -- conv1 takes "relu", the shortcut "raw")
+        x = self.block1(x, pc, emit=both, f32_dead=True)
         jx1, jx2 = ops.GradJoin(), ops.GradJoin()   # x1 and x2 are each read by a trunk block and by an object-path block
-        x1 = self.block2(x, pc, emit=both, sole_reader=True, join_src=jx1)
-        x2 = self.block3(x1, pc, emit=both, join_in=jx1, sole_reader=JOIN_READERS, join_src=jx2)
-        x = self.block4(x2, pc, emit=both, join_in=jx2, sole_reader=JOIN_READERS)
+        x1 = self.block2(x, pc, emit=both, sole_reader=True, join_src=jx1, f32_dead=True)
+        x2 = self.block3(x1, pc, emit=both, join_in=jx1, sole_reader=JOIN_READERS, join_src=jx2, f32_dead=True)
+        x = self.block4(x2, pc, emit=both, join_in=jx2, sole_reader=JOIN_READERS, f32_dead=True)
         x = self.block5(x, pc, emit=("relu",), sole_reader=True)
         x = self.block6(x, pc, sole_reader=True)
         P = _passes(pc)
         out_im = [ops.proj_head(xk, self.l7, p) for xk, p in zip(_rows(x, pc), P)]            # l7(sum_hw relu(x))
 
-        feat_s = self.block_obj4(self.block_obj3(x1, pc, emit=both, join_out=jx1 if JOIN_READERS else None), pc, use=0, sole_reader=True)   # reference order :136-141
+        feat_s = self.block_obj4(self.block_obj3(x1, pc, emit=both, join_out=jx1 if JOIN_READERS else None, f32_dead=True), pc, use=0, sole_reader=True)   # reference order :136-141
         feat_l = self.block_obj4(x2, pc, use=1, join_out=jx2 if JOIN_READERS else None)
         # the ROI features are read by block_obj5 and by app_conv: the one created LATER (its backward runs first) leaves its complete
         # gradient in jobj, block_obj5's shortcut launch adds it; ROI-align's backward is the taker of last resort (a loss over d_app alone)

@@ -563,7 +563,7 @@ class FusedConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, res, bias, mask, wproj, bproj, holder: GemmWeight, pc: PassCtx, pro, up2, pool2, nimg=None,
-                emit=(), dx_raw=False, join=None, op_out=False, lazy_sc=False, join_in=None, join_out=None, join_src=None):
+                emit=(), dx_raw=False, join=None, op_out=False, lazy_sc=False, join_in=None, join_out=None, join_src=None, f32_dead=False):
         opd = pc.arena.op_dtype
         _chk(x, opd if (pro.kind in ("op", "opraw") and not pc.arena.split) else torch.float32)
         B, H, W, C = x.shape
@@ -629,11 +629,17 @@ class FusedConvFn(Function):
         else:
         # `op_out`: the ONLY reader of the result is a pre-activation conv -- the epilogue writes relu(result) in the operand
         # dtype and nothing else; that tensor is the autograd edge (its gradient arrives, and is used, in the operand dtype)
+            # `f32_dead` (L2I_F32_DEAD=1, opt-in): every reader of this result takes the emitted operand copies (a D block's result read by a
+            # block with a learnable shortcut: conv1 reads "relu", the shortcut "raw") -- the f32 stream is then not written at all; the tensor
+            # that stays the autograd edge is a placeholder nothing reads (tests/test_cpu_dryrun.py proves that for every traced configuration)
+            phantom = (F32_DEAD and f32_dead and not op_out and opd == torch.bfloat16 and "relu" in emit and "raw" in emit and "stats" not in emit)
             out, o_relu, o_raw = conv_raw(x_op, pc.fwd_span(holder), holder.kpad, holder.co_p, holder.kh, bias=bias_p,
                                           res=None if sc is not None else res, sc=sc, wpack_b=pc.fwd_span_b(holder),
                                           up2=up2, pool2=pool2, alpha=0.25 if pool2 else 1.0, flops=flops, nimg=nimg,
-                                          want_f32=not op_out, want_op=op_out or "relu" in emit, relu_op=True,
+                                          want_f32=not op_out and not phantom, want_op=op_out or "relu" in emit, relu_op=True,
                                           want_raw="raw" in emit, stats="stats" in emit and not op_out)
+            if phantom:
+                out = torch.empty(o_raw.shape, dtype=torch.float32, device=x.device)
             if op_out:
                 out = o_relu
             elif emit and (o_raw is not None or o_relu is not None):
@@ -738,7 +744,7 @@ class FusedConvFn(Function):
                 ctx.join[0].give(dict(x_op=dy_op, wpack=pc.dgrad_span(h), kpad=h.kpad_d, up2=bool(ctx.pool2), alpha=alpha, flops=ctx.flops,
                                       res=joined, mask_first=True, nimg=ctx.nimg))
                 d_res = dy if ctx.has_res else None
-                return None, d_res, d_bias, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
+                return None, d_res, d_bias, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
             # (b) the taker's side of (a)
             sc_fold = None
             if isinstance(joined, dict):
@@ -767,7 +773,7 @@ class FusedConvFn(Function):
         d_res = dy if ctx.has_res else None
         if d_res is not None and ctx.join is not None and ctx.join[1] == "give_res":
             d_res = ctx.join[0].give(d_res)
-        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, d_res, d_bias, d_mask, d_w, d_b, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _attach(t, raw=None, relu=None):
@@ -797,8 +803,9 @@ def precast(x, op_dtype):
 
 
 def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None, bproj=None, up2=False, pool2=False, nimg=None,
-               emit=(), dx_raw=False, join=None, relu_op_out=False, lazy_sc=False, join_in=None, join_out=None, join_src=None):
-    """join_src: the GradJoin(s) of the two readers of THIS conv's result (a tuple is accepted): see GradJoin.leftover.
+               emit=(), dx_raw=False, join=None, relu_op_out=False, lazy_sc=False, join_in=None, join_out=None, join_src=None, f32_dead=False):
+    """f32_dead: the caller guarantees that every reader of the result takes the emitted operand copies (see FusedConvFn.forward; opt-in).
+    join_src: the GradJoin(s) of the two readers of THIS conv's result (a tuple is accepted): see GradJoin.leftover.
     join_in / join_out: a GradJoin shared with ANOTHER reader of x (a tensor read by two blocks): the reader whose backward runs
     first (the one created later) leaves its complete dx there (join_out), the other one's launch with a free residual slot (a
     block's 1x1 shortcut) adds it in its data-gradient epilogue (join_in) -- no autograd accumulation pass over the two gradients.
@@ -828,7 +835,7 @@ def fused_conv(x, holder, pc, *, prologue=None, res=None, mask=None, wproj=None,
         if res is not None or pool2 or _atomics_split(B, Ho, Wo, holder.co_p, holder.kh, holder.ci_p, pc.arena.op_dtype) or not OP_EDGES:
             relu_op_out, emit = False, tuple(emit) + ("relu",)
     out = FusedConvFn.apply(x, res, holder.bias, mask, wproj, bproj, holder, pc, pro, up2, pool2, nimg, tuple(emit), dx_raw, join,
-                            relu_op_out, bool(lazy_sc) and SC_FOLD, join_in, join_out, join_src)
+                            relu_op_out, bool(lazy_sc) and SC_FOLD, join_in, join_out, join_src, bool(f32_dead))
     if relu_op_out:
         out._l2i_relu_op = True
     return out
@@ -845,6 +852,7 @@ SC_WGRAD = __import__("os").environ.get("L2I_SC_WGRAD_PY", "1") != "0"   # conv2
 SC_FOLD = __import__("os").environ.get("L2I_SC_LAZY", "1") != "0"   # blocks hand their 1x1 shortcut to conv2's launch (A/B switch; L2I_SC_FOLD=0 keeps the hand-over but un-folds in the library)
 DGRAD_FOLD = __import__("os").environ.get("L2I_DGRAD_FOLD", "1") != "0"   # a D block's 1x1 shortcut data gradient rides on conv1's data-gradient launch (A/B switch)
 OP_EDGES = __import__("os").environ.get("L2I_OP_EDGES", "1") != "0"   # operand-dtype autograd edges inside D blocks (A/B switch)
+F32_DEAD = __import__("os").environ.get("L2I_F32_DEAD", "0") == "1"   # opt-in: f32 result streams that no reader takes are not written (CPU-verified only)
 
 
 class NormActFn(Function):

@@ -270,3 +270,27 @@ def test_no_launch_reads_a_temporary_that_nothing_has_written(cfg):
     assert kinds[entry][k] == "out"
     kinds[entry] = kinds[entry][:k] + ["in"] + kinds[entry][k + 1:]
     assert len(dryrun.uninitialised_reads(its[1], its[2], kinds)) > 50
+
+
+@pytest.mark.parametrize("dual", [False, True], ids=["two-passes", "dual"])
+def test_opt_in_dead_f32_streams_are_read_by_nothing(monkeypatch, dual):
+    """L2I_F32_DEAD=1 (ops.F32_DEAD, opt-in until it has run on a GPU): the discriminator blocks whose results are read through the emitted
+    operand copies only hand the convolution no f32 result pointer; the tensor that remains the autograd edge is never written -- so nothing
+    may read it: the detector of unwritten reads stays empty, at the test batch and at the headline batch."""
+    from layout2img_amd import ops
+    from layout2img_amd.synthetic import make_batch
+    monkeypatch.setattr(ops, "F32_DEAD", True)
+    names = dryrun.header_parameters()["l2i_conv2d_fwd_dual"]
+    for batch in (4, 32):
+        with dryrun.dry_run(pointers=True, aten=True) as trace:
+            tr, _ = dryrun.build("coco", torch.bfloat16)
+            tr.dual_d = dual
+            real, label, bbox, z, z_im = (t.to("meta") for t in make_batch(batch, 128, "coco", seed=1234, device="cpu"))
+            its = []
+            for _ in range(3):
+                del trace[:]
+                tr.step(real, label, bbox, z, None)
+                its.append(list(trace))
+        assert dryrun.uninitialised_reads(its[1], its[2]) == []
+        copies_only = [a for n, a in its[2] if n == "l2i_conv2d_fwd_dual" and (lambda d: d["out"] is None and d["out_op"] is not None and d["out_op_raw"] is not None)(dict(zip(names, a)))]
+        assert len(copies_only) == (10 if dual else 15)   # block1-4 and block_obj3 of every D pass (the dual step runs two passes as one)
