@@ -294,3 +294,19 @@ def test_opt_in_dead_f32_streams_are_read_by_nothing(monkeypatch, dual):
         assert dryrun.uninitialised_reads(its[1], its[2]) == []
         copies_only = [a for n, a in its[2] if n == "l2i_conv2d_fwd_dual" and (lambda d: d["out"] is None and d["out_op"] is not None and d["out_op_raw"] is not None)(dict(zip(names, a)))]
         assert len(copies_only) == (10 if dual else 15)   # block1-4 and block_obj3 of every D pass (the dual step runs two passes as one)
+
+
+def test_inference_forward_reads_no_unwritten_temporary():
+    """The sampler's path (eval mode, no gradients; cached eval-mode weight packs) under the same detector."""
+    with dryrun.dry_run(pointers=True, aten=True) as trace, torch.no_grad():
+        tr, (real, label, bbox, z, z_im) = dryrun.build("coco", torch.bfloat16)
+        g = tr.netG.eval()
+        runs = []
+        for _ in range(3):
+            del trace[:]
+            g(z, bbox, y=label.view(4, 8))
+            runs.append(list(trace))
+        g.train()
+    assert dryrun.uninitialised_reads(runs[1], runs[2]) == []
+    assert dryrun.canonical(runs[1]) == dryrun.canonical(runs[2])
+    assert not any(n == "l2i_weights_prepare" for n, _ in runs[2])   # the eval-mode packs are cached: no power iteration, no repack per call
